@@ -1,0 +1,2 @@
+def register_model(fn):
+    return fn

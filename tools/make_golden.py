@@ -1,0 +1,155 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by running the REFERENCE model (read-only import from /root/reference).
+
+Authoring-container only: /root/reference does not exist on the GPU box and nothing here is imported by the
+product or the tests.  The reference publishes no golden vectors, so these fixtures ARE the pin
+for oracle/cavp_oracle.py: weights and inputs come from cavp_amd.synth (pure function of key/shape/seed), are
+loaded into the reference `CAVP` with strict=True, and the reference's outputs are stored as
+  * full tensors where small (final logits of the B=2/C=2 case, fea_a, attn_v samples ...)
+  * for big tensors: a fixed strided sample (<= 4096 values) + fp64 sum / abs-sum checksums.
+
+Import recipe = SURVEY.md Appendix C (stub packages in tools/_shims for loguru/easydict/timm/torchvision which
+are not installed here; hard-coded checkpoint load at resnet.py:224-227 neutralised).
+
+usage: python tools/make_golden.py [--out tests/golden]
+"""
+import argparse
+import os
+import sys
+
+sys.dont_write_bytecode = True
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(HERE)
+sys.path[:0] = [os.path.join(HERE, "_shims"), "/root/reference", REPO]
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.nn.functional as F  # noqa: E402
+
+import models.visual.backbones.resnet as _R  # noqa: E402
+
+_R.load_model = lambda model, f, is_restore=False: model
+from easydict import EasyDict  # noqa: E402
+from models.cavp_model import CAVP  # noqa: E402
+
+from cavp_amd.synth import synth_inputs, synth_state_dict  # noqa: E402
+
+NSAMP = 4096
+
+CASES = {
+    # name: dict(os, C, B, hw, mode)
+    "c1p_eval": dict(lds=[False, False, False], C=2, B=2, hw=(224, 224), mode="eval"),     # config_avss_binary.py shape
+    "c1_eval": dict(lds=[False, True, True], C=22, B=2, hw=(224, 224), mode="eval"),        # config_vpo_ss.py plumbing @224
+    "ragged_eval": dict(lds=[False, False, False], C=24, B=3, hw=(96, 160), mode="eval"),   # odd batch, H != W
+    "c1p_train": dict(lds=[False, False, False], C=2, B=2, hw=(224, 224), mode="train"),   # BN batch stats, audio 2B, CE grads
+}
+
+SENTINELS = [
+    "backbone.backbone.conv1.0.weight", "backbone.backbone.layer1.0.conv1.weight",
+    "backbone.backbone.layer4.2.conv3.weight", "backbone.backbone.layer4.2.bn3.weight",
+    "segment.aspp.red_conv.weight", "segment.aspp.map_convs.2.weight", "segment.reduce.0.weight",
+    "cross_att.blocks.0.attn.q.weight", "cross_att.blocks.0.attn.k.weight", "cross_att.blocks.0.mlp.fc2.weight",
+    "cross_att.blocks.0.norm1.weight", "cross_att.patch_embed_a.proj.weight", "visual_projector.fc1.weight",
+    "audio_backbone.backbone.embeddings.0.weight", "audio_backbone.backbone.features.0.weight",
+    "segment.upsample.last_conv.0.weight", "segment.upsample.classifier.weight", "segment.upsample.classifier.bias",
+]
+
+
+def sample(t):
+    t = t.detach().to(torch.float32).contiguous().flatten()
+    n = t.numel()
+    stride = max(1, n // NSAMP)
+    return t[::stride][:NSAMP].numpy().copy(), np.array([t.double().sum().item(), t.double().abs().sum().item(), n],
+                                                        dtype=np.float64)
+
+
+def run_case(name, cfg, out_dir):
+    args = EasyDict(seg_model="DeepLabV3Plus", last_three_dilation_stride=cfg["lds"], audio_backbone="vgg",
+                    num_classes=cfg["C"], batch_size=cfg["B"], local_rank="cpu")
+    m = CAVP(50, None, num_classes=cfg["C"], audio_backbone_pretrain_path=None, visual_backbone=50, args=args)
+    sd = synth_state_dict({k: tuple(v.shape) for k, v in m.state_dict().items()}, seed=1)
+    m.load_state_dict(sd, strict=True)
+    if name == "c1p_eval":  # the key tree + shapes of the reference state_dict, C = num_classes
+        import json
+        shapes = {k: ["C" if (k.startswith("segment.upsample.classifier") and i == 0) else int(d)
+                      for i, d in enumerate(v.shape)] for k, v in m.state_dict().items()}
+        with open(os.path.join(out_dir, "state_dict_shapes.json"), "w") as f:
+            json.dump(shapes, f, indent=0)
+    train = cfg["mode"] == "train"
+    B = cfg["B"]
+    image, audio, label = synth_inputs(B, cfg["hw"], audio_batch=2 * B if train else B, num_classes=cfg["C"], seed=0)
+
+    taps = {}
+
+    def hook(key):
+        def fn(mod, inp, out):
+            taps[key] = out
+        return fn
+
+    bb = m.backbone.backbone
+    for i in range(4):
+        getattr(bb, f"layer{i + 1}").register_forward_hook(hook(f"layer{i + 1}"))
+    m.segment.aspp.register_forward_hook(hook("aspp"))
+    m.segment.upsample.last_conv.register_forward_hook(hook("last_conv"))
+    m.segment.upsample.classifier.register_forward_hook(hook("logits_lowres"))
+    orig_fusion = m.forward_fusion
+
+    def fusion(visual, fea_a):
+        taps["fea_v"], taps["fea_a"] = visual, fea_a
+        return orig_fusion(visual, fea_a)
+
+    m.forward_fusion = fusion
+
+    store = {}
+    if train:
+        m.train()
+        out, fus, pack = m(image, audio, None, False)
+        output = out[:B] + out[B:] * 0.0                       # trainer_cavp_vpo_mono.py:171
+        loss = F.cross_entropy(output, label, ignore_index=255)  # loss/losser.py:60-62
+        loss.backward()
+        store["loss"] = np.array([loss.item()], dtype=np.float64)
+        gn = {}
+        for k, p in m.named_parameters():
+            if p.grad is not None:
+                gn[k] = p.grad.double().norm().item()
+        store["grad_norm_keys"] = np.array(sorted(gn), dtype=object)
+        store["grad_norm_vals"] = np.array([gn[k] for k in sorted(gn)], dtype=np.float64)
+        params = dict(m.named_parameters())
+        for k in SENTINELS:
+            s, c = sample(params[k].grad)
+            store["grad_sample/" + k], store["grad_cksum/" + k] = s, c
+    else:
+        m.eval()
+        with torch.no_grad():
+            out, fus, pack = m(image, audio, eval_mode=True)
+
+    taps.update(out_pred=out, out_fusion=fus, pack_audio=pack["audio"], pack_visual=pack["visual"],
+                pack_attn_v=pack["attn_v"])
+    for k, t in taps.items():
+        s, c = sample(t)
+        store["sample/" + k], store["cksum/" + k] = s, c
+        store["shape/" + k] = np.array(t.shape, dtype=np.int64)
+    if out.numel() <= 2 * 2 * 224 * 224:
+        store["full/out_pred"] = out.detach().numpy().astype(np.float32)
+    store["full/fea_a"] = taps["fea_a"].detach().numpy().astype(np.float32)
+    store["cfg/lds"] = np.array(cfg["lds"], dtype=np.int64)
+    store["cfg/CBHW"] = np.array([cfg["C"], B, cfg["hw"][0], cfg["hw"][1]], dtype=np.int64)
+    store["cfg/train"] = np.array([int(train)], dtype=np.int64)
+    path = os.path.join(out_dir, name + ".npz")
+    np.savez_compressed(path, **store)
+    print(f"{name}: wrote {path} ({os.path.getsize(path) / 1e3:.0f} kB); |out|max={out.abs().max().item():.3f} "
+          f"std={out.std().item():.3f}; fusion std={fus.std().item():.3f}; fea_a mean={taps['fea_a'].mean().item():.3f}; "
+          + " ".join(f"{k}:{taps[k].std().item():.2f}" for k in ("layer1", "layer2", "layer3", "layer4", "aspp")))
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--out", default=os.path.join(REPO, "tests", "golden"))
+    ap.add_argument("--only", default=None)
+    a = ap.parse_args()
+    os.makedirs(a.out, exist_ok=True)
+    torch.set_num_threads(8)
+    for name, cfg in CASES.items():
+        if a.only and name != a.only:
+            continue
+        run_case(name, cfg, a.out)
