@@ -1,0 +1,79 @@
+"""ctypes binding of libcavp_hip.so (include/cavp_hip.h).  There is NO fallback: if the library is missing or a
+symbol does not resolve, importing the compute path raises."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libcavp_hip.so")
+
+F32, BF16 = 0, 1
+ACT_NONE, ACT_RELU, ACT_LEAKY, ACT_GELU = 0, 1, 2, 3
+ABI_VERSION = 1
+
+
+class CavpError(RuntimeError):
+    pass
+
+
+class ConvDesc(C.Structure):
+    """struct cavp_conv_desc (include/cavp_hip.h)."""
+    _fields_ = [(n, C.c_int32) for n in (
+        "dtype", "N", "H", "W", "Cin", "ldx", "Cout", "ldy", "KH", "KW", "stride", "pad", "dil", "ldr", "act",
+        "splitk", "tile")]
+
+
+_vp, _i32, _i64, _f32, _sz = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_size_t
+
+# name -> (restype, argtypes): every symbol include/cavp_hip.h declares
+PROTOTYPES = {
+    "cavp_abi_version": (_i32, []),
+    "cavp_error_string": (C.c_char_p, [_i32]),
+    "cavp_conv2d_workspace_bytes": (_sz, [C.POINTER(ConvDesc)]),
+    "cavp_conv2d_nhwc": (_i32, [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "cavp_conv3x3_smallcin_nchw": (_i32, [_i32, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "cavp_maxpool_nhwc": (_i32, [_i32, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "cavp_global_avgpool_nhwc": (_i32, [_i32, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
+    "cavp_bilinear_nhwc": (_i32, [_i32, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "cavp_bilinear_nhwc_to_nchw": (_i32, [_i32, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "cavp_layernorm": (_i32, [_i32, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _vp]),
+    "cavp_attn_gate": (_i32, [_i32, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _vp]),
+    "cavp_bn_fold": (_i32, [_vp, _vp, _vp, _vp, _f32, _vp, _vp, _i32, _vp]),
+    "cavp_pack_weight_ohwi": (_i32, [_i32, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
+    "cavp_cast": (_i32, [_i32, _vp, _i32, _vp, _i64, _vp]),
+}
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """dlopen the library and bind every prototype.  Raises CavpError (never falls back) when it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise CavpError(
+            f"{LIB_PATH} not found: the CAVP MI355X path has no CPU/PyTorch fallback. Build it with "
+            f"`python -m cavp_amd.build` (needs hipcc, cross-compiles gfx950 without a GPU).")
+    try:
+        lib = C.CDLL(LIB_PATH)
+    except OSError as e:  # e.g. libamdhip64 missing
+        raise CavpError(f"cannot dlopen {LIB_PATH}: {e}") from e
+    for name, (res, args) in PROTOTYPES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise CavpError(f"{LIB_PATH} does not export {name}; rebuild with `python -m cavp_amd.build --force`") from e
+        fn.restype, fn.argtypes = res, args
+    v = lib.cavp_abi_version()
+    if v != ABI_VERSION:
+        raise CavpError(f"libcavp_hip.so ABI {v} != expected {ABI_VERSION}; rebuild")
+    _lib = lib
+    return lib
+
+
+def check(status: int, what: str = "") -> None:
+    if status != 0:
+        msg = load().cavp_error_string(status).decode()
+        raise CavpError(f"{what}: libcavp_hip status {status} ({msg})")

@@ -1,0 +1,57 @@
+// Shared device helpers for the CAVP gfx950 kernels.  Written for MI355X only (wave64, MFMA, 160 KiB LDS).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/cavp_hip.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+
+typedef unsigned short bf16_t;  // raw bfloat16 bits
+
+#define CAVP_WAVE 64
+
+__device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float(((unsigned)h) << 16); }
+__device__ __forceinline__ bf16_t f2bf(float f) {  // round-to-nearest-even (same as torch .to(bfloat16))
+  unsigned u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);  // quiet NaN
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (bf16_t)(u >> 16);
+}
+
+template <typename T> struct Elem;
+template <> struct Elem<float> {
+  static constexpr int VE = 4;  // elements per 16-byte vector
+  __device__ static __forceinline__ float ld(const float* p) { return *p; }
+  __device__ static __forceinline__ void st(float* p, float v) { *p = v; }
+};
+template <> struct Elem<bf16_t> {
+  static constexpr int VE = 8;
+  __device__ static __forceinline__ float ld(const bf16_t* p) { return bf2f(*p); }
+  __device__ static __forceinline__ void st(bf16_t* p, float v) { *p = f2bf(v); }
+};
+
+// activation codes = cavp_act_t in include/cavp_hip.h
+__device__ __forceinline__ float apply_act(float v, int act) {
+  switch (act) {
+    case CAVP_ACT_RELU: return v > 0.f ? v : 0.f;
+    case CAVP_ACT_LEAKY: return v > 0.f ? v : 0.01f * v;                      // nn.LeakyReLU() default slope
+    case CAVP_ACT_GELU: return 0.5f * v * (1.f + erff(v * 0.70710678118654752f));  // exact-erf GELU
+    default: return v;
+  }
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// Bijective XCD-aware block remap (8 XCDs, block b is dispatched to XCD b % 8): gives each XCD a contiguous
+// range of logical tile ids so neighbouring tiles (which share an operand panel) hit the same private L2.
+__device__ __forceinline__ int xcd_remap(int bid, int nblk) {
+  const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, idx = bid >> 3;
+  const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + idx;
+}

@@ -1,0 +1,486 @@
+// Implicit-GEMM convolution / linear for gfx950 (MI355X), NHWC activations, OHWI weights, f32 accumulate on MFMA.
+//
+//   D[cout][pixel] = sum_{tap, ci} W[cout][tap][ci] * X[pixel @ tap][ci]
+//
+// * The weights are the MFMA "A" operand (rows = cout) and the gathered activations the "B" operand (cols = pixels),
+//   so each lane's 4 accumulator registers are 4 CONSECUTIVE output channels of ONE pixel: the epilogue applies
+//   the per-channel scale/shift (+ per-image bias, + residual, + activation) and stores 16 B (f32) / 8 B (bf16)
+//   vectors straight into the NHWC output (optionally a channel slice of a wider tensor = free torch.cat).
+// * Both operand tiles are staged in LDS as rows of 128 bytes = 8 x 16-byte slots with the slot index XOR-swizzled
+//   by (row >> 1) & 7, which makes every ds_read_b128 lane group hit 16 distinct slots of the 256-byte bank row.
+// * One K step consumes 4 slots: lane l reads slot j*4 + (l >> 4) of row (l & 15) for BOTH operands.  For bf16
+//   that is exactly the 16x16x32 fragment; for f32 it is a K-permutation shared by A and B (sum order only), fed
+//   to four exact-f32 v_mfma_f32_16x16x4_f32.
+// * Global -> register -> LDS software pipeline with two LDS buffers and one barrier per K tile; loads of tile
+//   k+1 are in flight while tile k is multiplied.  Out-of-image taps, K tails (Cin not a multiple of the tile)
+//   and M / Cout tails are zero-filled at load time (unconditional load from a clamped address + select).
+// * Taps that cannot touch the image for any output pixel (dilation >= extent, e.g. ASPP d=18 on 14x14) are
+//   removed on the host; split-K writes f32 slabs that a small epilogue kernel reduces deterministically.
+#include "common.h"
+
+struct IgemmParams {
+  const void* x;
+  const void* w;
+  void* y;
+  const float* scale;
+  const float* shift;
+  const float* nbias;
+  const void* res;
+  float* partial;
+  int N, H, W, Cin, ldx, Cout, ldy, KW, stride, pad, dil, ldr, act;
+  int Ho, Wo, M, K;
+  int ntaps;
+  unsigned long long taps;  // 4 bits per live tap id (kh*KW + kw)
+  int cpt;                  // K tiles per tap
+  int iters;                // ntaps * cpt
+  int splitk;
+  int tiles_c, tiles_p;
+  int vec_io;               // epilogue may use vector loads/stores (Cout, ldy, ldr multiples of 4, pointers aligned)
+};
+
+template <typename T> struct Mma;
+template <> struct Mma<float> {
+  __device__ static __forceinline__ void run(f32x4_t& acc, const uint4& a, const uint4& b) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.x), __uint_as_float(b.x), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.y), __uint_as_float(b.y), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.z), __uint_as_float(b.z), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.w), __uint_as_float(b.w), acc, 0, 0, 0);
+  }
+};
+template <> struct Mma<bf16_t> {
+  __device__ static __forceinline__ void run(f32x4_t& acc, const uint4& a, const uint4& b) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), acc,
+                                                  0, 0, 0);
+  }
+};
+
+// Shared epilogue math for one output element.
+__device__ __forceinline__ float epi_one(float v, int cc, int n_img, const IgemmParams& p) {
+  if (p.nbias) v += p.nbias[(size_t)n_img * p.Cout + cc];
+  if (p.scale) v *= p.scale[cc];
+  if (p.shift) v += p.shift[cc];
+  return v;
+}
+
+template <typename T>
+__device__ __forceinline__ void epilogue_store4(const IgemmParams& p, float v0, float v1, float v2, float v3, int pix,
+                                                int c) {
+  const int n_img = p.nbias ? pix / (p.Ho * p.Wo) : 0;
+  float v[4] = {v0, v1, v2, v3};
+  T* yp = (T*)p.y + (size_t)pix * p.ldy + c;
+  const T* rp = p.res ? (const T*)p.res + (size_t)pix * p.ldr + c : nullptr;
+  if (p.vec_io) {
+    if (c >= p.Cout) return;
+    if (p.nbias) {
+      const float4 nb = *(const float4*)(p.nbias + (size_t)n_img * p.Cout + c);
+      v[0] += nb.x; v[1] += nb.y; v[2] += nb.z; v[3] += nb.w;
+    }
+    if (p.scale) {
+      const float4 s = *(const float4*)(p.scale + c);
+      v[0] *= s.x; v[1] *= s.y; v[2] *= s.z; v[3] *= s.w;
+    }
+    if (p.shift) {
+      const float4 s = *(const float4*)(p.shift + c);
+      v[0] += s.x; v[1] += s.y; v[2] += s.z; v[3] += s.w;
+    }
+    if constexpr (sizeof(T) == 4) {
+      if (rp) {
+        const float4 r = *(const float4*)rp;
+        v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w;
+      }
+      float4 o;
+      o.x = apply_act(v[0], p.act); o.y = apply_act(v[1], p.act);
+      o.z = apply_act(v[2], p.act); o.w = apply_act(v[3], p.act);
+      *(float4*)yp = o;
+    } else {
+      if (rp) {
+        const uint2 r = *(const uint2*)rp;
+        v[0] += bf2f((bf16_t)(r.x & 0xffff)); v[1] += bf2f((bf16_t)(r.x >> 16));
+        v[2] += bf2f((bf16_t)(r.y & 0xffff)); v[3] += bf2f((bf16_t)(r.y >> 16));
+      }
+      uint2 o;
+      o.x = (unsigned)f2bf(apply_act(v[0], p.act)) | ((unsigned)f2bf(apply_act(v[1], p.act)) << 16);
+      o.y = (unsigned)f2bf(apply_act(v[2], p.act)) | ((unsigned)f2bf(apply_act(v[3], p.act)) << 16);
+      *(uint2*)yp = o;
+    }
+  } else {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int cc = c + e;
+      if (cc < p.Cout) {
+        float t = epi_one(v[e], cc, n_img, p);
+        if (rp) t += Elem<T>::ld(rp + e);
+        Elem<T>::st(yp + e, apply_act(t, p.act));
+      }
+    }
+  }
+}
+
+template <typename T, int BC, int BP, int WC, int WP>
+__global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
+  constexpr int VE = Elem<T>::VE;
+  constexpr int BK = 8 * VE;  // one 128-byte LDS row of K
+  constexpr int TC = BC / WC, TP = BP / WP;
+  constexpr int MC = TC / 16, MP = TP / 16;
+  constexpr int NVW = BC * 8, NVX = BP * 8;
+  constexpr int LW = (NVW + 255) / 256, LX = (NVX + 255) / 256;
+  constexpr int TILE_BYTES = (BC + BP) * 128;
+  static_assert(WC * WP == 4, "4 waves per workgroup");
+  static_assert(TC % 16 == 0 && TP % 16 == 0, "wave tile must be a multiple of the 16x16 MFMA block");
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int sid = xcd_remap(blockIdx.x, gridDim.x);
+  const int tiles = p.tiles_c * p.tiles_p;
+  const int z = sid / tiles;
+  const int rem = sid - z * tiles;
+  const int tp = rem / p.tiles_c, tc = rem - tp * p.tiles_c;
+  const int c_base = tc * BC, p_base = tp * BP;
+  const int it_begin = (int)((long long)p.iters * z / p.splitk);
+  const int it_end = (int)((long long)p.iters * (z + 1) / p.splitk);
+
+  const T* __restrict__ xg = (const T*)p.x;
+  const T* __restrict__ wg = (const T*)p.w;
+
+  // ---- per-thread load descriptors (fixed for the whole K loop) ----
+  size_t w_off[LW];
+  bool w_ok[LW];
+  int w_lds[LW];
+#pragma unroll
+  for (int i = 0; i < LW; ++i) {
+    const int v = tid + i * 256, row = v >> 3, slot = v & 7;
+    const int c = c_base + row;
+    w_ok[i] = (v < NVW) && (c < p.Cout);
+    w_off[i] = (size_t)(w_ok[i] ? c : 0) * p.K + slot * VE;
+    w_lds[i] = row * 128 + ((slot ^ ((row >> 1) & 7)) << 4);
+  }
+  int x_nb[LX], x_h0[LX], x_w0[LX], x_lds[LX];
+  bool x_ok[LX];
+  const int HoWo = p.Ho * p.Wo;
+#pragma unroll
+  for (int i = 0; i < LX; ++i) {
+    const int v = tid + i * 256, row = v >> 3, slot = v & 7;
+    const int pix = p_base + row;
+    x_ok[i] = (v < NVX) && (pix < p.M);
+    const int pp = x_ok[i] ? pix : 0;
+    const int n = pp / HoWo, r = pp - n * HoWo;
+    const int ho = r / p.Wo, wo = r - ho * p.Wo;
+    x_nb[i] = n * p.H * p.W;
+    x_h0[i] = ho * p.stride - p.pad;
+    x_w0[i] = wo * p.stride - p.pad;
+    x_lds[i] = BC * 128 + row * 128 + ((slot ^ ((row >> 1) & 7)) << 4);
+  }
+  const int kslot = (tid & 7) * VE;  // this thread's channel offset inside a K tile (same for W and X vectors)
+
+  uint4 wreg[LW], xreg[LX];
+  const uint4 zero4 = make_uint4(0, 0, 0, 0);
+
+  auto gload = [&](int it) {
+    const int ti = it / p.cpt;
+    const int c0 = (it - ti * p.cpt) * BK;
+    const int tap = (int)((p.taps >> (4 * ti)) & 15ull);
+    const int kh = tap / p.KW, kw = tap - kh * p.KW;
+    const bool c_ok = (c0 + kslot) < p.Cin;
+    const int koff = tap * p.Cin + c0;
+#pragma unroll
+    for (int i = 0; i < LW; ++i) {
+      const bool ok = w_ok[i] && c_ok;
+      const T* ptr = ok ? (wg + w_off[i] + koff) : wg;  // clamped address, unconditional load
+      uint4 v = *(const uint4*)ptr;
+      wreg[i] = ok ? v : zero4;
+    }
+#pragma unroll
+    for (int i = 0; i < LX; ++i) {
+      const int hi = x_h0[i] + kh * p.dil, wi = x_w0[i] + kw * p.dil;
+      const bool ok = x_ok[i] && c_ok && ((unsigned)hi < (unsigned)p.H) && ((unsigned)wi < (unsigned)p.W);
+      const T* ptr = ok ? (xg + (size_t)(x_nb[i] + hi * p.W + wi) * p.ldx + c0 + kslot) : xg;
+      uint4 v = *(const uint4*)ptr;
+      xreg[i] = ok ? v : zero4;
+    }
+  };
+  auto lstore = [&](int buf) {
+    char* base = smem + buf * TILE_BYTES;
+#pragma unroll
+    for (int i = 0; i < LW; ++i)
+      if (tid + i * 256 < NVW) *(uint4*)(base + w_lds[i]) = wreg[i];
+#pragma unroll
+    for (int i = 0; i < LX; ++i)
+      if (tid + i * 256 < NVX) *(uint4*)(base + x_lds[i]) = xreg[i];
+  };
+
+  const int wc0 = (wave % WC) * TC, wp0 = (wave / WC) * TP;
+  const int lrow = lane & 15, lgrp = lane >> 4;
+
+  f32x4_t acc[MC][MP];
+#pragma unroll
+  for (int a = 0; a < MC; ++a)
+#pragma unroll
+    for (int b = 0; b < MP; ++b) acc[a][b] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+  auto compute = [&](int buf) {
+    const char* wb = smem + buf * TILE_BYTES;
+    const char* xb = wb + BC * 128;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      uint4 af[MC], bfv[MP];
+      const int s = j * 4 + lgrp;
+#pragma unroll
+      for (int a = 0; a < MC; ++a) {
+        const int r = wc0 + a * 16 + lrow;
+        af[a] = *(const uint4*)(wb + r * 128 + ((s ^ ((r >> 1) & 7)) << 4));
+      }
+#pragma unroll
+      for (int b = 0; b < MP; ++b) {
+        const int r = wp0 + b * 16 + lrow;
+        bfv[b] = *(const uint4*)(xb + r * 128 + ((s ^ ((r >> 1) & 7)) << 4));
+      }
+#pragma unroll
+      for (int a = 0; a < MC; ++a)
+#pragma unroll
+        for (int b = 0; b < MP; ++b) Mma<T>::run(acc[a][b], af[a], bfv[b]);
+    }
+  };
+
+  if (it_begin < it_end) {
+    gload(it_begin);
+    lstore(0);
+    __syncthreads();
+    int buf = 0;
+    for (int it = it_begin; it < it_end; ++it) {
+      const bool more = (it + 1) < it_end;
+      if (more) gload(it + 1);
+      compute(buf);
+      if (more) lstore(buf ^ 1);
+      __syncthreads();
+      buf ^= 1;
+    }
+  }
+
+  // ---- epilogue ----
+#pragma unroll
+  for (int a = 0; a < MC; ++a) {
+#pragma unroll
+    for (int b = 0; b < MP; ++b) {
+      const int c = c_base + wc0 + a * 16 + lgrp * 4;
+      const int pix = p_base + wp0 + b * 16 + lrow;
+      if (pix >= p.M) continue;
+      const f32x4_t v = acc[a][b];
+      if (p.splitk > 1) {
+        float* dst = p.partial + ((size_t)z * p.M + pix) * p.Cout + c;
+        if ((p.Cout & 3) == 0) {
+          if (c < p.Cout) *(float4*)dst = make_float4(v[0], v[1], v[2], v[3]);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (c + e < p.Cout) dst[e] = v[e];
+        }
+      } else {
+        epilogue_store4<T>(p, v[0], v[1], v[2], v[3], pix, c);
+      }
+    }
+  }
+}
+
+// Reduce split-K slabs (deterministic order) and apply the epilogue.  One thread per 4 consecutive channels.
+template <typename T>
+__global__ __launch_bounds__(256) void splitk_epilogue_kernel(const IgemmParams p) {
+  const int cq = (p.Cout + 3) >> 2;
+  const long long total = (long long)p.M * cq;
+  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int pix = (int)(i / cq);
+    const int c = (int)(i - (long long)pix * cq) * 4;
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int z = 0; z < p.splitk; ++z) {
+      const float* src = p.partial + ((size_t)z * p.M + pix) * p.Cout + c;
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (c + e < p.Cout) v[e] += src[e];
+    }
+    epilogue_store4<T>(p, v[0], v[1], v[2], v[3], pix, c);
+  }
+}
+
+// --------------------------------------------------------------------------------------------------------------
+// host side
+// --------------------------------------------------------------------------------------------------------------
+namespace {
+
+struct TileCfg {
+  int id, BC, BP;
+  float eff;  // relative per-WG efficiency (bigger tiles reuse LDS operands more)
+};
+const TileCfg kTiles[] = {
+    {1, 128, 128, 1.00f}, {2, 64, 128, 0.85f}, {3, 64, 64, 0.70f}, {4, 128, 64, 0.85f},
+    {5, 128, 32, 0.55f},  {6, 16, 128, 0.35f}, {7, 32, 128, 0.60f},
+};
+constexpr int kNumTiles = sizeof(kTiles) / sizeof(kTiles[0]);
+
+template <typename T, int BC, int BP, int WC, int WP>
+hipError_t launch_cfg(const IgemmParams& p, int nblk, hipStream_t s) {
+  constexpr int lds = 2 * (BC + BP) * 128;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)igemm_kernel<T, BC, BP, WC, WP>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              lds);
+    attr_set = true;
+  }
+  igemm_kernel<T, BC, BP, WC, WP><<<dim3(nblk), dim3(256), lds, s>>>(p);
+  return hipGetLastError();
+}
+
+template <typename T>
+hipError_t launch_tile(int id, const IgemmParams& p, int nblk, hipStream_t s) {
+  switch (id) {
+    case 1: return launch_cfg<T, 128, 128, 2, 2>(p, nblk, s);
+    case 2: return launch_cfg<T, 64, 128, 2, 2>(p, nblk, s);
+    case 3: return launch_cfg<T, 64, 64, 2, 2>(p, nblk, s);
+    case 4: return launch_cfg<T, 128, 64, 2, 2>(p, nblk, s);
+    case 5: return launch_cfg<T, 128, 32, 4, 1>(p, nblk, s);
+    case 6: return launch_cfg<T, 16, 128, 1, 4>(p, nblk, s);
+    case 7: return launch_cfg<T, 32, 128, 1, 4>(p, nblk, s);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+struct Plan {
+  IgemmParams p;
+  int tile_id;
+  int nblk;
+  size_t ws_bytes;
+  int status;
+};
+
+inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+Plan make_plan(const cavp_conv_desc* d) {
+  Plan pl{};
+  pl.status = CAVP_OK;
+  if (!d) { pl.status = CAVP_ERR_BAD_ARG; return pl; }
+  if (d->N <= 0 || d->H <= 0 || d->W <= 0 || d->Cin <= 0 || d->Cout <= 0 || d->KH <= 0 || d->KW <= 0 ||
+      d->stride <= 0 || d->dil <= 0 || d->pad < 0 || d->ldx < d->Cin || d->ldy < d->Cout) {
+    pl.status = CAVP_ERR_BAD_ARG;
+    return pl;
+  }
+  if (d->dtype != CAVP_F32 && d->dtype != CAVP_BF16) { pl.status = CAVP_ERR_UNSUPPORTED; return pl; }
+  const int VE = d->dtype == CAVP_F32 ? 4 : 8;
+  if (d->Cin % VE || d->ldx % VE) { pl.status = CAVP_ERR_UNSUPPORTED; return pl; }
+  if (d->KH * d->KW > 9) { pl.status = CAVP_ERR_UNSUPPORTED; return pl; }
+  IgemmParams& p = pl.p;
+  p.N = d->N; p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.ldx = d->ldx; p.Cout = d->Cout; p.ldy = d->ldy;
+  p.KW = d->KW; p.stride = d->stride; p.pad = d->pad; p.dil = d->dil; p.ldr = d->ldr; p.act = d->act;
+  p.Ho = (d->H + 2 * d->pad - d->dil * (d->KH - 1) - 1) / d->stride + 1;
+  p.Wo = (d->W + 2 * d->pad - d->dil * (d->KW - 1) - 1) / d->stride + 1;
+  if (p.Ho <= 0 || p.Wo <= 0) { pl.status = CAVP_ERR_BAD_ARG; return pl; }
+  const long long M = (long long)d->N * p.Ho * p.Wo;
+  if (M > 0x7fffffffll / 4) { pl.status = CAVP_ERR_UNSUPPORTED; return pl; }
+  p.M = (int)M;
+  p.K = d->KH * d->KW * d->Cin;
+  // live taps: tap (kh,kw) is live iff some output row/col maps it inside the image
+  p.ntaps = 0;
+  p.taps = 0;
+  for (int kh = 0; kh < d->KH; ++kh) {
+    bool hlive = false;
+    for (int ho = 0; ho < p.Ho && !hlive; ++ho) {
+      const int hi = ho * d->stride - d->pad + kh * d->dil;
+      hlive = hi >= 0 && hi < d->H;
+    }
+    for (int kw = 0; kw < d->KW; ++kw) {
+      bool wlive = false;
+      for (int wo = 0; wo < p.Wo && !wlive; ++wo) {
+        const int wi = wo * d->stride - d->pad + kw * d->dil;
+        wlive = wi >= 0 && wi < d->W;
+      }
+      if (hlive && wlive) {
+        p.taps |= (unsigned long long)(kh * d->KW + kw) << (4 * p.ntaps);
+        ++p.ntaps;
+      }
+    }
+  }
+  const int BK = 8 * VE;
+  p.cpt = cdiv(d->Cin, BK);
+  p.iters = p.ntaps * p.cpt;
+  // ---- tile choice ----
+  int best = -1;
+  if (d->tile > 0) {
+    for (int i = 0; i < kNumTiles; ++i)
+      if (kTiles[i].id == d->tile) best = i;
+    if (best < 0) { pl.status = CAVP_ERR_BAD_ARG; return pl; }
+  } else {
+    double best_score = -1.0;
+    for (int i = 0; i < kNumTiles; ++i) {
+      const TileCfg& t = kTiles[i];
+      const long long nwg = (long long)cdiv(p.Cout, t.BC) * cdiv(p.M, t.BP);
+      const double useful = ((double)p.Cout * p.M) / ((double)nwg * t.BC * t.BP);
+      // 256 CUs x 2 resident workgroups; the last partial "wave" of workgroups is the quantisation loss
+      const double slots = 512.0;
+      const double rounds = (double)((nwg + 511) / 512);
+      const double fill = (double)nwg / (rounds * slots);
+      const double score = useful * t.eff * (0.25 + 0.75 * fill);
+      if (score > best_score) { best_score = score; best = i; }
+    }
+  }
+  const TileCfg& t = kTiles[best];
+  pl.tile_id = t.id;
+  p.tiles_c = cdiv(p.Cout, t.BC);
+  p.tiles_p = cdiv(p.M, t.BP);
+  const int nwg = p.tiles_c * p.tiles_p;
+  int sk = d->splitk;
+  if (sk <= 0) {
+    sk = 1;
+    if (nwg < 256 && p.iters >= 16) {
+      sk = cdiv(512, nwg);
+      if (sk > p.iters / 8) sk = p.iters / 8;
+      if (sk > 32) sk = 32;
+      if (sk < 1) sk = 1;
+    }
+  }
+  if (sk > p.iters) sk = p.iters > 0 ? p.iters : 1;
+  p.splitk = sk;
+  pl.nblk = nwg * sk;
+  pl.ws_bytes = sk > 1 ? (size_t)sk * p.M * p.Cout * sizeof(float) : 0;
+  return pl;
+}
+
+inline bool aligned(const void* ptr, size_t a) { return ((uintptr_t)ptr % a) == 0; }
+
+}  // namespace
+
+extern "C" size_t cavp_conv2d_workspace_bytes(const cavp_conv_desc* d) {
+  Plan pl = make_plan(d);
+  return pl.status == CAVP_OK ? pl.ws_bytes : 0;
+}
+
+extern "C" int cavp_conv2d_nhwc(const cavp_conv_desc* d, const void* x, const void* w, const float* scale,
+                                const float* shift, const float* nbias, const void* residual, void* y, void* workspace,
+                                size_t workspace_bytes, void* stream) {
+  if (!d || !x || !w || !y) return CAVP_ERR_BAD_ARG;
+  Plan pl = make_plan(d);
+  if (pl.status != CAVP_OK) return pl.status;
+  if (!aligned(x, 16) || !aligned(w, 16)) return CAVP_ERR_ALIGN;
+  if (residual && d->ldr < d->Cout) return CAVP_ERR_BAD_ARG;
+  if (pl.ws_bytes > 0 && (!workspace || workspace_bytes < pl.ws_bytes || !aligned(workspace, 16)))
+    return CAVP_ERR_WORKSPACE;
+  IgemmParams& p = pl.p;
+  p.x = x; p.w = w; p.y = y; p.scale = scale; p.shift = shift; p.nbias = nbias; p.res = residual;
+  p.partial = (float*)workspace;
+  const size_t es = d->dtype == CAVP_F32 ? 4 : 2;
+  p.vec_io = (d->Cout % 4 == 0) && (d->ldy % 4 == 0) && aligned(y, 4 * es) &&
+             (!residual || (d->ldr % 4 == 0 && aligned(residual, 4 * es))) && (!scale || aligned(scale, 16)) &&
+             (!shift || aligned(shift, 16)) && (!nbias || aligned(nbias, 16));
+  hipStream_t s = (hipStream_t)stream;
+  hipError_t e = d->dtype == CAVP_F32 ? launch_tile<float>(pl.tile_id, p, pl.nblk, s)
+                                      : launch_tile<bf16_t>(pl.tile_id, p, pl.nblk, s);
+  if (e != hipSuccess) return CAVP_ERR_LAUNCH;
+  if (p.splitk > 1) {
+    const long long total = (long long)p.M * ((p.Cout + 3) / 4);
+    int nb = (int)((total + 255) / 256);
+    if (nb > 4096) nb = 4096;
+    if (d->dtype == CAVP_F32)
+      splitk_epilogue_kernel<float><<<dim3(nb), dim3(256), 0, s>>>(p);
+    else
+      splitk_epilogue_kernel<bf16_t><<<dim3(nb), dim3(256), 0, s>>>(p);
+    if (hipGetLastError() != hipSuccess) return CAVP_ERR_LAUNCH;
+  }
+  return CAVP_OK;
+}

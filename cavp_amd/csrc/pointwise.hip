@@ -1,0 +1,485 @@
+// Bandwidth-bound kernels of the CAVP forward path for gfx950: small-Cin direct conv, pooling, bilinear resize,
+// LayerNorm, the sigmoid attention gate, BN folding and weight packing.  All NHWC, 16-byte vector accesses along
+// the channel dimension, wave64 shuffles for the row reductions.
+#include "common.h"
+
+namespace {
+
+inline int nblocks(long long total, int per_block, int cap = 1 << 20) {
+  long long nb = (total + per_block - 1) / per_block;
+  if (nb < 1) nb = 1;
+  if (nb > cap) nb = cap;
+  return (int)nb;
+}
+
+// load / store VE consecutive channels as floats
+template <typename T> struct Vec;
+template <> struct Vec<float> {
+  static constexpr int VE = 4;
+  __device__ static __forceinline__ void load(const float* p, float* v) {
+    const float4 t = *(const float4*)p;
+    v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+  }
+  __device__ static __forceinline__ void store(float* p, const float* v) { *(float4*)p = make_float4(v[0], v[1], v[2], v[3]); }
+};
+template <> struct Vec<bf16_t> {
+  static constexpr int VE = 8;
+  __device__ static __forceinline__ void load(const bf16_t* p, float* v) {
+    const uint4 t = *(const uint4*)p;
+    const unsigned u[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      v[2 * i] = __uint_as_float(u[i] << 16);
+      v[2 * i + 1] = __uint_as_float(u[i] & 0xffff0000u);
+    }
+  }
+  __device__ static __forceinline__ void store(bf16_t* p, const float* v) {
+    uint4 t;
+    t.x = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16);
+    t.y = (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
+    t.z = (unsigned)f2bf(v[4]) | ((unsigned)f2bf(v[5]) << 16);
+    t.w = (unsigned)f2bf(v[6]) | ((unsigned)f2bf(v[7]) << 16);
+    *(uint4*)p = t;
+  }
+};
+
+// ------------------------------------------------------------------------------------------------------------
+// direct 3x3 conv, Cin <= 3, pad 1, NCHW f32 in -> NHWC out.  thread = (pixel, group of 16 output channels)
+// ------------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void conv3x3_smallcin_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                               const float* __restrict__ scale,
+                                                               const float* __restrict__ shift, T* __restrict__ y, int N,
+                                                               int Cin, int H, int W, int Cout, int stride, int Ho,
+                                                               int Wo, int act) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float* ws = (float*)smem_raw;  // [Cin*9][Cout]
+  const int K = Cin * 9;
+  for (int i = threadIdx.x; i < K * Cout; i += 256) {
+    const int co = i / K, k = i - co * K;  // w is [Cout][Cin][3][3] -> k = ci*9 + kh*3 + kw
+    ws[k * Cout + co] = w[i];
+  }
+  __syncthreads();
+  const int G = Cout >> 4;
+  const long long total = (long long)N * Ho * Wo * G;
+  for (long long idx = blockIdx.x * 256ll + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+    const int g = (int)(idx % G);
+    const long long pix = idx / G;
+    const int wo = (int)(pix % Wo);
+    const int ho = (int)((pix / Wo) % Ho);
+    const int n = (int)(pix / ((long long)Wo * Ho));
+    float acc[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[j] = 0.f;
+    for (int ci = 0; ci < Cin; ++ci) {
+      const float* xp = x + ((size_t)n * Cin + ci) * H * W;
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh) {
+        const int hi = ho * stride - 1 + kh;
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+          const int wi = wo * stride - 1 + kw;
+          const bool ok = (unsigned)hi < (unsigned)H && (unsigned)wi < (unsigned)W;
+          const float xv = ok ? xp[(size_t)hi * W + wi] : 0.f;
+          const float* wk = ws + (ci * 9 + kh * 3 + kw) * Cout + g * 16;
+#pragma unroll
+          for (int j = 0; j < 16; ++j) acc[j] = fmaf(xv, wk[j], acc[j]);
+        }
+      }
+    }
+    T* yp = y + (size_t)pix * Cout + g * 16;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const int c = g * 16 + j;
+      float v = acc[j];
+      if (scale) v *= scale[c];
+      if (shift) v += shift[c];
+      acc[j] = apply_act(v, act);
+    }
+#pragma unroll
+    for (int j = 0; j < 16; j += Vec<T>::VE) Vec<T>::store(yp + j, acc + j);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// max pool NHWC.  thread = (output pixel, 16-byte channel vector)
+// ------------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_kernel(const T* __restrict__ x, T* __restrict__ y, int N, int H, int W,
+                                                      int C, int k, int stride, int pad, int Ho, int Wo) {
+  constexpr int VE = Vec<T>::VE;
+  const int CV = C / VE;
+  const long long total = (long long)N * Ho * Wo * CV;
+  for (long long idx = blockIdx.x * 256ll + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+    const int cv = (int)(idx % CV);
+    const long long pix = idx / CV;
+    const int wo = (int)(pix % Wo);
+    const int ho = (int)((pix / Wo) % Ho);
+    const int n = (int)(pix / ((long long)Wo * Ho));
+    float m[VE];
+#pragma unroll
+    for (int j = 0; j < VE; ++j) m[j] = -INFINITY;
+    for (int kh = 0; kh < k; ++kh) {
+      const int hi = ho * stride - pad + kh;
+      if ((unsigned)hi >= (unsigned)H) continue;
+      for (int kw = 0; kw < k; ++kw) {
+        const int wi = wo * stride - pad + kw;
+        if ((unsigned)wi >= (unsigned)W) continue;
+        float v[VE];
+        Vec<T>::load(x + ((size_t)(n * H + hi) * W + wi) * C + cv * VE, v);
+#pragma unroll
+        for (int j = 0; j < VE; ++j) m[j] = fmaxf(m[j], v[j]);
+      }
+    }
+    Vec<T>::store(y + (size_t)pix * C + cv * VE, m);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// global average pool: block = (image n, 64-channel chunk); 4 waves split the pixels, lane = channel
+// ------------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void gap_kernel(const T* __restrict__ x, float* __restrict__ y, int HW, int C,
+                                                  int ldx) {
+  __shared__ float part[4][64];
+  const int n = blockIdx.y, c = blockIdx.x * 64 + (threadIdx.x & 63), wv = threadIdx.x >> 6;
+  float s = 0.f;
+  if (c < C) {
+    const T* xp = x + (size_t)n * HW * ldx + c;
+    for (int i = wv; i < HW; i += 4) s += Elem<T>::ld(xp + (size_t)i * ldx);
+  }
+  part[wv][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (wv == 0 && c < C) {
+    const int l = threadIdx.x;
+    y[(size_t)n * C + c] = (part[0][l] + part[1][l] + part[2][l] + part[3][l]) / (float)HW;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// bilinear resize (PyTorch area_pixel_compute_source_index semantics, f32 index math)
+// ------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void src_index(int dst, int in, int out, int align, int& i0, int& i1, float& lam) {
+  float src;
+  if (align) {
+    const float sc = out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.f;
+    src = sc * (float)dst;
+  } else {
+    const float sc = (float)in / (float)out;
+    src = sc * ((float)dst + 0.5f) - 0.5f;
+    if (src < 0.f) src = 0.f;
+  }
+  i0 = (int)src;
+  if (i0 > in - 1) i0 = in - 1;
+  i1 = i0 + (i0 < in - 1 ? 1 : 0);
+  lam = src - (float)i0;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bilinear_nhwc_kernel(const T* __restrict__ x, T* __restrict__ y, int N, int Hi,
+                                                            int Wi, int C, int ldx, int Ho, int Wo, int ldy, int align) {
+  constexpr int VE = Vec<T>::VE;
+  const int CV = C / VE;
+  const long long total = (long long)N * Ho * Wo * CV;
+  for (long long idx = blockIdx.x * 256ll + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+    const int cv = (int)(idx % CV);
+    const long long pix = idx / CV;
+    const int wo = (int)(pix % Wo);
+    const int ho = (int)((pix / Wo) % Ho);
+    const int n = (int)(pix / ((long long)Wo * Ho));
+    int h0, h1, w0, w1;
+    float lh, lw;
+    src_index(ho, Hi, Ho, align, h0, h1, lh);
+    src_index(wo, Wi, Wo, align, w0, w1, lw);
+    const T* base = x + (size_t)n * Hi * Wi * ldx + cv * VE;
+    float a[VE], b[VE], c[VE], d[VE], o[VE];
+    Vec<T>::load(base + ((size_t)h0 * Wi + w0) * ldx, a);
+    Vec<T>::load(base + ((size_t)h0 * Wi + w1) * ldx, b);
+    Vec<T>::load(base + ((size_t)h1 * Wi + w0) * ldx, c);
+    Vec<T>::load(base + ((size_t)h1 * Wi + w1) * ldx, d);
+    const float w00 = (1.f - lh) * (1.f - lw), w01 = (1.f - lh) * lw, w10 = lh * (1.f - lw), w11 = lh * lw;
+#pragma unroll
+    for (int j = 0; j < VE; ++j) o[j] = w00 * a[j] + w01 * b[j] + w10 * c[j] + w11 * d[j];
+    Vec<T>::store(y + (size_t)pix * ldy + cv * VE, o);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bilinear_to_nchw_kernel(const T* __restrict__ x, float* __restrict__ y, int N,
+                                                               int Hi, int Wi, int C, int ldx, int Ho, int Wo,
+                                                               int align) {
+  const long long total = (long long)N * Ho * Wo;
+  for (long long pix = blockIdx.x * 256ll + threadIdx.x; pix < total; pix += (long long)gridDim.x * 256) {
+    const int wo = (int)(pix % Wo);
+    const int ho = (int)((pix / Wo) % Ho);
+    const int n = (int)(pix / ((long long)Wo * Ho));
+    int h0, h1, w0, w1;
+    float lh, lw;
+    src_index(ho, Hi, Ho, align, h0, h1, lh);
+    src_index(wo, Wi, Wo, align, w0, w1, lw);
+    const T* base = x + (size_t)n * Hi * Wi * ldx;
+    const T* pa = base + ((size_t)h0 * Wi + w0) * ldx;
+    const T* pb = base + ((size_t)h0 * Wi + w1) * ldx;
+    const T* pc = base + ((size_t)h1 * Wi + w0) * ldx;
+    const T* pd = base + ((size_t)h1 * Wi + w1) * ldx;
+    const float w00 = (1.f - lh) * (1.f - lw), w01 = (1.f - lh) * lw, w10 = lh * (1.f - lw), w11 = lh * lw;
+    float* yp = y + (size_t)n * C * Ho * Wo + (size_t)ho * Wo + wo;
+    for (int c = 0; c < C; ++c) {
+      const float v = w00 * Elem<T>::ld(pa + c) + w01 * Elem<T>::ld(pb + c) + w10 * Elem<T>::ld(pc + c) +
+                      w11 * Elem<T>::ld(pd + c);
+      yp[(size_t)c * Ho * Wo] = v;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// LayerNorm: one wave per row, two-pass statistics (mean, then centred variance) with wave shuffles
+// ------------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, T* __restrict__ y, int rows,
+                                                        int C, int ldx, int ldy, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int wpb = 4;
+  for (long long row = blockIdx.x * (long long)wpb + (threadIdx.x >> 6); row < rows; row += (long long)gridDim.x * wpb) {
+    const T* xp = x + (size_t)row * ldx;
+    float s = 0.f;
+    for (int c = lane; c < C; c += 64) s += Elem<T>::ld(xp + c);
+    const float mean = wave_sum(s) / (float)C;
+    float q = 0.f;
+    for (int c = lane; c < C; c += 64) {
+      const float d = Elem<T>::ld(xp + c) - mean;
+      q += d * d;
+    }
+    const float rstd = rsqrtf(wave_sum(q) / (float)C + eps);
+    T* yp = y + (size_t)row * ldy;
+    for (int c = lane; c < C; c += 64) {
+      const float v = (Elem<T>::ld(xp + c) - mean) * rstd * gamma[c] + beta[c];
+      Elem<T>::st(yp + c, v);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// sigmoid attention gate with a single key/value token: one wave per (b, t)
+// ------------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void attn_gate_kernel(const T* __restrict__ q, const T* __restrict__ k,
+                                                        const T* __restrict__ v, T* __restrict__ o,
+                                                        float* __restrict__ attn, int B, int Tn, int heads, int hd,
+                                                        float scale) {
+  const int lane = threadIdx.x & 63;
+  const int C = heads * hd;
+  const long long rows = (long long)B * Tn;
+  for (long long row = blockIdx.x * 4ll + (threadIdx.x >> 6); row < rows; row += (long long)gridDim.x * 4) {
+    const int b = (int)(row / Tn), t = (int)(row - (long long)b * Tn);
+    const T* qp = q + (size_t)row * C;
+    const T* kp = k + (size_t)b * C;
+    const T* vp = v + (size_t)b * C;
+    T* op = o + (size_t)row * C;
+    for (int h = 0; h < heads; ++h) {
+      float s = 0.f;
+      for (int d = lane; d < hd; d += 64) s += Elem<T>::ld(qp + h * hd + d) * Elem<T>::ld(kp + h * hd + d);
+      s = wave_sum(s) * scale;
+      const float g = 1.f / (1.f + expf(-s));
+      if (lane == 0) attn[((size_t)b * heads + h) * Tn + t] = g;
+      for (int d = lane; d < hd; d += 64) Elem<T>::st(op + h * hd + d, g * Elem<T>::ld(vp + h * hd + d));
+    }
+  }
+}
+
+__global__ void bn_fold_kernel(const float* gamma, const float* beta, const float* mean, const float* var, float eps,
+                               float* scale, float* shift, int C) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c < C) {
+    const float s = gamma[c] / sqrtf(var[c] + eps);
+    scale[c] = s;
+    shift[c] = beta[c] - mean[c] * s;
+  }
+}
+
+template <typename T>
+__global__ void pack_ohwi_kernel(const float* __restrict__ w, T* __restrict__ o, int Cout, int Cin, int KHW) {
+  const long long total = (long long)Cout * Cin * KHW;
+  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    // destination index i = (co*KHW + t)*Cin + ci ; source = (co*Cin + ci)*KHW + t
+    const int ci = (int)(i % Cin);
+    const long long r = i / Cin;
+    const int t = (int)(r % KHW);
+    const long long co = r / KHW;
+    Elem<T>::st(o + i, w[(co * Cin + ci) * KHW + t]);
+  }
+}
+
+template <typename S, typename D>
+__global__ void cast_kernel(const S* __restrict__ s, D* __restrict__ d, long long n) {
+  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
+    Elem<D>::st(d + i, Elem<S>::ld(s + i));
+}
+
+inline bool al16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+inline bool dtype_ok(int dt) { return dt == CAVP_F32 || dt == CAVP_BF16; }
+#define CHECK_LAUNCH() return hipGetLastError() == hipSuccess ? CAVP_OK : CAVP_ERR_LAUNCH
+
+}  // namespace
+
+extern "C" int cavp_abi_version(void) { return CAVP_ABI_VERSION; }
+
+extern "C" const char* cavp_error_string(int s) {
+  switch (s) {
+    case CAVP_OK: return "ok";
+    case CAVP_ERR_BAD_ARG: return "bad argument";
+    case CAVP_ERR_UNSUPPORTED: return "unsupported shape/dtype";
+    case CAVP_ERR_ALIGN: return "misaligned pointer or leading dimension";
+    case CAVP_ERR_WORKSPACE: return "workspace missing or too small";
+    case CAVP_ERR_LAUNCH: return "kernel launch failed";
+    default: return "unknown status";
+  }
+}
+
+extern "C" int cavp_conv3x3_smallcin_nchw(int32_t dtype, const float* x, const float* w, const float* scale,
+                                          const float* shift, void* y, int32_t N, int32_t Cin, int32_t H, int32_t W,
+                                          int32_t Cout, int32_t stride, int32_t act, void* stream) {
+  if (!x || !w || !y || N <= 0 || H <= 0 || W <= 0 || stride <= 0) return CAVP_ERR_BAD_ARG;
+  if (!dtype_ok(dtype) || Cin < 1 || Cin > 3 || Cout % 16 || Cout > 128) return CAVP_ERR_UNSUPPORTED;
+  if (!al16(y)) return CAVP_ERR_ALIGN;
+  const int Ho = (H + 2 - 3) / stride + 1, Wo = (W + 2 - 3) / stride + 1;
+  const long long total = (long long)N * Ho * Wo * (Cout / 16);
+  const int nb = nblocks(total, 256, 8192);
+  const size_t lds = (size_t)Cin * 9 * Cout * sizeof(float);
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == CAVP_F32)
+    conv3x3_smallcin_kernel<float><<<nb, 256, lds, s>>>(x, w, scale, shift, (float*)y, N, Cin, H, W, Cout, stride, Ho, Wo, act);
+  else
+    conv3x3_smallcin_kernel<bf16_t><<<nb, 256, lds, s>>>(x, w, scale, shift, (bf16_t*)y, N, Cin, H, W, Cout, stride, Ho, Wo, act);
+  CHECK_LAUNCH();
+}
+
+extern "C" int cavp_maxpool_nhwc(int32_t dtype, const void* x, void* y, int32_t N, int32_t H, int32_t W, int32_t C,
+                                 int32_t k, int32_t stride, int32_t pad, void* stream) {
+  if (!x || !y || N <= 0 || H <= 0 || W <= 0 || C <= 0 || k <= 0 || stride <= 0 || pad < 0) return CAVP_ERR_BAD_ARG;
+  if (!dtype_ok(dtype)) return CAVP_ERR_UNSUPPORTED;
+  const int VE = dtype == CAVP_F32 ? 4 : 8;
+  if (C % VE) return CAVP_ERR_UNSUPPORTED;
+  if (!al16(x) || !al16(y)) return CAVP_ERR_ALIGN;
+  const int Ho = (H + 2 * pad - k) / stride + 1, Wo = (W + 2 * pad - k) / stride + 1;
+  if (Ho <= 0 || Wo <= 0) return CAVP_ERR_BAD_ARG;
+  const long long total = (long long)N * Ho * Wo * (C / VE);
+  const int nb = nblocks(total, 256, 16384);
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == CAVP_F32)
+    maxpool_kernel<float><<<nb, 256, 0, s>>>((const float*)x, (float*)y, N, H, W, C, k, stride, pad, Ho, Wo);
+  else
+    maxpool_kernel<bf16_t><<<nb, 256, 0, s>>>((const bf16_t*)x, (bf16_t*)y, N, H, W, C, k, stride, pad, Ho, Wo);
+  CHECK_LAUNCH();
+}
+
+extern "C" int cavp_global_avgpool_nhwc(int32_t dtype, const void* x, float* y, int32_t N, int32_t HW, int32_t C,
+                                        int32_t ldx, void* stream) {
+  if (!x || !y || N <= 0 || HW <= 0 || C <= 0 || ldx < C) return CAVP_ERR_BAD_ARG;
+  if (!dtype_ok(dtype)) return CAVP_ERR_UNSUPPORTED;
+  hipStream_t s = (hipStream_t)stream;
+  dim3 grid((C + 63) / 64, N);
+  if (dtype == CAVP_F32)
+    gap_kernel<float><<<grid, 256, 0, s>>>((const float*)x, y, HW, C, ldx);
+  else
+    gap_kernel<bf16_t><<<grid, 256, 0, s>>>((const bf16_t*)x, y, HW, C, ldx);
+  CHECK_LAUNCH();
+}
+
+extern "C" int cavp_bilinear_nhwc(int32_t dtype, const void* x, void* y, int32_t N, int32_t Hi, int32_t Wi, int32_t C,
+                                  int32_t ldx, int32_t Ho, int32_t Wo, int32_t ldy, int32_t align_corners,
+                                  void* stream) {
+  if (!x || !y || N <= 0 || Hi <= 0 || Wi <= 0 || Ho <= 0 || Wo <= 0 || C <= 0 || ldx < C || ldy < C)
+    return CAVP_ERR_BAD_ARG;
+  if (!dtype_ok(dtype)) return CAVP_ERR_UNSUPPORTED;
+  const int VE = dtype == CAVP_F32 ? 4 : 8;
+  if (C % VE || ldx % VE || ldy % VE) return CAVP_ERR_UNSUPPORTED;
+  if (!al16(x) || !al16(y)) return CAVP_ERR_ALIGN;
+  const long long total = (long long)N * Ho * Wo * (C / VE);
+  const int nb = nblocks(total, 256, 16384);
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == CAVP_F32)
+    bilinear_nhwc_kernel<float><<<nb, 256, 0, s>>>((const float*)x, (float*)y, N, Hi, Wi, C, ldx, Ho, Wo, ldy, align_corners);
+  else
+    bilinear_nhwc_kernel<bf16_t><<<nb, 256, 0, s>>>((const bf16_t*)x, (bf16_t*)y, N, Hi, Wi, C, ldx, Ho, Wo, ldy, align_corners);
+  CHECK_LAUNCH();
+}
+
+extern "C" int cavp_bilinear_nhwc_to_nchw(int32_t dtype, const void* x, float* y, int32_t N, int32_t Hi, int32_t Wi,
+                                          int32_t C, int32_t ldx, int32_t Ho, int32_t Wo, int32_t align_corners,
+                                          void* stream) {
+  if (!x || !y || N <= 0 || Hi <= 0 || Wi <= 0 || Ho <= 0 || Wo <= 0 || C <= 0 || ldx < C) return CAVP_ERR_BAD_ARG;
+  if (!dtype_ok(dtype)) return CAVP_ERR_UNSUPPORTED;
+  const long long total = (long long)N * Ho * Wo;
+  const int nb = nblocks(total, 256, 16384);
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == CAVP_F32)
+    bilinear_to_nchw_kernel<float><<<nb, 256, 0, s>>>((const float*)x, y, N, Hi, Wi, C, ldx, Ho, Wo, align_corners);
+  else
+    bilinear_to_nchw_kernel<bf16_t><<<nb, 256, 0, s>>>((const bf16_t*)x, y, N, Hi, Wi, C, ldx, Ho, Wo, align_corners);
+  CHECK_LAUNCH();
+}
+
+extern "C" int cavp_layernorm(int32_t dtype, const void* x, const float* gamma, const float* beta, void* y,
+                              int32_t rows, int32_t C, int32_t ldx, int32_t ldy, float eps, void* stream) {
+  if (!x || !gamma || !beta || !y || rows <= 0 || C <= 0 || ldx < C || ldy < C) return CAVP_ERR_BAD_ARG;
+  if (!dtype_ok(dtype)) return CAVP_ERR_UNSUPPORTED;
+  const int nb = nblocks(rows, 4, 16384);
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == CAVP_F32)
+    layernorm_kernel<float><<<nb, 256, 0, s>>>((const float*)x, gamma, beta, (float*)y, rows, C, ldx, ldy, eps);
+  else
+    layernorm_kernel<bf16_t><<<nb, 256, 0, s>>>((const bf16_t*)x, gamma, beta, (bf16_t*)y, rows, C, ldx, ldy, eps);
+  CHECK_LAUNCH();
+}
+
+extern "C" int cavp_attn_gate(int32_t dtype, const void* q, const void* k, const void* v, void* o, float* attn,
+                              int32_t B, int32_t T, int32_t heads, int32_t hd, float scale, void* stream) {
+  if (!q || !k || !v || !o || !attn || B <= 0 || T <= 0 || heads <= 0 || hd <= 0) return CAVP_ERR_BAD_ARG;
+  if (!dtype_ok(dtype)) return CAVP_ERR_UNSUPPORTED;
+  const int nb = nblocks((long long)B * T, 4, 16384);
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == CAVP_F32)
+    attn_gate_kernel<float><<<nb, 256, 0, s>>>((const float*)q, (const float*)k, (const float*)v, (float*)o, attn, B, T, heads, hd, scale);
+  else
+    attn_gate_kernel<bf16_t><<<nb, 256, 0, s>>>((const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)o, attn, B, T, heads, hd, scale);
+  CHECK_LAUNCH();
+}
+
+extern "C" int cavp_bn_fold(const float* gamma, const float* beta, const float* mean, const float* var, float eps,
+                            float* scale, float* shift, int32_t C, void* stream) {
+  if (!gamma || !beta || !mean || !var || !scale || !shift || C <= 0) return CAVP_ERR_BAD_ARG;
+  bn_fold_kernel<<<(C + 255) / 256, 256, 0, (hipStream_t)stream>>>(gamma, beta, mean, var, eps, scale, shift, C);
+  CHECK_LAUNCH();
+}
+
+extern "C" int cavp_pack_weight_ohwi(int32_t dtype, const float* w, void* o, int32_t Cout, int32_t Cin, int32_t KH,
+                                     int32_t KW, void* stream) {
+  if (!w || !o || Cout <= 0 || Cin <= 0 || KH <= 0 || KW <= 0) return CAVP_ERR_BAD_ARG;
+  if (!dtype_ok(dtype)) return CAVP_ERR_UNSUPPORTED;
+  const long long total = (long long)Cout * Cin * KH * KW;
+  const int nb = nblocks(total, 256, 8192);
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == CAVP_F32)
+    pack_ohwi_kernel<float><<<nb, 256, 0, s>>>(w, (float*)o, Cout, Cin, KH * KW);
+  else
+    pack_ohwi_kernel<bf16_t><<<nb, 256, 0, s>>>(w, (bf16_t*)o, Cout, Cin, KH * KW);
+  CHECK_LAUNCH();
+}
+
+extern "C" int cavp_cast(int32_t sdt, const void* src, int32_t ddt, void* dst, int64_t n, void* stream) {
+  if (!src || !dst || n <= 0) return CAVP_ERR_BAD_ARG;
+  if (!dtype_ok(sdt) || !dtype_ok(ddt)) return CAVP_ERR_UNSUPPORTED;
+  const int nb = nblocks(n, 256, 8192);
+  hipStream_t s = (hipStream_t)stream;
+  if (sdt == CAVP_F32 && ddt == CAVP_BF16)
+    cast_kernel<float, bf16_t><<<nb, 256, 0, s>>>((const float*)src, (bf16_t*)dst, n);
+  else if (sdt == CAVP_BF16 && ddt == CAVP_F32)
+    cast_kernel<bf16_t, float><<<nb, 256, 0, s>>>((const bf16_t*)src, (float*)dst, n);
+  else if (sdt == CAVP_F32)
+    cast_kernel<float, float><<<nb, 256, 0, s>>>((const float*)src, (float*)dst, n);
+  else
+    cast_kernel<bf16_t, bf16_t><<<nb, 256, 0, s>>>((const bf16_t*)src, (bf16_t*)dst, n);
+  CHECK_LAUNCH();
+}

@@ -1,0 +1,273 @@
+"""Thin Python wrappers over the C-ABI (include/cavp_hip.h).  torch is used only for device memory and the current
+HIP stream; every arithmetic operation is a kernel in libcavp_hip.so.
+
+Tensors are NHWC "views": a torch tensor of shape [N, H, W, C] whose strides are (H*W*ld, W*ld, ld, 1) with
+ld >= C — i.e. possibly a channel slice `buf[..., c0:c1]` of a wider buffer (free concat)."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import ACT_GELU, ACT_LEAKY, ACT_NONE, ACT_RELU, BF16, F32, ConvDesc  # noqa: F401
+
+_TORCH_DTYPE = {F32: torch.float32, BF16: torch.bfloat16}
+_CODE = {torch.float32: F32, torch.bfloat16: BF16}
+
+_workspace = {}
+
+
+def torch_dtype(code: int) -> torch.dtype:
+    return _TORCH_DTYPE[code]
+
+
+def dtype_code(t: torch.dtype) -> int:
+    try:
+        return _CODE[t]
+    except KeyError:
+        raise _lib.CavpError(f"unsupported dtype {t}: the HIP path computes in float32 or bfloat16") from None
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _need_gpu(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise _lib.CavpError("libcavp_hip kernels need HIP device tensors; got a CPU tensor (there is no CPU fallback)")
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _nhwc(t: torch.Tensor) -> Tuple[int, int, int, int, int]:
+    """(N, H, W, C, ld) of an NHWC view; validates the stride pattern."""
+    if t.dim() != 4:
+        raise _lib.CavpError(f"expected an NHWC 4-d view, got shape {tuple(t.shape)}")
+    n, h, w, c = t.shape
+    sn, sh, sw, sc = t.stride()
+    # size-1 dims carry arbitrary strides: take ld from the innermost spatial dim that actually strides
+    if w > 1:
+        ld = sw
+    elif h > 1:
+        ld = sh
+    elif n > 1:
+        ld = sn
+    else:
+        ld = c
+    if c > 1 and sc != 1:
+        raise _lib.CavpError("NHWC view must be dense along channels")
+    if (w > 1 and sw != ld) or (h > 1 and sh != w * ld) or (n > 1 and sn != h * w * ld) or ld < c:
+        raise _lib.CavpError(f"not a dense NHWC view: shape {tuple(t.shape)} stride {t.stride()}")
+    return n, h, w, c, ld
+
+
+def workspace(nbytes: int, device) -> Optional[torch.Tensor]:
+    """Grow-only scratch buffer per device (split-K slabs).  Must not grow while a graph is being captured."""
+    if nbytes <= 0:
+        return None
+    key = torch.device(device).index or 0
+    ws = _workspace.get(key)
+    if ws is None or ws.numel() < nbytes:
+        if torch.cuda.is_current_stream_capturing():
+            raise _lib.CavpError("workspace would grow during hipGraph capture; run one eager warm-up pass first")
+        ws = torch.empty(max(nbytes, 64 << 20), dtype=torch.uint8, device=device)
+        _workspace[key] = ws
+    return ws
+
+
+def conv2d(x: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, kh: int = 1, kw: int = 1, stride: int = 1,
+           pad: int = 0, dil: int = 1, scale: Optional[torch.Tensor] = None, shift: Optional[torch.Tensor] = None,
+           nbias: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None, act: int = ACT_NONE,
+           splitk: int = 0, tile: int = 0) -> torch.Tensor:
+    """out = act((conv(x, w) + nbias[n]) * scale + shift + residual); x/out/residual NHWC views, w OHWI packed."""
+    _need_gpu(x, w, out, scale, shift, nbias, residual)
+    lib = _lib.load()
+    n, h, wd, cin, ldx = _nhwc(x)
+    no, ho, wo, cout, ldy = _nhwc(out)
+    dt = dtype_code(x.dtype)
+    if w.dtype != x.dtype or out.dtype != x.dtype:
+        raise _lib.CavpError("conv2d: x, w and out must share one dtype")
+    if w.numel() != cout * kh * kw * cin or not w.is_contiguous():
+        raise _lib.CavpError(f"conv2d: packed weight has {w.numel()} elements, expected {cout}x{kh}x{kw}x{cin}")
+    eho = (h + 2 * pad - dil * (kh - 1) - 1) // stride + 1
+    ewo = (wd + 2 * pad - dil * (kw - 1) - 1) // stride + 1
+    if (no, ho, wo) != (n, eho, ewo):
+        raise _lib.CavpError(f"conv2d: out view is {(no, ho, wo)}, expected {(n, eho, ewo)}")
+    ldr = 0
+    if residual is not None:
+        rn, rh, rw, rc, ldr = _nhwc(residual)
+        if (rn, rh, rw, rc) != (n, eho, ewo, cout) or residual.dtype != x.dtype:
+            raise _lib.CavpError("conv2d: residual must match the output view")
+    for name, v in (("scale", scale), ("shift", shift)):
+        if v is not None and (v.dtype != torch.float32 or v.numel() != cout or not v.is_contiguous()):
+            raise _lib.CavpError(f"conv2d: {name} must be a contiguous f32 [{cout}]")
+    if nbias is not None and (nbias.dtype != torch.float32 or nbias.numel() != n * cout or not nbias.is_contiguous()):
+        raise _lib.CavpError(f"conv2d: nbias must be a contiguous f32 [{n},{cout}]")
+    d = ConvDesc(dtype=dt, N=n, H=h, W=wd, Cin=cin, ldx=ldx, Cout=cout, ldy=ldy, KH=kh, KW=kw, stride=stride, pad=pad,
+                 dil=dil, ldr=ldr, act=act, splitk=splitk, tile=tile)
+    nbytes = lib.cavp_conv2d_workspace_bytes(C.byref(d))
+    ws = workspace(nbytes, x.device)
+    st = lib.cavp_conv2d_nhwc(C.byref(d), _ptr(x), _ptr(w), _ptr(scale), _ptr(shift), _ptr(nbias), _ptr(residual),
+                              _ptr(out), _ptr(ws), C.c_size_t(ws.numel() if ws is not None else 0), C.c_void_p(_stream()))
+    _lib.check(st, f"cavp_conv2d_nhwc N{n} H{h} W{wd} Cin{cin} Cout{cout} k{kh}x{kw} s{stride} p{pad} d{dil}")
+    return out
+
+
+def linear(x: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, bias=None, scale=None, residual=None,
+           nbias=None, act: int = ACT_NONE, splitk: int = 0, tile: int = 0) -> torch.Tensor:
+    """x: [B, T, Cin] (or [B, Cin]) view, out: [B, T, Cout].  Linear = 1x1 conv over N=B, H=1, W=T."""
+    def as4(t):
+        if t is None:
+            return None
+        if t.dim() == 2:
+            return t.unsqueeze(1).unsqueeze(1)
+        if t.dim() == 3:
+            return t.unsqueeze(1)
+        return t
+    conv2d(as4(x), w, as4(out), scale=scale, shift=bias, nbias=nbias, residual=as4(residual), act=act,
+           splitk=splitk, tile=tile)
+    return out
+
+
+def conv3x3_smallcin_nchw(x_nchw: torch.Tensor, w_oihw: torch.Tensor, out: torch.Tensor, *, stride: int, scale=None,
+                          shift=None, act: int = ACT_NONE) -> torch.Tensor:
+    _need_gpu(x_nchw, w_oihw, out, scale, shift)
+    lib = _lib.load()
+    if x_nchw.dtype != torch.float32 or w_oihw.dtype != torch.float32 or not x_nchw.is_contiguous() or not w_oihw.is_contiguous():
+        raise _lib.CavpError("conv3x3_smallcin_nchw: x and w must be contiguous f32 (NCHW / OIHW)")
+    n, cin, h, w = x_nchw.shape
+    cout = w_oihw.shape[0]
+    no, ho, wo, co, ldy = _nhwc(out)
+    if tuple(w_oihw.shape) != (cout, cin, 3, 3) or co != cout or ldy != cout:
+        raise _lib.CavpError("conv3x3_smallcin_nchw: shape mismatch")
+    if (no, ho, wo) != (n, (h - 1) // stride + 1, (w - 1) // stride + 1):
+        raise _lib.CavpError("conv3x3_smallcin_nchw: bad output view")
+    st = lib.cavp_conv3x3_smallcin_nchw(dtype_code(out.dtype), _ptr(x_nchw), _ptr(w_oihw), _ptr(scale), _ptr(shift),
+                                        _ptr(out), n, cin, h, w, cout, stride, act, C.c_void_p(_stream()))
+    _lib.check(st, "cavp_conv3x3_smallcin_nchw")
+    return out
+
+
+def maxpool(x: torch.Tensor, out: torch.Tensor, k: int, stride: int, pad: int) -> torch.Tensor:
+    _need_gpu(x, out)
+    n, h, w, c, ld = _nhwc(x)
+    no, ho, wo, co, ldo = _nhwc(out)
+    if ld != c or ldo != co or co != c or out.dtype != x.dtype:
+        raise _lib.CavpError("maxpool: dense NHWC tensors of one dtype required")
+    if (no, ho, wo) != (n, (h + 2 * pad - k) // stride + 1, (w + 2 * pad - k) // stride + 1):
+        raise _lib.CavpError("maxpool: bad output shape")
+    st = _lib.load().cavp_maxpool_nhwc(dtype_code(x.dtype), _ptr(x), _ptr(out), n, h, w, c, k, stride, pad,
+                                       C.c_void_p(_stream()))
+    _lib.check(st, "cavp_maxpool_nhwc")
+    return out
+
+
+def global_avgpool(x: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
+    _need_gpu(x, out)
+    n, h, w, c, ld = _nhwc(x)
+    if out.dtype != torch.float32 or out.numel() != n * c or not out.is_contiguous():
+        raise _lib.CavpError("global_avgpool: out must be contiguous f32 [N, C]")
+    st = _lib.load().cavp_global_avgpool_nhwc(dtype_code(x.dtype), _ptr(x), _ptr(out), n, h * w, c, ld,
+                                              C.c_void_p(_stream()))
+    _lib.check(st, "cavp_global_avgpool_nhwc")
+    return out
+
+
+def bilinear(x: torch.Tensor, out: torch.Tensor, align_corners: bool) -> torch.Tensor:
+    _need_gpu(x, out)
+    n, hi, wi, c, ldx = _nhwc(x)
+    no, ho, wo, co, ldy = _nhwc(out)
+    if no != n or co != c or out.dtype != x.dtype:
+        raise _lib.CavpError("bilinear: batch / channel / dtype mismatch")
+    st = _lib.load().cavp_bilinear_nhwc(dtype_code(x.dtype), _ptr(x), _ptr(out), n, hi, wi, c, ldx, ho, wo, ldy,
+                                        int(align_corners), C.c_void_p(_stream()))
+    _lib.check(st, "cavp_bilinear_nhwc")
+    return out
+
+
+def bilinear_to_nchw(x: torch.Tensor, out_nchw: torch.Tensor, align_corners: bool) -> torch.Tensor:
+    _need_gpu(x, out_nchw)
+    n, hi, wi, c, ldx = _nhwc(x)
+    if out_nchw.dtype != torch.float32 or not out_nchw.is_contiguous() or out_nchw.shape[:2] != (n, c):
+        raise _lib.CavpError("bilinear_to_nchw: out must be contiguous f32 [N, C, Ho, Wo]")
+    ho, wo = out_nchw.shape[-2:]
+    st = _lib.load().cavp_bilinear_nhwc_to_nchw(dtype_code(x.dtype), _ptr(x), _ptr(out_nchw), n, hi, wi, c, ldx, ho, wo,
+                                                int(align_corners), C.c_void_p(_stream()))
+    _lib.check(st, "cavp_bilinear_nhwc_to_nchw")
+    return out_nchw
+
+
+def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, out: torch.Tensor, eps: float) -> torch.Tensor:
+    """x, out: [..., C] row-dense views (last-dim stride 1, uniform row stride)."""
+    _need_gpu(x, gamma, beta, out)
+    c = x.shape[-1]
+    rows = x.numel() // c
+    x2, o2 = x.reshape(rows, c), out.reshape(rows, c)
+    if x2.data_ptr() != x.data_ptr() or o2.data_ptr() != out.data_ptr() or x2.stride(1) != 1 or o2.stride(1) != 1:
+        raise _lib.CavpError("layernorm: rows must be viewable as [rows, C] without a copy")
+    if gamma.dtype != torch.float32 or beta.dtype != torch.float32 or out.dtype != x.dtype:
+        raise _lib.CavpError("layernorm: gamma/beta f32, out dtype == x dtype")
+    st = _lib.load().cavp_layernorm(dtype_code(x.dtype), _ptr(x2), _ptr(gamma), _ptr(beta), _ptr(o2), rows, c,
+                                    x2.stride(0) if rows > 1 else c, o2.stride(0) if rows > 1 else c,
+                                    C.c_float(eps), C.c_void_p(_stream()))
+    _lib.check(st, "cavp_layernorm")
+    return out
+
+
+def attn_gate(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Tensor, attn: torch.Tensor, heads: int,
+              scale: float) -> torch.Tensor:
+    _need_gpu(q, k, v, out, attn)
+    b, t, c = q.shape
+    for name, ten in (("q", q), ("k", k), ("v", v), ("out", out), ("attn", attn)):
+        if not ten.is_contiguous():
+            raise _lib.CavpError(f"attn_gate: {name} must be contiguous")
+    if k.numel() != b * c or v.numel() != b * c or out.shape != q.shape or attn.numel() != b * heads * t:
+        raise _lib.CavpError("attn_gate: shape mismatch")
+    if attn.dtype != torch.float32 or len({q.dtype, k.dtype, v.dtype, out.dtype}) != 1:
+        raise _lib.CavpError("attn_gate: dtype mismatch")
+    st = _lib.load().cavp_attn_gate(dtype_code(q.dtype), _ptr(q), _ptr(k), _ptr(v), _ptr(out), _ptr(attn), b, t, heads,
+                                    c // heads, C.c_float(scale), C.c_void_p(_stream()))
+    _lib.check(st, "cavp_attn_gate")
+    return out
+
+
+def bn_fold(gamma, beta, mean, var, eps: float, scale: torch.Tensor, shift: torch.Tensor) -> None:
+    _need_gpu(gamma, beta, mean, var, scale, shift)
+    for t in (gamma, beta, mean, var, scale, shift):
+        if t.dtype != torch.float32 or not t.is_contiguous():
+            raise _lib.CavpError("bn_fold: contiguous f32 tensors required")
+    st = _lib.load().cavp_bn_fold(_ptr(gamma), _ptr(beta), _ptr(mean), _ptr(var), C.c_float(eps), _ptr(scale),
+                                  _ptr(shift), gamma.numel(), C.c_void_p(_stream()))
+    _lib.check(st, "cavp_bn_fold")
+
+
+def pack_weight(w: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
+    """torch OIHW (or [out, in]) f32 parameter -> OHWI packed tensor of `dtype` on the same device."""
+    _need_gpu(w)
+    wd = w.detach()
+    if wd.dtype != torch.float32 or not wd.is_contiguous():
+        raise _lib.CavpError("pack_weight: contiguous f32 parameter required")
+    if wd.dim() == 2:
+        cout, cin, kh, kw = wd.shape[0], wd.shape[1], 1, 1
+    else:
+        cout, cin, kh, kw = wd.shape
+    out = torch.empty((cout, kh, kw, cin), dtype=dtype, device=w.device)
+    st = _lib.load().cavp_pack_weight_ohwi(dtype_code(dtype), _ptr(wd), _ptr(out), cout, cin, kh, kw,
+                                           C.c_void_p(_stream()))
+    _lib.check(st, "cavp_pack_weight_ohwi")
+    return out
+
+
+def cast(src: torch.Tensor, dst: torch.Tensor) -> torch.Tensor:
+    _need_gpu(src, dst)
+    if not src.is_contiguous() or not dst.is_contiguous() or src.numel() != dst.numel():
+        raise _lib.CavpError("cast: contiguous tensors of equal size required")
+    st = _lib.load().cavp_cast(dtype_code(src.dtype), _ptr(src), dtype_code(dst.dtype), _ptr(dst), src.numel(),
+                               C.c_void_p(_stream()))
+    _lib.check(st, "cavp_cast")
+    return dst
