@@ -1,0 +1,283 @@
+#!/usr/bin/env python3
+"""bench.py — frames/s of the CAVP hot path on MI355X (driver contract in the task statement).
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path (`CAVP.forward`) over one batch of B=32 synthetic frames
+(224x224 RGB + 96x64 log-mel) per GPU, inputs resident in HBM before the timed region.  Frames shard over the batch
+(SURVEY.md §8e): every rank runs the same per-GPU batch (weak scaling) and the inference path needs no collective;
+`value` = N * B * K / max-over-ranks(elapsed).
+
+Extra objects on the JSON line:
+  roofline     — the dominant kernel (MFMA implicit-GEMM conv/linear): algorithmic FLOPs / bytes of all its launches in
+                 one step ÷ their summed duration, measured live with HIP events on the launching stream.
+  cpu_baseline — the CPU oracle (pure-PyTorch restatement pinned to the reference by tests/golden) timed on this box's
+                 host cores on a bounded sample of the same workload (rank 0, N=1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+import types
+
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+HBM_PEAK_GBS = 8000.0                      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
+MFMA_PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0}   # dense matrix peaks, same guide
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=32, help="frames per GPU per step")
+    ap.add_argument("--dtype", choices=["bf16", "f32"], default="bf16")
+    ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--cpu-sample-batch", type=int, default=8)
+    return ap.parse_args()
+
+
+def model_cfg():
+    # C1' (SURVEY.md §8d): config_avss_binary.py shape — 224x224, OS16, VGGish audio, num_classes=2
+    return dict(C=2, lds=[False, False, False], hw=(224, 224))
+
+
+def build_model(cfg, B, dtype, device):
+    from cavp_amd.cavp_model import CAVP
+    from cavp_amd.synth import synth_state_dict
+    args = types.SimpleNamespace(seg_model="DeepLabV3Plus", last_three_dilation_stride=cfg["lds"], audio_backbone="vgg",
+                                 num_classes=cfg["C"], batch_size=B, local_rank="cpu")
+    m = CAVP(50, None, num_classes=cfg["C"], audio_backbone_pretrain_path=None, visual_backbone=50, args=args)
+    sd = synth_state_dict({k: tuple(v.shape) for k, v in m.state_dict().items()}, seed=1)
+    m.load_state_dict(sd, strict=True)
+    m.eval().to(device).set_compute_dtype(dtype)
+    return m, sd
+
+
+class KernelTimer:
+    """HIP-event timing of every libcavp_hip launch on the launching (current) stream."""
+
+    def __init__(self):
+        self.records = []
+
+    def wrap(self, ops_mod):
+        self._orig = {}
+        for name in ("conv2d", "conv3x3_smallcin_nchw", "maxpool", "global_avgpool", "bilinear", "bilinear_to_nchw",
+                     "layernorm", "attn_gate", "cast"):
+            fn = getattr(ops_mod, name)
+            self._orig[name] = fn
+            setattr(ops_mod, name, self._timed(name, fn))
+        return self
+
+    def unwrap(self, ops_mod):
+        for name, fn in self._orig.items():
+            setattr(ops_mod, name, fn)
+
+    def _timed(self, name, fn):
+        def run(*a, **k):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            r = fn(*a, **k)
+            e1.record()
+            flops = nbytes = 0
+            if name == "conv2d":
+                x, w, out = a[0], a[1], a[2]
+                es = x.element_size()
+                m = out.shape[0] * out.shape[1] * out.shape[2]
+                flops = 2 * m * out.shape[3] * (w.numel() // out.shape[3])
+                nbytes = (x.shape[0] * x.shape[1] * x.shape[2] * x.shape[3] + w.numel() + m * out.shape[3]) * es
+                if k.get("residual") is not None:
+                    nbytes += m * out.shape[3] * es
+            desc = ""
+            if name == "conv2d":
+                desc = (f"x{tuple(a[0].shape)} -> y{tuple(a[2].shape)} k{k.get('kh', 1)} s{k.get('stride', 1)} "
+                        f"d{k.get('dil', 1)}")
+            self.records.append((name, e0, e1, flops, nbytes, desc))
+            return r
+        return run
+
+    def per_layer(self, reps):
+        torch.cuda.synchronize()
+        n = len(self.records) // reps
+        rows = []
+        for i in range(n):
+            name, _, _, fl, nb, desc = self.records[i]
+            ms = sum(self.records[i + r * n][1].elapsed_time(self.records[i + r * n][2]) for r in range(reps)) / reps
+            rows.append(f"{i:3d} {name:22s} {ms * 1e3:9.1f} us {fl / 1e9:9.2f} GF {fl / (ms * 1e-3) / 1e12 if ms > 0 else 0:8.2f} TF/s "
+                        f"{nb / 1e6:8.1f} MB {nb / (ms * 1e-3) / 1e9 if ms > 0 else 0:8.1f} GB/s  {desc}")
+        return "\n".join(rows)
+
+    def summary(self):
+        torch.cuda.synchronize()
+        agg = {}
+        for name, e0, e1, fl, nb, _ in self.records:
+            a = agg.setdefault(name, [0, 0.0, 0, 0])
+            a[0] += 1
+            a[1] += e0.elapsed_time(e1)
+            a[2] += fl
+            a[3] += nb
+        return agg
+
+
+def measure_roofline(model, image, audio, dtype_name, reps=3):
+    from cavp_amd import cavp_model, ops
+    kt = KernelTimer().wrap(ops)
+    try:
+        with torch.no_grad():
+            for _ in range(reps):
+                model(image, audio, eval_mode=True)
+        agg = kt.summary()
+        if os.environ.get("CAVP_BENCH_PER_LAYER"):
+            with open(os.environ["CAVP_BENCH_PER_LAYER"], "w") as f:
+                f.write(kt.per_layer(reps) + "\n")
+    finally:
+        kt.unwrap(ops)
+    launches, ms, flops, nbytes = agg["conv2d"]
+    launches //= reps
+    ms /= reps
+    flops //= reps
+    nbytes //= reps
+    total_ms = sum(v[1] for v in agg.values()) / reps
+    tflops = flops / (ms * 1e-3) / 1e12
+    gbs = nbytes / (ms * 1e-3) / 1e9
+    frac_mfma = tflops / MFMA_PEAK_TFLOPS[dtype_name]
+    frac_hbm = gbs / HBM_PEAK_GBS
+    if frac_mfma >= frac_hbm:
+        roof = {"bound": "mfma", "achieved": round(tflops, 2), "peak": MFMA_PEAK_TFLOPS[dtype_name], "unit": "TFLOP/s",
+                "frac": round(frac_mfma, 4)}
+    else:
+        roof = {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(frac_hbm, 4)}
+    roof.update({
+        "traffic": None,
+        "kernel": "igemm_kernel (cavp_conv2d_nhwc: all conv / linear launches of one step)",
+        "launches_per_step": launches,
+        "avg_launch_us": round(ms * 1e3 / launches, 2),
+        "algorithmic_gflop_per_step": round(flops / 1e9, 2),
+        "algorithmic_mb_per_step": round(nbytes / 1e6, 1),
+        "achieved_tflops": round(tflops, 2), "achieved_gbs": round(gbs, 1),
+        "frac_of_mfma_peak": round(frac_mfma, 4), "frac_of_hbm_peak": round(frac_hbm, 4),
+        "share_of_step_kernel_time": round(ms / total_ms, 3),
+        "other_kernels_ms": {k: round(v[1] / reps, 3) for k, v in agg.items() if k != "conv2d"},
+    })
+    return roof
+
+
+def cpu_baseline(sd, cfg, sample_batch):
+    """The oracle (kind 'port': our restatement of the reference, pinned by golden vectors) on the host cores."""
+    from cavp_amd.synth import synth_inputs
+    from oracle import cavp_oracle as O
+    cores = os.cpu_count() or 1
+    try:
+        import psutil
+        cores = psutil.cpu_count(logical=False) or cores
+    except Exception:
+        pass
+    torch.set_num_threads(cores)
+    image, audio, _ = synth_inputs(sample_batch, cfg["hw"], num_classes=cfg["C"], seed=0)
+    with torch.no_grad():
+        O.cavp_forward(sd, image[:2], audio[:2], cfg["lds"], eval_mode=True)  # warm-up
+        t0, n = time.perf_counter(), 0
+        while True:
+            O.cavp_forward(sd, image, audio, cfg["lds"], eval_mode=True)
+            n += 1
+            dt = time.perf_counter() - t0
+            if dt > 12.0 or n >= 8:
+                break
+    return {"value": round(n * sample_batch / dt, 2), "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": f"{n} x eval forward of B={sample_batch} frames, fp32, torch CPU ({torch.get_num_threads()} threads), "
+                      f"same C1' model and synthetic inputs"}
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    import torch.distributed as dist
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+    dtype = torch.bfloat16 if a.dtype == "bf16" else torch.float32
+    cfg = model_cfg()
+    B = a.batch
+    from cavp_amd.synth import synth_inputs
+    model, sd = build_model(cfg, B, dtype, dev)
+    image, audio, _ = synth_inputs(B, cfg["hw"], num_classes=cfg["C"], seed=100 + rank)
+    image, audio = image.to(dev), audio.to(dev)
+
+    with torch.no_grad():
+        model(image, audio, eval_mode=True)      # eager warm-up: packs weights, sizes the workspace
+        torch.cuda.synchronize()
+        if a.no_graph:
+            def step():
+                return model(image, audio, eval_mode=True)
+        else:
+            graph = torch.cuda.CUDAGraph()
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                model(image, audio, eval_mode=True)
+            torch.cuda.current_stream().wait_stream(side)
+            with torch.cuda.graph(graph):
+                outs = model(image, audio, eval_mode=True)
+
+            def step():
+                graph.replay()
+                return outs
+
+        for _ in range(a.warmup):
+            step()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            step()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        value = world * B * a.steps / elapsed
+        line = {
+            "metric": "frames/sec end-to-end CAVP forward, B=32 224x224 (backward not built yet)",
+            "value": round(value, 2), "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(elapsed / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
+            "config": {"workload": f"C1' (config_avss_binary shape): CAVP ResNet-50 OS16 + VGGish, eval forward, "
+                                   f"B={B}/GPU, 224x224 RGB + 96x64 mel, num_classes=2, random-init (synthetic) weights",
+                       "global_batch": world * B, "per_gpu_batch": B, "parallelism": f"dp{world}",
+                       "launch": "eager" if a.no_graph else "hipGraph replay"},
+        }
+        if not a.no_roofline:
+            line["roofline"] = measure_roofline(model, image, audio, a.dtype)
+        if world == 1 and not a.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(sd, cfg, a.cpu_sample_batch)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -5,6 +5,11 @@ from __future__ import annotations
 import ctypes as C
 import os
 
+# torch ships its own libamdhip64 (SONAME libamdhip64.so.7, found through its RPATH).  It must be in the process
+# BEFORE libcavp_hip.so is dlopen'ed so that our NEEDED libamdhip64.so.7 binds to that same runtime instance;
+# the other order loads /opt/rocm's copy as a second HIP runtime and every launch on a torch stream fails.
+import torch  # noqa: F401  (ordering dependency, see above)
+
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libcavp_hip.so")
 

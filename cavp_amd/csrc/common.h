@@ -7,6 +7,7 @@
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
 
 typedef unsigned short bf16_t;  // raw bfloat16 bits
 

@@ -36,19 +36,20 @@ struct IgemmParams {
   int splitk;
   int tiles_c, tiles_p;
   int vec_io;               // epilogue may use vector loads/stores (Cout, ldy, ldr multiples of 4, pointers aligned)
+  int x_bytes, w_bytes;     // buffer-descriptor extents (< 2 GiB)
 };
 
 template <typename T> struct Mma;
 template <> struct Mma<float> {
-  __device__ static __forceinline__ void run(f32x4_t& acc, const uint4& a, const uint4& b) {
-    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.x), __uint_as_float(b.x), acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.y), __uint_as_float(b.y), acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.z), __uint_as_float(b.z), acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.w), __uint_as_float(b.w), acc, 0, 0, 0);
+  __device__ static __forceinline__ void run(f32x4_t& acc, const u32x4_t& a, const u32x4_t& b) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a[0]), __uint_as_float(b[0]), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a[1]), __uint_as_float(b[1]), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a[2]), __uint_as_float(b[2]), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a[3]), __uint_as_float(b[3]), acc, 0, 0, 0);
   }
 };
 template <> struct Mma<bf16_t> {
-  __device__ static __forceinline__ void run(f32x4_t& acc, const uint4& a, const uint4& b) {
+  __device__ static __forceinline__ void run(f32x4_t& acc, const u32x4_t& a, const u32x4_t& b) {
     acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), acc,
                                                   0, 0, 0);
   }
@@ -140,41 +141,42 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
   const int it_begin = (int)((long long)p.iters * z / p.splitk);
   const int it_end = (int)((long long)p.iters * (z + 1) / p.splitk);
 
-  const T* __restrict__ xg = (const T*)p.x;
-  const T* __restrict__ wg = (const T*)p.w;
+  // Buffer descriptors (wave-uniform, from kernel arguments): the hardware bounds check returns 0 for any offset
+  // >= num_records, so padding taps / K tails / M and Cout tails are "loaded" as zeros by pointing the lane at
+  // kOOB instead of branching or selecting on the loaded data.
+  constexpr unsigned kOOB = 0x80000000u;
+  const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.w_bytes, 0x00020000);
 
   // ---- per-thread load descriptors (fixed for the whole K loop) ----
-  size_t w_off[LW];
-  bool w_ok[LW];
+  const int kslot = (tid & 7) * VE;  // this thread's channel offset inside a K tile (same for W and X vectors)
+  unsigned w_off[LW];                // byte offset of (row cout, k = kslot) or kOOB
   int w_lds[LW];
 #pragma unroll
   for (int i = 0; i < LW; ++i) {
     const int v = tid + i * 256, row = v >> 3, slot = v & 7;
     const int c = c_base + row;
-    w_ok[i] = (v < NVW) && (c < p.Cout);
-    w_off[i] = (size_t)(w_ok[i] ? c : 0) * p.K + slot * VE;
+    const bool ok = (v < NVW) && (c < p.Cout);
+    w_off[i] = ok ? (unsigned)(((size_t)c * p.K + kslot) * sizeof(T)) : kOOB;
     w_lds[i] = row * 128 + ((slot ^ ((row >> 1) & 7)) << 4);
   }
   int x_nb[LX], x_h0[LX], x_w0[LX], x_lds[LX];
-  bool x_ok[LX];
   const int HoWo = p.Ho * p.Wo;
 #pragma unroll
   for (int i = 0; i < LX; ++i) {
     const int v = tid + i * 256, row = v >> 3, slot = v & 7;
     const int pix = p_base + row;
-    x_ok[i] = (v < NVX) && (pix < p.M);
-    const int pp = x_ok[i] ? pix : 0;
+    const bool ok = (v < NVX) && (pix < p.M);
+    const int pp = ok ? pix : 0;
     const int n = pp / HoWo, r = pp - n * HoWo;
     const int ho = r / p.Wo, wo = r - ho * p.Wo;
     x_nb[i] = n * p.H * p.W;
-    x_h0[i] = ho * p.stride - p.pad;
+    x_h0[i] = ok ? ho * p.stride - p.pad : -0x10000000;  // invalid rows fail the bounds test below
     x_w0[i] = wo * p.stride - p.pad;
     x_lds[i] = BC * 128 + row * 128 + ((slot ^ ((row >> 1) & 7)) << 4);
   }
-  const int kslot = (tid & 7) * VE;  // this thread's channel offset inside a K tile (same for W and X vectors)
 
-  uint4 wreg[LW], xreg[LX];
-  const uint4 zero4 = make_uint4(0, 0, 0, 0);
+  u32x4_t wreg[LW], xreg[LX];
 
   auto gload = [&](int it) {
     const int ti = it / p.cpt;
@@ -182,31 +184,30 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
     const int tap = (int)((p.taps >> (4 * ti)) & 15ull);
     const int kh = tap / p.KW, kw = tap - kh * p.KW;
     const bool c_ok = (c0 + kslot) < p.Cin;
-    const int koff = tap * p.Cin + c0;
+    const unsigned koff = (unsigned)((tap * p.Cin + c0) * (int)sizeof(T));
+    const int dh = kh * p.dil, dw = kw * p.dil;
+    const int xk = (c0 + kslot) * (int)sizeof(T);
 #pragma unroll
     for (int i = 0; i < LW; ++i) {
-      const bool ok = w_ok[i] && c_ok;
-      const T* ptr = ok ? (wg + w_off[i] + koff) : wg;  // clamped address, unconditional load
-      uint4 v = *(const uint4*)ptr;
-      wreg[i] = ok ? v : zero4;
+      const unsigned off = c_ok ? (w_off[i] + koff) : kOOB;  // kOOB + koff stays >= 2^31 (tensors are < 2 GiB)
+      wreg[i] = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, (int)off, 0, 0);
     }
 #pragma unroll
     for (int i = 0; i < LX; ++i) {
-      const int hi = x_h0[i] + kh * p.dil, wi = x_w0[i] + kw * p.dil;
-      const bool ok = x_ok[i] && c_ok && ((unsigned)hi < (unsigned)p.H) && ((unsigned)wi < (unsigned)p.W);
-      const T* ptr = ok ? (xg + (size_t)(x_nb[i] + hi * p.W + wi) * p.ldx + c0 + kslot) : xg;
-      uint4 v = *(const uint4*)ptr;
-      xreg[i] = ok ? v : zero4;
+      const int hi = x_h0[i] + dh, wi = x_w0[i] + dw;
+      const bool ok = c_ok && ((unsigned)hi < (unsigned)p.H) && ((unsigned)wi < (unsigned)p.W);
+      const unsigned off = (unsigned)(x_nb[i] + hi * p.W + wi) * (unsigned)(p.ldx * (int)sizeof(T)) + (unsigned)xk;
+      xreg[i] = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, (int)(ok ? off : kOOB), 0, 0);
     }
   };
   auto lstore = [&](int buf) {
     char* base = smem + buf * TILE_BYTES;
 #pragma unroll
     for (int i = 0; i < LW; ++i)
-      if (tid + i * 256 < NVW) *(uint4*)(base + w_lds[i]) = wreg[i];
+      if (tid + i * 256 < NVW) *(u32x4_t*)(base + w_lds[i]) = wreg[i];
 #pragma unroll
     for (int i = 0; i < LX; ++i)
-      if (tid + i * 256 < NVX) *(uint4*)(base + x_lds[i]) = xreg[i];
+      if (tid + i * 256 < NVX) *(u32x4_t*)(base + x_lds[i]) = xreg[i];
   };
 
   const int wc0 = (wave % WC) * TC, wp0 = (wave / WC) * TP;
@@ -223,17 +224,17 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
     const char* xb = wb + BC * 128;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-      uint4 af[MC], bfv[MP];
+      u32x4_t af[MC], bfv[MP];
       const int s = j * 4 + lgrp;
 #pragma unroll
       for (int a = 0; a < MC; ++a) {
         const int r = wc0 + a * 16 + lrow;
-        af[a] = *(const uint4*)(wb + r * 128 + ((s ^ ((r >> 1) & 7)) << 4));
+        af[a] = *(const u32x4_t*)(wb + r * 128 + ((s ^ ((r >> 1) & 7)) << 4));
       }
 #pragma unroll
       for (int b = 0; b < MP; ++b) {
         const int r = wp0 + b * 16 + lrow;
-        bfv[b] = *(const uint4*)(xb + r * 128 + ((s ^ ((r >> 1) & 7)) << 4));
+        bfv[b] = *(const u32x4_t*)(xb + r * 128 + ((s ^ ((r >> 1) & 7)) << 4));
       }
 #pragma unroll
       for (int a = 0; a < MC; ++a)
@@ -465,6 +466,13 @@ extern "C" int cavp_conv2d_nhwc(const cavp_conv_desc* d, const void* x, const vo
   p.x = x; p.w = w; p.y = y; p.scale = scale; p.shift = shift; p.nbias = nbias; p.res = residual;
   p.partial = (float*)workspace;
   const size_t es = d->dtype == CAVP_F32 ? 4 : 2;
+  {
+    const size_t xb = ((size_t)d->N * d->H * d->W - 1) * d->ldx * es + (size_t)d->Cin * es;
+    const size_t wb = (size_t)d->Cout * p.K * es;
+    if (xb >= 0x7fffffffull || wb >= 0x7fffffffull) return CAVP_ERR_UNSUPPORTED;  // 32-bit buffer offsets
+    p.x_bytes = (int)xb;
+    p.w_bytes = (int)wb;
+  }
   p.vec_io = (d->Cout % 4 == 0) && (d->ldy % 4 == 0) && aligned(y, 4 * es) &&
              (!residual || (d->ldr % 4 == 0 && aligned(residual, 4 * es))) && (!scale || aligned(scale, 16)) &&
              (!shift || aligned(shift, 16)) && (!nbias || aligned(nbias, 16));
