@@ -157,8 +157,16 @@ def measure_roofline(model, image, audio, dtype_name, reps=3):
                 "frac": round(frac_mfma, 4)}
     else:
         roof = {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(frac_hbm, 4)}
+    traffic = None
+    tpath = os.path.join(REPO, "profiles", f"r01_traffic_{dtype_name}.json")
+    if os.path.exists(tpath):  # PMC counters cannot be read from inside the process: measured with rocprofv3 --pmc
+        with open(tpath) as f:
+            tj = json.load(f)
+        if tj.get("batch") == image.shape[0] and tj.get("dtype") == dtype_name:
+            traffic = {"hbm_bytes_per_step": tj["hbm_bytes_per_step"], "hbm_bytes_per_launch": tj["hbm_bytes_per_launch"],
+                       "vs_algorithmic": round(tj["hbm_bytes_per_step"] / nbytes, 3), "source": "profiles/" + os.path.basename(tpath)}
     roof.update({
-        "traffic": None,
+        "traffic": traffic,
         "kernel": "igemm_kernel (cavp_conv2d_nhwc: all conv / linear launches of one step)",
         "launches_per_step": launches,
         "avg_launch_us": round(ms * 1e3 / launches, 2),

@@ -1,0 +1,58 @@
+#!/usr/bin/env python3
+"""Summarise rocprofv3 CSV output (kernel trace + optional PMC counters) into a small text table for profiles/.
+
+usage: python tools/summarize_rocprof.py <rocprof output dir> [--out profiles/xxx.txt]
+Handles *_kernel_trace.csv (Kernel_Name, Start_Timestamp, End_Timestamp), *_kernel_stats.csv and
+*_counter_collection.csv (Kernel_Name, Counter_Name, Counter_Value)."""
+import argparse
+import csv
+import glob
+import os
+import re
+from collections import defaultdict
+
+
+def short(name):
+    name = name.replace("(anonymous namespace)::", "").replace("void ", "")
+    name = re.sub(r"\(.*$", "", name)
+    return name[:110]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("dir")
+    ap.add_argument("--out", default=None)
+    a = ap.parse_args()
+    lines = []
+    traces = glob.glob(os.path.join(a.dir, "**", "*kernel_trace.csv"), recursive=True)
+    for t in traces:
+        agg = defaultdict(lambda: [0, 0.0, 1e30, 0.0])
+        with open(t) as f:
+            for r in csv.DictReader(f):
+                d = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+                g = agg[short(r["Kernel_Name"])]
+                g[0] += 1; g[1] += d; g[2] = min(g[2], d); g[3] = max(g[3], d)
+        tot = sum(v[1] for v in agg.values())
+        lines.append(f"# kernel trace: {os.path.relpath(t, a.dir)}  total kernel time {tot / 1e3:.3f} ms")
+        lines.append(f"{'calls':>7} {'total_us':>12} {'avg_us':>10} {'min_us':>9} {'max_us':>9} {'%':>6}  kernel")
+        for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+            lines.append(f"{v[0]:7d} {v[1]:12.1f} {v[1] / v[0]:10.2f} {v[2]:9.2f} {v[3]:9.2f} {100 * v[1] / tot:6.2f}  {k}")
+    for t in glob.glob(os.path.join(a.dir, "**", "*counter_collection.csv"), recursive=True):
+        agg = defaultdict(lambda: defaultdict(lambda: [0, 0.0]))
+        with open(t) as f:
+            for r in csv.DictReader(f):
+                g = agg[short(r["Kernel_Name"])][r["Counter_Name"]]
+                g[0] += 1; g[1] += float(r["Counter_Value"])
+        lines.append(f"# counters: {os.path.relpath(t, a.dir)}  (sum over dispatches; per-dispatch avg in brackets)")
+        for k, cs in sorted(agg.items(), key=lambda kv: -sum(v[1] for v in kv[1].values())):
+            for c, v in sorted(cs.items()):
+                lines.append(f"{c:>22} {v[1]:18.1f} [{v[1] / v[0]:14.1f} x {v[0]:5d}]  {k}")
+    text = "\n".join(lines) + "\n"
+    if a.out:
+        with open(a.out, "w") as f:
+            f.write(text)
+    print(text)
+
+
+if __name__ == "__main__":
+    main()
