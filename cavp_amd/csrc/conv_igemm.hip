@@ -37,6 +37,7 @@ struct IgemmParams {
   int tiles_c, tiles_p;
   int vec_io;               // epilogue may use vector loads/stores (Cout, ldy, ldr multiples of 4, pointers aligned)
   int x_bytes, w_bytes;     // buffer-descriptor extents (< 2 GiB)
+  int coalesced;            // LDS-staged, fully coalesced 16-byte epilogue (needs Cout, ldy, ldr % VE == 0, 16-B aligned)
 };
 
 template <typename T> struct Mma;
@@ -117,8 +118,8 @@ __device__ __forceinline__ void epilogue_store4(const IgemmParams& p, float v0, 
   }
 }
 
-template <typename T, int BC, int BP, int WC, int WP>
-__global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
+template <typename T, int BC, int BP, int WC, int WP, int PIPE>
+__global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p) {
   constexpr int VE = Elem<T>::VE;
   constexpr int BK = 8 * VE;  // one 128-byte LDS row of K
   constexpr int TC = BC / WC, TP = BP / WP;
@@ -149,36 +150,44 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
   const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.w_bytes, 0x00020000);
 
   // ---- per-thread load descriptors (fixed for the whole K loop) ----
-  const int kslot = (tid & 7) * VE;  // this thread's channel offset inside a K tile (same for W and X vectors)
+  // Row / slot owned by this thread for its i-th 16-byte vector of a tile.
+  //  PIPE 1,2 (register staging): vector v = tid + 256 i -> row (tid >> 3) + 32 i, slot tid & 7 (swizzled on the
+  //            ds_write side).
+  //  PIPE 3 (LDS-DMA): a wave-instruction writes 1 KiB = rows 8g..8g+7 LINEARLY (lane l -> byte 16 l), g = wave + 4 i,
+  //            so the swizzle moves to the SOURCE: lane l fetches logical slot (l & 7) ^ ((row >> 1) & 7).
+  const int row0 = PIPE == 3 ? 8 * wave + (lane >> 3) : (tid >> 3);
+  const int kslot = (PIPE == 3 ? ((lane & 7) ^ ((4 * wave + (lane >> 4)) & 7)) : (tid & 7)) * VE;
   unsigned w_off[LW];                // byte offset of (row cout, k = kslot) or kOOB
-  int w_lds[LW];
+  // vector v = tid + 256 i sits in row (tid >> 3) + 32 i, and ((row >> 1) & 7) does not depend on i, so the LDS
+  // address of vector i is lds0 + 4096 i (one register instead of LW + LX)
+  const int lds0 = (tid >> 3) * 128 + (((tid & 7) ^ ((tid >> 4) & 7)) << 4);
 #pragma unroll
   for (int i = 0; i < LW; ++i) {
-    const int v = tid + i * 256, row = v >> 3, slot = v & 7;
+    const int row = row0 + 32 * i;
     const int c = c_base + row;
-    const bool ok = (v < NVW) && (c < p.Cout);
+    const bool ok = (row < BC) && (c < p.Cout);
     w_off[i] = ok ? (unsigned)(((size_t)c * p.K + kslot) * sizeof(T)) : kOOB;
-    w_lds[i] = row * 128 + ((slot ^ ((row >> 1) & 7)) << 4);
   }
-  int x_nb[LX], x_h0[LX], x_w0[LX], x_lds[LX];
+  int x_nb[LX], x_h0[LX], x_w0[LX];
   const int HoWo = p.Ho * p.Wo;
 #pragma unroll
   for (int i = 0; i < LX; ++i) {
-    const int v = tid + i * 256, row = v >> 3, slot = v & 7;
+    const int row = row0 + 32 * i;
     const int pix = p_base + row;
-    const bool ok = (v < NVX) && (pix < p.M);
+    const bool ok = (row < BP) && (pix < p.M);
     const int pp = ok ? pix : 0;
     const int n = pp / HoWo, r = pp - n * HoWo;
     const int ho = r / p.Wo, wo = r - ho * p.Wo;
     x_nb[i] = n * p.H * p.W;
     x_h0[i] = ok ? ho * p.stride - p.pad : -0x10000000;  // invalid rows fail the bounds test below
     x_w0[i] = wo * p.stride - p.pad;
-    x_lds[i] = BC * 128 + row * 128 + ((slot ^ ((row >> 1) & 7)) << 4);
   }
 
-  u32x4_t wreg[LW], xreg[LX];
+  // two register sets: with PIPE == 2 the loads of tile k+2 are issued while tile k is multiplied and tile k+1 is
+  // still in flight, so a load has two compute phases to land (HBM/L2 latency under load ~ 2 phases).
+  u32x4_t wregA[LW], xregA[LX], wregB[LW], xregB[LX];
 
-  auto gload = [&](int it) {
+  auto gload = [&](u32x4_t (&wr)[LW], u32x4_t (&xr)[LX], int it) {
     const int ti = it / p.cpt;
     const int c0 = (it - ti * p.cpt) * BK;
     const int tap = (int)((p.taps >> (4 * ti)) & 15ull);
@@ -190,24 +199,55 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
 #pragma unroll
     for (int i = 0; i < LW; ++i) {
       const unsigned off = c_ok ? (w_off[i] + koff) : kOOB;  // kOOB + koff stays >= 2^31 (tensors are < 2 GiB)
-      wreg[i] = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, (int)off, 0, 0);
+      wr[i] = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, (int)off, 0, 0);
     }
 #pragma unroll
     for (int i = 0; i < LX; ++i) {
       const int hi = x_h0[i] + dh, wi = x_w0[i] + dw;
       const bool ok = c_ok && ((unsigned)hi < (unsigned)p.H) && ((unsigned)wi < (unsigned)p.W);
       const unsigned off = (unsigned)(x_nb[i] + hi * p.W + wi) * (unsigned)(p.ldx * (int)sizeof(T)) + (unsigned)xk;
-      xreg[i] = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, (int)(ok ? off : kOOB), 0, 0);
+      xr[i] = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, (int)(ok ? off : kOOB), 0, 0);
     }
   };
-  auto lstore = [&](int buf) {
+  // PIPE 3: global -> LDS directly (buffer_load ... lds), no VGPR staging, no ds_write; out-of-range lanes land zeros.
+  auto gdma = [&](int it, int buf) {
+    const int ti = it / p.cpt;
+    const int c0 = (it - ti * p.cpt) * BK;
+    const int tap = (int)((p.taps >> (4 * ti)) & 15ull);
+    const int kh = tap / p.KW, kw = tap - kh * p.KW;
+    const bool c_ok = (c0 + kslot) < p.Cin;
+    const unsigned koff = (unsigned)((tap * p.Cin + c0) * (int)sizeof(T));
+    const int dh = kh * p.dil, dw = kw * p.dil;
+    const int xk = (c0 + kslot) * (int)sizeof(T);
+    char* base = smem + buf * TILE_BYTES + wave * 1024;
+#pragma unroll
+    for (int i = 0; i < LW; ++i) {
+      if (BC % 32 == 0 || 8 * wave + 32 * i < BC) {
+        const unsigned off = c_ok ? (w_off[i] + koff) : kOOB;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (__attribute__((address_space(3))) void*)(base + i * 4096), 16,
+                                                 (int)off, 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < LX; ++i) {
+      if (BP % 32 == 0 || 8 * wave + 32 * i < BP) {
+        const int hi = x_h0[i] + dh, wi = x_w0[i] + dw;
+        const bool ok = c_ok && ((unsigned)hi < (unsigned)p.H) && ((unsigned)wi < (unsigned)p.W);
+        const unsigned off = (unsigned)(x_nb[i] + hi * p.W + wi) * (unsigned)(p.ldx * (int)sizeof(T)) + (unsigned)xk;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc,
+                                                 (__attribute__((address_space(3))) void*)(base + BC * 128 + i * 4096),
+                                                 16, (int)(ok ? off : kOOB), 0, 0, 0);
+      }
+    }
+  };
+  auto lstore = [&](const u32x4_t (&wr)[LW], const u32x4_t (&xr)[LX], int buf) {
     char* base = smem + buf * TILE_BYTES;
 #pragma unroll
     for (int i = 0; i < LW; ++i)
-      if (tid + i * 256 < NVW) *(u32x4_t*)(base + w_lds[i]) = wreg[i];
+      if (NVW % 256 == 0 || tid + i * 256 < NVW) *(u32x4_t*)(base + lds0 + i * 4096) = wr[i];
 #pragma unroll
     for (int i = 0; i < LX; ++i)
-      if (tid + i * 256 < NVX) *(u32x4_t*)(base + x_lds[i]) = xreg[i];
+      if (NVX % 256 == 0 || tid + i * 256 < NVX) *(u32x4_t*)(base + BC * 128 + lds0 + i * 4096) = xr[i];
   };
 
   const int wc0 = (wave % WC) * TC, wp0 = (wave / WC) * TP;
@@ -244,21 +284,118 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
   };
 
   if (it_begin < it_end) {
-    gload(it_begin);
-    lstore(0);
-    __syncthreads();
-    int buf = 0;
-    for (int it = it_begin; it < it_end; ++it) {
-      const bool more = (it + 1) < it_end;
-      if (more) gload(it + 1);
-      compute(buf);
-      if (more) lstore(buf ^ 1);
+    if constexpr (PIPE == 1) {
+      gload(wregA, xregA, it_begin);
+      lstore(wregA, xregA, 0);
       __syncthreads();
-      buf ^= 1;
+      int buf = 0;
+      for (int it = it_begin; it < it_end; ++it) {
+        const bool more = (it + 1) < it_end;
+        if (more) gload(wregA, xregA, it + 1);
+        compute(buf);
+        if (more) lstore(wregA, xregA, buf ^ 1);
+        __syncthreads();
+        buf ^= 1;
+      }
+    } else if constexpr (PIPE == 3) {
+      gdma(it_begin, 0);
+      __syncthreads();  // (drains the DMA: hipcc emits vmcnt(0) before the barrier while an LDS-DMA is in flight)
+      int buf = 0;
+      for (int it = it_begin; it < it_end; ++it) {
+        if (it + 1 < it_end) gdma(it + 1, buf ^ 1);
+        compute(buf);
+        __syncthreads();
+        buf ^= 1;
+      }
+    } else {
+      gload(wregA, xregA, it_begin);
+      if (it_begin + 1 < it_end) gload(wregB, xregB, it_begin + 1);
+      lstore(wregA, xregA, 0);
+      __syncthreads();
+      for (int it = it_begin; it < it_end; it += 2) {
+        if (it + 2 < it_end) gload(wregA, xregA, it + 2);
+        compute(0);
+        if (it + 1 < it_end) lstore(wregB, xregB, 1);
+        __syncthreads();
+        if (it + 1 >= it_end) break;
+        if (it + 3 < it_end) gload(wregB, xregB, it + 3);
+        compute(1);
+        if (it + 2 < it_end) lstore(wregA, xregA, 0);
+        __syncthreads();
+      }
     }
   }
 
   // ---- epilogue ----
+  if (p.coalesced) {
+    // Stage the f32 accumulators in LDS as [pixel][cout] (16-byte slots XOR-swizzled by pixel & 7), then let each
+    // thread finish VE consecutive channels of one pixel: scale/shift/bias/residual are 16-byte vector loads and the
+    // output leaves as full 16-byte stores, BC*sizeof(T) contiguous bytes per pixel (vs 8-byte pieces scattered
+    // over 16 pixels straight from the MFMA layout).  All K-loop LDS reads are behind the loop's last barrier.
+    float* st = (float*)smem;
+    constexpr int SLOTS = BC / 4;  // 16-byte f32 slots per pixel row
+    constexpr int SWZ = SLOTS >= 8 ? 7 : SLOTS - 1;
+#pragma unroll
+    for (int a = 0; a < MC; ++a)
+#pragma unroll
+      for (int b = 0; b < MP; ++b) {
+        const int prow = wp0 + b * 16 + lrow;
+        const int slot = (wc0 + a * 16) / 4 + lgrp;
+        *(f32x4_t*)(st + (size_t)prow * BC + ((slot ^ (prow & SWZ)) << 2)) = acc[a][b];
+      }
+    __syncthreads();
+    constexpr int CH = BC / VE;                 // output chunks (16 B of T) per pixel row
+    constexpr int NCH = BP * CH;
+    for (int ch = tid; ch < NCH; ch += 256) {
+      const int prow = ch / CH, cc = (ch - prow * CH) * VE;
+      const int pix = p_base + prow, c = c_base + cc;
+      if (pix >= p.M || c >= p.Cout) continue;
+      float v[VE];
+#pragma unroll
+      for (int q = 0; q < VE / 4; ++q) {
+        const int slot = cc / 4 + q;
+        const f32x4_t t = *(const f32x4_t*)(st + (size_t)prow * BC + ((slot ^ (prow & SWZ)) << 2));
+        v[4 * q] = t[0]; v[4 * q + 1] = t[1]; v[4 * q + 2] = t[2]; v[4 * q + 3] = t[3];
+      }
+      if (p.nbias) {
+        const float* nb = p.nbias + (size_t)(pix / HoWo) * p.Cout + c;
+#pragma unroll
+        for (int e = 0; e < VE; ++e) v[e] += nb[e];
+      }
+      if (p.scale) {
+#pragma unroll
+        for (int e = 0; e < VE; ++e) v[e] *= p.scale[c + e];
+      }
+      if (p.shift) {
+#pragma unroll
+        for (int e = 0; e < VE; ++e) v[e] += p.shift[c + e];
+      }
+      if (p.res) {
+        const u32x4_t r = *(const u32x4_t*)((const T*)p.res + (size_t)pix * p.ldr + c);
+        if constexpr (sizeof(T) == 4) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] += __uint_as_float(r[e]);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            v[2 * e] += __uint_as_float(r[e] << 16);
+            v[2 * e + 1] += __uint_as_float(r[e] & 0xffff0000u);
+          }
+        }
+      }
+      u32x4_t o;
+      if constexpr (sizeof(T) == 4) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = __float_as_uint(apply_act(v[e], p.act));
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          o[e] = (unsigned)f2bf(apply_act(v[2 * e], p.act)) | ((unsigned)f2bf(apply_act(v[2 * e + 1], p.act)) << 16);
+      }
+      *(u32x4_t*)((T*)p.y + (size_t)pix * p.ldy + c) = o;
+    }
+    return;
+  }
 #pragma unroll
   for (int a = 0; a < MC; ++a) {
 #pragma unroll
@@ -317,29 +454,50 @@ const TileCfg kTiles[] = {
 };
 constexpr int kNumTiles = sizeof(kTiles) / sizeof(kTiles[0]);
 
-template <typename T, int BC, int BP, int WC, int WP>
+template <typename T, int BC, int BP, int WC, int WP, int PIPE>
 hipError_t launch_cfg(const IgemmParams& p, int nblk, hipStream_t s) {
   constexpr int lds = 2 * (BC + BP) * 128;
+  static_assert(BP * BC * 4 <= lds, "epilogue staging must fit in the K-loop LDS");
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)igemm_kernel<T, BC, BP, WC, WP>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                              lds);
+    (void)hipFuncSetAttribute((const void*)igemm_kernel<T, BC, BP, WC, WP, PIPE>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr_set = true;
   }
-  igemm_kernel<T, BC, BP, WC, WP><<<dim3(nblk), dim3(256), lds, s>>>(p);
+  igemm_kernel<T, BC, BP, WC, WP, PIPE><<<dim3(nblk), dim3(256), lds, s>>>(p);
   return hipGetLastError();
 }
 
 template <typename T>
-hipError_t launch_tile(int id, const IgemmParams& p, int nblk, hipStream_t s) {
+hipError_t launch_tile(int id, int pipe, const IgemmParams& p, int nblk, hipStream_t s) {
+  if (pipe == 1) {
+    switch (id) {
+      case 1: return launch_cfg<T, 128, 128, 2, 2, 1>(p, nblk, s);
+      case 2: return launch_cfg<T, 64, 128, 2, 2, 1>(p, nblk, s);
+      case 3: return launch_cfg<T, 64, 64, 2, 2, 1>(p, nblk, s);
+      case 4: return launch_cfg<T, 128, 64, 2, 2, 1>(p, nblk, s);
+      case 5: return launch_cfg<T, 128, 32, 4, 1, 1>(p, nblk, s);
+      case 6: return launch_cfg<T, 16, 128, 1, 4, 1>(p, nblk, s);
+      case 7: return launch_cfg<T, 32, 128, 1, 4, 1>(p, nblk, s);
+      default: return hipErrorInvalidValue;
+    }
+  }
+  if (pipe == 2) {
+    switch (id) {
+      case 1: return launch_cfg<T, 128, 128, 2, 2, 2>(p, nblk, s);
+      case 2: return launch_cfg<T, 64, 128, 2, 2, 2>(p, nblk, s);
+      case 3: return launch_cfg<T, 64, 64, 2, 2, 2>(p, nblk, s);
+      default: return hipErrorInvalidValue;
+    }
+  }
   switch (id) {
-    case 1: return launch_cfg<T, 128, 128, 2, 2>(p, nblk, s);
-    case 2: return launch_cfg<T, 64, 128, 2, 2>(p, nblk, s);
-    case 3: return launch_cfg<T, 64, 64, 2, 2>(p, nblk, s);
-    case 4: return launch_cfg<T, 128, 64, 2, 2>(p, nblk, s);
-    case 5: return launch_cfg<T, 128, 32, 4, 1>(p, nblk, s);
-    case 6: return launch_cfg<T, 16, 128, 1, 4>(p, nblk, s);
-    case 7: return launch_cfg<T, 32, 128, 1, 4>(p, nblk, s);
+    case 1: return launch_cfg<T, 128, 128, 2, 2, 3>(p, nblk, s);
+    case 2: return launch_cfg<T, 64, 128, 2, 2, 3>(p, nblk, s);
+    case 3: return launch_cfg<T, 64, 64, 2, 2, 3>(p, nblk, s);
+    case 4: return launch_cfg<T, 128, 64, 2, 2, 3>(p, nblk, s);
+    case 5: return launch_cfg<T, 128, 32, 4, 1, 3>(p, nblk, s);
+    case 6: return launch_cfg<T, 16, 128, 1, 4, 3>(p, nblk, s);
+    case 7: return launch_cfg<T, 32, 128, 1, 4, 3>(p, nblk, s);
     default: return hipErrorInvalidValue;
   }
 }
@@ -347,6 +505,8 @@ hipError_t launch_tile(int id, const IgemmParams& p, int nblk, hipStream_t s) {
 struct Plan {
   IgemmParams p;
   int tile_id;
+  int pipe;      // software-pipeline depth of the K loop (1 or 2 tiles of loads in flight)
+  int direct_epi;  // testing: force the direct (MFMA-layout) epilogue
   int nblk;
   size_t ws_bytes;
   int status;
@@ -403,9 +563,17 @@ Plan make_plan(const cavp_conv_desc* d) {
   p.iters = p.ntaps * p.cpt;
   // ---- tile choice ----
   int best = -1;
-  if (d->tile > 0) {
+  // d->tile = id + 100 * (pipe==1) + 1000 * (direct epilogue): testing / A-B knobs
+  {  // hundreds digit of the knob: 0 = default pipeline, 1/2 = register staging depth 1/2, 3 = LDS-DMA
+    const int pk = (d->tile / 100) % 10;
+    pl.pipe = pk == 0 ? 3 : pk;
+    if (pl.pipe < 1 || pl.pipe > 3) { pl.status = CAVP_ERR_BAD_ARG; return pl; }
+  }
+  pl.direct_epi = (d->tile / 1000) % 10;
+  const int want_tile = d->tile % 100;
+  if (want_tile > 0) {
     for (int i = 0; i < kNumTiles; ++i)
-      if (kTiles[i].id == d->tile) best = i;
+      if (kTiles[i].id == want_tile) best = i;
     if (best < 0) { pl.status = CAVP_ERR_BAD_ARG; return pl; }
   } else {
     double best_score = -1.0;
@@ -476,9 +644,12 @@ extern "C" int cavp_conv2d_nhwc(const cavp_conv_desc* d, const void* x, const vo
   p.vec_io = (d->Cout % 4 == 0) && (d->ldy % 4 == 0) && aligned(y, 4 * es) &&
              (!residual || (d->ldr % 4 == 0 && aligned(residual, 4 * es))) && (!scale || aligned(scale, 16)) &&
              (!shift || aligned(shift, 16)) && (!nbias || aligned(nbias, 16));
+  const int VE = d->dtype == CAVP_F32 ? 4 : 8;
+  p.coalesced = !pl.direct_epi && p.splitk == 1 && (d->Cout % VE == 0) && (d->ldy % VE == 0) && aligned(y, 16) &&
+                (!residual || (d->ldr % VE == 0 && aligned(residual, 16)));
   hipStream_t s = (hipStream_t)stream;
-  hipError_t e = d->dtype == CAVP_F32 ? launch_tile<float>(pl.tile_id, p, pl.nblk, s)
-                                      : launch_tile<bf16_t>(pl.tile_id, p, pl.nblk, s);
+  hipError_t e = d->dtype == CAVP_F32 ? launch_tile<float>(pl.tile_id, pl.pipe, p, pl.nblk, s)
+                                      : launch_tile<bf16_t>(pl.tile_id, pl.pipe, p, pl.nblk, s);
   if (e != hipSuccess) return CAVP_ERR_LAUNCH;
   if (p.splitk > 1) {
     const long long total = (long long)p.M * ((p.Cout + 3) / 4);

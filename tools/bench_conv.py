@@ -1,0 +1,84 @@
+#!/usr/bin/env python3
+"""Micro-benchmark of cavp_conv2d_nhwc on the CAVP layer shapes (B=32, C1').  GPU box only.
+usage: python tools/bench_conv.py [--dtype bf16|f32] [--variants 0,101,1001,...] [--shapes name,...]
+A variant is the `tile` knob of cavp_conv_desc: tile id + 100*(pipe depth 1) + 1000*(direct epilogue); 0 = auto."""
+import argparse
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from cavp_amd import ops  # noqa: E402
+
+SHAPES = {
+    # name: (N, H, W, Cin, Cout, k, stride, pad, dil, residual)
+    "head0_3x3_304_256@56": (32, 56, 56, 304, 256, 3, 1, 1, 1, False),
+    "stem2_3x3_64_128@112": (32, 112, 112, 64, 128, 3, 1, 1, 1, False),
+    "l1_1x1_64_256@56+res": (32, 56, 56, 64, 256, 1, 1, 0, 1, True),
+    "l1_1x1_256_64@56": (32, 56, 56, 256, 64, 1, 1, 0, 1, False),
+    "l1_3x3_64_64@56": (32, 56, 56, 64, 64, 3, 1, 1, 1, False),
+    "l2_1x1_128_512@28+res": (32, 28, 28, 128, 512, 1, 1, 0, 1, True),
+    "l3_3x3_256_256@14": (32, 14, 14, 256, 256, 3, 1, 1, 1, False),
+    "l3_1x1_1024_256@14": (32, 14, 14, 1024, 256, 1, 1, 0, 1, False),
+    "l4_3x3_512_512@14d2": (32, 14, 14, 512, 512, 3, 1, 2, 2, False),
+    "l4_1x1_512_2048@14+res": (32, 14, 14, 512, 2048, 1, 1, 0, 1, True),
+    "aspp_3x3_2048_256@14d6": (32, 14, 14, 2048, 256, 3, 1, 6, 6, False),
+    "ca_fc1_304_1216@3136": (32, 1, 3136, 304, 1216, 1, 1, 0, 1, False),
+    "ca_fc2_1216_304@3136+res": (32, 1, 3136, 1216, 304, 1, 1, 0, 1, True),
+    "ca_q_304_304@3136": (32, 1, 3136, 304, 304, 1, 1, 0, 1, False),
+    "a_fc0_12288_4096@1": (32, 1, 1, 12288, 4096, 1, 1, 0, 1, False),
+}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--dtype", default="bf16")
+    ap.add_argument("--variants", default="0")
+    ap.add_argument("--shapes", default="")
+    ap.add_argument("--reps", type=int, default=20)
+    a = ap.parse_args()
+    dt = torch.bfloat16 if a.dtype == "bf16" else torch.float32
+    dev = "cuda:0"
+    variants = [int(v) for v in a.variants.split(",")]
+    names = [n for n in SHAPES if not a.shapes or any(s in n for s in a.shapes.split(","))]
+    print(f"{'shape':28s} " + " ".join(f"{'v' + str(v):>22s}" for v in variants))
+    for name in names:
+        n, h, w, cin, cout, k, s, p, d, res = SHAPES[name]
+        ho, wo = (h + 2 * p - d * (k - 1) - 1) // s + 1, (w + 2 * p - d * (k - 1) - 1) // s + 1
+        x = torch.randn((n, h, w, cin), device=dev).to(dt)
+        wt = (torch.randn((cout, k, k, cin), device=dev) * (cin * k * k) ** -0.5).to(dt)
+        y = torch.empty((n, ho, wo, cout), dtype=dt, device=dev)
+        r = torch.randn((n, ho, wo, cout), device=dev).to(dt) if res else None
+        sc, sh = torch.rand(cout, device=dev) + 0.5, torch.randn(cout, device=dev)
+        flops = 2.0 * n * ho * wo * cout * cin * k * k
+        nbytes = (x.numel() + wt.numel() + y.numel() * (2 if res else 1)) * x.element_size()
+        cells, ref = [], None
+        for v in variants:
+            try:
+                f = lambda: ops.conv2d(x, wt, y, kh=k, kw=k, stride=s, pad=p, dil=d, scale=sc, shift=sh, residual=r,
+                                       act=ops.ACT_RELU, tile=v)
+                f(); f()
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(a.reps):
+                    f()
+                e1.record()
+                torch.cuda.synchronize()
+                us = e0.elapsed_time(e1) / a.reps * 1e3
+                yy = y.float()
+                if ref is None:
+                    ref = yy.clone()
+                    ok = ""
+                else:
+                    err = float((yy - ref).abs().max())
+                    ok = "" if err <= 2e-2 * max(1.0, float(ref.abs().max())) else f" !ERR{err:.2g}"
+                cells.append(f"{us:7.1f}us {flops / us / 1e6:6.1f}TF {nbytes / us / 1e3:5.0f}GB{ok}")
+            except Exception as ex:  # noqa: BLE001
+                cells.append(f"{'fail: ' + str(ex)[:14]:>22s}")
+        print(f"{name:28s} " + " ".join(f"{c:>22s}" for c in cells), flush=True)
+
+
+if __name__ == "__main__":
+    main()
