@@ -37,6 +37,7 @@ struct IgemmParams {
   int tiles_c, tiles_p;
   int vec_io;               // epilogue may use vector loads/stores (Cout, ldy, ldr multiples of 4, pointers aligned)
   int x_bytes, w_bytes;     // buffer-descriptor extents (< 2 GiB)
+  int up_shift, up_mask;    // transposed-conv input upsampling (log2, mask); 0, 0 for an ordinary conv
   int coalesced;            // LDS-staged, fully coalesced 16-byte epilogue (needs Cout, ldy, ldr % VE == 0, 16-B aligned)
 };
 
@@ -203,8 +204,10 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p) {
     }
 #pragma unroll
     for (int i = 0; i < LX; ++i) {
-      const int hi = x_h0[i] + dh, wi = x_w0[i] + dw;
-      const bool ok = c_ok && ((unsigned)hi < (unsigned)p.H) && ((unsigned)wi < (unsigned)p.W);
+      const int hv = x_h0[i] + dh, wv = x_w0[i] + dw;  // position in the (virtually zero-upsampled) input
+      const int hi = hv >> p.up_shift, wi = wv >> p.up_shift;
+      const bool ok = c_ok && (((hv | wv) & p.up_mask) == 0) && ((unsigned)hi < (unsigned)p.H) &&
+                      ((unsigned)wi < (unsigned)p.W);
       const unsigned off = (unsigned)(x_nb[i] + hi * p.W + wi) * (unsigned)(p.ldx * (int)sizeof(T)) + (unsigned)xk;
       xr[i] = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, (int)(ok ? off : kOOB), 0, 0);
     }
@@ -231,8 +234,10 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p) {
 #pragma unroll
     for (int i = 0; i < LX; ++i) {
       if (BP % 32 == 0 || 8 * wave + 32 * i < BP) {
-        const int hi = x_h0[i] + dh, wi = x_w0[i] + dw;
-        const bool ok = c_ok && ((unsigned)hi < (unsigned)p.H) && ((unsigned)wi < (unsigned)p.W);
+        const int hv = x_h0[i] + dh, wv = x_w0[i] + dw;
+        const int hi = hv >> p.up_shift, wi = wv >> p.up_shift;
+        const bool ok = c_ok && (((hv | wv) & p.up_mask) == 0) && ((unsigned)hi < (unsigned)p.H) &&
+                        ((unsigned)wi < (unsigned)p.W);
         const unsigned off = (unsigned)(x_nb[i] + hi * p.W + wi) * (unsigned)(p.ldx * (int)sizeof(T)) + (unsigned)xk;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc,
                                                  (__attribute__((address_space(3))) void*)(base + BC * 128 + i * 4096),
@@ -530,8 +535,17 @@ Plan make_plan(const cavp_conv_desc* d) {
   IgemmParams& p = pl.p;
   p.N = d->N; p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.ldx = d->ldx; p.Cout = d->Cout; p.ldy = d->ldy;
   p.KW = d->KW; p.stride = d->stride; p.pad = d->pad; p.dil = d->dil; p.ldr = d->ldr; p.act = d->act;
-  p.Ho = (d->H + 2 * d->pad - d->dil * (d->KH - 1) - 1) / d->stride + 1;
-  p.Wo = (d->W + 2 * d->pad - d->dil * (d->KW - 1) - 1) / d->stride + 1;
+  const int up = d->up > 1 ? d->up : 1;
+  if (up > 1) {  // transposed conv: stride-1 gather over the zero-upsampled input, explicit output extent
+    if ((up & (up - 1)) || d->stride != 1 || d->Ho <= 0 || d->Wo <= 0) { pl.status = CAVP_ERR_UNSUPPORTED; return pl; }
+    p.Ho = d->Ho; p.Wo = d->Wo;
+  } else {
+    p.Ho = (d->H + 2 * d->pad - d->dil * (d->KH - 1) - 1) / d->stride + 1;
+    p.Wo = (d->W + 2 * d->pad - d->dil * (d->KW - 1) - 1) / d->stride + 1;
+  }
+  p.up_mask = up - 1;
+  p.up_shift = 0;
+  while ((1 << p.up_shift) < up) ++p.up_shift;
   if (p.Ho <= 0 || p.Wo <= 0) { pl.status = CAVP_ERR_BAD_ARG; return pl; }
   const long long M = (long long)d->N * p.Ho * p.Wo;
   if (M > 0x7fffffffll / 4) { pl.status = CAVP_ERR_UNSUPPORTED; return pl; }
@@ -544,13 +558,13 @@ Plan make_plan(const cavp_conv_desc* d) {
     bool hlive = false;
     for (int ho = 0; ho < p.Ho && !hlive; ++ho) {
       const int hi = ho * d->stride - d->pad + kh * d->dil;
-      hlive = hi >= 0 && hi < d->H;
+      hlive = hi >= 0 && (hi % up) == 0 && hi / up < d->H;
     }
     for (int kw = 0; kw < d->KW; ++kw) {
       bool wlive = false;
       for (int wo = 0; wo < p.Wo && !wlive; ++wo) {
         const int wi = wo * d->stride - d->pad + kw * d->dil;
-        wlive = wi >= 0 && wi < d->W;
+        wlive = wi >= 0 && (wi % up) == 0 && wi / up < d->W;
       }
       if (hlive && wlive) {
         p.taps |= (unsigned long long)(kh * d->KW + kw) << (4 * p.ntaps);

@@ -1,0 +1,258 @@
+// Weight gradient of conv / linear for gfx950:  dW[co][tap][ci] += sum_pix dY[pix][co] * X[pix @ tap][ci]
+//
+// A "TN" GEMM whose reduction dimension (pixels) is the SLOW dimension of both NHWC operands.  Design:
+// * One workgroup = (ci tile x co tile) of one live tap and one slice of the pixel range (split-K); results are
+//   added into the f32 OHWI gradient with hardware f32 atomics (the caller zeroes it).
+// * Both operands are streamed global -> LDS with LDS-DMA (buffer_load ... lds) exactly as they lie in memory:
+//   64 pixel rows x 256 bytes of channels per stage (128 bf16 / 64 f32 channels), two stages.  Rows that fall
+//   outside the image (padding taps), beyond the pixel range or beyond Cin/Cout are zero-filled by the buffer
+//   descriptor's bounds check.
+// * bf16: the MFMA 16x16x32 fragment (8 consecutive k = pixels for one channel) is gathered with the gfx950 LDS
+//   transpose read ds_read_b64_tr_b16: within a 16-lane group lane s passes the address of row r0 + (s >> 2),
+//   channels c0 + 4 (s & 3) .. +3 and lane i receives channel c0 + i of rows r0 .. r0+3 (probed on hardware:
+//   profiles/r01_ds_read_b64_tr_b16_probe.txt).  Two reads give the 8 k values.  The 32-byte chunk index of a row
+//   is XOR-swizzled with (row & 3) | ((row >> 3) & 1) << 2 (on the DMA source side) so the 8 rows of a 32-lane
+//   group fall into 8 different bank groups.
+// * f32: v_mfma_f32_16x16x4_f32 fragments are plain ds_read_b32 (lanes 0-15 = 16 consecutive channels of one row).
+// * X (rows = ci) is the MFMA A operand and dY (cols = co) the B operand, so a lane's 4 accumulators are 4
+//   consecutive ci of one co = 16 contiguous bytes of dW.
+#include "common.h"
+
+struct WgradParams {
+  const void* x;
+  const void* dy;
+  float* dw;
+  int N, H, W, Cin, ldx, Cout, ldy, KW, stride, pad, dil;
+  int Ho, Wo, M;
+  int ntaps, ntaps_all;
+  unsigned long long taps;
+  int tiles_co, tiles_ci, ksplit;
+  int rows_per_split;  // multiple of 64
+  int x_bytes, dy_bytes;
+};
+
+typedef short s16x4_t __attribute__((ext_vector_type(4)));
+
+template <typename T>
+__global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
+  constexpr int ES = (int)sizeof(T);
+  constexpr int TCH = 256 / ES;      // channels per tile row (256 bytes)
+  constexpr int BK = 64;             // pixel rows per stage
+  constexpr int STAGE = 2 * BK * 256;  // X tile + dY tile
+  constexpr int WT = TCH / 2;        // per-wave tile edge (2 x 2 waves)
+  constexpr int MB = WT / 16;        // 16x16 blocks per wave edge
+  constexpr unsigned kOOB = 0x80000000u;
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+  int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int tco = bid % p.tiles_co; bid /= p.tiles_co;
+  const int tci = bid % p.tiles_ci; bid /= p.tiles_ci;
+  const int ti = bid % p.ntaps;
+  const int z = bid / p.ntaps;
+  const int tap = (int)((p.taps >> (4 * ti)) & 15ull);
+  const int kh = tap / p.KW, kw = tap - kh * p.KW;
+  const int co_base = tco * TCH, ci_base = tci * TCH;
+  const int r_begin = z * p.rows_per_split;
+  int r_end = r_begin + p.rows_per_split;
+  if (r_end > p.M) r_end = p.M;
+
+  const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.dy, 0, p.dy_bytes, 0x00020000);
+
+  // DMA geometry: wave-instruction g (= wave + 4 i, i < 4) fills rows 4g .. 4g+3 of a tile; lane l lands at byte
+  // 16 l of that 1 KiB, i.e. row 4g + (l >> 4), physical 16-byte slot l & 15.
+  const int drow0 = 4 * wave + (lane >> 4);  // + 16 i
+  const int HoWo = p.Ho * p.Wo;
+  auto swz_key = [](int row) { return (row & 3) | (((row >> 3) & 1) << 2); };
+
+  auto gdma = [&](int r0, int buf) {
+    char* base = smem + buf * STAGE + wave * 1024;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = drow0 + 16 * i;
+      const int pix = r0 + row;
+      // logical channel byte offset of this lane inside the 256-byte row (inverse swizzle on the source)
+      const int chunk = ((lane & 15) >> 1) ^ swz_key(row);
+      const int cbyte = chunk * 32 + (lane & 1) * 16;
+      const int cel = cbyte / ES;
+      const bool pok = pix < r_end;
+      const int pp = pok ? pix : 0;
+      const int n = pp / HoWo, rr = pp - n * HoWo;
+      const int ho = rr / p.Wo, wo = rr - ho * p.Wo;
+      const int hi = ho * p.stride - p.pad + kh * p.dil, wi = wo * p.stride - p.pad + kw * p.dil;
+      const bool xok = pok && ((unsigned)hi < (unsigned)p.H) && ((unsigned)wi < (unsigned)p.W) && (ci_base + cel < p.Cin);
+      const unsigned xoff = (unsigned)((n * p.H + hi) * p.W + wi) * (unsigned)(p.ldx * ES) + (unsigned)((ci_base + cel) * ES);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (__attribute__((address_space(3))) void*)(base + i * 4096), 16,
+                                               (int)(xok ? xoff : kOOB), 0, 0, 0);
+      const bool yok = pok && (co_base + cel < p.Cout);
+      const unsigned yoff = (unsigned)pp * (unsigned)(p.ldy * ES) + (unsigned)((co_base + cel) * ES);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(yrsrc,
+                                               (__attribute__((address_space(3))) void*)(base + BK * 256 + i * 4096), 16,
+                                               (int)(yok ? yoff : kOOB), 0, 0, 0);
+    }
+  };
+
+  const int wci0 = (wave & 1) * WT, wco0 = (wave >> 1) * WT;  // wave's sub-tile origin (channels)
+  const int lrow = lane & 15, lgrp = lane >> 4;
+
+  f32x4_t acc[MB][MB];
+#pragma unroll
+  for (int a = 0; a < MB; ++a)
+#pragma unroll
+    for (int b = 0; b < MB; ++b) acc[a][b] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+  auto compute = [&](int buf) {
+    const char* xb = smem + buf * STAGE;
+    const char* yb = xb + BK * 256;
+    if constexpr (ES == 2) {
+#pragma unroll
+      for (int ks = 0; ks < BK / 32; ++ks) {
+        // rows this lane ADDRESSES: r0 + (s >> 2) with s = lane & 15; r0 = ks*32 + 8*lgrp (+4 for the second read)
+        const int ra = ks * 32 + 8 * lgrp + (lrow >> 2);
+        const int rb = ra + 4;
+        const int ka = swz_key(ra), kb = swz_key(rb);
+        const int sub = (lrow & 3) * 8;
+        u32x4_t af[MB], bfv[MB];
+#pragma unroll
+        for (int a = 0; a < MB; ++a) {
+          const int ch = (wci0 >> 4) + a;  // 32-byte chunk = 16 bf16 channels
+          const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+              (__attribute__((address_space(3))) s16x4_t*)(xb + ra * 256 + ((ch ^ ka) << 5) + sub));
+          const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+              (__attribute__((address_space(3))) s16x4_t*)(xb + rb * 256 + ((ch ^ kb) << 5) + sub));
+          const uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
+          af[a] = (u32x4_t){l2.x, l2.y, h2.x, h2.y};
+        }
+#pragma unroll
+        for (int b = 0; b < MB; ++b) {
+          const int ch = (wco0 >> 4) + b;
+          const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+              (__attribute__((address_space(3))) s16x4_t*)(yb + ra * 256 + ((ch ^ ka) << 5) + sub));
+          const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+              (__attribute__((address_space(3))) s16x4_t*)(yb + rb * 256 + ((ch ^ kb) << 5) + sub));
+          const uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
+          bfv[b] = (u32x4_t){l2.x, l2.y, h2.x, h2.y};
+        }
+#pragma unroll
+        for (int a = 0; a < MB; ++a)
+#pragma unroll
+          for (int b = 0; b < MB; ++b)
+            acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, af[a]),
+                                                                __builtin_bit_cast(bf16x8_t, bfv[b]), acc[a][b], 0, 0, 0);
+      }
+    } else {
+#pragma unroll 4
+      for (int ks = 0; ks < BK / 4; ++ks) {
+        const int r = ks * 4 + lgrp;  // k index of this lane
+        const int key = swz_key(r);
+        float af[MB], bfv[MB];
+#pragma unroll
+        for (int a = 0; a < MB; ++a) {
+          const int cb = (wci0 + a * 16 + lrow) * 4;  // logical byte offset in the row
+          af[a] = *(const float*)(xb + r * 256 + ((((cb >> 5) ^ key) << 5) | (cb & 31)));
+        }
+#pragma unroll
+        for (int b = 0; b < MB; ++b) {
+          const int cb = (wco0 + b * 16 + lrow) * 4;
+          bfv[b] = *(const float*)(yb + r * 256 + ((((cb >> 5) ^ key) << 5) | (cb & 31)));
+        }
+#pragma unroll
+        for (int a = 0; a < MB; ++a)
+#pragma unroll
+          for (int b = 0; b < MB; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[a], bfv[b], acc[a][b], 0, 0, 0);
+      }
+    }
+  };
+
+  if (r_begin < r_end) {
+    gdma(r_begin, 0);
+    __syncthreads();
+    int buf = 0;
+    for (int r0 = r_begin; r0 < r_end; r0 += BK) {
+      if (r0 + BK < r_end) gdma(r0 + BK, buf ^ 1);
+      compute(buf);
+      __syncthreads();
+      buf ^= 1;
+    }
+  }
+
+  // D[i = ci][j = co]: lane holds ci = 4*lgrp + {0..3} (rows) of co = lrow (col) in each 16x16 block
+#pragma unroll
+  for (int a = 0; a < MB; ++a) {
+#pragma unroll
+    for (int b = 0; b < MB; ++b) {
+      const int ci = ci_base + wci0 + a * 16 + lgrp * 4;
+      const int co = co_base + wco0 + b * 16 + lrow;
+      if (co < p.Cout) {
+        float* dst = p.dw + ((size_t)co * p.ntaps_all + tap) * p.Cin + ci;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (ci + e < p.Cin) atomicAdd(dst + e, acc[a][b][e]);
+      }
+    }
+  }
+}
+
+extern "C" int cavp_conv2d_wgrad_nhwc(const cavp_conv_desc* d, const void* x, const void* dy, float* dw, void* stream) {
+  if (!d || !x || !dy || !dw) return CAVP_ERR_BAD_ARG;
+  if (d->N <= 0 || d->H <= 0 || d->W <= 0 || d->Cin <= 0 || d->Cout <= 0 || d->KH <= 0 || d->KW <= 0 || d->stride <= 0 ||
+      d->dil <= 0 || d->pad < 0 || d->ldx < d->Cin || d->ldy < d->Cout)
+    return CAVP_ERR_BAD_ARG;
+  if (d->dtype != CAVP_F32 && d->dtype != CAVP_BF16) return CAVP_ERR_UNSUPPORTED;
+  const int es = d->dtype == CAVP_F32 ? 4 : 2;
+  const int VE = 16 / es;
+  if (d->Cin % VE || d->Cout % VE || d->ldx % VE || d->ldy % VE || d->KH * d->KW > 9) return CAVP_ERR_UNSUPPORTED;
+  if (((uintptr_t)x & 15) || ((uintptr_t)dy & 15)) return CAVP_ERR_ALIGN;
+  WgradParams p{};
+  p.x = x; p.dy = dy; p.dw = dw;
+  p.N = d->N; p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.ldx = d->ldx; p.Cout = d->Cout; p.ldy = d->ldy;
+  p.KW = d->KW; p.stride = d->stride; p.pad = d->pad; p.dil = d->dil;
+  p.Ho = (d->H + 2 * d->pad - d->dil * (d->KH - 1) - 1) / d->stride + 1;
+  p.Wo = (d->W + 2 * d->pad - d->dil * (d->KW - 1) - 1) / d->stride + 1;
+  if (p.Ho <= 0 || p.Wo <= 0) return CAVP_ERR_BAD_ARG;
+  const long long M = (long long)d->N * p.Ho * p.Wo;
+  const size_t xb = ((size_t)d->N * d->H * d->W - 1) * d->ldx * es + (size_t)d->Cin * es;
+  const size_t yb = ((size_t)M - 1) * d->ldy * es + (size_t)d->Cout * es;
+  if (M > 0x3fffffff || xb >= 0x7fffffffull || yb >= 0x7fffffffull) return CAVP_ERR_UNSUPPORTED;
+  p.M = (int)M; p.x_bytes = (int)xb; p.dy_bytes = (int)yb;
+  p.ntaps_all = d->KH * d->KW;
+  p.ntaps = 0; p.taps = 0;
+  for (int kh = 0; kh < d->KH; ++kh) {
+    bool hl = false;
+    for (int ho = 0; ho < p.Ho && !hl; ++ho) { const int hi = ho * d->stride - d->pad + kh * d->dil; hl = hi >= 0 && hi < d->H; }
+    for (int kw = 0; kw < d->KW; ++kw) {
+      bool wl = false;
+      for (int wo = 0; wo < p.Wo && !wl; ++wo) { const int wi = wo * d->stride - d->pad + kw * d->dil; wl = wi >= 0 && wi < d->W; }
+      if (hl && wl) { p.taps |= (unsigned long long)(kh * d->KW + kw) << (4 * p.ntaps); ++p.ntaps; }
+    }
+  }
+  if (p.ntaps == 0) return CAVP_OK;
+  const int TCH = 256 / es;
+  p.tiles_co = (d->Cout + TCH - 1) / TCH;
+  p.tiles_ci = (d->Cin + TCH - 1) / TCH;
+  const int base = p.tiles_co * p.tiles_ci * p.ntaps;
+  const int chunks = (p.M + 63) / 64;
+  int ks = d->splitk > 0 ? d->splitk : (1024 + base - 1) / base;
+  if (ks > chunks) ks = chunks;
+  if (ks < 1) ks = 1;
+  int cps = (chunks + ks - 1) / ks;  // 64-row chunks per split
+  ks = (chunks + cps - 1) / cps;
+  p.ksplit = ks;
+  p.rows_per_split = cps * 64;
+  const int nblk = base * ks;
+  const int lds = 2 * 2 * 64 * 256;
+  hipStream_t s = (hipStream_t)stream;
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)wgrad_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute((const void*)wgrad_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    attr = true;
+  }
+  if (d->dtype == CAVP_F32)
+    wgrad_kernel<float><<<nblk, 256, lds, s>>>(p);
+  else
+    wgrad_kernel<bf16_t><<<nblk, 256, lds, s>>>(p);
+  return hipGetLastError() == hipSuccess ? CAVP_OK : CAVP_ERR_LAUNCH;
+}

@@ -1,0 +1,1019 @@
+// Training-side bandwidth-bound kernels for gfx950: batch-statistics BatchNorm (forward statistics, finalize,
+// apply, backward reduce / apply), activation backward, column sums (bias grads), LayerNorm backward, the sigmoid
+// attention-gate backward, pooling / resize backward, cross-entropy forward+backward, small-Cin conv weight
+// gradient and weight (un)packing for the backward GEMMs.  NHWC rows, 16-byte channel vectors, f32 accumulation,
+// per-block partial reductions in LDS followed by one f32 atomic per (block, channel).
+#include "common.h"
+
+namespace {
+
+template <typename T> struct VecT;
+template <> struct VecT<float> {
+  static constexpr int VE = 4;
+  __device__ static __forceinline__ void load(const float* p, float* v) {
+    const float4 t = *(const float4*)p;
+    v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+  }
+  __device__ static __forceinline__ void store(float* p, const float* v) { *(float4*)p = make_float4(v[0], v[1], v[2], v[3]); }
+};
+template <> struct VecT<bf16_t> {
+  static constexpr int VE = 8;
+  __device__ static __forceinline__ void load(const bf16_t* p, float* v) {
+    const uint4 t = *(const uint4*)p;
+    const unsigned u[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      v[2 * i] = __uint_as_float(u[i] << 16);
+      v[2 * i + 1] = __uint_as_float(u[i] & 0xffff0000u);
+    }
+  }
+  __device__ static __forceinline__ void store(bf16_t* p, const float* v) {
+    uint4 t;
+    t.x = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16);
+    t.y = (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
+    t.z = (unsigned)f2bf(v[4]) | ((unsigned)f2bf(v[5]) << 16);
+    t.w = (unsigned)f2bf(v[6]) | ((unsigned)f2bf(v[7]) << 16);
+    *(uint4*)p = t;
+  }
+};
+
+__device__ __forceinline__ float act_grad_from_out(float y, int act) {  // d act(x)/dx expressed through y = act(x)
+  switch (act) {
+    case CAVP_ACT_RELU: return y > 0.f ? 1.f : 0.f;
+    case CAVP_ACT_LEAKY: return y > 0.f ? 1.f : 0.01f;
+    default: return 1.f;
+  }
+}
+__device__ __forceinline__ float gelu_grad(float x) {  // d/dx [0.5 x (1 + erf(x / sqrt 2))]
+  const float cdf = 0.5f * (1.f + erff(x * 0.70710678118654752f));
+  const float pdf = 0.3989422804014327f * expf(-0.5f * x * x);
+  return cdf + x * pdf;
+}
+
+inline int cdiv_h(long long a, long long b) { return (int)((a + b - 1) / b); }
+inline bool dt_ok(int dt) { return dt == CAVP_F32 || dt == CAVP_BF16; }
+inline bool al16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+#define CHECK_LAUNCH() return hipGetLastError() == hipSuccess ? CAVP_OK : CAVP_ERR_LAUNCH
+
+// ------------------------------------------------------------------------------------------------------------
+// Column reductions over [rows][C] (C contiguous).  256 threads = 16 column groups (VE channels each) x 16 row
+// lanes; grid.y = column chunks of 16*VE channels, grid.x = row chunks.  NACC accumulators per channel.
+// ------------------------------------------------------------------------------------------------------------
+struct ColArgs {
+  const void* a;   // primary tensor (z / dy / x)
+  const void* b;   // y (activation output) or nullptr
+  const void* c;   // z (pre-BN conv output) or nullptr
+  const float* mean;
+  const float* rstd;
+  float* out0;
+  float* out1;
+  int rows, C, lda, ldb, ldc, act, rows_per_block;
+};
+
+// MODE 0: out0 += sum a, out1 += sum a^2       (BN forward statistics)
+// MODE 1: g = a * act'(b); out0 += sum g, out1 += sum g * (c - mean) * rstd   (BN backward reduce)
+// MODE 2: out0 += sum a                        (bias gradient)
+template <typename T, int MODE>
+__global__ __launch_bounds__(256) void col_reduce_kernel(const ColArgs p) {
+  constexpr int VE = VecT<T>::VE;
+  __shared__ float red[2][16][16 * VE + 1];
+  const int cg = threadIdx.x & 15, rl = threadIdx.x >> 4;
+  const int c0 = (blockIdx.y * 16 + cg) * VE;
+  const bool col_ok = c0 < p.C;
+  float s0[VE], s1[VE];
+#pragma unroll
+  for (int e = 0; e < VE; ++e) s0[e] = s1[e] = 0.f;
+  float mu[VE], rs[VE];
+  if (MODE == 1 && col_ok) {
+#pragma unroll
+    for (int e = 0; e < VE; ++e) { mu[e] = p.mean[c0 + e]; rs[e] = p.rstd[c0 + e]; }
+  }
+  const long long r_begin = (long long)blockIdx.x * p.rows_per_block;
+  long long r_end = r_begin + p.rows_per_block;
+  if (r_end > p.rows) r_end = p.rows;
+  if (col_ok) {
+    for (long long r = r_begin + rl; r < r_end; r += 16) {
+      float a[VE];
+      VecT<T>::load((const T*)p.a + r * p.lda + c0, a);
+      if (MODE == 0) {
+#pragma unroll
+        for (int e = 0; e < VE; ++e) { s0[e] += a[e]; s1[e] += a[e] * a[e]; }
+      } else if (MODE == 1) {
+        float y[VE], z[VE];
+        VecT<T>::load((const T*)p.b + r * p.ldb + c0, y);
+        VecT<T>::load((const T*)p.c + r * p.ldc + c0, z);
+#pragma unroll
+        for (int e = 0; e < VE; ++e) {
+          const float g = a[e] * act_grad_from_out(y[e], p.act);
+          s0[e] += g;
+          s1[e] += g * (z[e] - mu[e]) * rs[e];
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < VE; ++e) s0[e] += a[e];
+      }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < VE; ++e) {
+    red[0][rl][cg * VE + e] = s0[e];
+    red[1][rl][cg * VE + e] = s1[e];
+  }
+  __syncthreads();
+  // 16*VE channels x (1 or 2) stats: thread t sums the 16 row lanes of one (stat, channel)
+  for (int i = threadIdx.x; i < 2 * 16 * VE; i += 256) {
+    const int st = i / (16 * VE), ch = i - st * (16 * VE);
+    if (MODE == 2 && st == 1) continue;
+    const int c = blockIdx.y * 16 * VE + ch;
+    if (c >= p.C) continue;
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) s += red[st][k][ch];
+    atomicAdd((st == 0 ? p.out0 : p.out1) + c, s);
+  }
+}
+
+template <int MODE>
+int launch_col_reduce(int dtype, ColArgs& a, hipStream_t s) {
+  const int VE = dtype == CAVP_F32 ? 4 : 8;
+  const int gy = cdiv_h(a.C, 16 * VE);
+  int gx = 2048 / gy;
+  if (gx < 1) gx = 1;
+  int rpb = cdiv_h(a.rows, gx);
+  if (rpb < 64) rpb = 64;
+  rpb = (rpb + 15) / 16 * 16;
+  gx = cdiv_h(a.rows, rpb);
+  a.rows_per_block = rpb;
+  if (dtype == CAVP_F32)
+    col_reduce_kernel<float, MODE><<<dim3(gx, gy), 256, 0, s>>>(a);
+  else
+    col_reduce_kernel<bf16_t, MODE><<<dim3(gx, gy), 256, 0, s>>>(a);
+  CHECK_LAUNCH();
+}
+
+__global__ void bn_finalize_kernel(const float* sum, const float* sumsq, float inv_count, float unbias,
+                                   const float* gamma, const float* beta, float eps, float momentum, float* rmean,
+                                   float* rvar, float* scale, float* shift, float* mean_out, float* rstd_out, int C) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  const float m = sum[c] * inv_count;
+  float var = sumsq[c] * inv_count - m * m;  // biased (normalisation) variance
+  if (var < 0.f) var = 0.f;
+  const float rstd = 1.f / sqrtf(var + eps);
+  const float sc = gamma[c] * rstd;
+  scale[c] = sc;
+  shift[c] = beta[c] - m * sc;
+  mean_out[c] = m;
+  rstd_out[c] = rstd;
+  if (rmean) {  // nn.BatchNorm2d running statistics: momentum update with the unbiased variance
+    rmean[c] = (1.f - momentum) * rmean[c] + momentum * m;
+    rvar[c] = (1.f - momentum) * rvar[c] + momentum * var * unbias;
+  }
+}
+
+// y = act(x * scale + shift + residual)
+template <typename T>
+__global__ __launch_bounds__(256) void scale_shift_act_kernel(const T* __restrict__ x, const float* __restrict__ scale,
+                                                              const float* __restrict__ shift, const T* __restrict__ res,
+                                                              T* __restrict__ y, long long rows, int C, int ldx, int ldr,
+                                                              int ldy, int act) {
+  constexpr int VE = VecT<T>::VE;
+  const int CV = C / VE;
+  const long long total = rows * CV;
+  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const long long r = i / CV;
+    const int c = (int)(i - r * CV) * VE;
+    float v[VE];
+    VecT<T>::load(x + r * ldx + c, v);
+    if (scale) {
+#pragma unroll
+      for (int e = 0; e < VE; ++e) v[e] = v[e] * scale[c + e] + (shift ? shift[c + e] : 0.f);
+    }
+    if (res) {
+      float rr[VE];
+      VecT<T>::load(res + r * ldr + c, rr);
+#pragma unroll
+      for (int e = 0; e < VE; ++e) v[e] += rr[e];
+    }
+#pragma unroll
+    for (int e = 0; e < VE; ++e) v[e] = apply_act(v[e], act);
+    VecT<T>::store(y + r * ldy + c, v);
+  }
+}
+
+// dz = gamma * rstd * (g - sum_g / M - zhat * sum_gz / M),  g = dy * act'(y);  optionally also writes g (skip path)
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ dy, const T* __restrict__ y,
+                                                           const T* __restrict__ z, const float* __restrict__ mean,
+                                                           const float* __restrict__ rstd,
+                                                           const float* __restrict__ gamma,
+                                                           const float* __restrict__ sum_g,
+                                                           const float* __restrict__ sum_gz, float inv_m, T* __restrict__ dz,
+                                                           T* __restrict__ g_out, long long rows, int C, int ld_dy,
+                                                           int ld_y, int ld_z, int ld_dz, int ld_g, int act) {
+  constexpr int VE = VecT<T>::VE;
+  const int CV = C / VE;
+  const long long total = rows * CV;
+  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const long long r = i / CV;
+    const int c = (int)(i - r * CV) * VE;
+    float a[VE], yy[VE], zz[VE], o[VE], g[VE];
+    VecT<T>::load(dy + r * ld_dy + c, a);
+    VecT<T>::load(y + r * ld_y + c, yy);
+    VecT<T>::load(z + r * ld_z + c, zz);
+#pragma unroll
+    for (int e = 0; e < VE; ++e) {
+      g[e] = a[e] * act_grad_from_out(yy[e], act);
+      const float zh = (zz[e] - mean[c + e]) * rstd[c + e];
+      o[e] = gamma[c + e] * rstd[c + e] * (g[e] - sum_g[c + e] * inv_m - zh * sum_gz[c + e] * inv_m);
+    }
+    VecT<T>::store(dz + r * ld_dz + c, o);
+    if (g_out) VecT<T>::store(g_out + r * ld_g + c, g);
+  }
+}
+
+// dx = dy * act'(.)   relu / leaky: from the output y;  gelu: from the pre-activation x
+template <typename T>
+__global__ __launch_bounds__(256) void act_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ ref,
+                                                      T* __restrict__ dx, long long rows, int C, int ld_dy, int ld_ref,
+                                                      int ld_dx, int act) {
+  constexpr int VE = VecT<T>::VE;
+  const int CV = C / VE;
+  const long long total = rows * CV;
+  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const long long r = i / CV;
+    const int c = (int)(i - r * CV) * VE;
+    float a[VE], b[VE];
+    VecT<T>::load(dy + r * ld_dy + c, a);
+    VecT<T>::load(ref + r * ld_ref + c, b);
+#pragma unroll
+    for (int e = 0; e < VE; ++e) a[e] *= (act == CAVP_ACT_GELU ? gelu_grad(b[e]) : act_grad_from_out(b[e], act));
+    VecT<T>::store(dx + r * ld_dx + c, a);
+  }
+}
+
+// out = a + b  (gradient accumulation of two same-shaped dense tensors)
+template <typename T>
+__global__ __launch_bounds__(256) void add_kernel(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ o,
+                                                  long long n) {
+  constexpr int VE = VecT<T>::VE;
+  for (long long i = (blockIdx.x * 256ll + threadIdx.x) * VE; i < n; i += (long long)gridDim.x * 256 * VE) {
+    float x[VE], y[VE];
+    VecT<T>::load(a + i, x);
+    VecT<T>::load(b + i, y);
+#pragma unroll
+    for (int e = 0; e < VE; ++e) x[e] += y[e];
+    VecT<T>::store(o + i, x);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// LayerNorm backward: one wave per row.  dx = rstd * (dyg - mean(dyg) - xhat * mean(dyg * xhat)), dyg = dy * gamma
+// dgamma += sum_rows dy * xhat, dbeta += sum_rows dy  (per-block LDS partials, one atomic per channel per block)
+// ------------------------------------------------------------------------------------------------------------
+template <typename T, int MAXC>
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+                                                            const float* __restrict__ gamma, T* __restrict__ dx,
+                                                            float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                            int rows, int C, int ld_dy, int ld_x, int ld_dx, float eps,
+                                                            int rows_per_block) {
+  constexpr int PL = MAXC / 64;  // channels per lane
+  __shared__ float part[2][4][MAXC];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  float ag[PL], ab[PL];
+#pragma unroll
+  for (int i = 0; i < PL; ++i) ag[i] = ab[i] = 0.f;
+  const int r_begin = blockIdx.x * rows_per_block;
+  int r_end = r_begin + rows_per_block;
+  if (r_end > rows) r_end = rows;
+  for (int r = r_begin + wv; r < r_end; r += 4) {
+    float xv[PL], dv[PL];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < PL; ++i) {
+      const int c = lane + 64 * i;
+      xv[i] = c < C ? Elem<T>::ld(x + (size_t)r * ld_x + c) : 0.f;
+      dv[i] = c < C ? Elem<T>::ld(dy + (size_t)r * ld_dy + c) : 0.f;
+      s += xv[i];
+    }
+    const float mean = wave_sum(s) / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < PL; ++i) {
+      const int c = lane + 64 * i;
+      const float d = c < C ? xv[i] - mean : 0.f;
+      q += d * d;
+    }
+    const float rstd = rsqrtf(wave_sum(q) / (float)C + eps);
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < PL; ++i) {
+      const int c = lane + 64 * i;
+      if (c < C) {
+        const float xh = (xv[i] - mean) * rstd;
+        const float dg = dv[i] * gamma[c];
+        s1 += dg;
+        s2 += dg * xh;
+        ag[i] += dv[i] * xh;
+        ab[i] += dv[i];
+        xv[i] = xh;
+        dv[i] = dg;
+      }
+    }
+    s1 = wave_sum(s1) / (float)C;
+    s2 = wave_sum(s2) / (float)C;
+#pragma unroll
+    for (int i = 0; i < PL; ++i) {
+      const int c = lane + 64 * i;
+      if (c < C) Elem<T>::st(dx + (size_t)r * ld_dx + c, rstd * (dv[i] - s1 - xv[i] * s2));
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < PL; ++i) {
+    part[0][wv][lane + 64 * i] = ag[i];
+    part[1][wv][lane + 64 * i] = ab[i];
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * C; i += 256) {
+    const int st = i / C, c = i - st * C;
+    const float s = part[st][0][c] + part[st][1][c] + part[st][2][c] + part[st][3][c];
+    atomicAdd((st == 0 ? dgamma : dbeta) + c, s);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// attention-gate backward (single key/value token).  grid = (chunks, B); one wave per token.
+//   ds_h = <do_h, v_h> (+ dattn);  da = ds * s (1 - s);  dq = da * scale * k;  dk += da * scale * q;  dv += s * do
+// ------------------------------------------------------------------------------------------------------------
+template <typename T, int MAXC>
+__global__ __launch_bounds__(256) void attn_gate_bwd_kernel(const T* __restrict__ dout, const T* __restrict__ q,
+                                                            const T* __restrict__ k, const T* __restrict__ v,
+                                                            const float* __restrict__ attn,
+                                                            const float* __restrict__ dattn, T* __restrict__ dq,
+                                                            float* __restrict__ dk, float* __restrict__ dv, int Tn,
+                                                            int heads, int hd, float scale, int tok_per_block) {
+  constexpr int PL = MAXC / 64;
+  __shared__ float part[2][4][MAXC];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, b = blockIdx.y;
+  const int C = heads * hd;
+  float kk[PL], vv[PL], adk[PL], adv[PL];
+  int hh[PL];
+#pragma unroll
+  for (int i = 0; i < PL; ++i) {
+    const int c = lane + 64 * i;
+    kk[i] = c < C ? Elem<T>::ld(k + (size_t)b * C + c) : 0.f;
+    vv[i] = c < C ? Elem<T>::ld(v + (size_t)b * C + c) : 0.f;
+    hh[i] = c < C ? c / hd : -1;
+    adk[i] = adv[i] = 0.f;
+  }
+  const int t_begin = blockIdx.x * tok_per_block;
+  int t_end = t_begin + tok_per_block;
+  if (t_end > Tn) t_end = Tn;
+  for (int t = t_begin + wv; t < t_end; t += 4) {
+    const size_t row = ((size_t)b * Tn + t) * C;
+    float dd[PL], qq[PL];
+#pragma unroll
+    for (int i = 0; i < PL; ++i) {
+      const int c = lane + 64 * i;
+      dd[i] = c < C ? Elem<T>::ld(dout + row + c) : 0.f;
+      qq[i] = c < C ? Elem<T>::ld(q + row + c) : 0.f;
+    }
+    float da_h[8];
+    for (int h = 0; h < heads; ++h) {
+      float s = 0.f;
+#pragma unroll
+      for (int i = 0; i < PL; ++i) s += (hh[i] == h) ? dd[i] * vv[i] : 0.f;
+      s = wave_sum(s);
+      const size_t ai = ((size_t)b * heads + h) * Tn + t;
+      if (dattn) s += dattn[ai];
+      const float g = attn[ai];
+      da_h[h] = s * g * (1.f - g) * scale;
+#pragma unroll
+      for (int i = 0; i < PL; ++i)
+        if (hh[i] == h) adv[i] += g * dd[i];
+    }
+#pragma unroll
+    for (int i = 0; i < PL; ++i) {
+      const int c = lane + 64 * i;
+      if (c < C) {
+        float da = 0.f;
+        for (int h = 0; h < heads; ++h) da = (hh[i] == h) ? da_h[h] : da;
+        Elem<T>::st(dq + row + c, da * kk[i]);
+        adk[i] += da * qq[i];
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < PL; ++i) {
+    part[0][wv][lane + 64 * i] = adk[i];
+    part[1][wv][lane + 64 * i] = adv[i];
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * C; i += 256) {
+    const int st = i / C, c = i - st * C;
+    const float s = part[st][0][c] + part[st][1][c] + part[st][2][c] + part[st][3][c];
+    atomicAdd((st == 0 ? dk : dv) + (size_t)b * C + c, s);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// max pool backward (gather form, deterministic): dx[p] = sum over windows containing p whose first arg-max is p
+// ------------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy,
+                                                          T* __restrict__ dx, int N, int H, int W, int C, int k,
+                                                          int stride, int pad, int Ho, int Wo) {
+  constexpr int VE = VecT<T>::VE;
+  const int CV = C / VE;
+  const long long total = (long long)N * H * W * CV;
+  for (long long idx = blockIdx.x * 256ll + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+    const int cv = (int)(idx % CV);
+    const long long pix = idx / CV;
+    const int wi = (int)(pix % W);
+    const int hi = (int)((pix / W) % H);
+    const int n = (int)(pix / ((long long)W * H));
+    float xc[VE], acc[VE];
+    VecT<T>::load(x + (size_t)pix * C + cv * VE, xc);
+#pragma unroll
+    for (int e = 0; e < VE; ++e) acc[e] = 0.f;
+    // windows (ho, wo) with ho*stride - pad <= hi < ho*stride - pad + k
+    int ho_lo = (hi + pad - k + stride) / stride;  // ceil((hi + pad - k + 1) / stride) for non-negative numerators
+    if (hi + pad - k + 1 <= 0) ho_lo = 0;
+    int ho_hi = (hi + pad) / stride;
+    if (ho_hi > Ho - 1) ho_hi = Ho - 1;
+    int wo_lo = (wi + pad - k + stride) / stride;
+    if (wi + pad - k + 1 <= 0) wo_lo = 0;
+    int wo_hi = (wi + pad) / stride;
+    if (wo_hi > Wo - 1) wo_hi = Wo - 1;
+    for (int ho = ho_lo; ho <= ho_hi; ++ho) {
+      for (int wo = wo_lo; wo <= wo_hi; ++wo) {
+        // does (hi, wi) win this window?  first maximum in (kh, kw) scan order wins (strict >), as in ATen
+        bool win[VE];
+#pragma unroll
+        for (int e = 0; e < VE; ++e) win[e] = true;
+        for (int kh = 0; kh < k; ++kh) {
+          const int h2 = ho * stride - pad + kh;
+          if ((unsigned)h2 >= (unsigned)H) continue;
+          for (int kw = 0; kw < k; ++kw) {
+            const int w2 = wo * stride - pad + kw;
+            if ((unsigned)w2 >= (unsigned)W) continue;
+            if (h2 == hi && w2 == wi) continue;
+            float o[VE];
+            VecT<T>::load(x + ((size_t)(n * H + h2) * W + w2) * C + cv * VE, o);
+            const bool before = (h2 < hi) || (h2 == hi && w2 < wi);
+#pragma unroll
+            for (int e = 0; e < VE; ++e) win[e] = win[e] && (before ? (xc[e] > o[e]) : (xc[e] >= o[e]));
+          }
+        }
+        float g[VE];
+        VecT<T>::load(dy + ((size_t)(n * Ho + ho) * Wo + wo) * C + cv * VE, g);
+#pragma unroll
+        for (int e = 0; e < VE; ++e) acc[e] += win[e] ? g[e] : 0.f;
+      }
+    }
+    VecT<T>::store(dx + (size_t)pix * C + cv * VE, acc);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// bilinear backward (gather form): dx[hi, wi] = sum_{ho, wo} wh(ho -> hi) * ww(wo -> wi) * dy[ho, wo]
+// ------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void src_index_t(int dst, int in, int out, int align, int& i0, int& i1, float& lam) {
+  float src;
+  if (align) {
+    const float sc = out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.f;
+    src = sc * (float)dst;
+  } else {
+    const float sc = (float)in / (float)out;
+    src = sc * ((float)dst + 0.5f) - 0.5f;
+    if (src < 0.f) src = 0.f;
+  }
+  i0 = (int)src;
+  if (i0 > in - 1) i0 = in - 1;
+  i1 = i0 + (i0 < in - 1 ? 1 : 0);
+  lam = src - (float)i0;
+}
+// conservative range of destination indices whose source footprint can include `src_i`
+__device__ __forceinline__ void dst_range(int src_i, int in, int out, int& lo, int& hi) {
+  const float ratio = (float)out / (float)(in > 1 ? in : 1);
+  lo = (int)floorf(((float)src_i - 1.5f) * ratio) - 2;
+  hi = (int)ceilf(((float)src_i + 1.5f) * ratio) + 2;
+  if (lo < 0) lo = 0;
+  if (hi > out - 1) hi = out - 1;
+}
+__device__ __forceinline__ float tap_weight(int dst, int src_i, int in, int out, int align) {
+  int i0, i1;
+  float lam;
+  src_index_t(dst, in, out, align, i0, i1, lam);
+  float w = 0.f;
+  if (i0 == src_i) w += 1.f - lam;
+  if (i1 == src_i) w += lam;
+  return w;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bilinear_bwd_nhwc_kernel(const T* __restrict__ dy, T* __restrict__ dx, int N,
+                                                                int Hi, int Wi, int C, int ld_dx, int Ho, int Wo,
+                                                                int ld_dy, int align) {
+  constexpr int VE = VecT<T>::VE;
+  const int CV = C / VE;
+  const long long total = (long long)N * Hi * Wi * CV;
+  for (long long idx = blockIdx.x * 256ll + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+    const int cv = (int)(idx % CV);
+    const long long pix = idx / CV;
+    const int wi = (int)(pix % Wi);
+    const int hi = (int)((pix / Wi) % Hi);
+    const int n = (int)(pix / ((long long)Wi * Hi));
+    int hlo, hhi, wlo, whi;
+    dst_range(hi, Hi, Ho, hlo, hhi);
+    dst_range(wi, Wi, Wo, wlo, whi);
+    float acc[VE];
+#pragma unroll
+    for (int e = 0; e < VE; ++e) acc[e] = 0.f;
+    for (int ho = hlo; ho <= hhi; ++ho) {
+      const float wh = tap_weight(ho, hi, Hi, Ho, align);
+      if (wh == 0.f) continue;
+      for (int wo = wlo; wo <= whi; ++wo) {
+        const float ww = tap_weight(wo, wi, Wi, Wo, align);
+        if (ww == 0.f) continue;
+        float g[VE];
+        VecT<T>::load(dy + ((size_t)(n * Ho + ho) * Wo + wo) * ld_dy + cv * VE, g);
+#pragma unroll
+        for (int e = 0; e < VE; ++e) acc[e] += wh * ww * g[e];
+      }
+    }
+    VecT<T>::store(dx + (size_t)pix * ld_dx + cv * VE, acc);
+  }
+}
+
+// dy: NCHW f32 [N][C][Ho][Wo] (only the first n_valid images carry gradient), dx: NHWC (T) [N][Hi][Wi][C]
+template <typename T>
+__global__ __launch_bounds__(256) void bilinear_bwd_from_nchw_kernel(const float* __restrict__ dy, T* __restrict__ dx,
+                                                                     int N, int n_valid, int Hi, int Wi, int C,
+                                                                     int ld_dx, int Ho, int Wo, int align) {
+  const long long total = (long long)N * Hi * Wi * C;
+  for (long long idx = blockIdx.x * 256ll + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+    const int c = (int)(idx % C);
+    const long long pix = idx / C;
+    const int wi = (int)(pix % Wi);
+    const int hi = (int)((pix / Wi) % Hi);
+    const int n = (int)(pix / ((long long)Wi * Hi));
+    float acc = 0.f;
+    if (n < n_valid) {
+      int hlo, hhi, wlo, whi;
+      dst_range(hi, Hi, Ho, hlo, hhi);
+      dst_range(wi, Wi, Wo, wlo, whi);
+      const float* base = dy + ((size_t)n * C + c) * Ho * Wo;
+      for (int ho = hlo; ho <= hhi; ++ho) {
+        const float wh = tap_weight(ho, hi, Hi, Ho, align);
+        if (wh == 0.f) continue;
+        for (int wo = wlo; wo <= whi; ++wo) {
+          const float ww = tap_weight(wo, wi, Wi, Wo, align);
+          if (ww != 0.f) acc += wh * ww * base[(size_t)ho * Wo + wo];
+        }
+      }
+    }
+    Elem<T>::st(dx + (size_t)pix * ld_dx + c, acc);
+  }
+}
+
+// x[n, p, c] += v[n, c] * alpha   (global-average-pool backward: alpha = 1 / HW)
+template <typename T>
+__global__ __launch_bounds__(256) void bcast_add_kernel(T* __restrict__ x, const float* __restrict__ v, float alpha,
+                                                        int N, int HW, int C, int ld) {
+  constexpr int VE = VecT<T>::VE;
+  const int CV = C / VE;
+  const long long total = (long long)N * HW * CV;
+  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const long long r = i / CV;
+    const int c = (int)(i - r * CV) * VE;
+    const int n = (int)(r / HW);
+    float a[VE];
+    VecT<T>::load(x + r * ld + c, a);
+#pragma unroll
+    for (int e = 0; e < VE; ++e) a[e] += alpha * v[(size_t)n * C + c + e];
+    VecT<T>::store(x + r * ld + c, a);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// cross entropy (ignore_index) on NCHW f32 logits: pass 1 = per-pixel loss + valid count; pass 2 = gradient
+// ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ce_fwd_kernel(const float* __restrict__ logits, const long long* __restrict__ label,
+                                                     int n_img, int C, long long HW, int ignore, float* __restrict__ acc) {
+  const long long total = (long long)n_img * HW;
+  float loss = 0.f, cnt = 0.f;
+  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const long long lb = label[i];
+    if (lb == ignore) continue;
+    const int n = (int)(i / HW);
+    const float* p = logits + (size_t)n * C * HW + (i - (long long)n * HW);
+    float m = -INFINITY;
+    for (int c = 0; c < C; ++c) m = fmaxf(m, p[(size_t)c * HW]);
+    float s = 0.f;
+    for (int c = 0; c < C; ++c) s += expf(p[(size_t)c * HW] - m);
+    loss += (m + logf(s)) - p[(size_t)lb * HW];
+    cnt += 1.f;
+  }
+  loss = wave_sum(loss);
+  cnt = wave_sum(cnt);
+  if ((threadIdx.x & 63) == 0) {
+    atomicAdd(acc, loss);
+    atomicAdd(acc + 1, cnt);
+  }
+}
+__global__ __launch_bounds__(256) void ce_bwd_kernel(const float* __restrict__ logits, const long long* __restrict__ label,
+                                                     int n_img, int n_total, int C, long long HW, int ignore,
+                                                     const float* __restrict__ acc, float gscale,
+                                                     float* __restrict__ dlogits) {
+  const long long total = (long long)n_total * HW;
+  const float inv = acc[1] > 0.f ? gscale / acc[1] : 0.f;
+  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int n = (int)(i / HW);
+    const long long off = (size_t)n * C * HW + (i - (long long)n * HW);
+    float* d = dlogits + off;
+    const long long lb = n < n_img ? label[i] : (long long)ignore;
+    if (lb == ignore) {
+      for (int c = 0; c < C; ++c) d[(size_t)c * HW] = 0.f;
+      continue;
+    }
+    const float* p = logits + off;
+    float m = -INFINITY;
+    for (int c = 0; c < C; ++c) m = fmaxf(m, p[(size_t)c * HW]);
+    float s = 0.f;
+    for (int c = 0; c < C; ++c) s += expf(p[(size_t)c * HW] - m);
+    const float is = 1.f / s;
+    for (int c = 0; c < C; ++c) {
+      const float sm = expf(p[(size_t)c * HW] - m) * is;
+      d[(size_t)c * HW] = (sm - (c == lb ? 1.f : 0.f)) * inv;
+    }
+  }
+}
+__global__ void ce_finish_kernel(const float* acc, float* loss) { loss[0] = acc[1] > 0.f ? acc[0] / acc[1] : 0.f; }
+
+// ------------------------------------------------------------------------------------------------------------
+// weight gradient of the small-Cin 3x3 conv (NCHW f32 input): dw[co][ci][kh][kw] += sum_p dy[p][co] * x[p @ tap]
+// block = one (ci, kh, kw) tap x a pixel chunk; thread = output channel; LDS-staged dy rows
+// ------------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void smallcin_wgrad_kernel(const float* __restrict__ x, const T* __restrict__ dy,
+                                                             float* __restrict__ dw, int N, int Cin, int H, int W,
+                                                             int Cout, int stride, int Ho, int Wo, int pix_per_block) {
+  const int tap = blockIdx.y;  // ci*9 + kh*3 + kw
+  const int ci = tap / 9, kh = (tap % 9) / 3, kw = tap % 3;
+  const long long M = (long long)N * Ho * Wo;
+  const long long p0 = (long long)blockIdx.x * pix_per_block;
+  long long p1 = p0 + pix_per_block;
+  if (p1 > M) p1 = M;
+  // thread layout: co = threadIdx.x % Cout, pixel lane = threadIdx.x / Cout
+  const int co = threadIdx.x % Cout, pl = threadIdx.x / Cout, npl = 256 / Cout;
+  float acc = 0.f;
+  for (long long p = p0 + pl; p < p1; p += npl) {
+    const int wo = (int)(p % Wo);
+    const int ho = (int)((p / Wo) % Ho);
+    const int n = (int)(p / ((long long)Wo * Ho));
+    const int hi = ho * stride - 1 + kh, wi = wo * stride - 1 + kw;
+    if ((unsigned)hi < (unsigned)H && (unsigned)wi < (unsigned)W) {
+      const float xv = x[(((size_t)n * Cin + ci) * H + hi) * W + wi];
+      acc += xv * Elem<T>::ld(dy + (size_t)p * Cout + co);
+    }
+  }
+  __shared__ float red[256];
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  if (pl == 0) {
+    float s = 0.f;
+    for (int j = 0; j < npl; ++j) s += red[j * Cout + co];
+    atomicAdd(dw + (size_t)co * Cin * 9 + tap, s);
+  }
+}
+
+// OHWI f32 gradient -> OIHW f32 parameter gradient (accumulate = add into existing .grad)
+__global__ void unpack_grad_kernel(const float* __restrict__ g, float* __restrict__ o, int Cout, int Cin, int KHW,
+                                   int accumulate) {
+  const long long total = (long long)Cout * Cin * KHW;
+  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    // i indexes the OIHW destination: (co*Cin + ci)*KHW + t ; source = (co*KHW + t)*Cin + ci
+    const int t = (int)(i % KHW);
+    const long long r = i / KHW;
+    const int ci = (int)(r % Cin);
+    const long long co = r / Cin;
+    const float v = g[(co * KHW + t) * Cin + ci];
+    o[i] = accumulate ? o[i] + v : v;
+  }
+}
+
+// dgrad weights: OIHW f32 -> [Cin][KH][KW][Cout] (dtype) with the taps flipped (rot180), i.e. the OHWI weight of the
+// transposed convolution
+template <typename T>
+__global__ void pack_dgrad_kernel(const float* __restrict__ w, T* __restrict__ o, int Cout, int Cin, int KH, int KW) {
+  const long long total = (long long)Cout * Cin * KH * KW;
+  const int KHW = KH * KW;
+  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    // destination i = ((ci*KH + kh')*KW + kw')*Cout + co
+    const int co = (int)(i % Cout);
+    const long long r = i / Cout;
+    const int t = (int)(r % KHW);
+    const int ci = (int)(r / KHW);
+    const int kh = KH - 1 - t / KW, kw = KW - 1 - t % KW;
+    Elem<T>::st(o + i, w[(((size_t)co * Cin + ci) * KH + kh) * KW + kw]);
+  }
+}
+
+}  // namespace
+
+extern "C" int cavp_colstats(int32_t dtype, const void* x, int64_t rows, int32_t C, int32_t ldx, float* sum,
+                             float* sumsq, void* stream) {
+  if (!x || !sum || !sumsq || rows <= 0 || C <= 0 || ldx < C) return CAVP_ERR_BAD_ARG;
+  if (!dt_ok(dtype) || rows > 0x7fffffff) return CAVP_ERR_UNSUPPORTED;
+  const int VE = dtype == CAVP_F32 ? 4 : 8;
+  if (C % VE || ldx % VE) return CAVP_ERR_UNSUPPORTED;
+  if (!al16(x)) return CAVP_ERR_ALIGN;
+  ColArgs a{};
+  a.a = x; a.out0 = sum; a.out1 = sumsq; a.rows = (int)rows; a.C = C; a.lda = ldx;
+  return launch_col_reduce<0>(dtype, a, (hipStream_t)stream);
+}
+
+extern "C" int cavp_bn_finalize(const float* sum, const float* sumsq, int64_t count, const float* gamma,
+                                const float* beta, float eps, float momentum, float* running_mean, float* running_var,
+                                float* scale, float* shift, float* mean, float* rstd, int32_t C, void* stream) {
+  if (!sum || !sumsq || !gamma || !beta || !scale || !shift || !mean || !rstd || count <= 0 || C <= 0)
+    return CAVP_ERR_BAD_ARG;
+  if ((running_mean == nullptr) != (running_var == nullptr)) return CAVP_ERR_BAD_ARG;
+  const float unbias = count > 1 ? (float)((double)count / (double)(count - 1)) : 1.f;
+  bn_finalize_kernel<<<(C + 255) / 256, 256, 0, (hipStream_t)stream>>>(sum, sumsq, (float)(1.0 / (double)count), unbias,
+                                                                     gamma, beta, eps, momentum, running_mean,
+                                                                     running_var, scale, shift, mean, rstd, C);
+  CHECK_LAUNCH();
+}
+
+extern "C" int cavp_scale_shift_act(int32_t dtype, const void* x, const float* scale, const float* shift,
+                                    const void* residual, void* y, int64_t rows, int32_t C, int32_t ldx, int32_t ldr,
+                                    int32_t ldy, int32_t act, void* stream) {
+  if (!x || !y || rows <= 0 || C <= 0 || ldx < C || ldy < C || (residual && ldr < C)) return CAVP_ERR_BAD_ARG;
+  if (!dt_ok(dtype)) return CAVP_ERR_UNSUPPORTED;
+  const int VE = dtype == CAVP_F32 ? 4 : 8;
+  if (C % VE || ldx % VE || ldy % VE || (residual && ldr % VE)) return CAVP_ERR_UNSUPPORTED;
+  if (!al16(x) || !al16(y) || (residual && !al16(residual))) return CAVP_ERR_ALIGN;
+  long long nb = (rows * (C / VE) + 255) / 256;
+  if (nb > 16384) nb = 16384;
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == CAVP_F32)
+    scale_shift_act_kernel<float><<<(int)nb, 256, 0, s>>>((const float*)x, scale, shift, (const float*)residual, (float*)y, rows, C, ldx, ldr, ldy, act);
+  else
+    scale_shift_act_kernel<bf16_t><<<(int)nb, 256, 0, s>>>((const bf16_t*)x, scale, shift, (const bf16_t*)residual, (bf16_t*)y, rows, C, ldx, ldr, ldy, act);
+  CHECK_LAUNCH();
+}
+
+extern "C" int cavp_bn_act_bwd_reduce(int32_t dtype, const void* dy, const void* y, const void* z, const float* mean,
+                                      const float* rstd, int64_t rows, int32_t C, int32_t ld_dy, int32_t ld_y,
+                                      int32_t ld_z, int32_t act, float* sum_g, float* sum_gz, void* stream) {
+  if (!dy || !y || !z || !mean || !rstd || !sum_g || !sum_gz || rows <= 0 || C <= 0) return CAVP_ERR_BAD_ARG;
+  if (!dt_ok(dtype) || rows > 0x7fffffff) return CAVP_ERR_UNSUPPORTED;
+  const int VE = dtype == CAVP_F32 ? 4 : 8;
+  if (C % VE || ld_dy % VE || ld_y % VE || ld_z % VE) return CAVP_ERR_UNSUPPORTED;
+  if (!al16(dy) || !al16(y) || !al16(z)) return CAVP_ERR_ALIGN;
+  ColArgs a{};
+  a.a = dy; a.b = y; a.c = z; a.mean = mean; a.rstd = rstd; a.out0 = sum_g; a.out1 = sum_gz;
+  a.rows = (int)rows; a.C = C; a.lda = ld_dy; a.ldb = ld_y; a.ldc = ld_z; a.act = act;
+  return launch_col_reduce<1>(dtype, a, (hipStream_t)stream);
+}
+
+extern "C" int cavp_bn_act_bwd_apply(int32_t dtype, const void* dy, const void* y, const void* z, const float* mean,
+                                     const float* rstd, const float* gamma, const float* sum_g, const float* sum_gz,
+                                     int64_t rows, int32_t C, int32_t ld_dy, int32_t ld_y, int32_t ld_z, int32_t act,
+                                     void* dz, int32_t ld_dz, void* g_out, int32_t ld_g, void* stream) {
+  if (!dy || !y || !z || !mean || !rstd || !gamma || !sum_g || !sum_gz || !dz || rows <= 0 || C <= 0)
+    return CAVP_ERR_BAD_ARG;
+  if (!dt_ok(dtype)) return CAVP_ERR_UNSUPPORTED;
+  const int VE = dtype == CAVP_F32 ? 4 : 8;
+  if (C % VE || ld_dy % VE || ld_y % VE || ld_z % VE || ld_dz % VE || (g_out && ld_g % VE)) return CAVP_ERR_UNSUPPORTED;
+  if (!al16(dy) || !al16(y) || !al16(z) || !al16(dz) || (g_out && !al16(g_out))) return CAVP_ERR_ALIGN;
+  long long nb = (rows * (C / VE) + 255) / 256;
+  if (nb > 16384) nb = 16384;
+  const float inv_m = (float)(1.0 / (double)rows);
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == CAVP_F32)
+    bn_bwd_apply_kernel<float><<<(int)nb, 256, 0, s>>>((const float*)dy, (const float*)y, (const float*)z, mean, rstd, gamma, sum_g, sum_gz, inv_m, (float*)dz, (float*)g_out, rows, C, ld_dy, ld_y, ld_z, ld_dz, ld_g, act);
+  else
+    bn_bwd_apply_kernel<bf16_t><<<(int)nb, 256, 0, s>>>((const bf16_t*)dy, (const bf16_t*)y, (const bf16_t*)z, mean, rstd, gamma, sum_g, sum_gz, inv_m, (bf16_t*)dz, (bf16_t*)g_out, rows, C, ld_dy, ld_y, ld_z, ld_dz, ld_g, act);
+  CHECK_LAUNCH();
+}
+
+extern "C" int cavp_act_bwd(int32_t dtype, const void* dy, const void* ref, void* dx, int64_t rows, int32_t C,
+                            int32_t ld_dy, int32_t ld_ref, int32_t ld_dx, int32_t act, void* stream) {
+  if (!dy || !ref || !dx || rows <= 0 || C <= 0) return CAVP_ERR_BAD_ARG;
+  if (!dt_ok(dtype)) return CAVP_ERR_UNSUPPORTED;
+  const int VE = dtype == CAVP_F32 ? 4 : 8;
+  if (C % VE || ld_dy % VE || ld_ref % VE || ld_dx % VE) return CAVP_ERR_UNSUPPORTED;
+  if (!al16(dy) || !al16(ref) || !al16(dx)) return CAVP_ERR_ALIGN;
+  long long nb = (rows * (C / VE) + 255) / 256;
+  if (nb > 16384) nb = 16384;
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == CAVP_F32)
+    act_bwd_kernel<float><<<(int)nb, 256, 0, s>>>((const float*)dy, (const float*)ref, (float*)dx, rows, C, ld_dy, ld_ref, ld_dx, act);
+  else
+    act_bwd_kernel<bf16_t><<<(int)nb, 256, 0, s>>>((const bf16_t*)dy, (const bf16_t*)ref, (bf16_t*)dx, rows, C, ld_dy, ld_ref, ld_dx, act);
+  CHECK_LAUNCH();
+}
+
+extern "C" int cavp_add(int32_t dtype, const void* a, const void* b, void* out, int64_t n, void* stream) {
+  if (!a || !b || !out || n <= 0) return CAVP_ERR_BAD_ARG;
+  if (!dt_ok(dtype)) return CAVP_ERR_UNSUPPORTED;
+  const int VE = dtype == CAVP_F32 ? 4 : 8;
+  if (n % VE) return CAVP_ERR_UNSUPPORTED;
+  if (!al16(a) || !al16(b) || !al16(out)) return CAVP_ERR_ALIGN;
+  long long nb = (n / VE + 255) / 256;
+  if (nb > 16384) nb = 16384;
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == CAVP_F32)
+    add_kernel<float><<<(int)nb, 256, 0, s>>>((const float*)a, (const float*)b, (float*)out, n);
+  else
+    add_kernel<bf16_t><<<(int)nb, 256, 0, s>>>((const bf16_t*)a, (const bf16_t*)b, (bf16_t*)out, n);
+  CHECK_LAUNCH();
+}
+
+extern "C" int cavp_colsum(int32_t dtype, const void* x, int64_t rows, int32_t C, int32_t ldx, float* out,
+                           void* stream) {
+  if (!x || !out || rows <= 0 || C <= 0 || ldx < C) return CAVP_ERR_BAD_ARG;
+  if (!dt_ok(dtype) || rows > 0x7fffffff) return CAVP_ERR_UNSUPPORTED;
+  const int VE = dtype == CAVP_F32 ? 4 : 8;
+  if (C % VE || ldx % VE) return CAVP_ERR_UNSUPPORTED;
+  if (!al16(x)) return CAVP_ERR_ALIGN;
+  ColArgs a{};
+  a.a = x; a.out0 = out; a.out1 = out; a.rows = (int)rows; a.C = C; a.lda = ldx;
+  return launch_col_reduce<2>(dtype, a, (hipStream_t)stream);
+}
+
+extern "C" int cavp_layernorm_bwd(int32_t dtype, const void* dy, const void* x, const float* gamma, void* dx,
+                                  float* dgamma, float* dbeta, int32_t rows, int32_t C, int32_t ld_dy, int32_t ld_x,
+                                  int32_t ld_dx, float eps, void* stream) {
+  if (!dy || !x || !gamma || !dx || !dgamma || !dbeta || rows <= 0 || C <= 0) return CAVP_ERR_BAD_ARG;
+  if (!dt_ok(dtype) || C > 1280) return CAVP_ERR_UNSUPPORTED;
+  int gx = 1024;
+  int rpb = (rows + gx - 1) / gx;
+  if (rpb < 4) rpb = 4;
+  rpb = (rpb + 3) / 4 * 4;
+  gx = (rows + rpb - 1) / rpb;
+  hipStream_t s = (hipStream_t)stream;
+#define LN_BWD(T, MAXC) layernorm_bwd_kernel<T, MAXC><<<gx, 256, 0, s>>>((const T*)dy, (const T*)x, gamma, (T*)dx, dgamma, dbeta, rows, C, ld_dy, ld_x, ld_dx, eps, rpb)
+  if (dtype == CAVP_F32) {
+    if (C <= 320) LN_BWD(float, 320); else LN_BWD(float, 1280);
+  } else {
+    if (C <= 320) LN_BWD(bf16_t, 320); else LN_BWD(bf16_t, 1280);
+  }
+#undef LN_BWD
+  CHECK_LAUNCH();
+}
+
+extern "C" int cavp_attn_gate_bwd(int32_t dtype, const void* dout, const void* q, const void* k, const void* v,
+                                  const float* attn, const float* dattn, void* dq, float* dk, float* dv, int32_t B,
+                                  int32_t T, int32_t heads, int32_t hd, float scale, void* stream) {
+  if (!dout || !q || !k || !v || !attn || !dq || !dk || !dv || B <= 0 || T <= 0 || heads <= 0 || hd <= 0)
+    return CAVP_ERR_BAD_ARG;
+  if (!dt_ok(dtype) || heads > 8 || heads * hd > 320) return CAVP_ERR_UNSUPPORTED;
+  int gx = 2048 / B;
+  if (gx < 1) gx = 1;
+  int tpb = (T + gx - 1) / gx;
+  if (tpb < 4) tpb = 4;
+  tpb = (tpb + 3) / 4 * 4;
+  gx = (T + tpb - 1) / tpb;
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == CAVP_F32)
+    attn_gate_bwd_kernel<float, 320><<<dim3(gx, B), 256, 0, s>>>((const float*)dout, (const float*)q, (const float*)k, (const float*)v, attn, dattn, (float*)dq, dk, dv, T, heads, hd, scale, tpb);
+  else
+    attn_gate_bwd_kernel<bf16_t, 320><<<dim3(gx, B), 256, 0, s>>>((const bf16_t*)dout, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, attn, dattn, (bf16_t*)dq, dk, dv, T, heads, hd, scale, tpb);
+  CHECK_LAUNCH();
+}
+
+extern "C" int cavp_maxpool_bwd_nhwc(int32_t dtype, const void* x, const void* dy, void* dx, int32_t N, int32_t H,
+                                     int32_t W, int32_t C, int32_t k, int32_t stride, int32_t pad, void* stream) {
+  if (!x || !dy || !dx || N <= 0 || H <= 0 || W <= 0 || C <= 0 || k <= 0 || stride <= 0 || pad < 0) return CAVP_ERR_BAD_ARG;
+  if (!dt_ok(dtype)) return CAVP_ERR_UNSUPPORTED;
+  const int VE = dtype == CAVP_F32 ? 4 : 8;
+  if (C % VE) return CAVP_ERR_UNSUPPORTED;
+  if (!al16(x) || !al16(dy) || !al16(dx)) return CAVP_ERR_ALIGN;
+  const int Ho = (H + 2 * pad - k) / stride + 1, Wo = (W + 2 * pad - k) / stride + 1;
+  long long nb = ((long long)N * H * W * (C / VE) + 255) / 256;
+  if (nb > 32768) nb = 32768;
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == CAVP_F32)
+    maxpool_bwd_kernel<float><<<(int)nb, 256, 0, s>>>((const float*)x, (const float*)dy, (float*)dx, N, H, W, C, k, stride, pad, Ho, Wo);
+  else
+    maxpool_bwd_kernel<bf16_t><<<(int)nb, 256, 0, s>>>((const bf16_t*)x, (const bf16_t*)dy, (bf16_t*)dx, N, H, W, C, k, stride, pad, Ho, Wo);
+  CHECK_LAUNCH();
+}
+
+extern "C" int cavp_bilinear_bwd_nhwc(int32_t dtype, const void* dy, void* dx, int32_t N, int32_t Hi, int32_t Wi,
+                                      int32_t C, int32_t ld_dx, int32_t Ho, int32_t Wo, int32_t ld_dy,
+                                      int32_t align_corners, void* stream) {
+  if (!dy || !dx || N <= 0 || Hi <= 0 || Wi <= 0 || Ho <= 0 || Wo <= 0 || C <= 0 || ld_dx < C || ld_dy < C)
+    return CAVP_ERR_BAD_ARG;
+  if (!dt_ok(dtype)) return CAVP_ERR_UNSUPPORTED;
+  const int VE = dtype == CAVP_F32 ? 4 : 8;
+  if (C % VE || ld_dx % VE || ld_dy % VE) return CAVP_ERR_UNSUPPORTED;
+  if (!al16(dy) || !al16(dx)) return CAVP_ERR_ALIGN;
+  long long nb = ((long long)N * Hi * Wi * (C / VE) + 255) / 256;
+  if (nb > 32768) nb = 32768;
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == CAVP_F32)
+    bilinear_bwd_nhwc_kernel<float><<<(int)nb, 256, 0, s>>>((const float*)dy, (float*)dx, N, Hi, Wi, C, ld_dx, Ho, Wo, ld_dy, align_corners);
+  else
+    bilinear_bwd_nhwc_kernel<bf16_t><<<(int)nb, 256, 0, s>>>((const bf16_t*)dy, (bf16_t*)dx, N, Hi, Wi, C, ld_dx, Ho, Wo, ld_dy, align_corners);
+  CHECK_LAUNCH();
+}
+
+extern "C" int cavp_bilinear_bwd_nchw_to_nhwc(int32_t dtype, const float* dy_nchw, void* dx, int32_t N,
+                                              int32_t n_valid, int32_t Hi, int32_t Wi, int32_t C, int32_t ld_dx,
+                                              int32_t Ho, int32_t Wo, int32_t align_corners, void* stream) {
+  if (!dy_nchw || !dx || N <= 0 || n_valid < 0 || n_valid > N || Hi <= 0 || Wi <= 0 || Ho <= 0 || Wo <= 0 || C <= 0 ||
+      ld_dx < C)
+    return CAVP_ERR_BAD_ARG;
+  if (!dt_ok(dtype)) return CAVP_ERR_UNSUPPORTED;
+  long long nb = ((long long)N * Hi * Wi * C + 255) / 256;
+  if (nb > 32768) nb = 32768;
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == CAVP_F32)
+    bilinear_bwd_from_nchw_kernel<float><<<(int)nb, 256, 0, s>>>(dy_nchw, (float*)dx, N, n_valid, Hi, Wi, C, ld_dx, Ho, Wo, align_corners);
+  else
+    bilinear_bwd_from_nchw_kernel<bf16_t><<<(int)nb, 256, 0, s>>>(dy_nchw, (bf16_t*)dx, N, n_valid, Hi, Wi, C, ld_dx, Ho, Wo, align_corners);
+  CHECK_LAUNCH();
+}
+
+extern "C" int cavp_bcast_add_nhwc(int32_t dtype, void* x, const float* v, float alpha, int32_t N, int32_t HW,
+                                   int32_t C, int32_t ld, void* stream) {
+  if (!x || !v || N <= 0 || HW <= 0 || C <= 0 || ld < C) return CAVP_ERR_BAD_ARG;
+  if (!dt_ok(dtype)) return CAVP_ERR_UNSUPPORTED;
+  const int VE = dtype == CAVP_F32 ? 4 : 8;
+  if (C % VE || ld % VE) return CAVP_ERR_UNSUPPORTED;
+  if (!al16(x)) return CAVP_ERR_ALIGN;
+  long long nb = ((long long)N * HW * (C / VE) + 255) / 256;
+  if (nb > 16384) nb = 16384;
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == CAVP_F32)
+    bcast_add_kernel<float><<<(int)nb, 256, 0, s>>>((float*)x, v, alpha, N, HW, C, ld);
+  else
+    bcast_add_kernel<bf16_t><<<(int)nb, 256, 0, s>>>((bf16_t*)x, v, alpha, N, HW, C, ld);
+  CHECK_LAUNCH();
+}
+
+extern "C" int cavp_ce_loss_nchw(const float* logits, const int64_t* labels, int32_t n_img, int32_t n_total, int32_t C,
+                                 int64_t HW, int32_t ignore_index, float grad_scale, float* loss, float* dlogits,
+                                 float* scratch2, void* stream) {
+  if (!logits || !labels || !loss || !scratch2 || n_img <= 0 || n_total < n_img || C <= 0 || HW <= 0)
+    return CAVP_ERR_BAD_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  if (hipMemsetAsync(scratch2, 0, 2 * sizeof(float), s) != hipSuccess) return CAVP_ERR_LAUNCH;
+  long long nb = ((long long)n_img * HW + 255) / 256;
+  if (nb > 4096) nb = 4096;
+  ce_fwd_kernel<<<(int)nb, 256, 0, s>>>(logits, (const long long*)labels, n_img, C, HW, ignore_index, scratch2);
+  ce_finish_kernel<<<1, 1, 0, s>>>(scratch2, loss);
+  if (dlogits) {
+    long long nb2 = ((long long)n_total * HW + 255) / 256;
+    if (nb2 > 8192) nb2 = 8192;
+    ce_bwd_kernel<<<(int)nb2, 256, 0, s>>>(logits, (const long long*)labels, n_img, n_total, C, HW, ignore_index,
+                                          scratch2, grad_scale, dlogits);
+  }
+  CHECK_LAUNCH();
+}
+
+extern "C" int cavp_conv3x3_smallcin_wgrad(int32_t dtype, const float* x_nchw, const void* dy_nhwc, float* dw_oihw,
+                                           int32_t N, int32_t Cin, int32_t H, int32_t W, int32_t Cout, int32_t stride,
+                                           void* stream) {
+  if (!x_nchw || !dy_nhwc || !dw_oihw || N <= 0 || H <= 0 || W <= 0 || stride <= 0) return CAVP_ERR_BAD_ARG;
+  if (!dt_ok(dtype) || Cin < 1 || Cin > 3 || Cout > 256 || 256 % Cout) return CAVP_ERR_UNSUPPORTED;
+  const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
+  const long long M = (long long)N * Ho * Wo;
+  int gx = 256;
+  int ppb = (int)((M + gx - 1) / gx);
+  gx = (int)((M + ppb - 1) / ppb);
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == CAVP_F32)
+    smallcin_wgrad_kernel<float><<<dim3(gx, Cin * 9), 256, 0, s>>>(x_nchw, (const float*)dy_nhwc, dw_oihw, N, Cin, H, W, Cout, stride, Ho, Wo, ppb);
+  else
+    smallcin_wgrad_kernel<bf16_t><<<dim3(gx, Cin * 9), 256, 0, s>>>(x_nchw, (const bf16_t*)dy_nhwc, dw_oihw, N, Cin, H, W, Cout, stride, Ho, Wo, ppb);
+  CHECK_LAUNCH();
+}
+
+extern "C" int cavp_unpack_weight_grad(const float* g_ohwi, float* g_oihw, int32_t Cout, int32_t Cin, int32_t KH,
+                                       int32_t KW, int32_t accumulate, void* stream) {
+  if (!g_ohwi || !g_oihw || Cout <= 0 || Cin <= 0 || KH <= 0 || KW <= 0) return CAVP_ERR_BAD_ARG;
+  long long nb = ((long long)Cout * Cin * KH * KW + 255) / 256;
+  if (nb > 8192) nb = 8192;
+  unpack_grad_kernel<<<(int)nb, 256, 0, (hipStream_t)stream>>>(g_ohwi, g_oihw, Cout, Cin, KH * KW, accumulate);
+  CHECK_LAUNCH();
+}
+
+extern "C" int cavp_pack_weight_dgrad(int32_t dtype, const float* w_oihw, void* w_t, int32_t Cout, int32_t Cin,
+                                      int32_t KH, int32_t KW, void* stream) {
+  if (!w_oihw || !w_t || Cout <= 0 || Cin <= 0 || KH <= 0 || KW <= 0) return CAVP_ERR_BAD_ARG;
+  if (!dt_ok(dtype)) return CAVP_ERR_UNSUPPORTED;
+  long long nb = ((long long)Cout * Cin * KH * KW + 255) / 256;
+  if (nb > 8192) nb = 8192;
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == CAVP_F32)
+    pack_dgrad_kernel<float><<<(int)nb, 256, 0, s>>>(w_oihw, (float*)w_t, Cout, Cin, KH, KW);
+  else
+    pack_dgrad_kernel<bf16_t><<<(int)nb, 256, 0, s>>>(w_oihw, (bf16_t*)w_t, Cout, Cin, KH, KW);
+  CHECK_LAUNCH();
+}

@@ -1,0 +1,287 @@
+"""ctypes wrappers for the training-side C-ABI entry points (include/cavp_hip.h, second half).  Same rules as ops.py:
+torch supplies device memory and the current stream only."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib, ops
+from ._lib import ConvDesc
+from .ops import _need_gpu, _nhwc, _ptr, _stream, dtype_code
+
+
+def _rows(t: torch.Tensor) -> Tuple[int, int, int]:
+    """(rows, C, ld) of a tensor viewed as [rows][C] with uniform row stride ld (NHWC views, [B,T,C], [M,C])."""
+    c = t.shape[-1]
+    if t.dim() == 1:
+        return 1, c, c
+    if t.stride(-1) != 1 and c > 1:
+        raise _lib.CavpError("last dim must be contiguous")
+    lead = [(s, st) for s, st in zip(t.shape[:-1], t.stride()[:-1]) if s > 1]
+    rows = 1
+    for s, _ in lead:
+        rows *= s
+    if not lead:
+        return 1, c, c
+    ld = lead[-1][1]
+    exp = ld
+    for s, st in reversed(lead):
+        if st != exp:
+            raise _lib.CavpError(f"not a uniform-row view: shape {tuple(t.shape)} stride {t.stride()}")
+        exp *= s
+    if ld < c:
+        raise _lib.CavpError("row stride smaller than the row")
+    return rows, c, ld
+
+
+def _check(st, what):
+    _lib.check(st, what)
+
+
+def _s():
+    return C.c_void_p(_stream())
+
+
+def conv2d_dgrad(dy: torch.Tensor, w_t: torch.Tensor, dx: torch.Tensor, *, kh: int, kw: int, stride: int, pad: int,
+                 dil: int, residual: Optional[torch.Tensor] = None, scale=None, shift=None, act: int = 0) -> torch.Tensor:
+    """Data gradient of a forward conv (kh x kw, stride, pad, dil): dx = conv_transpose(dy, w) (+ residual).
+    dy: [N,Ho,Wo,Cout_f] view, w_t: cavp_pack_weight_dgrad weights [Cin_f][kh][kw][Cout_f], dx: [N,H,W,Cin_f] view."""
+    _need_gpu(dy, w_t, dx, residual)
+    lib = _lib.load()
+    n, ho, wo, cof, ldx = _nhwc(dy)
+    n2, h, w, cif, ldy = _nhwc(dx)
+    if n2 != n or w_t.numel() != cif * kh * kw * cof or w_t.dtype != dy.dtype or dx.dtype != dy.dtype:
+        raise _lib.CavpError("conv2d_dgrad: shape / dtype mismatch")
+    ldr = 0
+    if residual is not None:
+        rn, rh, rw, rc, ldr = _nhwc(residual)
+        if (rn, rh, rw, rc) != (n, h, w, cif):
+            raise _lib.CavpError("conv2d_dgrad: residual must match dx")
+    padt = dil * (kh - 1) - pad
+    if padt < 0:
+        raise _lib.CavpError("conv2d_dgrad: pad > dil*(k-1) is not supported")
+    d = ConvDesc(dtype=dtype_code(dy.dtype), N=n, H=ho, W=wo, Cin=cof, ldx=ldx, Cout=cif, ldy=ldy, KH=kh, KW=kw,
+                 stride=1, pad=padt, dil=dil, ldr=ldr, act=act, splitk=0, tile=0, up=stride, Ho=h, Wo=w)
+    if stride == 1:
+        eh, ew = ho + 2 * padt - dil * (kh - 1), wo + 2 * padt - dil * (kw - 1)
+        if (eh, ew) != (h, w):
+            raise _lib.CavpError(f"conv2d_dgrad: dx extent {(h, w)} != {(eh, ew)}")
+    nbytes = lib.cavp_conv2d_workspace_bytes(C.byref(d))
+    ws = ops.workspace(nbytes, dy.device)
+    st = lib.cavp_conv2d_nhwc(C.byref(d), _ptr(dy), _ptr(w_t), _ptr(scale), _ptr(shift), None, _ptr(residual), _ptr(dx),
+                              _ptr(ws), C.c_size_t(ws.numel() if ws is not None else 0), _s())
+    _check(st, "cavp_conv2d_nhwc(dgrad)")
+    return dx
+
+
+def conv2d_wgrad(x: torch.Tensor, dy: torch.Tensor, dw_ohwi: torch.Tensor, *, kh: int, kw: int, stride: int, pad: int,
+                 dil: int, splitk: int = 0) -> torch.Tensor:
+    """dw_ohwi (f32 [Cout][kh][kw][Cin], pre-zeroed) += wgrad(x, dy)."""
+    _need_gpu(x, dy, dw_ohwi)
+    n, h, w, cin, ldx = _nhwc(x)
+    n2, ho, wo, cout, ldy = _nhwc(dy)
+    if n2 != n or x.dtype != dy.dtype or dw_ohwi.dtype != torch.float32 or dw_ohwi.numel() != cout * kh * kw * cin \
+            or not dw_ohwi.is_contiguous():
+        raise _lib.CavpError("conv2d_wgrad: shape / dtype mismatch")
+    eho = (h + 2 * pad - dil * (kh - 1) - 1) // stride + 1
+    ewo = (w + 2 * pad - dil * (kw - 1) - 1) // stride + 1
+    if (ho, wo) != (eho, ewo):
+        raise _lib.CavpError("conv2d_wgrad: dy extent does not match the forward conv")
+    d = ConvDesc(dtype=dtype_code(x.dtype), N=n, H=h, W=w, Cin=cin, ldx=ldx, Cout=cout, ldy=ldy, KH=kh, KW=kw,
+                 stride=stride, pad=pad, dil=dil, ldr=0, act=0, splitk=splitk, tile=0, up=0, Ho=0, Wo=0)
+    _check(_lib.load().cavp_conv2d_wgrad_nhwc(C.byref(d), _ptr(x), _ptr(dy), _ptr(dw_ohwi), _s()), "cavp_conv2d_wgrad_nhwc")
+    return dw_ohwi
+
+
+def linear_wgrad(x: torch.Tensor, dy: torch.Tensor, dw: torch.Tensor) -> torch.Tensor:
+    """x: [..., Cin], dy: [..., Cout] -> dw f32 [Cout][Cin] (pre-zeroed) += dy^T x."""
+    rx, cin, ldx = _rows(x)
+    ry, cout, ldy = _rows(dy)
+    xv = torch.as_strided(x, (1, 1, rx, cin), (rx * ldx, rx * ldx, ldx, 1))
+    yv = torch.as_strided(dy, (1, 1, ry, cout), (ry * ldy, ry * ldy, ldy, 1))
+    return conv2d_wgrad(xv, yv, dw, kh=1, kw=1, stride=1, pad=0, dil=1)
+
+
+def pack_weight_dgrad(w: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
+    wd = w.detach()
+    _need_gpu(wd)
+    if wd.dim() == 2:
+        cout, cin, kh, kw = wd.shape[0], wd.shape[1], 1, 1
+    else:
+        cout, cin, kh, kw = wd.shape
+    out = torch.empty((cin, kh, kw, cout), dtype=dtype, device=w.device)
+    _check(_lib.load().cavp_pack_weight_dgrad(dtype_code(dtype), _ptr(wd.contiguous()), _ptr(out), cout, cin, kh, kw, _s()),
+           "cavp_pack_weight_dgrad")
+    return out
+
+
+def unpack_weight_grad(g_ohwi: torch.Tensor, grad_oihw: torch.Tensor, accumulate: bool) -> torch.Tensor:
+    _need_gpu(g_ohwi, grad_oihw)
+    if grad_oihw.dim() == 2:
+        cout, cin, kh, kw = grad_oihw.shape[0], grad_oihw.shape[1], 1, 1
+    else:
+        cout, cin, kh, kw = grad_oihw.shape
+    if g_ohwi.numel() != grad_oihw.numel() or g_ohwi.dtype != torch.float32 or grad_oihw.dtype != torch.float32 \
+            or not grad_oihw.is_contiguous():
+        raise _lib.CavpError("unpack_weight_grad: f32 tensors of equal size required")
+    _check(_lib.load().cavp_unpack_weight_grad(_ptr(g_ohwi), _ptr(grad_oihw), cout, cin, kh, kw, int(accumulate), _s()),
+           "cavp_unpack_weight_grad")
+    return grad_oihw
+
+
+def smallcin_wgrad(x_nchw: torch.Tensor, dy: torch.Tensor, dw_oihw: torch.Tensor, stride: int) -> torch.Tensor:
+    _need_gpu(x_nchw, dy, dw_oihw)
+    n, cin, h, w = x_nchw.shape
+    cout = dy.shape[-1]
+    if dw_oihw.dtype != torch.float32 or tuple(dw_oihw.shape) != (cout, cin, 3, 3) or not dy.is_contiguous():
+        raise _lib.CavpError("smallcin_wgrad: bad shapes")
+    _check(_lib.load().cavp_conv3x3_smallcin_wgrad(dtype_code(dy.dtype), _ptr(x_nchw), _ptr(dy), _ptr(dw_oihw), n, cin, h, w,
+                                                   cout, stride, _s()), "cavp_conv3x3_smallcin_wgrad")
+    return dw_oihw
+
+
+def colstats(x: torch.Tensor, sums: torch.Tensor, sumsq: torch.Tensor) -> None:
+    rows, c, ld = _rows(x)
+    _need_gpu(x, sums, sumsq)
+    _check(_lib.load().cavp_colstats(dtype_code(x.dtype), _ptr(x), rows, c, ld, _ptr(sums), _ptr(sumsq), _s()), "cavp_colstats")
+
+
+def bn_finalize(sums, sumsq, count: int, gamma, beta, eps: float, momentum: float, running_mean, running_var, scale,
+                shift, mean, rstd) -> None:
+    _need_gpu(sums, sumsq, gamma, beta, scale, shift, mean, rstd)
+    _check(_lib.load().cavp_bn_finalize(_ptr(sums), _ptr(sumsq), count, _ptr(gamma), _ptr(beta), C.c_float(eps),
+                                        C.c_float(momentum), _ptr(running_mean), _ptr(running_var), _ptr(scale), _ptr(shift),
+                                        _ptr(mean), _ptr(rstd), gamma.numel(), _s()), "cavp_bn_finalize")
+
+
+def scale_shift_act(x, scale, shift, y, act: int, residual=None) -> torch.Tensor:
+    rows, c, ldx = _rows(x)
+    r2, c2, ldy = _rows(y)
+    ldr = 0
+    if residual is not None:
+        _, _, ldr = _rows(residual)
+    _need_gpu(x, y, scale, shift, residual)
+    if (rows, c) != (r2, c2) or y.dtype != x.dtype:
+        raise _lib.CavpError("scale_shift_act: shape mismatch")
+    _check(_lib.load().cavp_scale_shift_act(dtype_code(x.dtype), _ptr(x), _ptr(scale), _ptr(shift), _ptr(residual), _ptr(y),
+                                            rows, c, ldx, ldr, ldy, act, _s()), "cavp_scale_shift_act")
+    return y
+
+
+def bn_act_bwd_reduce(dy, y, z, mean, rstd, act: int, sum_g, sum_gz) -> None:
+    rows, c, ld_dy = _rows(dy)
+    _, _, ld_y = _rows(y)
+    _, _, ld_z = _rows(z)
+    _need_gpu(dy, y, z, mean, rstd, sum_g, sum_gz)
+    _check(_lib.load().cavp_bn_act_bwd_reduce(dtype_code(dy.dtype), _ptr(dy), _ptr(y), _ptr(z), _ptr(mean), _ptr(rstd), rows,
+                                              c, ld_dy, ld_y, ld_z, act, _ptr(sum_g), _ptr(sum_gz), _s()),
+           "cavp_bn_act_bwd_reduce")
+
+
+def bn_act_bwd_apply(dy, y, z, mean, rstd, gamma, sum_g, sum_gz, act: int, dz, g_out=None) -> torch.Tensor:
+    rows, c, ld_dy = _rows(dy)
+    _, _, ld_y = _rows(y)
+    _, _, ld_z = _rows(z)
+    _, _, ld_dz = _rows(dz)
+    ld_g = _rows(g_out)[2] if g_out is not None else 0
+    _need_gpu(dy, y, z, dz, g_out)
+    _check(_lib.load().cavp_bn_act_bwd_apply(dtype_code(dy.dtype), _ptr(dy), _ptr(y), _ptr(z), _ptr(mean), _ptr(rstd),
+                                             _ptr(gamma), _ptr(sum_g), _ptr(sum_gz), rows, c, ld_dy, ld_y, ld_z, act, _ptr(dz),
+                                             ld_dz, _ptr(g_out), ld_g, _s()), "cavp_bn_act_bwd_apply")
+    return dz
+
+
+def act_bwd(dy, ref, dx, act: int) -> torch.Tensor:
+    rows, c, ld_dy = _rows(dy)
+    _, _, ld_ref = _rows(ref)
+    _, _, ld_dx = _rows(dx)
+    _need_gpu(dy, ref, dx)
+    _check(_lib.load().cavp_act_bwd(dtype_code(dy.dtype), _ptr(dy), _ptr(ref), _ptr(dx), rows, c, ld_dy, ld_ref, ld_dx, act,
+                                    _s()), "cavp_act_bwd")
+    return dx
+
+
+def add(a, b, out) -> torch.Tensor:
+    _need_gpu(a, b, out)
+    if not (a.is_contiguous() and b.is_contiguous() and out.is_contiguous()) or a.numel() != b.numel():
+        raise _lib.CavpError("add: dense tensors of equal size required")
+    _check(_lib.load().cavp_add(dtype_code(a.dtype), _ptr(a), _ptr(b), _ptr(out), a.numel(), _s()), "cavp_add")
+    return out
+
+
+def colsum(x, out) -> torch.Tensor:
+    rows, c, ld = _rows(x)
+    _need_gpu(x, out)
+    _check(_lib.load().cavp_colsum(dtype_code(x.dtype), _ptr(x), rows, c, ld, _ptr(out), _s()), "cavp_colsum")
+    return out
+
+
+def layernorm_bwd(dy, x, gamma, dx, dgamma, dbeta, eps: float) -> torch.Tensor:
+    rows, c, ld_dy = _rows(dy)
+    _, _, ld_x = _rows(x)
+    _, _, ld_dx = _rows(dx)
+    _need_gpu(dy, x, gamma, dx, dgamma, dbeta)
+    _check(_lib.load().cavp_layernorm_bwd(dtype_code(dy.dtype), _ptr(dy), _ptr(x), _ptr(gamma), _ptr(dx), _ptr(dgamma),
+                                          _ptr(dbeta), rows, c, ld_dy, ld_x, ld_dx, C.c_float(eps), _s()), "cavp_layernorm_bwd")
+    return dx
+
+
+def attn_gate_bwd(dout, q, k, v, attn, dattn, dq, dk, dv, heads: int, scale: float) -> None:
+    _need_gpu(dout, q, k, v, attn, dq, dk, dv)
+    b, t, c = q.shape
+    _check(_lib.load().cavp_attn_gate_bwd(dtype_code(q.dtype), _ptr(dout), _ptr(q), _ptr(k), _ptr(v), _ptr(attn), _ptr(dattn),
+                                          _ptr(dq), _ptr(dk), _ptr(dv), b, t, heads, c // heads, C.c_float(scale), _s()),
+           "cavp_attn_gate_bwd")
+
+
+def maxpool_bwd(x, dy, dx, k: int, stride: int, pad: int) -> torch.Tensor:
+    n, h, w, c, _ = _nhwc(x)
+    _need_gpu(x, dy, dx)
+    _check(_lib.load().cavp_maxpool_bwd_nhwc(dtype_code(x.dtype), _ptr(x), _ptr(dy), _ptr(dx), n, h, w, c, k, stride, pad, _s()),
+           "cavp_maxpool_bwd_nhwc")
+    return dx
+
+
+def bilinear_bwd(dy, dx, align_corners: bool) -> torch.Tensor:
+    n, ho, wo, c, ld_dy = _nhwc(dy)
+    _, hi, wi, _, ld_dx = _nhwc(dx)
+    _need_gpu(dy, dx)
+    _check(_lib.load().cavp_bilinear_bwd_nhwc(dtype_code(dy.dtype), _ptr(dy), _ptr(dx), n, hi, wi, c, ld_dx, ho, wo, ld_dy,
+                                              int(align_corners), _s()), "cavp_bilinear_bwd_nhwc")
+    return dx
+
+
+def bilinear_bwd_from_nchw(dy_nchw, dx, n_valid: int, align_corners: bool) -> torch.Tensor:
+    n, hi, wi, c, ld_dx = _nhwc(dx)
+    _need_gpu(dy_nchw, dx)
+    ho, wo = dy_nchw.shape[-2:]
+    if dy_nchw.dtype != torch.float32 or not dy_nchw.is_contiguous():
+        raise _lib.CavpError("bilinear_bwd_from_nchw: dy must be contiguous f32 NCHW")
+    _check(_lib.load().cavp_bilinear_bwd_nchw_to_nhwc(dtype_code(dx.dtype), _ptr(dy_nchw), _ptr(dx), n, n_valid, hi, wi, c, ld_dx,
+                                                      ho, wo, int(align_corners), _s()), "cavp_bilinear_bwd_nchw_to_nhwc")
+    return dx
+
+
+def bcast_add(x, v, alpha: float) -> torch.Tensor:
+    n, h, w, c, ld = _nhwc(x)
+    _need_gpu(x, v)
+    _check(_lib.load().cavp_bcast_add_nhwc(dtype_code(x.dtype), _ptr(x), _ptr(v), C.c_float(alpha), n, h * w, c, ld, _s()),
+           "cavp_bcast_add_nhwc")
+    return x
+
+
+def ce_loss(logits_nchw, labels, n_img: int, ignore_index: int = 255, grad_scale: float = 1.0, want_grad: bool = True):
+    """Returns (loss f32[1], dlogits or None)."""
+    _need_gpu(logits_nchw, labels)
+    nt, c, h, w = logits_nchw.shape
+    if logits_nchw.dtype != torch.float32 or not logits_nchw.is_contiguous() or labels.dtype != torch.int64 \
+            or not labels.is_contiguous():
+        raise _lib.CavpError("ce_loss: contiguous f32 NCHW logits and int64 labels required")
+    loss = torch.empty(1, dtype=torch.float32, device=logits_nchw.device)
+    scratch = torch.empty(2, dtype=torch.float32, device=logits_nchw.device)
+    dl = torch.empty_like(logits_nchw) if want_grad else None
+    _check(_lib.load().cavp_ce_loss_nchw(_ptr(logits_nchw), _ptr(labels), n_img, nt, c, h * w, ignore_index,
+                                         C.c_float(grad_scale), _ptr(loss), _ptr(dl), _ptr(scratch), _s()), "cavp_ce_loss_nchw")
+    return loss, dl

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define CAVP_ABI_VERSION 1
+#define CAVP_ABI_VERSION 2
 
 typedef enum { CAVP_F32 = 0, CAVP_BF16 = 1 } cavp_dtype_t;
 typedef enum { CAVP_ACT_NONE = 0, CAVP_ACT_RELU = 1, CAVP_ACT_LEAKY = 2, CAVP_ACT_GELU = 3 } cavp_act_t;
@@ -68,6 +68,9 @@ typedef struct cavp_conv_desc {
   int32_t act;        /* cavp_act_t */
   int32_t splitk;     /* 0 = let the library choose; >= 1 forces that many K slices */
   int32_t tile;       /* 0 = auto; otherwise a tile-config id (testing / tuning) */
+  int32_t up;         /* 0/1 = ordinary conv.  up = s > 1 (power of two): x is read as if zero-upsampled by s, i.e. the
+                         data-gradient of a stride-s conv (transposed conv); Ho/Wo below then give the output size */
+  int32_t Ho, Wo;     /* only read when up > 1 (the forward conv's input extent) */
 } cavp_conv_desc;
 
 size_t cavp_conv2d_workspace_bytes(const cavp_conv_desc* d);
@@ -117,6 +120,81 @@ int cavp_pack_weight_ohwi(int32_t dtype, const float* w_oihw, void* w_ohwi, int3
 
 /* Element-wise cast between f32 and dtype (n elements): src_dtype -> dst_dtype. */
 int cavp_cast(int32_t src_dtype, const void* src, int32_t dst_dtype, void* dst, int64_t n, void* stream);
+
+/* =========================================================================================================
+ * Training side: batch-statistics BatchNorm and the backward kernels.  The reference gets all
+ * of this from torch.autograd over the modules cited above (trainer_cavp_vpo_mono.py:168-193 `loss.backward()`).
+ * Data gradients of conv / linear reuse cavp_conv2d_nhwc with cavp_pack_weight_dgrad weights (+ `up` for strides).
+ * ======================================================================================================= */
+
+/* Weight gradient of a conv / linear: dw[co][kh][kw][ci] += sum_pixels dy[pix][co] * x[pix @ tap][ci] (f32, OHWI,
+ * accumulated with f32 atomics: the caller zeroes dw).  Fields of `d` describe the FORWARD conv (x is its input,
+ * dy its output gradient with pixel stride d->ldy). */
+int cavp_conv2d_wgrad_nhwc(const cavp_conv_desc* d, const void* x, const void* dy, float* dw_ohwi, void* stream);
+
+/* OIHW f32 -> [Cin][KH][KW][Cout] (dtype), taps rotated by 180 degrees: the OHWI weight of the transposed conv. */
+int cavp_pack_weight_dgrad(int32_t dtype, const float* w_oihw, void* w_t, int32_t Cout, int32_t Cin, int32_t KH,
+                           int32_t KW, void* stream);
+/* OHWI f32 gradient -> OIHW f32 (.grad layout); accumulate != 0 adds into the destination. */
+int cavp_unpack_weight_grad(const float* g_ohwi, float* g_oihw, int32_t Cout, int32_t Cin, int32_t KH, int32_t KW,
+                            int32_t accumulate, void* stream);
+/* Weight gradient of cavp_conv3x3_smallcin_nchw (OIHW f32, atomically accumulated; caller zeroes). */
+int cavp_conv3x3_smallcin_wgrad(int32_t dtype, const float* x_nchw, const void* dy_nhwc, float* dw_oihw, int32_t N,
+                                int32_t Cin, int32_t H, int32_t W, int32_t Cout, int32_t stride, void* stream);
+
+/* nn.BatchNorm2d in training mode (resnet.py / encoder_decoder.py BN layers under model.train()):
+ *   cavp_colstats     sum[c] += sum_rows x, sumsq[c] += sum_rows x^2   (f32 atomics; caller zeroes)
+ *   cavp_bn_finalize  mean/var -> scale = gamma*rstd, shift = beta - mean*scale; saves mean, rstd; updates the running
+ *                     statistics in place (momentum, unbiased variance) when running_mean/var are non-NULL
+ *   cavp_scale_shift_act  y = act(x*scale + shift + residual)
+ *   cavp_bn_act_bwd_reduce / _apply  g = dy*act'(y); dbeta = sum g; dgamma = sum g*zhat;
+ *                     dz = gamma*rstd*(g - dbeta/M - zhat*dgamma/M); optional g_out = g (skip-path gradient) */
+int cavp_colstats(int32_t dtype, const void* x, int64_t rows, int32_t C, int32_t ldx, float* sum, float* sumsq,
+                  void* stream);
+int cavp_bn_finalize(const float* sum, const float* sumsq, int64_t count, const float* gamma, const float* beta,
+                     float eps, float momentum, float* running_mean, float* running_var, float* scale, float* shift,
+                     float* mean, float* rstd, int32_t C, void* stream);
+int cavp_scale_shift_act(int32_t dtype, const void* x, const float* scale, const float* shift, const void* residual,
+                         void* y, int64_t rows, int32_t C, int32_t ldx, int32_t ldr, int32_t ldy, int32_t act,
+                         void* stream);
+int cavp_bn_act_bwd_reduce(int32_t dtype, const void* dy, const void* y, const void* z, const float* mean,
+                           const float* rstd, int64_t rows, int32_t C, int32_t ld_dy, int32_t ld_y, int32_t ld_z,
+                           int32_t act, float* sum_g, float* sum_gz, void* stream);
+int cavp_bn_act_bwd_apply(int32_t dtype, const void* dy, const void* y, const void* z, const float* mean,
+                          const float* rstd, const float* gamma, const float* sum_g, const float* sum_gz, int64_t rows,
+                          int32_t C, int32_t ld_dy, int32_t ld_y, int32_t ld_z, int32_t act, void* dz, int32_t ld_dz,
+                          void* g_out, int32_t ld_g, void* stream);
+/* dx = dy * act'(.): ReLU / LeakyReLU from the activation OUTPUT, GELU from the pre-activation (ref). */
+int cavp_act_bwd(int32_t dtype, const void* dy, const void* ref, void* dx, int64_t rows, int32_t C, int32_t ld_dy,
+                 int32_t ld_ref, int32_t ld_dx, int32_t act, void* stream);
+int cavp_add(int32_t dtype, const void* a, const void* b, void* out, int64_t n, void* stream);
+/* out[c] += sum_rows x[r][c]  (bias gradients; f32 atomics, caller zeroes) */
+int cavp_colsum(int32_t dtype, const void* x, int64_t rows, int32_t C, int32_t ldx, float* out, void* stream);
+/* nn.LayerNorm backward; dgamma / dbeta are accumulated with f32 atomics (caller zeroes). */
+int cavp_layernorm_bwd(int32_t dtype, const void* dy, const void* x, const float* gamma, void* dx, float* dgamma,
+                       float* dbeta, int32_t rows, int32_t C, int32_t ld_dy, int32_t ld_x, int32_t ld_dx, float eps,
+                       void* stream);
+/* backward of cavp_attn_gate; dk, dv: f32 [B][heads*hd] accumulated with atomics (caller zeroes); dattn optional. */
+int cavp_attn_gate_bwd(int32_t dtype, const void* dout, const void* q, const void* k, const void* v, const float* attn,
+                       const float* dattn, void* dq, float* dk, float* dv, int32_t B, int32_t T, int32_t heads,
+                       int32_t hd, float scale, void* stream);
+int cavp_maxpool_bwd_nhwc(int32_t dtype, const void* x, const void* dy, void* dx, int32_t N, int32_t H, int32_t W,
+                          int32_t C, int32_t k, int32_t stride, int32_t pad, void* stream);
+int cavp_bilinear_bwd_nhwc(int32_t dtype, const void* dy, void* dx, int32_t N, int32_t Hi, int32_t Wi, int32_t C,
+                           int32_t ld_dx, int32_t Ho, int32_t Wo, int32_t ld_dy, int32_t align_corners, void* stream);
+/* backward of cavp_bilinear_nhwc_to_nchw: dy NCHW f32 (images >= n_valid carry zero gradient), dx NHWC (dtype) */
+int cavp_bilinear_bwd_nchw_to_nhwc(int32_t dtype, const float* dy_nchw, void* dx, int32_t N, int32_t n_valid,
+                                   int32_t Hi, int32_t Wi, int32_t C, int32_t ld_dx, int32_t Ho, int32_t Wo,
+                                   int32_t align_corners, void* stream);
+/* x[n, p, :] += alpha * v[n, :]  (global-average-pool backward) */
+int cavp_bcast_add_nhwc(int32_t dtype, void* x, const float* v, float alpha, int32_t N, int32_t HW, int32_t C,
+                        int32_t ld, void* stream);
+/* nn.CrossEntropyLoss(ignore_index) on NCHW f32 logits of the first n_img images (loss/losser.py:60-62 applied to
+ * `out[:B] + out[B:]*0`, trainer_cavp_vpo_mono.py:171,187): loss[0] = mean over valid pixels; dlogits (optional,
+ * [n_total][C][HW]) = grad_scale * dloss/dlogits, zero for images >= n_img.  scratch2: 2 floats. */
+int cavp_ce_loss_nchw(const float* logits, const int64_t* labels, int32_t n_img, int32_t n_total, int32_t C, int64_t HW,
+                      int32_t ignore_index, float grad_scale, float* loss, float* dlogits, float* scratch2,
+                      void* stream);
 
 #ifdef __cplusplus
 }

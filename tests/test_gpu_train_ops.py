@@ -1,0 +1,253 @@
+"""Training-side kernels vs torch.autograd on CPU (fp32 reference).  -m gpu."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+DTYPES = [torch.float32, torch.bfloat16]
+IDS = ["f32", "bf16"]
+
+
+def _mods():
+    from cavp_amd import ops, train_ops
+    return ops, train_ops
+
+
+def _rand(*shape, seed=0, scale=1.0):
+    return torch.randn(*shape, generator=torch.Generator().manual_seed(seed)) * scale
+
+
+def _q(t, dt):
+    return t.to(dt).to(torch.float32)
+
+
+def _nhwc(x_nchw, dt):
+    return x_nchw.permute(0, 2, 3, 1).contiguous().to(dt).to(DEV)
+
+
+def _check(got, ref, dt, what, f32_tol=3e-5, bf16_tol=1.5e-2):
+    got = got.float().cpu()
+    assert got.shape == ref.shape, (what, got.shape, ref.shape)
+    assert torch.isfinite(got).all(), what
+    scale = max(1e-6, float(ref.abs().max()))
+    tol = (f32_tol if dt == torch.float32 else bf16_tol) * scale
+    err = float((got - ref).abs().max())
+    assert err <= tol, f"{what}: max err {err:.3e} > {tol:.3e} (ref max {scale:.3g})"
+
+
+CONV = [
+    # name, N, H, W, Cin, Cout, k, s, p, d
+    ("1x1", 2, 14, 14, 64, 128, 1, 1, 0, 1),
+    ("3x3", 2, 14, 12, 64, 64, 3, 1, 1, 1),
+    ("3x3_s2", 2, 16, 16, 64, 128, 3, 2, 1, 1),
+    ("3x3_s2_odd", 1, 15, 13, 64, 64, 3, 2, 1, 1),
+    ("1x1_s2", 2, 16, 16, 128, 256, 1, 2, 0, 1),
+    ("3x3_d2", 1, 14, 14, 128, 128, 3, 1, 2, 2),
+    ("3x3_d12", 1, 14, 14, 128, 64, 3, 1, 12, 12),
+    ("3x3_304", 1, 12, 12, 304, 256, 3, 1, 1, 1),
+    ("1x1_304_48", 2, 9, 7, 256, 48, 1, 1, 0, 1),
+]
+
+
+@pytest.mark.parametrize("dt", DTYPES, ids=IDS)
+@pytest.mark.parametrize("case", CONV, ids=[c[0] for c in CONV])
+def test_conv_dgrad_wgrad(case, dt):
+    ops, T = _mods()
+    name, n, h, w, cin, cout, k, s, p, d = case
+    x = _q(_rand(n, cin, h, w, seed=1), dt).requires_grad_(True)
+    wt = _q(_rand(cout, cin, k, k, seed=2, scale=(cin * k * k) ** -0.5), dt).requires_grad_(True)
+    y = F.conv2d(x, wt, None, s, p, d)
+    dy = _q(_rand(*y.shape, seed=3), dt)
+    y.backward(dy)
+    dyv = _nhwc(dy, dt)
+    # dgrad (+ accumulate into an existing gradient through the residual input)
+    prev = _q(_rand(n, cin, h, w, seed=4), dt)
+    dx = torch.empty((n, h, w, cin), dtype=dt, device=DEV)
+    wT = T.pack_weight_dgrad(wt.detach().to(DEV), dt)
+    T.conv2d_dgrad(dyv, wT, dx, kh=k, kw=k, stride=s, pad=p, dil=d, residual=_nhwc(prev, dt))
+    _check(dx.permute(0, 3, 1, 2), x.grad + prev, dt, name + ".dgrad")
+    # wgrad
+    dw = torch.zeros((cout, k, k, cin), dtype=torch.float32, device=DEV)
+    T.conv2d_wgrad(_nhwc(x.detach(), dt), dyv, dw, kh=k, kw=k, stride=s, pad=p, dil=d)
+    g = torch.zeros((cout, cin, k, k), dtype=torch.float32, device=DEV)
+    T.unpack_weight_grad(dw, g, accumulate=False)
+    _check(g, wt.grad, dt, name + ".wgrad", f32_tol=5e-5, bf16_tol=2e-2)
+    T.unpack_weight_grad(dw, g, accumulate=True)
+    _check(g, 2 * wt.grad, dt, name + ".wgrad.acc", f32_tol=5e-5, bf16_tol=2e-2)
+
+
+@pytest.mark.parametrize("dt", DTYPES, ids=IDS)
+@pytest.mark.parametrize("rows,cin,cout", [(6272, 304, 1216), (64, 4096, 304), (4, 12288, 512), (6272, 256, 304)])
+def test_linear_wgrad(rows, cin, cout, dt):
+    ops, T = _mods()
+    x, dy = _q(_rand(rows, cin, seed=5), dt), _q(_rand(rows, cout, seed=6), dt)
+    dw = torch.zeros((cout, cin), dtype=torch.float32, device=DEV)
+    T.linear_wgrad(x.to(dt).to(DEV), dy.to(dt).to(DEV), dw)
+    _check(dw, dy.t() @ x, dt, "linear_wgrad", f32_tol=5e-5, bf16_tol=2e-2)
+
+
+@pytest.mark.parametrize("dt", DTYPES, ids=IDS)
+@pytest.mark.parametrize("act", [1, 2, 0])
+def test_bn_train_fwd_bwd(act, dt):
+    ops, T = _mods()
+    n, c, h, w = 4, 96, 9, 11
+    z = _q(_rand(n, c, h, w, seed=7) * 2 + 0.5, dt).requires_grad_(True)
+    res = _q(_rand(n, c, h, w, seed=8), dt).requires_grad_(True)
+    gamma = (torch.rand(c, generator=torch.Generator().manual_seed(9)) + 0.5).requires_grad_(True)
+    beta = _rand(c, seed=10).requires_grad_(True)
+    rm, rv = _rand(c, seed=11) * 0.1, torch.rand(c, generator=torch.Generator().manual_seed(12)) + 0.5
+    rm_ref, rv_ref = rm.clone(), rv.clone()
+    pre = F.batch_norm(z, rm_ref, rv_ref, gamma, beta, True, 0.1, 1e-5) + res
+    y = F.relu(pre) if act == 1 else (F.leaky_relu(pre, 0.01) if act == 2 else pre)
+    dy = _q(_rand(n, c, h, w, seed=13), dt)
+    y.backward(dy)
+    zv, rvw = _nhwc(z.detach(), dt), _nhwc(res.detach(), dt)
+    sums, sq = torch.zeros(c, device=DEV), torch.zeros(c, device=DEV)
+    T.colstats(zv, sums, sq)
+    f = lambda: torch.empty(c, device=DEV)
+    scale, shift, mean, rstd = f(), f(), f(), f()
+    rmd, rvd = rm.to(DEV), rv.to(DEV)
+    T.bn_finalize(sums, sq, n * h * w, gamma.detach().to(DEV), beta.detach().to(DEV), 1e-5, 0.1, rmd, rvd, scale, shift, mean, rstd)
+    yv = torch.empty_like(zv)
+    T.scale_shift_act(zv, scale, shift, yv, act, residual=rvw)
+    tolf, tolb = 5e-5, 2e-2
+    _check(yv.permute(0, 3, 1, 2), y.detach(), dt, "bn fwd", tolf, tolb)
+    _check(rmd, rm_ref, torch.float32, "running_mean", 1e-4)
+    _check(rvd, rv_ref, torch.float32, "running_var", 1e-4)
+    # backward
+    dyv = _nhwc(dy, dt)
+    sg, sgz = torch.zeros(c, device=DEV), torch.zeros(c, device=DEV)
+    T.bn_act_bwd_reduce(dyv, yv, zv, mean, rstd, act, sg, sgz)
+    _check(sg, beta.grad, dt, "dbeta", 1e-4, 2e-2)
+    _check(sgz, gamma.grad, dt, "dgamma", 1e-4, 2e-2)
+    dz, g = torch.empty_like(zv), torch.empty_like(zv)
+    T.bn_act_bwd_apply(dyv, yv, zv, mean, rstd, gamma.detach().to(DEV), sg, sgz, act, dz, g_out=g)
+    _check(dz.permute(0, 3, 1, 2), z.grad, dt, "dz", 1e-4, 2.5e-2)
+    _check(g.permute(0, 3, 1, 2), res.grad, dt, "dres", 1e-5, 1e-2)
+
+
+@pytest.mark.parametrize("dt", DTYPES, ids=IDS)
+def test_act_bwd_colsum_add(dt):
+    ops, T = _mods()
+    x = _q(_rand(333, 304, seed=14), dt).requires_grad_(True)
+    dy = _q(_rand(333, 304, seed=15), dt)
+    F.gelu(x).backward(dy)
+    dx = torch.empty((333, 304), dtype=dt, device=DEV)
+    T.act_bwd(dy.to(dt).to(DEV), x.detach().to(dt).to(DEV), dx, ops.ACT_GELU)
+    _check(dx, x.grad, dt, "gelu bwd")
+    y = F.relu(x.detach())
+    T.act_bwd(dy.to(dt).to(DEV), y.to(dt).to(DEV), dx, ops.ACT_RELU)
+    _check(dx, dy * (y > 0), dt, "relu bwd")
+    cs = torch.zeros(304, device=DEV)
+    T.colsum(dy.to(dt).to(DEV), cs)
+    _check(cs, dy.sum(0), dt, "colsum", 1e-4, 1e-2)
+    o = torch.empty((333, 304), dtype=dt, device=DEV)
+    T.add(dy.to(dt).to(DEV), x.detach().to(dt).to(DEV), o)
+    _check(o, dy + x.detach(), dt, "add")
+
+
+@pytest.mark.parametrize("dt", DTYPES, ids=IDS)
+@pytest.mark.parametrize("rows,C", [(3136 * 2, 304), (3, 304), (50, 1216)])
+def test_layernorm_bwd(rows, C, dt):
+    ops, T = _mods()
+    x = _q(_rand(rows, C, seed=16) * 2 + 0.3, dt).requires_grad_(True)
+    g = (torch.rand(C, generator=torch.Generator().manual_seed(17)) + 0.5).requires_grad_(True)
+    b = _rand(C, seed=18).requires_grad_(True)
+    dy = _q(_rand(rows, C, seed=19), dt)
+    F.layer_norm(x, (C,), g, b, 1e-5).backward(dy)
+    dx = torch.empty((rows, C), dtype=dt, device=DEV)
+    dg, db = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+    T.layernorm_bwd(dy.to(dt).to(DEV), x.detach().to(dt).to(DEV), g.detach().to(DEV), dx, dg, db, 1e-5)
+    _check(dx, x.grad, dt, "ln dx", 5e-5, 2e-2)
+    _check(dg, g.grad, dt, "ln dgamma", 1e-4, 1e-2)
+    _check(db, b.grad, dt, "ln dbeta", 1e-4, 1e-2)
+
+
+@pytest.mark.parametrize("dt", DTYPES, ids=IDS)
+def test_attn_gate_bwd(dt):
+    ops, T = _mods()
+    B, Tn, H, hd = 3, 150, 4, 76
+    q = _q(_rand(B, Tn, H * hd, seed=20), dt).requires_grad_(True)
+    k = _q(_rand(B, H * hd, seed=21), dt).requires_grad_(True)
+    v = _q(_rand(B, H * hd, seed=22), dt).requires_grad_(True)
+    s = torch.sigmoid((q.view(B, Tn, H, hd) * k.view(B, 1, H, hd)).sum(-1) * hd ** -0.5)
+    o = (s[..., None] * v.view(B, 1, H, hd)).reshape(B, Tn, H * hd)
+    do = _q(_rand(B, Tn, H * hd, seed=23), dt)
+    dattn = _rand(B, H, Tn, seed=24) * 0.1
+    (o * do).sum().backward(retain_graph=True)
+    (s.permute(0, 2, 1) * dattn).sum().backward()
+    attn = s.detach().permute(0, 2, 1).contiguous().to(DEV)
+    dq = torch.empty((B, Tn, H * hd), dtype=dt, device=DEV)
+    dk, dv = torch.zeros((B, H * hd), device=DEV), torch.zeros((B, H * hd), device=DEV)
+    T.attn_gate_bwd(do.to(dt).to(DEV), q.detach().to(dt).to(DEV), k.detach().to(dt).to(DEV), v.detach().to(dt).to(DEV), attn,
+                    dattn.to(DEV), dq, dk, dv, H, hd ** -0.5)
+    _check(dq, q.grad, dt, "dq", 5e-5, 2e-2)
+    _check(dk, k.grad, dt, "dk", 1e-4, 2e-2)
+    _check(dv, v.grad, dt, "dv", 1e-4, 2e-2)
+
+
+@pytest.mark.parametrize("dt", DTYPES, ids=IDS)
+@pytest.mark.parametrize("k,s,p,hw", [(3, 2, 1, (28, 30)), (2, 2, 0, (12, 8)), (3, 2, 1, (15, 9))])
+def test_maxpool_bwd(k, s, p, hw, dt):
+    ops, T = _mods()
+    x = _q(_rand(2, 64, *hw, seed=25), dt).requires_grad_(True)
+    y = F.max_pool2d(x, k, s, p)
+    dy = _q(_rand(*y.shape, seed=26), dt)
+    y.backward(dy)
+    dx = torch.empty((2, hw[0], hw[1], 64), dtype=dt, device=DEV)
+    T.maxpool_bwd(_nhwc(x.detach(), dt), _nhwc(dy, dt), dx, k, s, p)
+    _check(dx.permute(0, 3, 1, 2), x.grad, dt, "maxpool bwd", 1e-6, 1e-2)
+
+
+@pytest.mark.parametrize("dt", DTYPES, ids=IDS)
+@pytest.mark.parametrize("align", [True, False])
+@pytest.mark.parametrize("hi,ho", [((14, 14), (56, 56)), ((7, 9), (24, 40)), ((28, 28), (56, 56))])
+def test_bilinear_bwd(hi, ho, align, dt):
+    ops, T = _mods()
+    x = _rand(2, 32, *hi, seed=27).requires_grad_(True)
+    y = F.interpolate(x, size=ho, mode="bilinear", align_corners=align)
+    dy = _q(_rand(*y.shape, seed=28), dt)
+    y.backward(dy)
+    big = torch.zeros((2, ho[0], ho[1], 48), dtype=dt, device=DEV)
+    big[..., :32] = _nhwc(dy, dt)
+    dx = torch.empty((2, hi[0], hi[1], 32), dtype=dt, device=DEV)
+    T.bilinear_bwd(big[..., :32], dx, align)
+    _check(dx.permute(0, 3, 1, 2), x.grad, dt, "bilinear bwd", 5e-5, 1.5e-2)
+
+
+@pytest.mark.parametrize("dt", DTYPES, ids=IDS)
+@pytest.mark.parametrize("C", [2, 22])
+def test_bilinear_bwd_from_nchw_and_ce(C, dt):
+    ops, T = _mods()
+    B = 2
+    lo = _rand(2 * B, C, 14, 14, seed=29).requires_grad_(True)
+    out = F.interpolate(lo, size=(56, 56), mode="bilinear", align_corners=False)
+    label = torch.randint(0, C, (B, 56, 56), generator=torch.Generator().manual_seed(30))
+    label[torch.rand((B, 56, 56), generator=torch.Generator().manual_seed(31)) < 0.05] = 255
+    loss = F.cross_entropy(out[:B] + out[B:] * 0.0, label, ignore_index=255)
+    loss.backward()
+    l, dl = T.ce_loss(out.detach().contiguous().to(DEV), label.to(DEV), B)
+    assert abs(float(l.item()) - float(loss.item())) <= 1e-5 * max(1.0, abs(float(loss.item())))
+    dx = torch.empty((2 * B, 14, 14, C), dtype=dt, device=DEV)
+    T.bilinear_bwd_from_nchw(dl, dx, n_valid=B, align_corners=False)
+    _check(dx.permute(0, 3, 1, 2), lo.grad, dt, "ce + upsample bwd", 5e-5, 1.5e-2)
+
+
+@pytest.mark.parametrize("dt", DTYPES, ids=IDS)
+def test_bcast_add_and_smallcin_wgrad(dt):
+    ops, T = _mods()
+    x = _q(_rand(3, 64, 5, 7, seed=32), dt)
+    v = _rand(3, 64, seed=33)
+    xv = _nhwc(x, dt)
+    T.bcast_add(xv, v.to(DEV), 1.0 / 35)
+    _check(xv.permute(0, 3, 1, 2), x + v[:, :, None, None] / 35, dt, "bcast_add")
+    for cin, stride, hw in [(3, 2, (32, 40)), (1, 1, (24, 16))]:
+        xi = _rand(2, cin, *hw, seed=34)
+        w = _rand(64, cin, 3, 3, seed=35, scale=0.3).requires_grad_(True)
+        y = F.conv2d(xi, w, None, stride, 1)
+        dy = _q(_rand(*y.shape, seed=36), dt)
+        y.backward(dy)
+        dw = torch.zeros((64, cin, 3, 3), device=DEV)
+        T.smallcin_wgrad(xi.to(DEV), _nhwc(dy, dt), dw, stride)
+        _check(dw, w.grad, dt, "smallcin wgrad", 1e-4, 1e-2)
