@@ -564,10 +564,19 @@ class CAVP(nn.Module):
         if audio_func:
             raise NotImplementedError("audio_func=True (forward_audio / SoundBank path) is dead under every reference "
                                       "trainer (SURVEY.md §8a row a11) and not built on the HIP path")
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            raise NotImplementedError("backward through the HIP path is not built yet: wrap the call in "
-                                      "torch.no_grad() (forward-only) — SURVEY.md §7 step 8")
-        return self._forward_hip(image, audio, duplicate_visual=True)
+        bn_train = any(m.training for m in self.modules() if isinstance(m, nn.modules.batchnorm._BatchNorm))
+        want_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
+        if not bn_train and not want_grad:
+            return self._forward_hip(image, audio, duplicate_visual=True)   # frozen-BN, forward only
+        if not bn_train:
+            raise NotImplementedError("backward with BatchNorm in eval mode (frozen statistics) is not built; the "
+                                      "reference trains with model.train() (trainer_cavp_vpo_mono.py:120)")
+        if not image.is_cuda:
+            raise CavpError("CAVP (MI355X path) needs inputs on a HIP device: there is no CPU fallback")
+        from .train import CAVPTrainFunction
+        params = [p for p in self.parameters() if p.requires_grad] if want_grad else []
+        out_pred, out_fusion, visual, audio_f, attn_v = CAVPTrainFunction.apply(self, image, audio, *params)
+        return out_pred, out_fusion, {"audio": audio_f, "visual": visual, "attn_v": attn_v}
 
     def forward(self, image, audio=None, shuffle_info=None, ow_flag=False, eval_mode=False, audio_func=False):
         if eval_mode:

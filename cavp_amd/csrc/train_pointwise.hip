@@ -63,7 +63,7 @@ struct ColArgs {
   const void* a;   // primary tensor (z / dy / x)
   const void* b;   // y (activation output) or nullptr
   const void* c;   // z (pre-BN conv output) or nullptr
-  const float* mean;
+  const float* mean;   // MODE 1: batch mean;  MODE 0: optional per-channel shift (robust variance)
   const float* rstd;
   float* out0;
   float* out1;
@@ -84,9 +84,15 @@ __global__ __launch_bounds__(256) void col_reduce_kernel(const ColArgs p) {
 #pragma unroll
   for (int e = 0; e < VE; ++e) s0[e] = s1[e] = 0.f;
   float mu[VE], rs[VE];
+#pragma unroll
+  for (int e = 0; e < VE; ++e) { mu[e] = 0.f; rs[e] = 1.f; }
   if (MODE == 1 && col_ok) {
 #pragma unroll
     for (int e = 0; e < VE; ++e) { mu[e] = p.mean[c0 + e]; rs[e] = p.rstd[c0 + e]; }
+  }
+  if (MODE == 0 && col_ok && p.mean) {
+#pragma unroll
+    for (int e = 0; e < VE; ++e) mu[e] = p.mean[c0 + e];
   }
   const long long r_begin = (long long)blockIdx.x * p.rows_per_block;
   long long r_end = r_begin + p.rows_per_block;
@@ -97,7 +103,7 @@ __global__ __launch_bounds__(256) void col_reduce_kernel(const ColArgs p) {
       VecT<T>::load((const T*)p.a + r * p.lda + c0, a);
       if (MODE == 0) {
 #pragma unroll
-        for (int e = 0; e < VE; ++e) { s0[e] += a[e]; s1[e] += a[e] * a[e]; }
+        for (int e = 0; e < VE; ++e) { const float d = a[e] - mu[e]; s0[e] += d; s1[e] += d * d; }
       } else if (MODE == 1) {
         float y[VE], z[VE];
         VecT<T>::load((const T*)p.b + r * p.ldb + c0, y);
@@ -151,13 +157,19 @@ int launch_col_reduce(int dtype, ColArgs& a, hipStream_t s) {
   CHECK_LAUNCH();
 }
 
-__global__ void bn_finalize_kernel(const float* sum, const float* sumsq, float inv_count, float unbias,
+__global__ void scale_vec_kernel(const float* in, float alpha, float* out, int n) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) out[i] = alpha * in[i];
+}
+
+__global__ void bn_finalize_kernel(const float* sum, const float* sumsq, const float* sh, float inv_count, float unbias,
                                    const float* gamma, const float* beta, float eps, float momentum, float* rmean,
                                    float* rvar, float* scale, float* shift, float* mean_out, float* rstd_out, int C) {
   const int c = blockIdx.x * 256 + threadIdx.x;
   if (c >= C) return;
-  const float m = sum[c] * inv_count;
-  float var = sumsq[c] * inv_count - m * m;  // biased (normalisation) variance
+  const float dm = sum[c] * inv_count;       // mean of (x - shift)
+  const float m = dm + (sh ? sh[c] : 0.f);
+  float var = sumsq[c] * inv_count - dm * dm;  // biased (normalisation) variance; exact when shift == mean
   if (var < 0.f) var = 0.f;
   const float rstd = 1.f / sqrtf(var + eps);
   const float sc = gamma[c] * rstd;
@@ -722,26 +734,32 @@ __global__ void pack_dgrad_kernel(const float* __restrict__ w, T* __restrict__ o
 
 }  // namespace
 
-extern "C" int cavp_colstats(int32_t dtype, const void* x, int64_t rows, int32_t C, int32_t ldx, float* sum,
-                             float* sumsq, void* stream) {
+extern "C" int cavp_scale_f32(const float* in, float alpha, float* out, int32_t n, void* stream) {
+  if (!in || !out || n <= 0) return CAVP_ERR_BAD_ARG;
+  scale_vec_kernel<<<(n + 255) / 256, 256, 0, (hipStream_t)stream>>>(in, alpha, out, n);
+  CHECK_LAUNCH();
+}
+
+extern "C" int cavp_colstats(int32_t dtype, const void* x, const float* shift, int64_t rows, int32_t C, int32_t ldx,
+                             float* sum, float* sumsq, void* stream) {
   if (!x || !sum || !sumsq || rows <= 0 || C <= 0 || ldx < C) return CAVP_ERR_BAD_ARG;
   if (!dt_ok(dtype) || rows > 0x7fffffff) return CAVP_ERR_UNSUPPORTED;
   const int VE = dtype == CAVP_F32 ? 4 : 8;
   if (C % VE || ldx % VE) return CAVP_ERR_UNSUPPORTED;
   if (!al16(x)) return CAVP_ERR_ALIGN;
   ColArgs a{};
-  a.a = x; a.out0 = sum; a.out1 = sumsq; a.rows = (int)rows; a.C = C; a.lda = ldx;
+  a.a = x; a.mean = shift; a.out0 = sum; a.out1 = sumsq; a.rows = (int)rows; a.C = C; a.lda = ldx;
   return launch_col_reduce<0>(dtype, a, (hipStream_t)stream);
 }
 
-extern "C" int cavp_bn_finalize(const float* sum, const float* sumsq, int64_t count, const float* gamma,
+extern "C" int cavp_bn_finalize(const float* sum, const float* sumsq, const float* stat_shift, int64_t count, const float* gamma,
                                 const float* beta, float eps, float momentum, float* running_mean, float* running_var,
                                 float* scale, float* shift, float* mean, float* rstd, int32_t C, void* stream) {
   if (!sum || !sumsq || !gamma || !beta || !scale || !shift || !mean || !rstd || count <= 0 || C <= 0)
     return CAVP_ERR_BAD_ARG;
   if ((running_mean == nullptr) != (running_var == nullptr)) return CAVP_ERR_BAD_ARG;
   const float unbias = count > 1 ? (float)((double)count / (double)(count - 1)) : 1.f;
-  bn_finalize_kernel<<<(C + 255) / 256, 256, 0, (hipStream_t)stream>>>(sum, sumsq, (float)(1.0 / (double)count), unbias,
+  bn_finalize_kernel<<<(C + 255) / 256, 256, 0, (hipStream_t)stream>>>(sum, sumsq, stat_shift, (float)(1.0 / (double)count), unbias,
                                                                      gamma, beta, eps, momentum, running_mean,
                                                                      running_var, scale, shift, mean, rstd, C);
   CHECK_LAUNCH();

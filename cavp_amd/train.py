@@ -1,0 +1,626 @@
+"""Training pass of the CAVP hot path on MI355X: forward with batch-statistics BatchNorm + hand-written backward.
+
+The reference trains through torch.autograd over stock modules (trainer_cavp_vpo_mono.py:168-193).  Here the whole
+model is ONE autograd node (`CAVPTrainFunction`): its forward runs the HIP kernels and records a tape of backward
+closures over the saved NHWC activations; its backward replays the tape (dgrad = the same MFMA implicit-GEMM on
+rot180/transposed weights, wgrad = the pixel-reduction MFMA GEMM, BN/LN/GELU/pool/resize backward kernels) and hands
+torch one f32 gradient per parameter, so the reference's losses / optimisers / DDP hooks run unchanged on top.
+
+Semantics kept from the reference:
+  * BatchNorm uses batch statistics when its module is in training mode and updates running_mean / running_var /
+    num_batches_tracked (momentum 0.1, unbiased variance); nn.SyncBatchNorm modules all-reduce their statistics over
+    torch.distributed (RCCL) when a process group is initialised (main_vpo_mono.py:130).
+  * forward_train duplicates the visual features to 2B (cavp_model.py:181) and runs audio / fusion / decoder on 2B.
+  * parameters that receive no gradient in the reference (pos_embed_*, audio_backbone.cls_head) get None.
+"""
+from __future__ import annotations
+
+from typing import Callable, Dict, List, Optional
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from . import train_ops as T
+from ._lib import ACT_GELU, ACT_LEAKY, ACT_NONE, ACT_RELU, CavpError
+
+
+class V:
+    """An activation (NHWC / token / vector tensor) and its gradient.  A channel slice of a wider buffer is a child
+    whose gradient is the matching slice of the parent's gradient (free concat in both directions)."""
+    __slots__ = ("t", "_g", "parent", "lo", "hi", "needs_grad")
+
+    def __init__(self, t: torch.Tensor, parent: Optional["V"] = None, lo: int = 0, hi: int = 0, needs_grad: bool = True):
+        self.t, self._g, self.parent, self.lo, self.hi, self.needs_grad = t, None, parent, lo, hi, needs_grad
+
+    @property
+    def g(self) -> Optional[torch.Tensor]:
+        if self.parent is not None:
+            pg = self.parent.g
+            return None if pg is None else pg[..., self.lo:self.hi]
+        return self._g
+
+    def set_g(self, g: torch.Tensor) -> None:
+        if self.parent is not None:
+            raise CavpError("gradient of a slice is owned by its parent")
+        self._g = g
+
+    def slice(self, lo: int, hi: int) -> "V":
+        return V(self.t[..., lo:hi], parent=self, lo=lo, hi=hi)
+
+
+def _as4(t: torch.Tensor) -> torch.Tensor:
+    if t.dim() == 4:
+        return t
+    if t.dim() == 3:
+        return t.unsqueeze(1)
+    if t.dim() == 2:
+        return t.unsqueeze(1).unsqueeze(1)
+    raise CavpError("expected a 2/3/4-d activation")
+
+
+class _P:
+    """Kernel-ready parameters of one conv / linear for the training pass."""
+    __slots__ = ("w", "wT", "weight", "bias", "kh", "kw", "stride", "pad", "dil", "cout", "cin", "real_weight",
+                 "real_bias", "real_cout")
+
+
+class TrainPass:
+    def __init__(self, model, dtype: torch.dtype):
+        self.m = model
+        self.dt = dtype
+        self.tape: List[Callable[[], None]] = []
+        self.grads: Dict[int, torch.Tensor] = {}
+        self.P: Dict[str, _P] = {}
+        self.dev = next(model.parameters()).device
+        self.named: Dict[str, V] = {}   # debug taps (activations + their gradients after backward)
+
+    # ---- parameter helpers -----------------------------------------------------------------------------------
+    def pack(self, key: str, mod, need_dgrad: bool = True, raw: bool = False, pad_cout_to: int = 0) -> _P:
+        p = _P()
+        p.weight, p.bias = mod.weight, getattr(mod, "bias", None)
+        p.real_weight = p.real_bias = None
+        p.real_cout = 0
+        if isinstance(mod, nn.Linear):
+            p.kh = p.kw = 1
+            p.stride, p.pad, p.dil = 1, 0, 1
+            p.cout, p.cin = mod.out_features, mod.in_features
+        else:
+            p.kh, p.kw = mod.kernel_size
+            p.stride, p.pad, p.dil = mod.stride[0], mod.padding[0], mod.dilation[0]
+            p.cout, p.cin = mod.out_channels, mod.in_channels
+        if pad_cout_to and p.cout % pad_cout_to:
+            # Output channels that are not a multiple of the 16-byte vector (the classifier: C = 2, 22, 24, 71 ...):
+            # run the layer on zero-padded weights so every kernel stays vectorised; the padding rows of the
+            # gradient are dropped in `finish_padded`.
+            cp = (p.cout + pad_cout_to - 1) // pad_cout_to * pad_cout_to
+            wpad = torch.zeros((cp,) + tuple(mod.weight.shape[1:]), dtype=torch.float32, device=self.dev)
+            ops.cast(mod.weight.detach().contiguous().view(-1), wpad[:p.cout].view(-1))
+            p.real_weight, p.real_cout, p.weight = mod.weight, p.cout, wpad
+            if p.bias is not None:
+                bpad = torch.zeros(cp, dtype=torch.float32, device=self.dev)
+                ops.cast(p.bias.detach().contiguous(), bpad[:p.cout])
+                p.real_bias, p.bias = p.bias, bpad
+            p.cout = cp
+        p.w = p.weight.detach() if raw else ops.pack_weight(p.weight, self.dt)
+        p.wT = T.pack_weight_dgrad(p.weight, self.dt) if (need_dgrad and not raw) else None
+        self.P[key] = p
+        return p
+
+    def finish_padded(self) -> None:
+        for p in self.P.values():
+            if p.real_weight is None:
+                continue
+            gw = self.grads.pop(id(p.weight), None)
+            if gw is not None:
+                self.grads[id(p.real_weight)] = gw[:p.real_cout]
+            if p.real_bias is not None:
+                gb = self.grads.pop(id(p.bias), None)
+                if gb is not None:
+                    self.grads[id(p.real_bias)] = gb[:p.real_cout]
+
+    def add_grad(self, param: torch.Tensor, g: torch.Tensor) -> None:
+        k = id(param)
+        if k in self.grads:
+            T.add(self.grads[k], g.reshape(self.grads[k].shape).contiguous(), self.grads[k])
+        else:
+            self.grads[k] = g.reshape(param.shape)
+
+    def grad_buffer(self, param: torch.Tensor) -> torch.Tensor:
+        """f32 zero-initialised gradient accumulator in the parameter's own layout (created on first use)."""
+        k = id(param)
+        if k not in self.grads:
+            self.grads[k] = torch.zeros(param.shape, dtype=torch.float32, device=self.dev)
+        return self.grads[k]
+
+    def empty(self, shape, dtype=None) -> torch.Tensor:
+        return torch.empty(shape, dtype=dtype or self.dt, device=self.dev)
+
+    def zeros_f32(self, *shape) -> torch.Tensor:
+        return torch.zeros(shape, dtype=torch.float32, device=self.dev)
+
+    # ---- gradient accumulation -------------------------------------------------------------------------------
+    def acc(self, x: V, compute: Callable[[torch.Tensor, Optional[torch.Tensor]], None]) -> None:
+        """Run compute(out, residual) so that x.g += result (residual-add fused in the producing kernel)."""
+        if not x.needs_grad:
+            return
+        if x.parent is not None:
+            raise CavpError("accumulating into a slice is not supported")
+        if x.g is None:
+            g = self.empty(x.t.shape, x.t.dtype)
+            compute(g, None)
+            x.set_g(g)
+        else:
+            compute(x.g, x.g)
+
+    def acc_add(self, x: V, g: torch.Tensor) -> None:
+        if not x.needs_grad:
+            return
+        if x.parent is not None:
+            raise CavpError("accumulating into a slice is not supported")
+        if x.g is None:
+            x.set_g(g if g.is_contiguous() else self._dense_copy(g))
+        else:
+            gg = g if g.is_contiguous() else self._dense_copy(g)
+            T.add(x.g, gg, x.g)
+
+    def _dense_copy(self, g: torch.Tensor) -> torch.Tensor:
+        out = self.empty(g.shape, g.dtype)
+        T.scale_shift_act(g, None, None, out, ACT_NONE)
+        return out
+
+    # ---- ops -------------------------------------------------------------------------------------------------
+    def conv(self, x: V, key: str, *, act: int = ACT_NONE, residual: Optional[V] = None, nbias: Optional[V] = None,
+             out: Optional[V] = None) -> V:
+        """y = act(conv(x) + nbias[n] + bias + residual); fused epilogue forward, tape entry for backward."""
+        p = self.P[key]
+        x4 = _as4(x.t)
+        n, h, w, _ = x4.shape
+        ho = (h + 2 * p.pad - p.dil * (p.kh - 1) - 1) // p.stride + 1
+        wo = (w + 2 * p.pad - p.dil * (p.kw - 1) - 1) // p.stride + 1
+        if out is None:
+            out = V(self.empty(x.t.shape[:-1] + (p.cout,)) if x.t.dim() != 4 else self.empty((n, ho, wo, p.cout)))
+        if act == ACT_GELU:
+            raise CavpError("GELU is applied by a separate op in the training pass (its backward needs the pre-activation)")
+        bias = p.bias.detach() if p.bias is not None else None
+        ops.conv2d(x4, p.w, _as4(out.t), kh=p.kh, kw=p.kw, stride=p.stride, pad=p.pad, dil=p.dil, shift=bias,
+                   nbias=nbias.t if nbias is not None else None,
+                   residual=_as4(residual.t) if residual is not None else None, act=act)
+        y = out
+
+        def bwd():
+            dy = y.g
+            if dy is None:
+                return
+            if act in (ACT_RELU, ACT_LEAKY):
+                g = self.empty(y.t.shape, y.t.dtype)
+                T.act_bwd(dy, y.t, g, act)
+            else:
+                g = dy
+            if residual is not None:
+                self.acc_add(residual, g)
+            if p.bias is not None:
+                T.colsum(g, self.grad_buffer(p.bias))
+            if nbias is not None:
+                nb = self.zeros_f32(*nbias.t.shape)
+                g4 = _as4(g)
+                for i in range(g4.shape[0]):
+                    T.colsum(g4[i], nb[i])
+                self.acc_add(nbias, nb)
+            self.wgrad(p, x4, _as4(g))
+            if x.needs_grad:
+                def dg(o, r):
+                    T.conv2d_dgrad(_as4(g), p.wT, _as4(o), kh=p.kh, kw=p.kw, stride=p.stride, pad=p.pad, dil=p.dil,
+                                   residual=_as4(r) if r is not None else None)
+                self.acc(x, dg)
+        self.tape.append(bwd)
+        return y
+
+    def wgrad(self, p: _P, x4: torch.Tensor, g4: torch.Tensor) -> None:
+        if p.kh * p.kw == 1:
+            dw = self.grad_buffer(p.weight)   # OHWI == OIHW for 1x1 / linear: accumulate in place
+            T.conv2d_wgrad(x4, g4, dw.view(p.cout, 1, 1, p.cin), kh=1, kw=1, stride=p.stride, pad=p.pad, dil=p.dil)
+        else:
+            tmp = self.zeros_f32(p.cout, p.kh, p.kw, p.cin)
+            T.conv2d_wgrad(x4, g4, tmp, kh=p.kh, kw=p.kw, stride=p.stride, pad=p.pad, dil=p.dil)
+            k = id(p.weight)
+            have = k in self.grads
+            T.unpack_weight_grad(tmp, self.grad_buffer(p.weight), accumulate=have)
+
+    def conv_smallcin(self, x_nchw: torch.Tensor, key: str, stride: int, act: int) -> V:
+        """First stem conv (raw, BN follows) / first VGG conv (bias + ReLU fused).  Input needs no gradient."""
+        p = self.P[key]
+        n, _, h, w = x_nchw.shape
+        y = V(self.empty((n, (h - 1) // stride + 1, (w - 1) // stride + 1, p.cout)))
+        bias = p.bias.detach() if p.bias is not None else None
+        ops.conv3x3_smallcin_nchw(x_nchw, p.w, y.t, stride=stride, scale=None, shift=bias, act=act)
+
+        def bwd():
+            dy = y.g
+            if dy is None:
+                return
+            g = dy
+            if act in (ACT_RELU, ACT_LEAKY):
+                g = self.empty(y.t.shape, y.t.dtype)
+                T.act_bwd(dy, y.t, g, act)
+            if p.bias is not None:
+                T.colsum(g, self.grad_buffer(p.bias))
+            T.smallcin_wgrad(x_nchw, g, self.grad_buffer(p.weight), stride)
+        self.tape.append(bwd)
+        return y
+
+    def _allreduce_stats(self, bn, buf: torch.Tensor, count: int) -> int:
+        import torch.distributed as dist
+        if isinstance(bn, nn.SyncBatchNorm) and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            dist.all_reduce(buf)
+            return count * dist.get_world_size()
+        return count
+
+    def bn_act(self, z: V, bn, act: int, residual: Optional[V] = None, out: Optional[V] = None) -> V:
+        """y = act(BN_train(z) + residual); `out` may be a channel slice of a concat buffer."""
+        c = bn.num_features
+        rows = z.t.numel() // z.t.shape[-1]
+        # two-pass statistics: sum -> mean (all-reduced for SyncBN), then centred second moment (cancellation-free)
+        s1 = self.zeros_f32(c)
+        T.colsum(z.t, s1)
+        count = self._allreduce_stats(bn, s1, rows)
+        m0 = T.scale_f32(s1, 1.0 / count, self.empty((c,), torch.float32))
+        stats = self.zeros_f32(2, c)
+        T.colstats(z.t, stats[0], stats[1], shift=m0)
+        self._allreduce_stats(bn, stats, rows)
+        scale, shift, mean, rstd = (self.empty((c,), torch.float32) for _ in range(4))
+        track = bn.track_running_stats and bn.running_mean is not None
+        T.bn_finalize(stats[0], stats[1], count, bn.weight.detach(), bn.bias.detach(), bn.eps,
+                      bn.momentum if bn.momentum is not None else 0.1, bn.running_mean if track else None,
+                      bn.running_var if track else None, scale, shift, mean, rstd, stat_shift=m0)
+        if track and bn.num_batches_tracked is not None:
+            bn.num_batches_tracked.add_(1)
+        y = out if out is not None else V(self.empty(z.t.shape, z.t.dtype))
+        T.scale_shift_act(z.t, scale, shift, y.t, act, residual=residual.t if residual is not None else None)
+
+        def bwd():
+            dy = y.g
+            if dy is None:
+                return
+            sums = self.zeros_f32(2, c)
+            T.bn_act_bwd_reduce(dy, y.t, z.t, mean, rstd, act, sums[0], sums[1])
+            local = sums
+            if count != rows:
+                # SyncBatchNorm: dz uses the GLOBAL sums / count, the affine gradients stay the LOCAL sums (DDP
+                # reduces them with every other parameter gradient) - same split as torch's SyncBatchNorm backward
+                local = sums.clone()
+                self._allreduce_stats(bn, sums, rows)
+                sums = sums * (float(rows) / float(count))
+            dz = self.empty(z.t.shape, z.t.dtype)
+            g_out = self.empty(z.t.shape, z.t.dtype) if (residual is not None and residual.needs_grad) else None
+            T.bn_act_bwd_apply(dy, y.t, z.t, mean, rstd, bn.weight.detach(), sums[0], sums[1], act, dz, g_out=g_out)
+            z.set_g(dz)
+            if g_out is not None:
+                self.acc_add(residual, g_out)
+            self.add_grad(bn.bias, local[0].clone())
+            self.add_grad(bn.weight, local[1].clone())
+        self.tape.append(bwd)
+        return y
+
+    def gelu(self, x: V) -> V:
+        y = V(self.empty(x.t.shape, x.t.dtype))
+        T.scale_shift_act(x.t, None, None, y.t, ACT_GELU)
+
+        def bwd():
+            if y.g is None:
+                return
+            def f(o, r):
+                if r is None:
+                    T.act_bwd(y.g, x.t, o, ACT_GELU)
+                else:
+                    tmp = self.empty(x.t.shape, x.t.dtype)
+                    T.act_bwd(y.g, x.t, tmp, ACT_GELU)
+                    T.add(r, tmp, o)
+            self.acc(x, f)
+        self.tape.append(bwd)
+        return y
+
+    def maxpool(self, x: V, k: int, stride: int, pad: int) -> V:
+        n, h, w, c = x.t.shape
+        y = V(self.empty((n, (h + 2 * pad - k) // stride + 1, (w + 2 * pad - k) // stride + 1, c)))
+        ops.maxpool(x.t, y.t, k, stride, pad)
+
+        def bwd():
+            if y.g is None:
+                return
+            dx = self.empty(x.t.shape, x.t.dtype)
+            T.maxpool_bwd(x.t, y.g if y.g.is_contiguous() else self._dense_copy(y.g), dx, k, stride, pad)
+            self.acc_add(x, dx)
+        self.tape.append(bwd)
+        return y
+
+    def gap(self, x: V) -> V:
+        n, h, w, c = x.t.shape
+        y = V(self.empty((n, c), torch.float32))
+        ops.global_avgpool(x.t, y.t)
+
+        def bwd():
+            if y.g is None:
+                return
+            if x.g is None:
+                x.set_g(torch.zeros(x.t.shape, dtype=x.t.dtype, device=self.dev))
+            T.bcast_add(x.g, y.g, 1.0 / (h * w))
+        self.tape.append(bwd)
+        return y
+
+    def cast(self, x: V, dtype: torch.dtype) -> V:
+        if x.t.dtype == dtype:
+            return x
+        y = V(ops.cast(x.t.contiguous(), self.empty(x.t.shape, dtype)))
+
+        def bwd():
+            if y.g is None:
+                return
+            g = ops.cast(y.g.contiguous(), self.empty(x.t.shape, x.t.dtype))
+            self.acc_add(x, g)
+        self.tape.append(bwd)
+        return y
+
+    def bilinear(self, x: V, out: V, align_corners: bool) -> V:
+        ops.bilinear(x.t, out.t, align_corners)
+
+        def bwd():
+            if out.g is None:
+                return
+            dx = self.empty(x.t.shape, x.t.dtype)
+            T.bilinear_bwd(out.g, dx, align_corners)
+            self.acc_add(x, dx)
+        self.tape.append(bwd)
+        return out
+
+    def layernorm(self, x: V, ln) -> V:
+        y = V(self.empty(x.t.shape, x.t.dtype))
+        ops.layernorm(x.t, ln.weight.detach(), ln.bias.detach(), y.t, ln.eps)
+
+        def bwd():
+            if y.g is None:
+                return
+            dx = self.empty(x.t.shape, x.t.dtype)
+            T.layernorm_bwd(y.g, x.t, ln.weight.detach(), dx, self.grad_buffer(ln.weight), self.grad_buffer(ln.bias), ln.eps)
+            self.acc_add(x, dx)
+        self.tape.append(bwd)
+        return y
+
+    def attn_gate(self, q: V, k: V, v: V, heads: int, scale: float):
+        b, t, c = q.t.shape
+        attn = V(self.empty((b, heads, t), torch.float32))
+        o = V(self.empty(q.t.shape, q.t.dtype))
+        ops.attn_gate(q.t, k.t, v.t, o.t, attn.t, heads, scale)
+
+        def bwd():
+            if o.g is None and attn.g is None:
+                return
+            do = o.g if o.g is not None else torch.zeros_like(o.t)
+            dq = self.empty(q.t.shape, q.t.dtype)
+            dk, dv = self.zeros_f32(b, c), self.zeros_f32(b, c)
+            T.attn_gate_bwd(do, q.t, k.t, v.t, attn.t, attn.g, dq, dk, dv, heads, scale)
+            self.acc_add(q, dq)
+            self.acc_add(k, dk if k.t.dtype == torch.float32 else ops.cast(dk, self.empty(dk.shape, k.t.dtype)))
+            self.acc_add(v, dv if v.t.dtype == torch.float32 else ops.cast(dv, self.empty(dv.shape, v.t.dtype)))
+        self.tape.append(bwd)
+        return o, attn
+
+    def dup2(self, x: V) -> V:
+        """torch.cat((x, x.clone()), 0) (cavp_model.py:181)."""
+        n = x.t.shape[0]
+        y = V(self.empty((2 * n,) + tuple(x.t.shape[1:]), x.t.dtype))
+        ops.cast(x.t, y.t[:n])
+        ops.cast(x.t, y.t[n:])
+
+        def bwd():
+            if y.g is None:
+                return
+            g = self.empty(x.t.shape, x.t.dtype)
+            T.add(y.g[:n], y.g[n:], g)
+            self.acc_add(x, g)
+        self.tape.append(bwd)
+        return y
+
+    def flatten(self, x: V) -> V:
+        """[B, H, W, C] -> [B, H*W*C] view (VGG NHWC flatten)."""
+        y = V(x.t.reshape(x.t.shape[0], -1))
+        shape = x.t.shape
+
+        def bwd():
+            if y.g is not None:
+                self.acc_add(x, y.g.reshape(shape))
+        self.tape.append(bwd)
+        return y
+
+    def reshape(self, x: V, shape) -> V:
+        y = V(x.t.view(shape))
+        old = x.t.shape
+
+        def bwd():
+            if y.g is not None:
+                self.acc_add(x, y.g.view(old))
+        self.tape.append(bwd)
+        return y
+
+    def backward(self) -> None:
+        for fn in reversed(self.tape):
+            fn()
+        self.tape = []
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# the model graph in training mode
+# ---------------------------------------------------------------------------------------------------------------
+def run_train_forward(model, image: torch.Tensor, audio: torch.Tensor, tp: TrainPass):
+    """Mirrors CAVP._forward_hip (eval) op by op with batch-statistics BN and a backward tape.  Returns the V's of
+    (logits_lowres, fusion NHWC, fea_v_proj NHWC, fea_a, attn)."""
+    from .cavp_model import VGG
+    m = model
+    rn = m.backbone.backbone
+    B = image.shape[0]
+    # ---- pack ----
+    tp.pack("stem0", rn.conv1[0], raw=True)
+    tp.pack("stem1", rn.conv1[3])
+    tp.pack("stem2", rn.conv1[6])
+    for si in range(4):
+        for bi, blk in enumerate(getattr(rn, f"layer{si + 1}")):
+            key = f"l{si + 1}.{bi}"
+            tp.pack(key + ".c1", blk.conv1)
+            tp.pack(key + ".c2", blk.conv2)
+            tp.pack(key + ".c3", blk.conv3)
+            if blk.downsample is not None:
+                tp.pack(key + ".ds", blk.downsample[0])
+    aspp = m.segment.aspp
+    for i, cv in enumerate(aspp.map_convs):
+        tp.pack(f"aspp.map{i}", cv)
+    tp.pack("aspp.gp", aspp.global_pooling_conv)
+    tp.pack("aspp.pool_red", aspp.pool_red_conv)
+    tp.pack("aspp.red", aspp.red_conv)
+    tp.pack("reduce", m.segment.reduce[0])
+    up = m.segment.upsample
+    tp.pack("head0", up.last_conv[0])
+    tp.pack("head1", up.last_conv[3])
+    tp.pack("cls", up.classifier, pad_cout_to=8)
+    vgg = m.audio_backbone.backbone
+    convs = [mm for mm in vgg.features if isinstance(mm, nn.Conv2d)]
+    tp.pack("a.conv0", convs[0], raw=True)
+    for i, cv in enumerate(convs[1:], 1):
+        tp.pack(f"a.conv{i}", cv)
+    for i, j in enumerate((0, 2, 4)):
+        tp.pack(f"a.fc{i}", vgg.embeddings[j])
+    tp.pack("proj.fc1", m.visual_projector.fc1)
+    tp.pack("proj.fc2", m.visual_projector.fc2)
+    ca, blk = m.cross_att, m.cross_att.blocks[0]
+    tp.pack("ca.pe_v", ca.patch_embed_v.proj)
+    tp.pack("ca.pe_a", ca.patch_embed_a.proj)
+    for nme in ("q", "k", "v", "proj"):
+        tp.pack("ca." + nme, getattr(blk.attn, nme))
+    tp.pack("ca.fc1", blk.mlp.fc1)
+    tp.pack("ca.fc2", blk.mlp.fc2)
+
+    dt = tp.dt
+    # ---- backbone (resnet.py:186-201) ----
+    z = tp.conv_smallcin(image, "stem0", 2, ACT_NONE)
+    x = tp.bn_act(z, rn.conv1[1], ACT_RELU)
+    x = tp.bn_act(tp.conv(x, "stem1"), rn.conv1[4], ACT_RELU)
+    x = tp.bn_act(tp.conv(x, "stem2"), rn.bn1, ACT_RELU)
+    x = tp.maxpool(x, 3, 2, 1)
+    feats = []
+    for si, stage in enumerate(rn.block_table):
+        for bi, (_, _, _, has_ds) in enumerate(stage):
+            blkm = getattr(rn, f"layer{si + 1}")[bi]
+            key = f"l{si + 1}.{bi}"
+            o = tp.bn_act(tp.conv(x, key + ".c1"), blkm.bn1, ACT_RELU)
+            o = tp.bn_act(tp.conv(o, key + ".c2"), blkm.bn2, ACT_RELU)
+            res = tp.bn_act(tp.conv(x, key + ".ds"), blkm.downsample[1], ACT_NONE) if has_ds else x
+            x = tp.bn_act(tp.conv(o, key + ".c3"), blkm.bn3, ACT_RELU, residual=res)
+            tp.named[key] = x
+        feats.append(x)
+    f1, f4 = feats[0], feats[-1]
+    # ---- ASPP + skip (encoder_decoder.py:97-105,137-156) ----
+    n, h, w, _ = f4.t.shape
+    hid = tp.P["aspp.map0"].cout
+    zcat = V(tp.empty((n, h, w, 4 * hid)))
+    for i in range(4):
+        tp.conv(f4, f"aspp.map{i}", out=zcat.slice(i * hid, (i + 1) * hid))
+    cat = tp.bn_act(zcat, aspp.map_bn, ACT_LEAKY)
+    pool = tp.cast(tp.gap(f4), dt)
+    g = tp.bn_act(tp.conv(pool, "aspp.gp"), aspp.global_pooling_bn, ACT_LEAKY)
+    g = tp.cast(tp.conv(g, "aspp.pool_red"), torch.float32)
+    zred = tp.conv(cat, "aspp.red", nbias=g)
+    asp = tp.bn_act(zred, aspp.red_bn, ACT_LEAKY)
+    _, lh, lw, _ = f1.t.shape
+    co = tp.P["aspp.red"].cout
+    fea_v = V(tp.empty((n, lh, lw, co + tp.P["reduce"].cout)))
+    tp.bilinear(asp, fea_v.slice(0, co), align_corners=True)
+    tp.bn_act(tp.conv(f1, "reduce"), m.segment.reduce[1], ACT_RELU, out=fea_v.slice(co, co + tp.P["reduce"].cout))
+    # ---- 2B duplication + audio (cavp_model.py:181-186; vgg.py:17-23) ----
+    fea_v2 = tp.dup2(fea_v)
+    if audio.shape[0] != 2 * B:
+        raise CavpError(f"train mode expects audio of 2B = {2 * B} (cavp_model.py:181), got {audio.shape[0]}")
+    a = tp.conv_smallcin(audio, "a.conv0", 1, ACT_RELU)
+    ci = 1
+    for v in VGG.CFG[1:]:
+        if v == "M":
+            a = tp.maxpool(a, 2, 2, 0)
+        else:
+            a = tp.conv(a, f"a.conv{ci}", act=ACT_RELU)
+            ci += 1
+    a = tp.flatten(a)
+    a = tp.conv(a, "a.fc0", act=ACT_RELU)
+    a = tp.conv(a, "a.fc1", act=ACT_RELU)
+    fea_a = tp.conv(a, "a.fc2", act=ACT_RELU)
+    # ---- fusion (cavp_model.py:143-154; attn.py:232-244) ----
+    B2, hh, ww, Cc = fea_v2.t.shape
+    tok = tp.reshape(fea_v2, (B2, hh * ww, Cc))
+    hidp = tp.gelu(tp.conv(tok, "proj.fc1"))
+    fea_v_proj = tp.conv(hidp, "proj.fc2")
+    v0 = tp.conv(fea_v_proj, "ca.pe_v")
+    a0 = tp.conv(fea_a, "ca.pe_a")
+    vn = tp.layernorm(v0, blk.norm1)
+    an = tp.layernorm(a0, blk.norm1)
+    q = tp.conv(vn, "ca.q")
+    k = tp.conv(an, "ca.k")
+    vv = tp.conv(an, "ca.v")
+    o, attn = tp.attn_gate(q, k, vv, blk.attn.num_heads, blk.attn.scale)
+    r1 = tp.conv(o, "ca.proj", residual=vn)
+    l2 = tp.layernorm(r1, blk.norm2)
+    hh2 = tp.gelu(tp.conv(l2, "ca.fc1"))
+    r2 = tp.conv(hh2, "ca.fc2", residual=r1)
+    fus_tok = tp.layernorm(r2, ca.norm)
+    fusion = tp.reshape(fus_tok, (B2, hh, ww, Cc))
+    # ---- decoder head (encoder_decoder.py:62-75) ----
+    z0h = tp.conv(fusion, "head0")
+    c1 = tp.bn_act(z0h, up.last_conv[1], ACT_RELU)
+    z1h = tp.conv(c1, "head1")
+    c2 = tp.bn_act(z1h, up.last_conv[4], ACT_RELU)
+    lo = tp.conv(c2, "cls")   # [2B, h, w, Cpad]; channels >= num_classes are exact zeros
+    tp.named.update(fusion=fusion, z0h=z0h, c1=c1, z1h=z1h, c2=c2, lo=lo, r2=r2, r1=r1, vn=vn, q=q, o=o, fea_v2=fea_v2,
+                    fea_v=fea_v, f4=f4, f1=f1, fea_a=fea_a, asp=asp, cat=cat, zcat=zcat)
+    return lo, fusion, fea_v_proj, fea_a, attn
+
+
+class CAVPTrainFunction(torch.autograd.Function):
+    """One autograd node for the whole model: inputs (image, audio, *parameters) -> (out_pred, out_fusion, visual,
+    audio_feat, attn_v).  Gradients flow from out_pred and out_fusion."""
+
+    @staticmethod
+    def forward(ctx, model, image, audio, *params):
+        tp = TrainPass(model, model.compute_dtype)
+        with torch.no_grad():
+            lo, fusion, fea_v_proj, fea_a, attn = run_train_forward(model, image.contiguous(), audio.contiguous(), tp)
+            B2, C = lo.t.shape[0], model.num_classes
+            out_pred = torch.empty((B2, C) + tuple(image.shape[-2:]), dtype=torch.float32, device=image.device)
+            ops.bilinear_to_nchw(lo.t[..., :C], out_pred, align_corners=False)
+            f32 = model._as_f32
+            out_fusion = f32(fusion.t).permute(0, 3, 1, 2)
+            visual = f32(fea_v_proj.t).view(fusion.t.shape).permute(0, 3, 1, 2)
+            audio_f = f32(fea_a.t)[:, :, None, None]
+            attn_v = attn.t.unsqueeze(-1)
+        ctx.tp, ctx.lo, ctx.fusion, ctx.params, ctx.hw = tp, lo, fusion, params, tuple(image.shape[-2:])
+        ctx.model_ref = model
+        ctx.mark_non_differentiable(visual, audio_f, attn_v)
+        return out_pred, out_fusion, visual, audio_f, attn_v
+
+    @staticmethod
+    def backward(ctx, d_pred, d_fusion, *_unused):
+        tp, lo, fusion = ctx.tp, ctx.lo, ctx.fusion
+        with torch.no_grad():
+            if d_pred is not None:
+                g = torch.zeros(lo.t.shape, dtype=lo.t.dtype, device=lo.t.device)
+                T.bilinear_bwd_from_nchw(d_pred.contiguous().float(), g[..., :d_pred.shape[1]], n_valid=lo.t.shape[0],
+                                         align_corners=False)
+                lo.set_g(g)
+            if d_fusion is not None:
+                gf = d_fusion.permute(0, 2, 3, 1).contiguous().float()   # boundary layout conversion of a foreign tensor
+                gf = gf if fusion.t.dtype == torch.float32 else ops.cast(gf, tp.empty(gf.shape, fusion.t.dtype))
+                fusion.set_g(gf)
+            tp.backward()
+            tp.finish_padded()
+        grads = []
+        for p in ctx.params:
+            g = tp.grads.get(id(p))
+            grads.append(None if g is None else g.view(p.shape))
+        ctx.model_ref._last_train_pass = tp if getattr(ctx.model_ref, '_keep_train_pass', False) else None
+        ctx.tp = None
+        return (None, None, None) + tuple(grads)

@@ -142,16 +142,23 @@ def smallcin_wgrad(x_nchw: torch.Tensor, dy: torch.Tensor, dw_oihw: torch.Tensor
     return dw_oihw
 
 
-def colstats(x: torch.Tensor, sums: torch.Tensor, sumsq: torch.Tensor) -> None:
+def colstats(x: torch.Tensor, sums: torch.Tensor, sumsq: torch.Tensor, shift: Optional[torch.Tensor] = None) -> None:
     rows, c, ld = _rows(x)
-    _need_gpu(x, sums, sumsq)
-    _check(_lib.load().cavp_colstats(dtype_code(x.dtype), _ptr(x), rows, c, ld, _ptr(sums), _ptr(sumsq), _s()), "cavp_colstats")
+    _need_gpu(x, sums, sumsq, shift)
+    _check(_lib.load().cavp_colstats(dtype_code(x.dtype), _ptr(x), _ptr(shift), rows, c, ld, _ptr(sums), _ptr(sumsq), _s()),
+           "cavp_colstats")
+
+
+def scale_f32(src: torch.Tensor, alpha: float, dst: torch.Tensor) -> torch.Tensor:
+    _need_gpu(src, dst)
+    _check(_lib.load().cavp_scale_f32(_ptr(src), C.c_float(alpha), _ptr(dst), src.numel(), _s()), "cavp_scale_f32")
+    return dst
 
 
 def bn_finalize(sums, sumsq, count: int, gamma, beta, eps: float, momentum: float, running_mean, running_var, scale,
-                shift, mean, rstd) -> None:
+                shift, mean, rstd, stat_shift=None) -> None:
     _need_gpu(sums, sumsq, gamma, beta, scale, shift, mean, rstd)
-    _check(_lib.load().cavp_bn_finalize(_ptr(sums), _ptr(sumsq), count, _ptr(gamma), _ptr(beta), C.c_float(eps),
+    _check(_lib.load().cavp_bn_finalize(_ptr(sums), _ptr(sumsq), _ptr(stat_shift), count, _ptr(gamma), _ptr(beta), C.c_float(eps),
                                         C.c_float(momentum), _ptr(running_mean), _ptr(running_var), _ptr(scale), _ptr(shift),
                                         _ptr(mean), _ptr(rstd), gamma.numel(), _s()), "cavp_bn_finalize")
 

@@ -143,16 +143,20 @@ int cavp_conv3x3_smallcin_wgrad(int32_t dtype, const float* x_nchw, const void* 
                                 int32_t Cin, int32_t H, int32_t W, int32_t Cout, int32_t stride, void* stream);
 
 /* nn.BatchNorm2d in training mode (resnet.py / encoder_decoder.py BN layers under model.train()):
- *   cavp_colstats     sum[c] += sum_rows x, sumsq[c] += sum_rows x^2   (f32 atomics; caller zeroes)
- *   cavp_bn_finalize  mean/var -> scale = gamma*rstd, shift = beta - mean*scale; saves mean, rstd; updates the running
+ *   cavp_colstats     sum[c] += sum_rows (x - s_c), sumsq[c] += sum_rows (x - s_c)^2 with an optional per-channel
+ *                     shift s (f32 atomics; caller zeroes).  Two passes (s = 0, then s = mean) give a cancellation-free
+ *                     variance, which matters for the tiny-M BatchNorms (ASPP pooled branch: M = batch size).
+ *   cavp_bn_finalize  mean = s + sum/M, var = sumsq/M - (sum/M)^2 -> scale = gamma*rstd, shift = beta - mean*scale;
+ *                     saves mean, rstd; updates the running
  *                     statistics in place (momentum, unbiased variance) when running_mean/var are non-NULL
  *   cavp_scale_shift_act  y = act(x*scale + shift + residual)
  *   cavp_bn_act_bwd_reduce / _apply  g = dy*act'(y); dbeta = sum g; dgamma = sum g*zhat;
  *                     dz = gamma*rstd*(g - dbeta/M - zhat*dgamma/M); optional g_out = g (skip-path gradient) */
-int cavp_colstats(int32_t dtype, const void* x, int64_t rows, int32_t C, int32_t ldx, float* sum, float* sumsq,
-                  void* stream);
-int cavp_bn_finalize(const float* sum, const float* sumsq, int64_t count, const float* gamma, const float* beta,
-                     float eps, float momentum, float* running_mean, float* running_var, float* scale, float* shift,
+int cavp_colstats(int32_t dtype, const void* x, const float* shift, int64_t rows, int32_t C, int32_t ldx, float* sum,
+                  float* sumsq, void* stream);
+int cavp_scale_f32(const float* in, float alpha, float* out, int32_t n, void* stream); /* out = alpha * in */
+int cavp_bn_finalize(const float* sum, const float* sumsq, const float* stat_shift, int64_t count, const float* gamma,
+                     const float* beta, float eps, float momentum, float* running_mean, float* running_var, float* scale, float* shift,
                      float* mean, float* rstd, int32_t C, void* stream);
 int cavp_scale_shift_act(int32_t dtype, const void* x, const float* scale, const float* shift, const void* residual,
                          void* y, int64_t rows, int32_t C, int32_t ldx, int32_t ldr, int32_t ldy, int32_t act,

@@ -1,0 +1,168 @@
+"""End-to-end training-step parity (forward with batch-stat BN + full backward through the HIP path) against the
+golden vectors captured from the reference's own autograd (tests/golden/c1p_train.npz)."""
+import types
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from cavp_amd.synth import synth_inputs, synth_state_dict
+from tests._golden_util import check_tap, load_case
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _build(cfg, dtype=torch.float32):
+    from cavp_amd.cavp_model import CAVP
+    args = types.SimpleNamespace(seg_model="DeepLabV3Plus", last_three_dilation_stride=cfg["lds"], audio_backbone="vgg",
+                                 num_classes=cfg["C"], batch_size=cfg["B"], local_rank="cpu")
+    m = CAVP(50, None, num_classes=cfg["C"], args=args)
+    sd = synth_state_dict({k: tuple(v.shape) for k, v in m.state_dict().items()}, seed=1)
+    m.load_state_dict(sd, strict=True)
+    m.train().to(DEV).set_compute_dtype(dtype)
+    return m, sd
+
+
+def _step(m, cfg, use_hip_ce):
+    B = cfg["B"]
+    image, audio, label = synth_inputs(B, cfg["hw"], audio_batch=2 * B, num_classes=cfg["C"], seed=0)
+    out, fus, pack = m(image.to(DEV), audio.to(DEV), None, False)      # trainer_cavp_vpo_mono.py:168
+    if use_hip_ce:
+        from cavp_amd import train_ops as T
+        loss, dl = T.ce_loss(out.detach(), label.to(DEV), B)
+        out.backward(dl)
+        loss = float(loss.item())
+    else:
+        output = out[:B] + out[B:] * 0.0                               # :171
+        loss_t = F.cross_entropy(output, label.to(DEV), ignore_index=255)   # loss/losser.py:60-62
+        loss_t.backward()
+        loss = float(loss_t.item())
+    torch.cuda.synchronize()
+    return out, fus, pack, loss
+
+
+@pytest.mark.parametrize("use_hip_ce", [False, True], ids=["torch_ce", "hip_ce"])
+def test_train_step_matches_reference_f32(use_hip_ce):
+    z, cfg = load_case("c1p_train")
+    m, _ = _build(cfg)
+    out, fus, pack, loss = _step(m, cfg, use_hip_ce)
+    assert abs(loss - float(z["loss"][0])) <= 2e-5 * max(1.0, abs(float(z["loss"][0]))), (loss, float(z["loss"][0]))
+    for k, t in dict(out_pred=out, out_fusion=fus, pack_visual=pack["visual"], pack_audio=pack["audio"],
+                     pack_attn_v=pack["attn_v"]).items():
+        scale = max(1.0, float(np.abs(z["sample/" + k]).max()))
+        # batch-statistics BN at B=2 amplifies rounding: the reference's own f32 forward is 3.8e-3 (4e-4 relative) away
+        # from an f64 evaluation of the same graph on these inputs (measured with the oracle), so two f32
+        # implementations can only be expected to agree to ~1e-3 relative here (eval-mode parity bar stays 1e-3 abs).
+        check_tap(z, k, t.detach(), 1.5e-3 * scale, what="train:")
+    params = dict(m.named_parameters())
+    keys, vals = list(z["grad_norm_keys"]), z["grad_norm_vals"]
+    worst = (0.0, None)
+    for k, v in zip(keys, vals):
+        g = params[k].grad
+        assert g is not None, f"no gradient for {k}"
+        n = float(g.double().norm().item())
+        rel = abs(n - v) / max(v, 1e-6)
+        if rel > worst[0]:
+            worst = (rel, k)
+        # tolerance: the reference's own f32 gradient norms differ from an f64 evaluation by up to 1.1e-2 relative
+        # (median 4e-3) on this B=2 batch-stat-BN step (measured with the oracle); 1.5e-2 is that noise floor.
+        assert rel <= 1.5e-2 or abs(n - v) <= 1e-6, f"{k}: |grad| {n:.6g} vs reference {v:.6g} (rel {rel:.2e})"
+    for k, p in params.items():
+        if k not in keys:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, f"{k} must not receive gradient"
+    for s in [s for s in z.files if s.startswith("grad_sample/")]:
+        k = s[len("grad_sample/"):]
+        g = params[k].grad.detach().float().cpu().contiguous().flatten()
+        ref = z[s]
+        smp = g[:: max(1, g.numel() // 4096)][:4096].numpy()
+        # elementwise noise floor of the reference itself (f32 vs f64, same measurement): 2.5-5.1e-2 of max|grad| for
+        # backbone / ASPP / reduce tensors (the ASPP pooled-branch BN normalises over M = B = 2 samples, where dz is
+        # analytically 0 and numerically rounding noise x rstd), <= 1e-2 elsewhere.
+        noisy = k.startswith(("backbone.", "segment.aspp", "segment.reduce"))
+        tol = (1.5e-1 if noisy else 2e-2) * max(1e-6, float(np.abs(ref).max()))  # 3x the measured floor; the tight bar is the B=8 test
+        assert np.abs(smp - ref).max() <= tol, f"{k}: sampled grad err {np.abs(smp - ref).max():.3e} > {tol:.3e}"
+    print("train step ok: loss", loss, "worst grad-norm rel err", worst)
+
+
+def test_running_stats_and_second_step():
+    """BN running statistics follow nn.BatchNorm2d semantics (momentum 0.1, unbiased var) and a second step works."""
+    from oracle import cavp_oracle as O
+    z, cfg = load_case("c1p_train")
+    m, sd = _build(cfg)
+    bn = m.backbone.backbone.conv1[1]
+    rm0, rv0 = bn.running_mean.clone(), bn.running_var.clone()
+    _step(m, cfg, True)
+    image, _, _ = synth_inputs(cfg["B"], cfg["hw"], audio_batch=2 * cfg["B"], num_classes=cfg["C"], seed=0)
+    zc = F.conv2d(image, sd["backbone.backbone.conv1.0.weight"], None, 2, 1)
+    mean, var = zc.mean((0, 2, 3)), zc.var((0, 2, 3), unbiased=True)
+    assert float((bn.running_mean.cpu() - (0.9 * rm0.cpu() + 0.1 * mean)).abs().max()) <= 1e-5
+    assert float((bn.running_var.cpu() - (0.9 * rv0.cpu() + 0.1 * var)).abs().max()) <= 1e-4
+    assert int(bn.num_batches_tracked.item()) == 1
+    g1 = m.segment.upsample.classifier.weight.grad.clone()
+    _step(m, cfg, True)     # gradients accumulate like torch (.grad += new)
+    g2 = m.segment.upsample.classifier.weight.grad
+    assert float((g2 - g1).abs().max()) > 0
+
+
+def _oracle_grads(sd, cfg, image, audio, label):
+    from oracle import cavp_oracle as O
+    params = {k: v.clone().requires_grad_(True) for k, v in sd.items() if v.is_floating_point() and "running_" not in k}
+    sd2 = dict(sd)
+    sd2.update(params)
+    out, fus, _ = O.cavp_forward(sd2, image, audio, cfg["lds"], eval_mode=False)
+    loss = O.ce_loss_train(out, label, cfg["B"])
+    loss.backward()
+    return out.detach(), float(loss.item()), {k: p.grad for k, p in params.items() if p.grad is not None}
+
+
+@pytest.mark.parametrize("dtype,norm_tol,cos_tol", [(torch.float32, 5e-3, 0.9995), (torch.bfloat16, 0.08, None)],
+                         ids=["f32", "bf16"])
+def test_train_step_b8_vs_oracle(dtype, norm_tol, cos_tol):
+    """A better-conditioned step (B=8, so no 2-sample BatchNorm) against the CPU oracle's autograd: every parameter's
+    gradient by norm and (f32) by direction.  bf16 is held to loss + gradient-norm statistics only: with random
+    weights and batch-statistics BN this graph is chaotic under storage rounding - rounding every conv / BN / linear
+    output of the *reference* graph to bf16 on the CPU (oracle monkey-patched, same inputs) already moves layer4 to
+    cosine 0.85 and the ASPP output to 0.71 of the f32 run, the same figures this path shows (0.86 / 0.72) - so a
+    directional bar against f32 would test the weights' conditioning, not the kernels (op-level bf16 parity:
+    tests/test_gpu_train_ops.py)."""
+    cfg = dict(C=3, B=8, hw=(64, 64), lds=[False, False, False])
+    m, sd = _build(cfg, dtype)
+    B = cfg["B"]
+    image, audio, label = synth_inputs(B, cfg["hw"], audio_batch=2 * B, num_classes=cfg["C"], seed=5)
+    from cavp_amd import train_ops as T
+    out, fus, pack = m(image.to(DEV), audio.to(DEV), None, False)
+    loss, dl = T.ce_loss(out.detach(), label.to(DEV), B)
+    out.backward(dl)
+    torch.cuda.synchronize()
+    ref_out, ref_loss, ref_g = _oracle_grads(sd, cfg, image, audio, label)
+    assert abs(float(loss.item()) - ref_loss) <= (1e-4 if dtype == torch.float32 else 3e-2) * max(1.0, abs(ref_loss))
+    params = dict(m.named_parameters())
+    rels, coss = [], []
+    for k, g in ref_g.items():
+        mine = params[k].grad
+        assert mine is not None, k
+        a, b = mine.detach().double().cpu().flatten(), g.double().flatten()
+        nb = float(b.norm())
+        if nb < 1e-8:
+            continue
+        rels.append(abs(float(a.norm()) - nb) / nb)
+        coss.append(float((a @ b) / (a.norm() * b.norm() + 1e-30)))
+    rels, coss = np.array(rels), np.array(coss)
+    print(f"{dtype}: loss {float(loss.item()):.5f} (oracle {ref_loss:.5f}); grad norm rel err median {np.median(rels):.2e} "
+          f"max {rels.max():.2e}; cosine min {coss.min():.5f} median {np.median(coss):.6f}")
+    assert np.median(rels) <= norm_tol and rels.max() <= 12 * norm_tol
+    if cos_tol is not None:
+        assert np.median(coss) >= cos_tol and coss.min() >= 1 - 6 * (1 - cos_tol)
+
+
+def test_train_step_bf16_b2_loss_only():
+    """B=2 golden step in bf16: only the forward/loss is meaningful (the 2-sample BatchNorm of the ASPP pooled branch
+    turns bf16 rounding into O(1) gradient noise; see test_train_step_b8_vs_oracle for the gradient bar)."""
+    z, cfg = load_case("c1p_train")
+    m, _ = _build(cfg, torch.bfloat16)
+    out, fus, pack, loss = _step(m, cfg, True)
+    ref_loss = float(z["loss"][0])
+    assert abs(loss - ref_loss) <= 0.03 * abs(ref_loss) + 0.02, (loss, ref_loss)
+    assert all(torch.isfinite(p.grad).all() for p in m.parameters() if p.grad is not None)
