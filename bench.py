@@ -40,6 +40,9 @@ def parse():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=32, help="frames per GPU per step")
     ap.add_argument("--dtype", choices=["bf16", "f32"], default="bf16")
+    ap.add_argument("--mode", choices=["train", "eval"], default="train",
+                    help="train = forward_train + CE + backward (+ gradient all-reduce when N > 1): the BASELINE.json "
+                         "metric; eval = inference forward only")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -70,18 +73,26 @@ class KernelTimer:
     def __init__(self):
         self.records = []
 
-    def wrap(self, ops_mod):
+    def wrap(self, ops_mod, train_mod=None):
         self._orig = {}
         for name in ("conv2d", "conv3x3_smallcin_nchw", "maxpool", "global_avgpool", "bilinear", "bilinear_to_nchw",
                      "layernorm", "attn_gate", "cast"):
             fn = getattr(ops_mod, name)
-            self._orig[name] = fn
+            self._orig[(ops_mod, name)] = fn
             setattr(ops_mod, name, self._timed(name, fn))
+        if train_mod is not None:
+            for name in ("conv2d_dgrad", "conv2d_wgrad", "colstats", "colsum", "scale_shift_act", "bn_act_bwd_reduce",
+                         "bn_act_bwd_apply", "act_bwd", "add", "layernorm_bwd", "attn_gate_bwd", "maxpool_bwd",
+                         "bilinear_bwd", "bilinear_bwd_from_nchw", "bcast_add", "ce_loss", "smallcin_wgrad",
+                         "unpack_weight_grad", "pack_weight_dgrad"):
+                fn = getattr(train_mod, name)
+                self._orig[(train_mod, name)] = fn
+                setattr(train_mod, name, self._timed(name, fn))
         return self
 
-    def unwrap(self, ops_mod):
-        for name, fn in self._orig.items():
-            setattr(ops_mod, name, fn)
+    def unwrap(self, *_):
+        for (mod, name), fn in self._orig.items():
+            setattr(mod, name, fn)
 
     def _timed(self, name, fn):
         def run(*a, **k):
@@ -90,6 +101,19 @@ class KernelTimer:
             r = fn(*a, **k)
             e1.record()
             flops = nbytes = 0
+            if name in ("conv2d_dgrad", "conv2d_wgrad"):
+                # dgrad(dy, w_t, dx): same MACs as the forward conv = M_dy * Cout_f * Cin_f * k * k (stride-1 form)
+                t0, t1, t2 = a[0], a[1], a[2]
+                es = t0.element_size()
+                kk = k.get("kh", 1) * k.get("kw", 1)
+                if name == "conv2d_dgrad":
+                    m_dy = t0.shape[0] * t0.shape[1] * t0.shape[2]
+                    flops = 2 * m_dy * t0.shape[3] * t2.shape[3] * kk
+                    nbytes = (t0.numel() + t1.numel() + t2.numel()) * es
+                else:
+                    m_dy = t1.shape[0] * t1.shape[1] * t1.shape[2]
+                    flops = 2 * m_dy * t1.shape[3] * t0.shape[3] * kk
+                    nbytes = (t0.numel() + t1.numel()) * es + t2.numel() * 4
             if name == "conv2d":
                 x, w, out = a[0], a[1], a[2]
                 es = x.element_size()
@@ -99,6 +123,8 @@ class KernelTimer:
                 if k.get("residual") is not None:
                     nbytes += m * out.shape[3] * es
             desc = ""
+            if name in ("conv2d_dgrad", "conv2d_wgrad"):
+                desc = f"{tuple(a[0].shape)} {tuple(a[1].shape)} -> {tuple(a[2].shape)} k{k.get('kh', 1)} s{k.get('stride', 1)} d{k.get('dil', 1)}"
             if name == "conv2d":
                 desc = (f"x{tuple(a[0].shape)} -> y{tuple(a[2].shape)} k{k.get('kh', 1)} s{k.get('stride', 1)} "
                         f"d{k.get('dil', 1)}")
@@ -129,20 +155,24 @@ class KernelTimer:
         return agg
 
 
-def measure_roofline(model, image, audio, dtype_name, reps=3):
-    from cavp_amd import cavp_model, ops
-    kt = KernelTimer().wrap(ops)
+def measure_roofline(model, run_step, image, dtype_name, reps=3):
+    from cavp_amd import ops, train_ops
+    kt = KernelTimer().wrap(ops, train_ops)
     try:
         with torch.no_grad():
             for _ in range(reps):
-                model(image, audio, eval_mode=True)
+                run_step()
         agg = kt.summary()
         if os.environ.get("CAVP_BENCH_PER_LAYER"):
             with open(os.environ["CAVP_BENCH_PER_LAYER"], "w") as f:
                 f.write(kt.per_layer(reps) + "\n")
     finally:
         kt.unwrap(ops)
+    # dominant kernel = igemm_kernel: forward convs / linears (conv2d) + data gradients (conv2d_dgrad, same kernel)
     launches, ms, flops, nbytes = agg["conv2d"]
+    if "conv2d_dgrad" in agg:
+        l2, m2, f2, b2 = agg["conv2d_dgrad"]
+        launches, ms, flops, nbytes = launches + l2, ms + m2, flops + f2, nbytes + b2
     launches //= reps
     ms /= reps
     flops //= reps
@@ -158,7 +188,8 @@ def measure_roofline(model, image, audio, dtype_name, reps=3):
     else:
         roof = {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(frac_hbm, 4)}
     traffic = None
-    tpath = os.path.join(REPO, "profiles", f"r01_traffic_{dtype_name}.json")
+    tpath = os.path.join(REPO, "profiles", f"r01_traffic_{dtype_name}.json" if not getattr(model, "training", False)
+                         else f"r01_traffic_train_{dtype_name}.json")
     if os.path.exists(tpath):  # PMC counters cannot be read from inside the process: measured with rocprofv3 --pmc
         with open(tpath) as f:
             tj = json.load(f)
@@ -175,9 +206,43 @@ def measure_roofline(model, image, audio, dtype_name, reps=3):
         "achieved_tflops": round(tflops, 2), "achieved_gbs": round(gbs, 1),
         "frac_of_mfma_peak": round(frac_mfma, 4), "frac_of_hbm_peak": round(frac_hbm, 4),
         "share_of_step_kernel_time": round(ms / total_ms, 3),
-        "other_kernels_ms": {k: round(v[1] / reps, 3) for k, v in agg.items() if k != "conv2d"},
+        "other_kernels_ms": {k: round(v[1] / reps, 3) for k, v in agg.items() if k not in ("conv2d", "conv2d_dgrad")},
     })
+    if "conv2d_wgrad" in agg:
+        wl, wms, wf, wb = agg["conv2d_wgrad"]
+        wms /= reps
+        roof["wgrad_kernel"] = {"launches_per_step": wl // reps, "ms_per_step": round(wms, 3),
+                                "achieved_tflops": round(wf / reps / (wms * 1e-3) / 1e12, 2),
+                                "frac_of_mfma_peak": round(wf / reps / (wms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS[dtype_name], 4)}
     return roof
+
+
+def cpu_baseline_train(sd, cfg, sample_batch):
+    """Oracle forward_train + CE + autograd backward on the host cores (bounded sample)."""
+    from cavp_amd.synth import synth_inputs
+    from oracle import cavp_oracle as O
+    cores = os.cpu_count() or 1
+    try:
+        import psutil
+        cores = psutil.cpu_count(logical=False) or cores
+    except Exception:
+        pass
+    torch.set_num_threads(cores)
+    image, audio, label = synth_inputs(sample_batch, cfg["hw"], audio_batch=2 * sample_batch, num_classes=cfg["C"], seed=0)
+    params = {k: v.clone().requires_grad_(True) for k, v in sd.items() if v.is_floating_point() and "running_" not in k}
+    sd2 = dict(sd)
+    sd2.update(params)
+    t0, n = time.perf_counter(), 0
+    while True:
+        out, _, _ = O.cavp_forward(sd2, image, audio, cfg["lds"], eval_mode=False)
+        O.ce_loss_train(out, label, sample_batch).backward()
+        n += 1
+        dt = time.perf_counter() - t0
+        if dt > 15.0 or n >= 4:
+            break
+    return {"value": round(n * sample_batch / dt, 2), "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": f"{n} x (forward_train + CE + backward) of B={sample_batch} frames (audio {2 * sample_batch}), fp32, torch CPU "
+                      f"autograd over the oracle ({torch.get_num_threads()} threads), same C1' model and synthetic inputs"}
 
 
 def cpu_baseline(sd, cfg, sample_batch):
@@ -223,13 +288,24 @@ def main():
     B = a.batch
     from cavp_amd.synth import synth_inputs
     model, sd = build_model(cfg, B, dtype, dev)
-    image, audio, _ = synth_inputs(B, cfg["hw"], num_classes=cfg["C"], seed=100 + rank)
-    image, audio = image.to(dev), audio.to(dev)
+    train = a.mode == "train"
+    image, audio, label = synth_inputs(B, cfg["hw"], audio_batch=2 * B if train else B, num_classes=cfg["C"], seed=100 + rank)
+    image, audio, label = image.to(dev), audio.to(dev), label.to(dev)
+    if train:
+        model.train()
+
+        def run_step():
+            return model.train_step(image, audio, label)
+    else:
+        def run_step():
+            return model(image, audio, eval_mode=True)
 
     with torch.no_grad():
-        model(image, audio, eval_mode=True)      # eager warm-up: packs weights, sizes the workspace
+        run_step()      # eager warm-up: packs weights, sizes the workspace
         torch.cuda.synchronize()
-        if a.no_graph:
+        if train:
+            step = run_step   # launched eagerly (the backward tape is host-driven; hipGraph capture is a later step)
+        elif a.no_graph:
             def step():
                 return model(image, audio, eval_mode=True)
         else:
@@ -268,19 +344,26 @@ def main():
     if rank == 0:
         value = world * B * a.steps / elapsed
         line = {
-            "metric": "frames/sec end-to-end CAVP forward, B=32 224x224 (backward not built yet)",
+            "metric": ("frames/sec end-to-end CAVP fwd+bwd, B=32 224x224" if train
+                       else "frames/sec end-to-end CAVP forward (inference), B=32 224x224"),
             "value": round(value, 2), "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(elapsed / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
-            "config": {"workload": f"C1' (config_avss_binary shape): CAVP ResNet-50 OS16 + VGGish, eval forward, "
-                                   f"B={B}/GPU, 224x224 RGB + 96x64 mel, num_classes=2, random-init (synthetic) weights",
+            "config": {"workload": (f"C1' (config_avss_binary shape): CAVP ResNet-50 OS16 + VGGish, training step = "
+                                    f"forward_train (batch-stat BN, {B} images + {2 * B} audio clips per GPU) + cross-entropy + "
+                                    f"full backward" + (" + one flat RCCL gradient all-reduce" if world > 1 else "") +
+                                    ", 224x224 RGB + 96x64 mel, num_classes=2, random-init (synthetic) weights"
+                                    if train else
+                                    f"C1' (config_avss_binary shape): CAVP ResNet-50 OS16 + VGGish, eval forward, "
+                                    f"B={B}/GPU, 224x224 RGB + 96x64 mel, num_classes=2, random-init (synthetic) weights"),
                        "global_batch": world * B, "per_gpu_batch": B, "parallelism": f"dp{world}",
-                       "launch": "eager" if a.no_graph else "hipGraph replay"},
+                       "launch": "eager" if (train or a.no_graph) else "hipGraph replay"},
         }
         if not a.no_roofline:
-            line["roofline"] = measure_roofline(model, image, audio, a.dtype)
+            line["roofline"] = measure_roofline(model, run_step, image, a.dtype)
         if world == 1 and not a.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(sd, cfg, a.cpu_sample_batch)
+            line["cpu_baseline"] = (cpu_baseline_train(sd, cfg, max(2, a.cpu_sample_batch // 2)) if train
+                                    else cpu_baseline(sd, cfg, a.cpu_sample_batch))
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

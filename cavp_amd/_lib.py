@@ -48,7 +48,8 @@ PROTOTYPES = {
     "cavp_pack_weight_ohwi": (_i32, [_i32, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "cavp_cast": (_i32, [_i32, _vp, _i32, _vp, _i64, _vp]),
     # ---- training side ----
-    "cavp_conv2d_wgrad_nhwc": (_i32, [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp]),
+    "cavp_conv2d_wgrad_workspace_bytes": (_sz, [C.POINTER(ConvDesc)]),
+    "cavp_conv2d_wgrad_nhwc": (_i32, [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _sz, _vp]),
     "cavp_pack_weight_dgrad": (_i32, [_i32, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "cavp_unpack_weight_grad": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
     "cavp_conv3x3_smallcin_wgrad": (_i32, [_i32, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),

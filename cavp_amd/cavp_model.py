@@ -578,6 +578,41 @@ class CAVP(nn.Module):
         out_pred, out_fusion, visual, audio_f, attn_v = CAVPTrainFunction.apply(self, image, audio, *params)
         return out_pred, out_fusion, {"audio": audio_f, "visual": visual, "attn_v": attn_v}
 
+    def train_step(self, image, audio, label, ignore_index: int = 255, loss_scale: float = 1.0, all_reduce: bool = True):
+        """MI355X-native fused training step (no torch.autograd): forward_train (batch-stat BN, audio 2B) -> HIP
+        cross-entropy on `out[:B] + out[B:]*0` (trainer_cavp_vpo_mono.py:171,187) -> hand-written backward.  Every
+        gradient lands in one flat f32 arena (`p.grad` are views of it); with a torch.distributed process group the
+        arena is all-reduced once over RCCL and averaged (DDP semantics, main_vpo_mono.py:131-135).
+        Returns the (local) loss as a 1-element device tensor."""
+        from . import train_ops as T
+        from .train import GradArena, TrainPass, run_train_forward
+        if not image.is_cuda:
+            raise CavpError("CAVP (MI355X path) needs inputs on a HIP device: there is no CPU fallback")
+        arena = getattr(self, "_grad_arena", None)
+        if arena is None or arena.flat.device != image.device:
+            arena = self._grad_arena = GradArena(list(self.parameters()), image.device)
+        arena.zero()
+        tp = TrainPass(self, self.compute_dtype, arena=arena)
+        B, C = image.shape[0], self.num_classes
+        with torch.no_grad():
+            lo, fusion, fea_v_proj, fea_a, attn = run_train_forward(self, image.contiguous(), audio.contiguous(), tp)
+            out_pred = torch.empty((lo.t.shape[0], C) + tuple(image.shape[-2:]), dtype=torch.float32, device=image.device)
+            ops.bilinear_to_nchw(lo.t[..., :C], out_pred, align_corners=False)
+            loss, dl = T.ce_loss(out_pred, label, B, ignore_index, grad_scale=loss_scale)
+            g = torch.zeros(lo.t.shape, dtype=lo.t.dtype, device=lo.t.device)
+            T.bilinear_bwd_from_nchw(dl, g[..., :C], n_valid=B, align_corners=False)
+            lo.set_g(g)
+            tp.backward()
+            tp.finish_padded()
+            import torch.distributed as dist
+            if all_reduce and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+                dist.all_reduce(arena.flat)                                   # ONE collective for all 119.8 M gradients
+                T.scale_f32(arena.flat, 1.0 / dist.get_world_size(), arena.flat)
+            for p in arena.params:
+                p.grad = arena.views[id(p)] if id(p) in tp.touched else None   # untouched = None, as torch would leave it
+        self._last_outputs = (out_pred, fusion, attn)
+        return loss
+
     def forward(self, image, audio=None, shuffle_info=None, ow_flag=False, eval_mode=False, audio_func=False):
         if eval_mode:
             return self.forward_inference(image, audio)

@@ -1,8 +1,10 @@
 // Weight gradient of conv / linear for gfx950:  dW[co][tap][ci] += sum_pix dY[pix][co] * X[pix @ tap][ci]
 //
 // A "TN" GEMM whose reduction dimension (pixels) is the SLOW dimension of both NHWC operands.  Design:
-// * One workgroup = (ci tile x co tile) of one live tap and one slice of the pixel range (split-K); results are
-//   added into the f32 OHWI gradient with hardware f32 atomics (the caller zeroes it).
+// * One workgroup = (ci tile x co tile) of one live tap and one slice of the pixel range (split-K).  With one slice
+//   the workgroup owns its tile and adds it to dW directly; otherwise every slice stores a private f32 slab and a
+//   second kernel reduces the slabs in a fixed order (deterministic; f32 atomics on a 32 K-element dW from 512
+//   workgroups were 2.3x slower - profiles/r01_notes.md).
 // * Both operands are streamed global -> LDS with LDS-DMA (buffer_load ... lds) exactly as they lie in memory:
 //   64 pixel rows x 256 bytes of channels per stage (128 bf16 / 64 f32 channels), two stages.  Rows that fall
 //   outside the image (padding taps), beyond the pixel range or beyond Cin/Cout are zero-filled by the buffer
@@ -29,6 +31,7 @@ struct WgradParams {
   int tiles_co, tiles_ci, ksplit;
   int rows_per_split;  // multiple of 64
   int x_bytes, dy_bytes;
+  float* slabs;        // ksplit > 1: per-split partial gradients [ksplit][Cout][taps][Cin] (plain stores, then reduced)
 };
 
 typedef short s16x4_t __attribute__((ext_vector_type(4)));
@@ -178,44 +181,72 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
     }
   }
 
-  // D[i = ci][j = co]: lane holds ci = 4*lgrp + {0..3} (rows) of co = lrow (col) in each 16x16 block
+  // D[i = ci][j = co]: lane holds ci = 4*lgrp + {0..3} (rows) of co = lrow (col) in each 16x16 block = 16 contiguous
+  // bytes of dW.  ksplit == 1: this workgroup owns the tile -> plain read-modify-write; otherwise plain stores into
+  // this split's slab (reduced afterwards, deterministic, no atomics).
+  float* out = p.ksplit > 1 ? p.slabs + (size_t)z * p.Cout * p.ntaps_all * p.Cin : p.dw;
 #pragma unroll
   for (int a = 0; a < MB; ++a) {
 #pragma unroll
     for (int b = 0; b < MB; ++b) {
       const int ci = ci_base + wci0 + a * 16 + lgrp * 4;
       const int co = co_base + wco0 + b * 16 + lrow;
-      if (co < p.Cout) {
-        float* dst = p.dw + ((size_t)co * p.ntaps_all + tap) * p.Cin + ci;
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-          if (ci + e < p.Cin) atomicAdd(dst + e, acc[a][b][e]);
+      if (co < p.Cout && ci < p.Cin) {   // Cin % 4 == 0: a quad is in range as a whole
+        float4* dst = (float4*)(out + ((size_t)co * p.ntaps_all + tap) * p.Cin + ci);
+        float4 v = make_float4(acc[a][b][0], acc[a][b][1], acc[a][b][2], acc[a][b][3]);
+        if (p.ksplit == 1) {
+          const float4 o = *dst;
+          v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+        }
+        *dst = v;
       }
     }
   }
 }
 
-extern "C" int cavp_conv2d_wgrad_nhwc(const cavp_conv_desc* d, const void* x, const void* dy, float* dw, void* stream) {
-  if (!d || !x || !dy || !dw) return CAVP_ERR_BAD_ARG;
-  if (d->N <= 0 || d->H <= 0 || d->W <= 0 || d->Cin <= 0 || d->Cout <= 0 || d->KH <= 0 || d->KW <= 0 || d->stride <= 0 ||
-      d->dil <= 0 || d->pad < 0 || d->ldx < d->Cin || d->ldy < d->Cout)
-    return CAVP_ERR_BAD_ARG;
-  if (d->dtype != CAVP_F32 && d->dtype != CAVP_BF16) return CAVP_ERR_UNSUPPORTED;
+// dw += sum_z slabs[z] over the live taps only (dead-tap regions of the slabs are never written)
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradParams p) {
+  const int cq = p.Cin >> 2;
+  const long long total = (long long)p.Cout * p.ntaps * cq;
+  const size_t slab = (size_t)p.Cout * p.ntaps_all * p.Cin;
+  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int c4 = (int)(i % cq);
+    const long long r = i / cq;
+    const int ti = (int)(r % p.ntaps);
+    const int co = (int)(r / p.ntaps);
+    const int tap = (int)((p.taps >> (4 * ti)) & 15ull);
+    const size_t off = ((size_t)co * p.ntaps_all + tap) * p.Cin + (size_t)c4 * 4;
+    float4 s = *(const float4*)(p.dw + off);
+    for (int z = 0; z < p.ksplit; ++z) {
+      const float4 v = *(const float4*)(p.slabs + (size_t)z * slab + off);
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    *(float4*)(p.dw + off) = s;
+  }
+}
+
+namespace {
+struct WgradPlan { WgradParams p; int nblk; size_t ws_bytes; int status; };
+
+WgradPlan make_wgrad_plan(const cavp_conv_desc* d) {
+  WgradPlan pl{};
+  pl.status = CAVP_OK;
+  if (!d || d->N <= 0 || d->H <= 0 || d->W <= 0 || d->Cin <= 0 || d->Cout <= 0 || d->KH <= 0 || d->KW <= 0 || d->stride <= 0 ||
+      d->dil <= 0 || d->pad < 0 || d->ldx < d->Cin || d->ldy < d->Cout) { pl.status = CAVP_ERR_BAD_ARG; return pl; }
+  if (d->dtype != CAVP_F32 && d->dtype != CAVP_BF16) { pl.status = CAVP_ERR_UNSUPPORTED; return pl; }
   const int es = d->dtype == CAVP_F32 ? 4 : 2;
   const int VE = 16 / es;
-  if (d->Cin % VE || d->Cout % VE || d->ldx % VE || d->ldy % VE || d->KH * d->KW > 9) return CAVP_ERR_UNSUPPORTED;
-  if (((uintptr_t)x & 15) || ((uintptr_t)dy & 15)) return CAVP_ERR_ALIGN;
-  WgradParams p{};
-  p.x = x; p.dy = dy; p.dw = dw;
+  if (d->Cin % VE || d->Cout % VE || d->ldx % VE || d->ldy % VE || d->KH * d->KW > 9) { pl.status = CAVP_ERR_UNSUPPORTED; return pl; }
+  WgradParams& p = pl.p;
   p.N = d->N; p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.ldx = d->ldx; p.Cout = d->Cout; p.ldy = d->ldy;
   p.KW = d->KW; p.stride = d->stride; p.pad = d->pad; p.dil = d->dil;
   p.Ho = (d->H + 2 * d->pad - d->dil * (d->KH - 1) - 1) / d->stride + 1;
   p.Wo = (d->W + 2 * d->pad - d->dil * (d->KW - 1) - 1) / d->stride + 1;
-  if (p.Ho <= 0 || p.Wo <= 0) return CAVP_ERR_BAD_ARG;
+  if (p.Ho <= 0 || p.Wo <= 0) { pl.status = CAVP_ERR_BAD_ARG; return pl; }
   const long long M = (long long)d->N * p.Ho * p.Wo;
   const size_t xb = ((size_t)d->N * d->H * d->W - 1) * d->ldx * es + (size_t)d->Cin * es;
   const size_t yb = ((size_t)M - 1) * d->ldy * es + (size_t)d->Cout * es;
-  if (M > 0x3fffffff || xb >= 0x7fffffffull || yb >= 0x7fffffffull) return CAVP_ERR_UNSUPPORTED;
+  if (M > 0x3fffffff || xb >= 0x7fffffffull || yb >= 0x7fffffffull) { pl.status = CAVP_ERR_UNSUPPORTED; return pl; }
   p.M = (int)M; p.x_bytes = (int)xb; p.dy_bytes = (int)yb;
   p.ntaps_all = d->KH * d->KW;
   p.ntaps = 0; p.taps = 0;
@@ -228,20 +259,42 @@ extern "C" int cavp_conv2d_wgrad_nhwc(const cavp_conv_desc* d, const void* x, co
       if (hl && wl) { p.taps |= (unsigned long long)(kh * d->KW + kw) << (4 * p.ntaps); ++p.ntaps; }
     }
   }
-  if (p.ntaps == 0) return CAVP_OK;
+  if (p.ntaps == 0) { pl.nblk = 0; return pl; }
   const int TCH = 256 / es;
   p.tiles_co = (d->Cout + TCH - 1) / TCH;
   p.tiles_ci = (d->Cin + TCH - 1) / TCH;
   const int base = p.tiles_co * p.tiles_ci * p.ntaps;
   const int chunks = (p.M + 63) / 64;
-  int ks = d->splitk > 0 ? d->splitk : (1024 + base - 1) / base;
-  if (ks > chunks) ks = chunks;
+  // ~2 workgroups per CU, but at least 4 K iterations (256 pixel rows) per workgroup: the split count multiplies the
+  // slab traffic (ksplit x |dW| written + read), so small outputs get many splits and big outputs few.
+  int ks = d->splitk > 0 ? d->splitk : (512 + base - 1) / base;
+  if (ks > chunks / 4) ks = chunks / 4;
   if (ks < 1) ks = 1;
-  int cps = (chunks + ks - 1) / ks;  // 64-row chunks per split
+  const int cps = (chunks + ks - 1) / ks;
   ks = (chunks + cps - 1) / cps;
   p.ksplit = ks;
   p.rows_per_split = cps * 64;
-  const int nblk = base * ks;
+  pl.nblk = base * ks;
+  pl.ws_bytes = ks > 1 ? (size_t)ks * d->Cout * p.ntaps_all * d->Cin * sizeof(float) : 0;
+  return pl;
+}
+}  // namespace
+
+extern "C" size_t cavp_conv2d_wgrad_workspace_bytes(const cavp_conv_desc* d) {
+  WgradPlan pl = make_wgrad_plan(d);
+  return pl.status == CAVP_OK ? pl.ws_bytes : 0;
+}
+
+extern "C" int cavp_conv2d_wgrad_nhwc(const cavp_conv_desc* d, const void* x, const void* dy, float* dw, void* workspace,
+                                      size_t workspace_bytes, void* stream) {
+  if (!d || !x || !dy || !dw) return CAVP_ERR_BAD_ARG;
+  WgradPlan pl = make_wgrad_plan(d);
+  if (pl.status != CAVP_OK) return pl.status;
+  if (pl.nblk == 0) return CAVP_OK;
+  if (((uintptr_t)x & 15) || ((uintptr_t)dy & 15) || ((uintptr_t)dw & 15)) return CAVP_ERR_ALIGN;
+  if (pl.ws_bytes > 0 && (!workspace || workspace_bytes < pl.ws_bytes || ((uintptr_t)workspace & 15))) return CAVP_ERR_WORKSPACE;
+  WgradParams& p = pl.p;
+  p.x = x; p.dy = dy; p.dw = dw; p.slabs = (float*)workspace;
   const int lds = 2 * 2 * 64 * 256;
   hipStream_t s = (hipStream_t)stream;
   static bool attr = false;
@@ -251,8 +304,15 @@ extern "C" int cavp_conv2d_wgrad_nhwc(const cavp_conv_desc* d, const void* x, co
     attr = true;
   }
   if (d->dtype == CAVP_F32)
-    wgrad_kernel<float><<<nblk, 256, lds, s>>>(p);
+    wgrad_kernel<float><<<pl.nblk, 256, lds, s>>>(p);
   else
-    wgrad_kernel<bf16_t><<<nblk, 256, lds, s>>>(p);
-  return hipGetLastError() == hipSuccess ? CAVP_OK : CAVP_ERR_LAUNCH;
+    wgrad_kernel<bf16_t><<<pl.nblk, 256, lds, s>>>(p);
+  if (hipGetLastError() != hipSuccess) return CAVP_ERR_LAUNCH;
+  if (p.ksplit > 1) {
+    long long nb = ((long long)p.Cout * p.ntaps * (p.Cin / 4) + 255) / 256;
+    if (nb > 8192) nb = 8192;
+    wgrad_reduce_kernel<<<(int)nb, 256, 0, s>>>(p);
+    if (hipGetLastError() != hipSuccess) return CAVP_ERR_LAUNCH;
+  }
+  return CAVP_OK;
 }

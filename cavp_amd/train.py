@@ -65,10 +65,30 @@ class _P:
                  "real_bias", "real_cout")
 
 
+class GradArena:
+    """One flat f32 buffer holding every parameter gradient (views per parameter): a single memset per step and a
+    single RCCL all-reduce over xGMI for data parallelism (C1 in SURVEY.md §2.3) instead of one per tensor/bucket."""
+
+    def __init__(self, params, device):
+        self.params = [p for p in params if p.requires_grad]
+        total = sum((p.numel() + 3) // 4 * 4 for p in self.params)   # keep every view 16-byte aligned
+        self.flat = torch.zeros(total, dtype=torch.float32, device=device)
+        self.views: Dict[int, torch.Tensor] = {}
+        off = 0
+        for p in self.params:
+            self.views[id(p)] = self.flat[off:off + p.numel()].view(p.shape)
+            off += (p.numel() + 3) // 4 * 4
+
+    def zero(self) -> None:
+        self.flat.zero_()
+
+
 class TrainPass:
-    def __init__(self, model, dtype: torch.dtype):
+    def __init__(self, model, dtype: torch.dtype, arena: Optional[GradArena] = None):
         self.m = model
         self.dt = dtype
+        self.arena = arena
+        self.touched = set()
         self.tape: List[Callable[[], None]] = []
         self.grads: Dict[int, torch.Tensor] = {}
         self.P: Dict[str, _P] = {}
@@ -111,26 +131,41 @@ class TrainPass:
         for p in self.P.values():
             if p.real_weight is None:
                 continue
-            gw = self.grads.pop(id(p.weight), None)
-            if gw is not None:
-                self.grads[id(p.real_weight)] = gw[:p.real_cout]
-            if p.real_bias is not None:
-                gb = self.grads.pop(id(p.bias), None)
-                if gb is not None:
-                    self.grads[id(p.real_bias)] = gb[:p.real_cout]
+            for padded, real in ((p.weight, p.real_weight), (p.bias, p.real_bias)):
+                if real is None:
+                    continue
+                g = self.grads.pop(id(padded), None)
+                if g is None:
+                    continue
+                g = g[:p.real_cout]
+                if self.arena is not None and id(real) in self.arena.views:
+                    dst = self.arena.views[id(real)]
+                    ops.cast(g.contiguous().view(-1), dst.view(-1))
+                    g = dst
+                self.grads[id(real)] = g
+                self.touched.add(id(real))
 
     def add_grad(self, param: torch.Tensor, g: torch.Tensor) -> None:
         k = id(param)
-        if k in self.grads:
-            T.add(self.grads[k], g.reshape(self.grads[k].shape).contiguous(), self.grads[k])
+        if k in self.grads or (self.arena is not None and k in self.arena.views):
+            buf = self.grad_buffer(param)
+            if g.numel() % 4 == 0:
+                T.add(buf, g.reshape(buf.shape).contiguous(), buf)
+            else:
+                buf.add_(g.reshape(buf.shape))   # odd-sized vectors (never on the CAVP path; kept for safety)
         else:
             self.grads[k] = g.reshape(param.shape)
+        self.touched.add(k)
 
     def grad_buffer(self, param: torch.Tensor) -> torch.Tensor:
         """f32 zero-initialised gradient accumulator in the parameter's own layout (created on first use)."""
         k = id(param)
+        self.touched.add(k)
         if k not in self.grads:
-            self.grads[k] = torch.zeros(param.shape, dtype=torch.float32, device=self.dev)
+            if self.arena is not None and k in self.arena.views:
+                self.grads[k] = self.arena.views[k]       # zeroed once per step by GradArena.zero()
+            else:
+                self.grads[k] = torch.zeros(param.shape, dtype=torch.float32, device=self.dev)
         return self.grads[k]
 
     def empty(self, shape, dtype=None) -> torch.Tensor:
@@ -223,9 +258,7 @@ class TrainPass:
         else:
             tmp = self.zeros_f32(p.cout, p.kh, p.kw, p.cin)
             T.conv2d_wgrad(x4, g4, tmp, kh=p.kh, kw=p.kw, stride=p.stride, pad=p.pad, dil=p.dil)
-            k = id(p.weight)
-            have = k in self.grads
-            T.unpack_weight_grad(tmp, self.grad_buffer(p.weight), accumulate=have)
+            T.unpack_weight_grad(tmp, self.grad_buffer(p.weight), accumulate=True)   # buffer starts at zero
 
     def conv_smallcin(self, x_nchw: torch.Tensor, key: str, stride: int, act: int) -> V:
         """First stem conv (raw, BN follows) / first VGG conv (bias + ReLU fused).  Input needs no gradient."""

@@ -91,7 +91,10 @@ def conv2d_wgrad(x: torch.Tensor, dy: torch.Tensor, dw_ohwi: torch.Tensor, *, kh
         raise _lib.CavpError("conv2d_wgrad: dy extent does not match the forward conv")
     d = ConvDesc(dtype=dtype_code(x.dtype), N=n, H=h, W=w, Cin=cin, ldx=ldx, Cout=cout, ldy=ldy, KH=kh, KW=kw,
                  stride=stride, pad=pad, dil=dil, ldr=0, act=0, splitk=splitk, tile=0, up=0, Ho=0, Wo=0)
-    _check(_lib.load().cavp_conv2d_wgrad_nhwc(C.byref(d), _ptr(x), _ptr(dy), _ptr(dw_ohwi), _s()), "cavp_conv2d_wgrad_nhwc")
+    lib = _lib.load()
+    ws = ops.workspace(lib.cavp_conv2d_wgrad_workspace_bytes(C.byref(d)), x.device)
+    _check(lib.cavp_conv2d_wgrad_nhwc(C.byref(d), _ptr(x), _ptr(dy), _ptr(dw_ohwi), _ptr(ws),
+                                      C.c_size_t(ws.numel() if ws is not None else 0), _s()), "cavp_conv2d_wgrad_nhwc")
     return dw_ohwi
 
 

@@ -127,10 +127,13 @@ int cavp_cast(int32_t src_dtype, const void* src, int32_t dst_dtype, void* dst, 
  * Data gradients of conv / linear reuse cavp_conv2d_nhwc with cavp_pack_weight_dgrad weights (+ `up` for strides).
  * ======================================================================================================= */
 
-/* Weight gradient of a conv / linear: dw[co][kh][kw][ci] += sum_pixels dy[pix][co] * x[pix @ tap][ci] (f32, OHWI,
- * accumulated with f32 atomics: the caller zeroes dw).  Fields of `d` describe the FORWARD conv (x is its input,
- * dy its output gradient with pixel stride d->ldy). */
-int cavp_conv2d_wgrad_nhwc(const cavp_conv_desc* d, const void* x, const void* dy, float* dw_ohwi, void* stream);
+/* Weight gradient of a conv / linear: dw[co][kh][kw][ci] += sum_pixels dy[pix][co] * x[pix @ tap][ci] (f32, OHWI; the
+ * result is ADDED to dw).  Fields of `d` describe the FORWARD conv (x is its input, dy its output gradient with pixel
+ * stride d->ldy).  The pixel reduction is split over workgroups; partial slabs go to `workspace`
+ * (cavp_conv2d_wgrad_workspace_bytes) and are reduced in a fixed order: deterministic, no atomics. */
+size_t cavp_conv2d_wgrad_workspace_bytes(const cavp_conv_desc* d);
+int cavp_conv2d_wgrad_nhwc(const cavp_conv_desc* d, const void* x, const void* dy, float* dw_ohwi, void* workspace,
+                           size_t workspace_bytes, void* stream);
 
 /* OIHW f32 -> [Cin][KH][KW][Cout] (dtype), taps rotated by 180 degrees: the OHWI weight of the transposed conv. */
 int cavp_pack_weight_dgrad(int32_t dtype, const float* w_oihw, void* w_t, int32_t Cout, int32_t Cin, int32_t KH,
