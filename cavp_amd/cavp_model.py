@@ -585,7 +585,7 @@ class CAVP(nn.Module):
         arena is all-reduced once over RCCL and averaged (DDP semantics, main_vpo_mono.py:131-135).
         Returns the (local) loss as a 1-element device tensor."""
         from . import train_ops as T
-        from .train import GradArena, TrainPass, run_train_forward
+        from .train import GradArena, TrainPass, allreduce_arena, dist_world, run_train_forward
         if not image.is_cuda:
             raise CavpError("CAVP (MI355X path) needs inputs on a HIP device: there is no CPU fallback")
         arena = getattr(self, "_grad_arena", None)
@@ -598,16 +598,15 @@ class CAVP(nn.Module):
             lo, fusion, fea_v_proj, fea_a, attn = run_train_forward(self, image.contiguous(), audio.contiguous(), tp)
             out_pred = torch.empty((lo.t.shape[0], C) + tuple(image.shape[-2:]), dtype=torch.float32, device=image.device)
             ops.bilinear_to_nchw(lo.t[..., :C], out_pred, align_corners=False)
-            loss, dl = T.ce_loss(out_pred, label, B, ignore_index, grad_scale=loss_scale)
+            world = dist_world() if all_reduce else 1
+            loss, dl = T.ce_loss(out_pred, label, B, ignore_index, grad_scale=loss_scale / world)   # SUM over ranks == mean
             g = torch.zeros(lo.t.shape, dtype=lo.t.dtype, device=lo.t.device)
             T.bilinear_bwd_from_nchw(dl, g[..., :C], n_valid=B, align_corners=False)
             lo.set_g(g)
             tp.backward()
             tp.finish_padded()
-            import torch.distributed as dist
-            if all_reduce and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-                dist.all_reduce(arena.flat)                                   # ONE collective for all 119.8 M gradients
-                T.scale_f32(arena.flat, 1.0 / dist.get_world_size(), arena.flat)
+            if world > 1:
+                allreduce_arena(arena)                                        # ONE collective for all 119.8 M gradients
             for p in arena.params:
                 p.grad = arena.views[id(p)] if id(p) in tp.touched else None   # untouched = None, as torch would leave it
         self._last_outputs = (out_pred, fusion, attn)

@@ -83,6 +83,29 @@ class GradArena:
         self.flat.zero_()
 
 
+def dist_world() -> int:
+    import torch.distributed as dist
+    return dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+
+
+def allreduce_arena(arena: GradArena) -> None:
+    """The single gradient collective of a data-parallel step: SUM over ranks of the flat arena (RCCL over xGMI on
+    MI355X; gloo in the CPU tests).  The loss gradient is pre-scaled by 1/world in train_step, so SUM == DDP's mean."""
+    import torch.distributed as dist
+    if dist_world() > 1:
+        dist.all_reduce(arena.flat)
+
+
+def allreduce_bn_stats(bn, buf: torch.Tensor, count: int) -> int:
+    """SyncBatchNorm statistics exchange (main_vpo_mono.py:130): SUM the per-channel partial sums over ranks and return
+    the global sample count; plain BatchNorm2d (or a single process) is left local."""
+    import torch.distributed as dist
+    if isinstance(bn, nn.SyncBatchNorm) and dist_world() > 1:
+        dist.all_reduce(buf)
+        return count * dist.get_world_size()
+    return count
+
+
 class TrainPass:
     def __init__(self, model, dtype: torch.dtype, arena: Optional[GradArena] = None):
         self.m = model
@@ -283,11 +306,7 @@ class TrainPass:
         return y
 
     def _allreduce_stats(self, bn, buf: torch.Tensor, count: int) -> int:
-        import torch.distributed as dist
-        if isinstance(bn, nn.SyncBatchNorm) and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-            dist.all_reduce(buf)
-            return count * dist.get_world_size()
-        return count
+        return allreduce_bn_stats(bn, buf, count)
 
     def bn_act(self, z: V, bn, act: int, residual: Optional[V] = None, out: Optional[V] = None) -> V:
         """y = act(BN_train(z) + residual); `out` may be a channel slice of a concat buffer."""

@@ -1,0 +1,72 @@
+"""world_size-2 gloo tests (CPU) of the multi-process plumbing of the data-parallel path: the single flat gradient
+all-reduce, the SyncBatchNorm statistics exchange and the bench's max-over-ranks timing reduction.  The kernels
+themselves need a GPU; here only the torch.distributed call pattern runs, on CPU tensors."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+import torch.nn as nn
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from cavp_amd.train import GradArena, allreduce_arena, allreduce_bn_stats, dist_world
+        assert dist_world() == world
+        # 1) one flat arena, one collective: local grads are pre-scaled by 1/world (train_step), SUM == mean
+        params = [nn.Parameter(torch.zeros(5, 3)), nn.Parameter(torch.zeros(7)), nn.Parameter(torch.zeros(2, 2, 3, 3))]
+        frozen = nn.Parameter(torch.zeros(4), requires_grad=False)
+        arena = GradArena(params + [frozen], "cpu")
+        assert id(frozen) not in arena.views and arena.flat.numel() % 4 == 0
+        for i, p in enumerate(params):
+            arena.views[id(p)].fill_((rank + 1) * (i + 1) / world)
+        allreduce_arena(arena)
+        for i, p in enumerate(params):
+            expect = sum((r + 1) * (i + 1) for r in range(world)) / world
+            assert torch.allclose(arena.views[id(p)], torch.full(p.shape, expect)), (rank, i)
+        # views alias the flat buffer (p.grad = view => the optimiser sees the reduced values with no copy)
+        arena.zero()
+        assert float(arena.views[id(params[0])].abs().sum()) == 0.0
+        # 2) SyncBatchNorm exchanges its partial sums, BatchNorm2d stays local
+        stats = torch.tensor([[1.0 + rank, 2.0], [3.0, 4.0 * (rank + 1)]])
+        n = allreduce_bn_stats(nn.SyncBatchNorm(2), stats, 10)
+        assert n == 10 * world
+        assert torch.allclose(stats, torch.tensor([[sum(1.0 + r for r in range(world)), 2.0 * world],
+                                                   [3.0 * world, sum(4.0 * (r + 1) for r in range(world))]]))
+        local = torch.tensor([[5.0 + rank, 1.0]])
+        assert allreduce_bn_stats(nn.BatchNorm2d(2), local, 10) == 10 and float(local[0, 0]) == 5.0 + rank
+        # 3) bench.py timing reduction: MAX over ranks
+        t = torch.tensor([1.0 + rank], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        assert float(t) == float(world)
+        dist.barrier()
+        q.put((rank, "ok"))
+    except Exception as e:  # noqa: BLE001
+        q.put((rank, repr(e)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_process_gloo_collectives():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(res) == [(0, "ok"), (1, "ok")], res
