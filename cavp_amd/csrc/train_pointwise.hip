@@ -183,24 +183,36 @@ __global__ void bn_finalize_kernel(const float* sum, const float* sumsq, const f
   }
 }
 
+// Row-loop geometry shared by the per-channel elementwise kernels: 256 threads = 16 column groups (VE channels each,
+// 256 contiguous bytes per row) x 16 row lanes; grid.y = column chunks, grid.x = row chunks.  Each thread keeps its
+// per-channel coefficients in registers for the whole row loop (the first version re-loaded 5 scalars per channel per
+// element and ran at 0.9 TB/s).
+struct RowLoop {
+  long long rows;
+  int C, rows_per_block;
+};
+
 // y = act(x * scale + shift + residual)
 template <typename T>
 __global__ __launch_bounds__(256) void scale_shift_act_kernel(const T* __restrict__ x, const float* __restrict__ scale,
                                                               const float* __restrict__ shift, const T* __restrict__ res,
-                                                              T* __restrict__ y, long long rows, int C, int ldx, int ldr,
-                                                              int ldy, int act) {
+                                                              T* __restrict__ y, RowLoop g, int ldx, int ldr, int ldy,
+                                                              int act) {
   constexpr int VE = VecT<T>::VE;
-  const int CV = C / VE;
-  const long long total = rows * CV;
-  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-    const long long r = i / CV;
-    const int c = (int)(i - r * CV) * VE;
+  const int cg = threadIdx.x & 15, rl = threadIdx.x >> 4;
+  const int c = (blockIdx.y * 16 + cg) * VE;
+  if (c >= g.C) return;
+  float sc[VE], sh[VE];
+#pragma unroll
+  for (int e = 0; e < VE; ++e) { sc[e] = scale ? scale[c + e] : 1.f; sh[e] = shift ? shift[c + e] : 0.f; }
+  const long long r0 = (long long)blockIdx.x * g.rows_per_block;
+  long long r1 = r0 + g.rows_per_block;
+  if (r1 > g.rows) r1 = g.rows;
+  for (long long r = r0 + rl; r < r1; r += 16) {
     float v[VE];
     VecT<T>::load(x + r * ldx + c, v);
-    if (scale) {
 #pragma unroll
-      for (int e = 0; e < VE; ++e) v[e] = v[e] * scale[c + e] + (shift ? shift[c + e] : 0.f);
-    }
+    for (int e = 0; e < VE; ++e) v[e] = v[e] * sc[e] + sh[e];
     if (res) {
       float rr[VE];
       VecT<T>::load(res + r * ldr + c, rr);
@@ -213,7 +225,8 @@ __global__ __launch_bounds__(256) void scale_shift_act_kernel(const T* __restric
   }
 }
 
-// dz = gamma * rstd * (g - sum_g / M - zhat * sum_gz / M),  g = dy * act'(y);  optionally also writes g (skip path)
+// dz = gamma * rstd * (g - sum_g / M - zhat * sum_gz / M) = a_c * g + b_c * z + c_c,  g = dy * act'(y);
+// optionally also writes g (skip-path gradient)
 template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ dy, const T* __restrict__ y,
                                                            const T* __restrict__ z, const float* __restrict__ mean,
@@ -221,14 +234,24 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
                                                            const float* __restrict__ gamma,
                                                            const float* __restrict__ sum_g,
                                                            const float* __restrict__ sum_gz, float inv_m, T* __restrict__ dz,
-                                                           T* __restrict__ g_out, long long rows, int C, int ld_dy,
-                                                           int ld_y, int ld_z, int ld_dz, int ld_g, int act) {
+                                                           T* __restrict__ g_out, RowLoop gm, int ld_dy, int ld_y,
+                                                           int ld_z, int ld_dz, int ld_g, int act) {
   constexpr int VE = VecT<T>::VE;
-  const int CV = C / VE;
-  const long long total = rows * CV;
-  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-    const long long r = i / CV;
-    const int c = (int)(i - r * CV) * VE;
+  const int cg = threadIdx.x & 15, rl = threadIdx.x >> 4;
+  const int c = (blockIdx.y * 16 + cg) * VE;
+  if (c >= gm.C) return;
+  float ca[VE], cb[VE], cc[VE];
+#pragma unroll
+  for (int e = 0; e < VE; ++e) {
+    const float rs = rstd[c + e], a = gamma[c + e] * rs;
+    ca[e] = a;
+    cb[e] = -a * rs * sum_gz[c + e] * inv_m;
+    cc[e] = -a * sum_g[c + e] * inv_m - cb[e] * mean[c + e];
+  }
+  const long long r0 = (long long)blockIdx.x * gm.rows_per_block;
+  long long r1 = r0 + gm.rows_per_block;
+  if (r1 > gm.rows) r1 = gm.rows;
+  for (long long r = r0 + rl; r < r1; r += 16) {
     float a[VE], yy[VE], zz[VE], o[VE], g[VE];
     VecT<T>::load(dy + r * ld_dy + c, a);
     VecT<T>::load(y + r * ld_y + c, yy);
@@ -236,12 +259,25 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
 #pragma unroll
     for (int e = 0; e < VE; ++e) {
       g[e] = a[e] * act_grad_from_out(yy[e], act);
-      const float zh = (zz[e] - mean[c + e]) * rstd[c + e];
-      o[e] = gamma[c + e] * rstd[c + e] * (g[e] - sum_g[c + e] * inv_m - zh * sum_gz[c + e] * inv_m);
+      o[e] = ca[e] * g[e] + cb[e] * zz[e] + cc[e];
     }
     VecT<T>::store(dz + r * ld_dz + c, o);
     if (g_out) VecT<T>::store(g_out + r * ld_g + c, g);
   }
+}
+
+inline RowLoop row_loop_geometry(long long rows, int C, int VE, dim3& grid) {
+  const int gy = cdiv_h(C, 16 * VE);
+  int gx = 4096 / gy;
+  if (gx < 1) gx = 1;
+  long long rpb = (rows + gx - 1) / gx;
+  if (rpb < 32) rpb = 32;
+  rpb = (rpb + 15) / 16 * 16;
+  gx = (int)((rows + rpb - 1) / rpb);
+  grid = dim3(gx, gy);
+  RowLoop g;
+  g.rows = rows; g.C = C; g.rows_per_block = (int)rpb;
+  return g;
 }
 
 // dx = dy * act'(.)   relu / leaky: from the output y;  gelu: from the pre-activation x
@@ -665,38 +701,62 @@ __global__ void ce_finish_kernel(const float* acc, float* loss) { loss[0] = acc[
 
 // ------------------------------------------------------------------------------------------------------------
 // weight gradient of the small-Cin 3x3 conv (NCHW f32 input): dw[co][ci][kh][kw] += sum_p dy[p][co] * x[p @ tap]
-// block = one (ci, kh, kw) tap x a pixel chunk; thread = output channel; LDS-staged dy rows
+// A workgroup walks a pixel range in chunks of 64: the dY rows and the <= 27 gathered input taps of the chunk are
+// staged in LDS once, thread (co, tap lane) accumulates its taps over the chunk (dY read conflict-free, the tap
+// value is a wave-wide broadcast), one f32 atomic per (workgroup, weight) at the end.
 // ------------------------------------------------------------------------------------------------------------
-template <typename T>
+template <typename T, int COUT>
 __global__ __launch_bounds__(256) void smallcin_wgrad_kernel(const float* __restrict__ x, const T* __restrict__ dy,
                                                              float* __restrict__ dw, int N, int Cin, int H, int W,
-                                                             int Cout, int stride, int Ho, int Wo, int pix_per_block) {
-  const int tap = blockIdx.y;  // ci*9 + kh*3 + kw
-  const int ci = tap / 9, kh = (tap % 9) / 3, kw = tap % 3;
+                                                             int stride, int Ho, int Wo, int pix_per_block) {
+  constexpr int P = 64, KMAX = 27, NPL = 256 / COUT, TPT = (KMAX + NPL - 1) / NPL;
+  __shared__ float sdy[P][COUT];
+  __shared__ float sx[P][KMAX + 1];
+  const int K = Cin * 9;
   const long long M = (long long)N * Ho * Wo;
   const long long p0 = (long long)blockIdx.x * pix_per_block;
   long long p1 = p0 + pix_per_block;
   if (p1 > M) p1 = M;
-  // thread layout: co = threadIdx.x % Cout, pixel lane = threadIdx.x / Cout
-  const int co = threadIdx.x % Cout, pl = threadIdx.x / Cout, npl = 256 / Cout;
-  float acc = 0.f;
-  for (long long p = p0 + pl; p < p1; p += npl) {
-    const int wo = (int)(p % Wo);
-    const int ho = (int)((p / Wo) % Ho);
-    const int n = (int)(p / ((long long)Wo * Ho));
-    const int hi = ho * stride - 1 + kh, wi = wo * stride - 1 + kw;
-    if ((unsigned)hi < (unsigned)H && (unsigned)wi < (unsigned)W) {
-      const float xv = x[(((size_t)n * Cin + ci) * H + hi) * W + wi];
-      acc += xv * Elem<T>::ld(dy + (size_t)p * Cout + co);
+  const int co = threadIdx.x % COUT, tl = threadIdx.x / COUT;
+  float acc[TPT];
+#pragma unroll
+  for (int j = 0; j < TPT; ++j) acc[j] = 0.f;
+  for (long long pc = p0; pc < p1; pc += P) {
+    for (int i = threadIdx.x; i < P * COUT; i += 256) {
+      const int pp = i / COUT, c = i - pp * COUT;
+      const long long p = pc + pp;
+      sdy[pp][c] = p < p1 ? Elem<T>::ld(dy + (size_t)p * COUT + c) : 0.f;
     }
+    for (int i = threadIdx.x; i < P * K; i += 256) {
+      const int pp = i / K, k = i - pp * K;
+      const long long p = pc + pp;
+      float v = 0.f;
+      if (p < p1) {
+        const int wo = (int)(p % Wo);
+        const int ho = (int)((p / Wo) % Ho);
+        const int n = (int)(p / ((long long)Wo * Ho));
+        const int ci = k / 9, kh = (k % 9) / 3, kw = k % 3;
+        const int hi = ho * stride - 1 + kh, wi = wo * stride - 1 + kw;
+        if ((unsigned)hi < (unsigned)H && (unsigned)wi < (unsigned)W) v = x[(((size_t)n * Cin + ci) * H + hi) * W + wi];
+      }
+      sx[pp][k] = v;
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int pp = 0; pp < P; ++pp) {
+      const float d = sdy[pp][co];
+#pragma unroll
+      for (int j = 0; j < TPT; ++j) {
+        const int t = tl + NPL * j;
+        if (t < K) acc[j] = fmaf(d, sx[pp][t], acc[j]);
+      }
+    }
+    __syncthreads();
   }
-  __shared__ float red[256];
-  red[threadIdx.x] = acc;
-  __syncthreads();
-  if (pl == 0) {
-    float s = 0.f;
-    for (int j = 0; j < npl; ++j) s += red[j * Cout + co];
-    atomicAdd(dw + (size_t)co * Cin * 9 + tap, s);
+#pragma unroll
+  for (int j = 0; j < TPT; ++j) {
+    const int t = tl + NPL * j;
+    if (t < K) atomicAdd(dw + (size_t)co * K + t, acc[j]);
   }
 }
 
@@ -773,13 +833,13 @@ extern "C" int cavp_scale_shift_act(int32_t dtype, const void* x, const float* s
   const int VE = dtype == CAVP_F32 ? 4 : 8;
   if (C % VE || ldx % VE || ldy % VE || (residual && ldr % VE)) return CAVP_ERR_UNSUPPORTED;
   if (!al16(x) || !al16(y) || (residual && !al16(residual))) return CAVP_ERR_ALIGN;
-  long long nb = (rows * (C / VE) + 255) / 256;
-  if (nb > 16384) nb = 16384;
+  dim3 grid;
+  const RowLoop g = row_loop_geometry(rows, C, VE, grid);
   hipStream_t s = (hipStream_t)stream;
   if (dtype == CAVP_F32)
-    scale_shift_act_kernel<float><<<(int)nb, 256, 0, s>>>((const float*)x, scale, shift, (const float*)residual, (float*)y, rows, C, ldx, ldr, ldy, act);
+    scale_shift_act_kernel<float><<<grid, 256, 0, s>>>((const float*)x, scale, shift, (const float*)residual, (float*)y, g, ldx, ldr, ldy, act);
   else
-    scale_shift_act_kernel<bf16_t><<<(int)nb, 256, 0, s>>>((const bf16_t*)x, scale, shift, (const bf16_t*)residual, (bf16_t*)y, rows, C, ldx, ldr, ldy, act);
+    scale_shift_act_kernel<bf16_t><<<grid, 256, 0, s>>>((const bf16_t*)x, scale, shift, (const bf16_t*)residual, (bf16_t*)y, g, ldx, ldr, ldy, act);
   CHECK_LAUNCH();
 }
 
@@ -807,14 +867,14 @@ extern "C" int cavp_bn_act_bwd_apply(int32_t dtype, const void* dy, const void* 
   const int VE = dtype == CAVP_F32 ? 4 : 8;
   if (C % VE || ld_dy % VE || ld_y % VE || ld_z % VE || ld_dz % VE || (g_out && ld_g % VE)) return CAVP_ERR_UNSUPPORTED;
   if (!al16(dy) || !al16(y) || !al16(z) || !al16(dz) || (g_out && !al16(g_out))) return CAVP_ERR_ALIGN;
-  long long nb = (rows * (C / VE) + 255) / 256;
-  if (nb > 16384) nb = 16384;
+  dim3 grid;
+  const RowLoop g = row_loop_geometry(rows, C, VE, grid);
   const float inv_m = (float)(1.0 / (double)rows);
   hipStream_t s = (hipStream_t)stream;
   if (dtype == CAVP_F32)
-    bn_bwd_apply_kernel<float><<<(int)nb, 256, 0, s>>>((const float*)dy, (const float*)y, (const float*)z, mean, rstd, gamma, sum_g, sum_gz, inv_m, (float*)dz, (float*)g_out, rows, C, ld_dy, ld_y, ld_z, ld_dz, ld_g, act);
+    bn_bwd_apply_kernel<float><<<grid, 256, 0, s>>>((const float*)dy, (const float*)y, (const float*)z, mean, rstd, gamma, sum_g, sum_gz, inv_m, (float*)dz, (float*)g_out, g, ld_dy, ld_y, ld_z, ld_dz, ld_g, act);
   else
-    bn_bwd_apply_kernel<bf16_t><<<(int)nb, 256, 0, s>>>((const bf16_t*)dy, (const bf16_t*)y, (const bf16_t*)z, mean, rstd, gamma, sum_g, sum_gz, inv_m, (bf16_t*)dz, (bf16_t*)g_out, rows, C, ld_dy, ld_y, ld_z, ld_dz, ld_g, act);
+    bn_bwd_apply_kernel<bf16_t><<<grid, 256, 0, s>>>((const bf16_t*)dy, (const bf16_t*)y, (const bf16_t*)z, mean, rstd, gamma, sum_g, sum_gz, inv_m, (bf16_t*)dz, (bf16_t*)g_out, g, ld_dy, ld_y, ld_z, ld_dz, ld_g, act);
   CHECK_LAUNCH();
 }
 
@@ -999,17 +1059,18 @@ extern "C" int cavp_conv3x3_smallcin_wgrad(int32_t dtype, const float* x_nchw, c
                                            int32_t N, int32_t Cin, int32_t H, int32_t W, int32_t Cout, int32_t stride,
                                            void* stream) {
   if (!x_nchw || !dy_nhwc || !dw_oihw || N <= 0 || H <= 0 || W <= 0 || stride <= 0) return CAVP_ERR_BAD_ARG;
-  if (!dt_ok(dtype) || Cin < 1 || Cin > 3 || Cout > 256 || 256 % Cout) return CAVP_ERR_UNSUPPORTED;
+  if (!dt_ok(dtype) || Cin < 1 || Cin > 3 || Cout != 64) return CAVP_ERR_UNSUPPORTED;
   const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
   const long long M = (long long)N * Ho * Wo;
-  int gx = 256;
-  int ppb = (int)((M + gx - 1) / gx);
+  int gx = 512;
+  long long ppb = (M + gx - 1) / gx;
+  ppb = (ppb + 63) / 64 * 64;
   gx = (int)((M + ppb - 1) / ppb);
   hipStream_t s = (hipStream_t)stream;
   if (dtype == CAVP_F32)
-    smallcin_wgrad_kernel<float><<<dim3(gx, Cin * 9), 256, 0, s>>>(x_nchw, (const float*)dy_nhwc, dw_oihw, N, Cin, H, W, Cout, stride, Ho, Wo, ppb);
+    smallcin_wgrad_kernel<float, 64><<<gx, 256, 0, s>>>(x_nchw, (const float*)dy_nhwc, dw_oihw, N, Cin, H, W, stride, Ho, Wo, (int)ppb);
   else
-    smallcin_wgrad_kernel<bf16_t><<<dim3(gx, Cin * 9), 256, 0, s>>>(x_nchw, (const bf16_t*)dy_nhwc, dw_oihw, N, Cin, H, W, Cout, stride, Ho, Wo, ppb);
+    smallcin_wgrad_kernel<bf16_t, 64><<<gx, 256, 0, s>>>(x_nchw, (const bf16_t*)dy_nhwc, dw_oihw, N, Cin, H, W, stride, Ho, Wo, (int)ppb);
   CHECK_LAUNCH();
 }
 

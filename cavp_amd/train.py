@@ -112,6 +112,8 @@ class TrainPass:
         self.dt = dtype
         self.arena = arena
         self.touched = set()
+        self._zpool = None
+        self._zoff = 0
         self.tape: List[Callable[[], None]] = []
         self.grads: Dict[int, torch.Tensor] = {}
         self.P: Dict[str, _P] = {}
@@ -195,7 +197,19 @@ class TrainPass:
         return torch.empty(shape, dtype=dtype or self.dt, device=self.dev)
 
     def zeros_f32(self, *shape) -> torch.Tensor:
-        return torch.zeros(shape, dtype=torch.float32, device=self.dev)
+        """Zero-initialised f32 scratch.  Small requests (BN statistics, bias / affine gradients: ~250 per step) are
+        carved out of one pre-zeroed pool = one memset per step instead of one fill launch each."""
+        n = 1
+        for d in shape:
+            n *= d
+        if n > (1 << 16):
+            return torch.zeros(shape, dtype=torch.float32, device=self.dev)
+        if self._zpool is None or self._zoff + n + 4 > self._zpool.numel():
+            self._zpool = torch.zeros(1 << 21, dtype=torch.float32, device=self.dev)
+            self._zoff = 0
+        t = self._zpool[self._zoff:self._zoff + n].view(shape)
+        self._zoff += (n + 3) // 4 * 4     # keep every carve 16-byte aligned
+        return t
 
     # ---- gradient accumulation -------------------------------------------------------------------------------
     def acc(self, x: V, compute: Callable[[torch.Tensor, Optional[torch.Tensor]], None]) -> None:
@@ -334,7 +348,13 @@ class TrainPass:
             dy = y.g
             if dy is None:
                 return
-            sums = self.zeros_f32(2, c)
+            direct = (count == rows and id(bn.weight) not in self.grads and id(bn.bias) not in self.grads)
+            if direct:
+                # local BatchNorm: sum g -> dbeta and sum g*zhat -> dgamma ARE the affine gradients: reduce straight
+                # into their (zeroed) gradient buffers and let the apply kernel read them from there
+                sums = (self.grad_buffer(bn.bias), self.grad_buffer(bn.weight))
+            else:
+                sums = self.zeros_f32(2, c)
             T.bn_act_bwd_reduce(dy, y.t, z.t, mean, rstd, act, sums[0], sums[1])
             local = sums
             if count != rows:
@@ -349,8 +369,9 @@ class TrainPass:
             z.set_g(dz)
             if g_out is not None:
                 self.acc_add(residual, g_out)
-            self.add_grad(bn.bias, local[0].clone())
-            self.add_grad(bn.weight, local[1].clone())
+            if not direct:
+                self.add_grad(bn.bias, local[0].clone())
+                self.add_grad(bn.weight, local[1].clone())
         self.tape.append(bwd)
         return y
 
