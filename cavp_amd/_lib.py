@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(HERE, "libcavp_hip.so")
 
 F32, BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_LEAKY, ACT_GELU = 0, 1, 2, 3
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class CavpError(RuntimeError):
@@ -36,7 +36,9 @@ PROTOTYPES = {
     "cavp_abi_version": (_i32, []),
     "cavp_error_string": (C.c_char_p, [_i32]),
     "cavp_conv2d_workspace_bytes": (_sz, [C.POINTER(ConvDesc)]),
-    "cavp_conv2d_nhwc": (_i32, [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "cavp_conv2d_nhwc": (_i32, [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _vp]),
+    "cavp_conv2d_tile_stats_layout": (_i32, [C.POINTER(ConvDesc), C.POINTER(_i32), C.POINTER(_i32)]),
+    "cavp_bn_finalize_tiles": (_i32, [_vp, _i32, _i32, _i64, _vp, _vp, _f32, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp]),
     "cavp_conv3x3_smallcin_nchw": (_i32, [_i32, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "cavp_maxpool_nhwc": (_i32, [_i32, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "cavp_global_avgpool_nhwc": (_i32, [_i32, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),

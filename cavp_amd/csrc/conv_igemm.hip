@@ -38,6 +38,7 @@ struct IgemmParams {
   int vec_io;               // epilogue may use vector loads/stores (Cout, ldy, ldr multiples of 4, pointers aligned)
   int x_bytes, w_bytes;     // buffer-descriptor extents (< 2 GiB)
   int up_shift, up_mask;    // transposed-conv input upsampling (log2, mask); 0, 0 for an ordinary conv
+  float* tile_stats;        // optional [tiles_p][Cout][2] per-tile (mean, M2) of the raw outputs (BatchNorm statistics)
   int coalesced;            // LDS-staged, fully coalesced 16-byte epilogue (needs Cout, ldy, ldr % VE == 0, 16-B aligned)
 };
 
@@ -349,6 +350,24 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p) {
         *(f32x4_t*)(st + (size_t)prow * BC + ((slot ^ (prow & SWZ)) << 2)) = acc[a][b];
       }
     __syncthreads();
+    if (p.tile_stats && tid < BC && c_base + tid < p.Cout) {
+      // BatchNorm batch statistics for free: per-channel mean and centred second moment of this tile's rows, straight
+      // from the f32 accumulators in LDS (two passes over <= BP values; combined across tiles with Chan's formula in
+      // cavp_bn_finalize_tiles - no extra pass over the activation, no atomics, no E[x^2]-E[x]^2 cancellation)
+      const int nrows = (p.M - p_base) < BP ? (p.M - p_base) : BP;
+      const int slot = tid >> 2, sub = tid & 3;
+      float sum = 0.f;
+      for (int r = 0; r < nrows; ++r) sum += st[(size_t)r * BC + ((slot ^ (r & SWZ)) << 2) + sub];
+      const float mean = sum / (float)nrows;
+      float m2 = 0.f;
+      for (int r = 0; r < nrows; ++r) {
+        const float dlt = st[(size_t)r * BC + ((slot ^ (r & SWZ)) << 2) + sub] - mean;
+        m2 += dlt * dlt;
+      }
+      float* o = p.tile_stats + ((size_t)tp * p.Cout + c_base + tid) * 2;
+      o[0] = mean;
+      o[1] = m2;
+    }
     constexpr int CH = BC / VE;                 // output chunks (16 B of T) per pixel row
     constexpr int NCH = BP * CH;
     for (int ch = tid; ch < NCH; ch += 256) {
@@ -629,6 +648,21 @@ inline bool aligned(const void* ptr, size_t a) { return ((uintptr_t)ptr % a) == 
 
 }  // namespace
 
+// Fused BatchNorm statistics are available when the launch uses the LDS-staged epilogue: no split-K, vector-aligned
+// Cout / ldy.  Returns 1 and the tile geometry, else 0 (caller falls back to cavp_colsum / cavp_colstats).
+extern "C" int cavp_conv2d_tile_stats_layout(const cavp_conv_desc* d, int32_t* tiles, int32_t* rows_per_tile) {
+  Plan pl = make_plan(d);
+  if (pl.status != CAVP_OK || !tiles || !rows_per_tile) return 0;
+  const int VE = d->dtype == CAVP_F32 ? 4 : 8;
+  if (pl.p.splitk != 1 || pl.direct_epi || d->Cout % VE || d->ldy % VE) return 0;
+  int BP = 0;
+  for (int i = 0; i < kNumTiles; ++i)
+    if (kTiles[i].id == pl.tile_id) BP = kTiles[i].BP;
+  *tiles = pl.p.tiles_p;
+  *rows_per_tile = BP;
+  return 1;
+}
+
 extern "C" size_t cavp_conv2d_workspace_bytes(const cavp_conv_desc* d) {
   Plan pl = make_plan(d);
   return pl.status == CAVP_OK ? pl.ws_bytes : 0;
@@ -636,8 +670,9 @@ extern "C" size_t cavp_conv2d_workspace_bytes(const cavp_conv_desc* d) {
 
 extern "C" int cavp_conv2d_nhwc(const cavp_conv_desc* d, const void* x, const void* w, const float* scale,
                                 const float* shift, const float* nbias, const void* residual, void* y, void* workspace,
-                                size_t workspace_bytes, void* stream) {
+                                size_t workspace_bytes, float* tile_stats, void* stream) {
   if (!d || !x || !w || !y) return CAVP_ERR_BAD_ARG;
+  if (tile_stats && (scale || shift || nbias || residual || d->act != CAVP_ACT_NONE)) return CAVP_ERR_BAD_ARG;
   Plan pl = make_plan(d);
   if (pl.status != CAVP_OK) return pl.status;
   if (!aligned(x, 16) || !aligned(w, 16)) return CAVP_ERR_ALIGN;
@@ -661,6 +696,8 @@ extern "C" int cavp_conv2d_nhwc(const cavp_conv_desc* d, const void* x, const vo
   const int VE = d->dtype == CAVP_F32 ? 4 : 8;
   p.coalesced = !pl.direct_epi && p.splitk == 1 && (d->Cout % VE == 0) && (d->ldy % VE == 0) && aligned(y, 16) &&
                 (!residual || (d->ldr % VE == 0 && aligned(residual, 16)));
+  p.tile_stats = tile_stats;
+  if (tile_stats && !p.coalesced) return CAVP_ERR_UNSUPPORTED;   // see cavp_conv2d_tile_stats_layout
   hipStream_t s = (hipStream_t)stream;
   hipError_t e = d->dtype == CAVP_F32 ? launch_tile<float>(pl.tile_id, pl.pipe, p, pl.nblk, s)
                                       : launch_tile<bf16_t>(pl.tile_id, pl.pipe, p, pl.nblk, s);

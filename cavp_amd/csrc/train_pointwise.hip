@@ -192,6 +192,58 @@ struct RowLoop {
   int C, rows_per_block;
 };
 
+// Combine the per-tile (mean, M2) pairs written by the conv epilogue into the batch statistics of each channel (Chan et
+// al. parallel variance), then the same outputs as bn_finalize.  One wave per channel: lanes stride over the tiles.
+__device__ __forceinline__ void chan_combine(float& n, float& mean, float& m2, float nb, float mb, float m2b) {
+  if (nb == 0.f) return;
+  const float nt = n + nb, dlt = mb - mean;
+  mean += dlt * (nb / nt);
+  m2 += m2b + dlt * dlt * (n * nb / nt);
+  n = nt;
+}
+__global__ __launch_bounds__(256) void bn_finalize_tiles_kernel(const float* __restrict__ ts, int tiles, int rows_per_tile,
+                                                                long long M, const float* gamma, const float* beta,
+                                                                float eps, float momentum, float* rmean, float* rvar,
+                                                                float* scale, float* shift, float* mean_out,
+                                                                float* rstd_out, int C) {
+  const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (c >= C) return;
+  float n = 0.f, mean = 0.f, m2 = 0.f;
+  for (int t = lane; t < tiles; t += 64) {
+    long long nb = M - (long long)t * rows_per_tile;
+    if (nb > rows_per_tile) nb = rows_per_tile;
+    const float* q = ts + ((size_t)t * C + c) * 2;
+    chan_combine(n, mean, m2, (float)nb, q[0], q[1]);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float nb = __shfl_xor(n, o, 64), mb = __shfl_xor(mean, o, 64), m2b = __shfl_xor(m2, o, 64);
+    // symmetric combine so every lane ends with the same value
+    const float nt = n + nb;
+    if (nt > 0.f) {
+      const float dlt = mb - mean;
+      const float nm = mean + dlt * (nb / nt);
+      m2 = m2 + m2b + dlt * dlt * (n * nb / nt);
+      mean = nm;
+      n = nt;
+    }
+  }
+  if (lane == 0) {
+    const float var = m2 / (float)M;
+    const float rstd = 1.f / sqrtf(var + eps);
+    const float sc = gamma[c] * rstd;
+    scale[c] = sc;
+    shift[c] = beta[c] - mean * sc;
+    mean_out[c] = mean;
+    rstd_out[c] = rstd;
+    if (rmean) {
+      const float unbias = M > 1 ? (float)((double)M / (double)(M - 1)) : 1.f;
+      rmean[c] = (1.f - momentum) * rmean[c] + momentum * mean;
+      rvar[c] = (1.f - momentum) * rvar[c] + momentum * var * unbias;
+    }
+  }
+}
+
 // y = act(x * scale + shift + residual)
 template <typename T>
 __global__ __launch_bounds__(256) void scale_shift_act_kernel(const T* __restrict__ x, const float* __restrict__ scale,
@@ -822,6 +874,20 @@ extern "C" int cavp_bn_finalize(const float* sum, const float* sumsq, const floa
   bn_finalize_kernel<<<(C + 255) / 256, 256, 0, (hipStream_t)stream>>>(sum, sumsq, stat_shift, (float)(1.0 / (double)count), unbias,
                                                                      gamma, beta, eps, momentum, running_mean,
                                                                      running_var, scale, shift, mean, rstd, C);
+  CHECK_LAUNCH();
+}
+
+extern "C" int cavp_bn_finalize_tiles(const float* tile_stats, int32_t tiles, int32_t rows_per_tile, int64_t count,
+                                      const float* gamma, const float* beta, float eps, float momentum,
+                                      float* running_mean, float* running_var, float* scale, float* shift, float* mean,
+                                      float* rstd, int32_t C, void* stream) {
+  if (!tile_stats || !gamma || !beta || !scale || !shift || !mean || !rstd || tiles <= 0 || rows_per_tile <= 0 || count <= 0 ||
+      C <= 0 || (long long)tiles * rows_per_tile < count)
+    return CAVP_ERR_BAD_ARG;
+  if ((running_mean == nullptr) != (running_var == nullptr)) return CAVP_ERR_BAD_ARG;
+  bn_finalize_tiles_kernel<<<(C + 3) / 4, 256, 0, (hipStream_t)stream>>>(tile_stats, tiles, rows_per_tile, count, gamma, beta,
+                                                                        eps, momentum, running_mean, running_var, scale,
+                                                                        shift, mean, rstd, C);
   CHECK_LAUNCH();
 }
 

@@ -83,8 +83,10 @@ def workspace(nbytes: int, device) -> Optional[torch.Tensor]:
 def conv2d(x: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, kh: int = 1, kw: int = 1, stride: int = 1,
            pad: int = 0, dil: int = 1, scale: Optional[torch.Tensor] = None, shift: Optional[torch.Tensor] = None,
            nbias: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None, act: int = ACT_NONE,
-           splitk: int = 0, tile: int = 0) -> torch.Tensor:
-    """out = act((conv(x, w) + nbias[n]) * scale + shift + residual); x/out/residual NHWC views, w OHWI packed."""
+           splitk: int = 0, tile: int = 0, want_tile_stats: bool = False):
+    """out = act((conv(x, w) + nbias[n]) * scale + shift + residual); x/out/residual NHWC views, w OHWI packed.
+    want_tile_stats=True (plain convs only) returns (out, stats) where stats is None when this launch cannot produce the
+    fused BatchNorm statistics, else (tile_stats f32 [tiles][Cout][2], tiles, rows_per_tile)."""
     _need_gpu(x, w, out, scale, shift, nbias, residual)
     lib = _lib.load()
     n, h, wd, cin, ldx = _nhwc(x)
@@ -112,9 +114,17 @@ def conv2d(x: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, kh: int = 1, 
                  dil=dil, ldr=ldr, act=act, splitk=splitk, tile=tile)
     nbytes = lib.cavp_conv2d_workspace_bytes(C.byref(d))
     ws = workspace(nbytes, x.device)
+    stats = None
+    if want_tile_stats:
+        tiles, rpt = C.c_int32(0), C.c_int32(0)
+        if lib.cavp_conv2d_tile_stats_layout(C.byref(d), C.byref(tiles), C.byref(rpt)) and out.data_ptr() % 16 == 0:
+            stats = (torch.empty((tiles.value, cout, 2), dtype=torch.float32, device=x.device), tiles.value, rpt.value)
     st = lib.cavp_conv2d_nhwc(C.byref(d), _ptr(x), _ptr(w), _ptr(scale), _ptr(shift), _ptr(nbias), _ptr(residual),
-                              _ptr(out), _ptr(ws), C.c_size_t(ws.numel() if ws is not None else 0), C.c_void_p(_stream()))
+                              _ptr(out), _ptr(ws), C.c_size_t(ws.numel() if ws is not None else 0),
+                              _ptr(stats[0]) if stats is not None else None, C.c_void_p(_stream()))
     _lib.check(st, f"cavp_conv2d_nhwc N{n} H{h} W{wd} Cin{cin} Cout{cout} k{kh}x{kw} s{stride} p{pad} d{dil}")
+    if want_tile_stats:
+        return out, stats
     return out
 
 

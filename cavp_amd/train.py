@@ -28,10 +28,11 @@ from ._lib import ACT_GELU, ACT_LEAKY, ACT_NONE, ACT_RELU, CavpError
 class V:
     """An activation (NHWC / token / vector tensor) and its gradient.  A channel slice of a wider buffer is a child
     whose gradient is the matching slice of the parent's gradient (free concat in both directions)."""
-    __slots__ = ("t", "_g", "parent", "lo", "hi", "needs_grad")
+    __slots__ = ("t", "_g", "parent", "lo", "hi", "needs_grad", "tile_stats")
 
     def __init__(self, t: torch.Tensor, parent: Optional["V"] = None, lo: int = 0, hi: int = 0, needs_grad: bool = True):
         self.t, self._g, self.parent, self.lo, self.hi, self.needs_grad = t, None, parent, lo, hi, needs_grad
+        self.tile_stats = None   # (buf, tiles, rows_per_tile) when the producing conv computed BN statistics
 
     @property
     def g(self) -> Optional[torch.Tensor]:
@@ -243,8 +244,9 @@ class TrainPass:
 
     # ---- ops -------------------------------------------------------------------------------------------------
     def conv(self, x: V, key: str, *, act: int = ACT_NONE, residual: Optional[V] = None, nbias: Optional[V] = None,
-             out: Optional[V] = None) -> V:
-        """y = act(conv(x) + nbias[n] + bias + residual); fused epilogue forward, tape entry for backward."""
+             out: Optional[V] = None, stats: bool = False) -> V:
+        """y = act(conv(x) + nbias[n] + bias + residual); fused epilogue forward, tape entry for backward.
+        stats=True: a plain conv feeding a BatchNorm - ask the epilogue for the per-tile batch statistics."""
         p = self.P[key]
         x4 = _as4(x.t)
         n, h, w, _ = x4.shape
@@ -255,9 +257,12 @@ class TrainPass:
         if act == ACT_GELU:
             raise CavpError("GELU is applied by a separate op in the training pass (its backward needs the pre-activation)")
         bias = p.bias.detach() if p.bias is not None else None
-        ops.conv2d(x4, p.w, _as4(out.t), kh=p.kh, kw=p.kw, stride=p.stride, pad=p.pad, dil=p.dil, shift=bias,
-                   nbias=nbias.t if nbias is not None else None,
-                   residual=_as4(residual.t) if residual is not None else None, act=act)
+        fuse = stats and bias is None and nbias is None and residual is None and act == ACT_NONE and out.parent is None
+        r = ops.conv2d(x4, p.w, _as4(out.t), kh=p.kh, kw=p.kw, stride=p.stride, pad=p.pad, dil=p.dil, shift=bias,
+                       nbias=nbias.t if nbias is not None else None,
+                       residual=_as4(residual.t) if residual is not None else None, act=act, want_tile_stats=fuse)
+        if fuse:
+            out.tile_stats = r[1]
         y = out
 
         def bwd():
@@ -326,19 +331,29 @@ class TrainPass:
         """y = act(BN_train(z) + residual); `out` may be a channel slice of a concat buffer."""
         c = bn.num_features
         rows = z.t.numel() // z.t.shape[-1]
-        # two-pass statistics: sum -> mean (all-reduced for SyncBN), then centred second moment (cancellation-free)
-        s1 = self.zeros_f32(c)
-        T.colsum(z.t, s1)
-        count = self._allreduce_stats(bn, s1, rows)
-        m0 = T.scale_f32(s1, 1.0 / count, self.empty((c,), torch.float32))
-        stats = self.zeros_f32(2, c)
-        T.colstats(z.t, stats[0], stats[1], shift=m0)
-        self._allreduce_stats(bn, stats, rows)
         scale, shift, mean, rstd = (self.empty((c,), torch.float32) for _ in range(4))
         track = bn.track_running_stats and bn.running_mean is not None
-        T.bn_finalize(stats[0], stats[1], count, bn.weight.detach(), bn.bias.detach(), bn.eps,
-                      bn.momentum if bn.momentum is not None else 0.1, bn.running_mean if track else None,
-                      bn.running_var if track else None, scale, shift, mean, rstd, stat_shift=m0)
+        mom = bn.momentum if bn.momentum is not None else 0.1
+        sync = isinstance(bn, nn.SyncBatchNorm) and dist_world() > 1
+        if z.tile_stats is not None and not sync:
+            # statistics came out of the producing conv's epilogue (per-tile mean / M2): just combine them
+            ts, tiles, rpt = z.tile_stats
+            count = rows
+            T.bn_finalize_tiles(ts, tiles, rpt, rows, bn.weight.detach(), bn.bias.detach(), bn.eps, mom,
+                                bn.running_mean if track else None, bn.running_var if track else None, scale, shift,
+                                mean, rstd)
+        else:
+            # two-pass statistics: sum -> mean (all-reduced for SyncBN), then centred second moment (cancellation-free)
+            s1 = self.zeros_f32(c)
+            T.colsum(z.t, s1)
+            count = self._allreduce_stats(bn, s1, rows)
+            m0 = T.scale_f32(s1, 1.0 / count, self.empty((c,), torch.float32))
+            stats = self.zeros_f32(2, c)
+            T.colstats(z.t, stats[0], stats[1], shift=m0)
+            self._allreduce_stats(bn, stats, rows)
+            T.bn_finalize(stats[0], stats[1], count, bn.weight.detach(), bn.bias.detach(), bn.eps, mom,
+                          bn.running_mean if track else None, bn.running_var if track else None, scale, shift, mean,
+                          rstd, stat_shift=m0)
         if track and bn.num_batches_tracked is not None:
             bn.num_batches_tracked.add_(1)
         y = out if out is not None else V(self.empty(z.t.shape, z.t.dtype))
@@ -575,18 +590,18 @@ def run_train_forward(model, image: torch.Tensor, audio: torch.Tensor, tp: Train
     # ---- backbone (resnet.py:186-201) ----
     z = tp.conv_smallcin(image, "stem0", 2, ACT_NONE)
     x = tp.bn_act(z, rn.conv1[1], ACT_RELU)
-    x = tp.bn_act(tp.conv(x, "stem1"), rn.conv1[4], ACT_RELU)
-    x = tp.bn_act(tp.conv(x, "stem2"), rn.bn1, ACT_RELU)
+    x = tp.bn_act(tp.conv(x, "stem1", stats=True), rn.conv1[4], ACT_RELU)
+    x = tp.bn_act(tp.conv(x, "stem2", stats=True), rn.bn1, ACT_RELU)
     x = tp.maxpool(x, 3, 2, 1)
     feats = []
     for si, stage in enumerate(rn.block_table):
         for bi, (_, _, _, has_ds) in enumerate(stage):
             blkm = getattr(rn, f"layer{si + 1}")[bi]
             key = f"l{si + 1}.{bi}"
-            o = tp.bn_act(tp.conv(x, key + ".c1"), blkm.bn1, ACT_RELU)
-            o = tp.bn_act(tp.conv(o, key + ".c2"), blkm.bn2, ACT_RELU)
-            res = tp.bn_act(tp.conv(x, key + ".ds"), blkm.downsample[1], ACT_NONE) if has_ds else x
-            x = tp.bn_act(tp.conv(o, key + ".c3"), blkm.bn3, ACT_RELU, residual=res)
+            o = tp.bn_act(tp.conv(x, key + ".c1", stats=True), blkm.bn1, ACT_RELU)
+            o = tp.bn_act(tp.conv(o, key + ".c2", stats=True), blkm.bn2, ACT_RELU)
+            res = tp.bn_act(tp.conv(x, key + ".ds", stats=True), blkm.downsample[1], ACT_NONE) if has_ds else x
+            x = tp.bn_act(tp.conv(o, key + ".c3", stats=True), blkm.bn3, ACT_RELU, residual=res)
             tp.named[key] = x
         feats.append(x)
     f1, f4 = feats[0], feats[-1]
@@ -606,7 +621,7 @@ def run_train_forward(model, image: torch.Tensor, audio: torch.Tensor, tp: Train
     co = tp.P["aspp.red"].cout
     fea_v = V(tp.empty((n, lh, lw, co + tp.P["reduce"].cout)))
     tp.bilinear(asp, fea_v.slice(0, co), align_corners=True)
-    tp.bn_act(tp.conv(f1, "reduce"), m.segment.reduce[1], ACT_RELU, out=fea_v.slice(co, co + tp.P["reduce"].cout))
+    tp.bn_act(tp.conv(f1, "reduce", stats=True), m.segment.reduce[1], ACT_RELU, out=fea_v.slice(co, co + tp.P["reduce"].cout))
     # ---- 2B duplication + audio (cavp_model.py:181-186; vgg.py:17-23) ----
     fea_v2 = tp.dup2(fea_v)
     if audio.shape[0] != 2 * B:
@@ -643,9 +658,9 @@ def run_train_forward(model, image: torch.Tensor, audio: torch.Tensor, tp: Train
     fus_tok = tp.layernorm(r2, ca.norm)
     fusion = tp.reshape(fus_tok, (B2, hh, ww, Cc))
     # ---- decoder head (encoder_decoder.py:62-75) ----
-    z0h = tp.conv(fusion, "head0")
+    z0h = tp.conv(fusion, "head0", stats=True)
     c1 = tp.bn_act(z0h, up.last_conv[1], ACT_RELU)
-    z1h = tp.conv(c1, "head1")
+    z1h = tp.conv(c1, "head1", stats=True)
     c2 = tp.bn_act(z1h, up.last_conv[4], ACT_RELU)
     lo = tp.conv(c2, "cls")   # [2B, h, w, Cpad]; channels >= num_classes are exact zeros
     tp.named.update(fusion=fusion, z0h=z0h, c1=c1, z1h=z1h, c2=c2, lo=lo, r2=r2, r1=r1, vn=vn, q=q, o=o, fea_v2=fea_v2,

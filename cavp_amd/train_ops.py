@@ -71,7 +71,7 @@ def conv2d_dgrad(dy: torch.Tensor, w_t: torch.Tensor, dx: torch.Tensor, *, kh: i
     nbytes = lib.cavp_conv2d_workspace_bytes(C.byref(d))
     ws = ops.workspace(nbytes, dy.device)
     st = lib.cavp_conv2d_nhwc(C.byref(d), _ptr(dy), _ptr(w_t), _ptr(scale), _ptr(shift), None, _ptr(residual), _ptr(dx),
-                              _ptr(ws), C.c_size_t(ws.numel() if ws is not None else 0), _s())
+                              _ptr(ws), C.c_size_t(ws.numel() if ws is not None else 0), None, _s())
     _check(st, "cavp_conv2d_nhwc(dgrad)")
     return dx
 
@@ -164,6 +164,15 @@ def bn_finalize(sums, sumsq, count: int, gamma, beta, eps: float, momentum: floa
     _check(_lib.load().cavp_bn_finalize(_ptr(sums), _ptr(sumsq), _ptr(stat_shift), count, _ptr(gamma), _ptr(beta), C.c_float(eps),
                                         C.c_float(momentum), _ptr(running_mean), _ptr(running_var), _ptr(scale), _ptr(shift),
                                         _ptr(mean), _ptr(rstd), gamma.numel(), _s()), "cavp_bn_finalize")
+
+
+def bn_finalize_tiles(tile_stats, tiles: int, rows_per_tile: int, count: int, gamma, beta, eps: float, momentum: float,
+                      running_mean, running_var, scale, shift, mean, rstd) -> None:
+    _need_gpu(tile_stats, gamma, beta, scale, shift, mean, rstd)
+    _check(_lib.load().cavp_bn_finalize_tiles(_ptr(tile_stats), tiles, rows_per_tile, count, _ptr(gamma), _ptr(beta),
+                                              C.c_float(eps), C.c_float(momentum), _ptr(running_mean), _ptr(running_var),
+                                              _ptr(scale), _ptr(shift), _ptr(mean), _ptr(rstd), gamma.numel(), _s()),
+           "cavp_bn_finalize_tiles")
 
 
 def scale_shift_act(x, scale, shift, y, act: int, residual=None) -> torch.Tensor:

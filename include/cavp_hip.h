@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define CAVP_ABI_VERSION 2
+#define CAVP_ABI_VERSION 3
 
 typedef enum { CAVP_F32 = 0, CAVP_BF16 = 1 } cavp_dtype_t;
 typedef enum { CAVP_ACT_NONE = 0, CAVP_ACT_RELU = 1, CAVP_ACT_LEAKY = 2, CAVP_ACT_GELU = 3 } cavp_act_t;
@@ -74,9 +74,14 @@ typedef struct cavp_conv_desc {
 } cavp_conv_desc;
 
 size_t cavp_conv2d_workspace_bytes(const cavp_conv_desc* d);
+/* tile_stats (optional, training): f32 [tiles][Cout][2]; the epilogue stores each pixel tile's per-channel mean and
+ * centred second moment of the raw conv output, so BatchNorm batch statistics cost no extra pass (combine with
+ * cavp_bn_finalize_tiles).  Only for plain convs (no scale/shift/nbias/residual/act) whose launch uses the staged
+ * epilogue: query cavp_conv2d_tile_stats_layout first (returns 0 -> fall back to cavp_colsum + cavp_colstats). */
+int cavp_conv2d_tile_stats_layout(const cavp_conv_desc* d, int32_t* tiles, int32_t* rows_per_tile);
 int cavp_conv2d_nhwc(const cavp_conv_desc* d, const void* x, const void* w, const float* scale, const float* shift,
                      const float* nbias, const void* residual, void* y, void* workspace, size_t workspace_bytes,
-                     void* stream);
+                     float* tile_stats, void* stream);
 
 /* Direct 3x3 conv for Cin in {1,2,3} reading an NCHW f32 tensor and writing NHWC (dtype) with scale/shift + act:
  * the ResNet deep-stem first conv (resnet.py:108-110, stride 2) and the first VGGish conv (vgg.py:26-36). */
@@ -161,6 +166,10 @@ int cavp_scale_f32(const float* in, float alpha, float* out, int32_t n, void* st
 int cavp_bn_finalize(const float* sum, const float* sumsq, const float* stat_shift, int64_t count, const float* gamma,
                      const float* beta, float eps, float momentum, float* running_mean, float* running_var, float* scale, float* shift,
                      float* mean, float* rstd, int32_t C, void* stream);
+int cavp_bn_finalize_tiles(const float* tile_stats, int32_t tiles, int32_t rows_per_tile, int64_t count,
+                           const float* gamma, const float* beta, float eps, float momentum, float* running_mean,
+                           float* running_var, float* scale, float* shift, float* mean, float* rstd, int32_t C,
+                           void* stream);
 int cavp_scale_shift_act(int32_t dtype, const void* x, const float* scale, const float* shift, const void* residual,
                          void* y, int64_t rows, int32_t C, int32_t ldx, int32_t ldr, int32_t ldy, int32_t act,
                          void* stream);

@@ -137,7 +137,7 @@ def test_train_step_b8_vs_oracle(dtype, norm_tol, cos_tol):
     out.backward(dl)
     torch.cuda.synchronize()
     ref_out, ref_loss, ref_g = _oracle_grads(sd, cfg, image, audio, label)
-    assert abs(float(loss.item()) - ref_loss) <= (1e-4 if dtype == torch.float32 else 3e-2) * max(1.0, abs(ref_loss))
+    assert abs(float(loss.item()) - ref_loss) <= (1e-4 if dtype == torch.float32 else 6e-2) * max(1.0, abs(ref_loss))
     params = dict(m.named_parameters())
     rels, coss = [], []
     for k, g in ref_g.items():

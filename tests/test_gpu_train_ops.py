@@ -251,3 +251,31 @@ def test_bcast_add_and_smallcin_wgrad(dt):
         dw = torch.zeros((64, cin, 3, 3), device=DEV)
         T.smallcin_wgrad(xi.to(DEV), _nhwc(dy, dt), dw, stride)
         _check(dw, w.grad, dt, "smallcin wgrad", 1e-4, 1e-2)
+
+
+@pytest.mark.parametrize("dt", DTYPES, ids=IDS)
+@pytest.mark.parametrize("shape", [(4, 56, 56, 64, 64, 3), (2, 28, 28, 128, 512, 1), (3, 13, 11, 64, 48, 1)])
+def test_fused_bn_statistics_from_conv_epilogue(shape, dt):
+    """per-tile (mean, M2) written by the conv epilogue + Chan combine == batch statistics of the conv output."""
+    ops, T = _mods()
+    n, h, w, cin, cout, k = shape
+    x = _q(_rand(n, cin, h, w, seed=40) + 0.7, dt)
+    wt = _q(_rand(cout, cin, k, k, seed=41, scale=(cin * k * k) ** -0.5), dt)
+    z = F.conv2d(x, wt, None, 1, k // 2)
+    out = torch.empty((n, h, w, cout), dtype=dt, device=DEV)
+    out, stats = ops.conv2d(_nhwc(x, dt), ops.pack_weight(wt.to(DEV), dt), out, kh=k, kw=k, pad=k // 2, want_tile_stats=True)
+    if stats is None:
+        pytest.skip("the library chose split-K for this launch: fused statistics not offered (fallback path is tested elsewhere)")
+    ts, tiles, rpt = stats
+    g, b = torch.rand(cout, generator=torch.Generator().manual_seed(42)) + 0.5, _rand(cout, seed=43)
+    rm, rv = torch.zeros(cout, device=DEV), torch.ones(cout, device=DEV)
+    f = lambda: torch.empty(cout, device=DEV)
+    scale, shift, mean, rstd = f(), f(), f(), f()
+    T.bn_finalize_tiles(ts, tiles, rpt, n * h * w, g.to(DEV), b.to(DEV), 1e-5, 0.1, rm, rv, scale, shift, mean, rstd)
+    m_ref, v_ref = z.mean((0, 2, 3)), z.var((0, 2, 3), unbiased=False)
+    _check(mean, m_ref, torch.float32, "mean", 2e-5)
+    _check(rstd, 1 / torch.sqrt(v_ref + 1e-5), torch.float32, "rstd", 5e-5)
+    _check(scale, g / torch.sqrt(v_ref + 1e-5), torch.float32, "scale", 5e-5)
+    _check(shift, b - m_ref * g / torch.sqrt(v_ref + 1e-5), torch.float32, "shift", 1e-4)
+    _check(rm, 0.1 * m_ref, torch.float32, "running_mean", 1e-4)
+    _check(rv, 0.9 + 0.1 * z.var((0, 2, 3), unbiased=True), torch.float32, "running_var", 1e-4)
