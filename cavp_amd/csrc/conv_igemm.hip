@@ -38,6 +38,9 @@ struct IgemmParams {
   int vec_io;               // epilogue may use vector loads/stores (Cout, ldy, ldr multiples of 4, pointers aligned)
   int x_bytes, w_bytes;     // buffer-descriptor extents (< 2 GiB)
   int up_shift, up_mask;    // transposed-conv input upsampling (log2, mask); 0, 0 for an ordinary conv
+  int tap_dh[9], tap_dw[9];  // per LIVE tap: kh*dil, kw*dil (input-space displacement)
+  int tap_xoff[9];          // per live tap: byte displacement (dh*W + dw)*ldx*sizeof(T) in x (ordinary conv only)
+  int tap_woff[9];          // per live tap: byte offset tap*Cin*sizeof(T) inside a weight row
   float* tile_stats;        // optional [tiles_p][Cout][2] per-tile (mean, M2) of the raw outputs (BatchNorm statistics)
   int coalesced;            // LDS-staged, fully coalesced 16-byte epilogue (needs Cout, ldy, ldr % VE == 0, 16-B aligned)
 };
@@ -120,7 +123,7 @@ __device__ __forceinline__ void epilogue_store4(const IgemmParams& p, float v0, 
   }
 }
 
-template <typename T, int BC, int BP, int WC, int WP, int PIPE>
+template <typename T, int BC, int BP, int WC, int WP, bool UP>
 __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p) {
   constexpr int VE = Elem<T>::VE;
   constexpr int BK = 8 * VE;  // one 128-byte LDS row of K
@@ -152,17 +155,15 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p) {
   const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.w_bytes, 0x00020000);
 
   // ---- per-thread load descriptors (fixed for the whole K loop) ----
-  // Row / slot owned by this thread for its i-th 16-byte vector of a tile.
-  //  PIPE 1,2 (register staging): vector v = tid + 256 i -> row (tid >> 3) + 32 i, slot tid & 7 (swizzled on the
-  //            ds_write side).
-  //  PIPE 3 (LDS-DMA): a wave-instruction writes 1 KiB = rows 8g..8g+7 LINEARLY (lane l -> byte 16 l), g = wave + 4 i,
-  //            so the swizzle moves to the SOURCE: lane l fetches logical slot (l & 7) ^ ((row >> 1) & 7).
-  const int row0 = PIPE == 3 ? 8 * wave + (lane >> 3) : (tid >> 3);
-  const int kslot = (PIPE == 3 ? ((lane & 7) ^ ((4 * wave + (lane >> 4)) & 7)) : (tid & 7)) * VE;
-  unsigned w_off[LW];                // byte offset of (row cout, k = kslot) or kOOB
-  // vector v = tid + 256 i sits in row (tid >> 3) + 32 i, and ((row >> 1) & 7) does not depend on i, so the LDS
-  // address of vector i is lds0 + 4096 i (one register instead of LW + LX)
-  const int lds0 = (tid >> 3) * 128 + (((tid & 7) ^ ((tid >> 4) & 7)) << 4);
+  // LDS-DMA geometry: a wave-instruction writes 1 KiB = rows 8g..8g+7 LINEARLY (lane l -> byte 16 l), g = wave + 4 i,
+  // so the bank swizzle moves to the SOURCE: lane l fetches logical slot (l & 7) ^ ((row >> 1) & 7) of its row.
+  // Everything that does not change over the K loop is folded into one byte offset + one tap-validity bitmask per
+  // row, so a K iteration costs ~4 VALU per load (the first version redid the bounds tests and two integer
+  // divisions every iteration: 80 VALU + 134 SALU per 32 MFMAs, i.e. the address math, not the MFMAs, set the pace).
+  const int row0 = 8 * wave + (lane >> 3);
+  const int kslot = ((lane & 7) ^ ((4 * wave + (lane >> 4)) & 7)) * VE;
+  const int kbyte = kslot * (int)sizeof(T);
+  unsigned w_off[LW];  // byte offset of (cout row, k = kslot) or kOOB
 #pragma unroll
   for (int i = 0; i < LW; ++i) {
     const int row = row0 + 32 * i;
@@ -170,7 +171,9 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p) {
     const bool ok = (row < BC) && (c < p.Cout);
     w_off[i] = ok ? (unsigned)(((size_t)c * p.K + kslot) * sizeof(T)) : kOOB;
   }
-  int x_nb[LX], x_h0[LX], x_w0[LX];
+  unsigned x_off[LX];   // byte offset of (pixel @ tap displacement 0, channel kslot); wraps are harmless (masked)
+  unsigned x_mask[LX];  // bit ti = live tap ti reads inside the image for this row
+  int x_h0[LX], x_w0[LX], x_nb[LX];  // UP only
   const int HoWo = p.Ho * p.Wo;
 #pragma unroll
   for (int i = 0; i < LX; ++i) {
@@ -180,80 +183,70 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p) {
     const int pp = ok ? pix : 0;
     const int n = pp / HoWo, r = pp - n * HoWo;
     const int ho = r / p.Wo, wo = r - ho * p.Wo;
-    x_nb[i] = n * p.H * p.W;
-    x_h0[i] = ok ? ho * p.stride - p.pad : -0x10000000;  // invalid rows fail the bounds test below
-    x_w0[i] = wo * p.stride - p.pad;
+    const int h0 = ho * p.stride - p.pad, w0 = wo * p.stride - p.pad;
+    if constexpr (UP) {
+      x_nb[i] = n * p.H * p.W;
+      x_h0[i] = ok ? h0 : -0x10000000;
+      x_w0[i] = w0;
+      x_off[i] = 0;
+      x_mask[i] = 0;
+    } else {
+      x_off[i] = (unsigned)((n * p.H + h0) * p.W + w0) * (unsigned)(p.ldx * (int)sizeof(T)) + (unsigned)kbyte;
+      unsigned m = 0;
+      for (int t = 0; t < p.ntaps; ++t) {
+        const int hi = h0 + p.tap_dh[t], wi = w0 + p.tap_dw[t];
+        m |= (ok && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W) ? (1u << t) : 0u;
+      }
+      x_mask[i] = m;
+    }
   }
 
-  // two register sets: with PIPE == 2 the loads of tile k+2 are issued while tile k is multiplied and tile k+1 is
-  // still in flight, so a load has two compute phases to land (HBM/L2 latency under load ~ 2 phases).
-  u32x4_t wregA[LW], xregA[LX], wregB[LW], xregB[LX];
+  // K-loop position (tap index, channel tile) kept incrementally: no division in the loop
+  int g_ti = it_begin / p.cpt;
+  int g_cc = it_begin - g_ti * p.cpt;
 
-  auto gload = [&](u32x4_t (&wr)[LW], u32x4_t (&xr)[LX], int it) {
-    const int ti = it / p.cpt;
-    const int c0 = (it - ti * p.cpt) * BK;
-    const int tap = (int)((p.taps >> (4 * ti)) & 15ull);
-    const int kh = tap / p.KW, kw = tap - kh * p.KW;
+  // global -> LDS directly (buffer_load ... lds), no VGPR staging, no ds_write; out-of-range lanes land zeros.
+  auto gdma = [&](int buf) {
+    const int ti = g_ti, c0 = g_cc * BK;
     const bool c_ok = (c0 + kslot) < p.Cin;
-    const unsigned koff = (unsigned)((tap * p.Cin + c0) * (int)sizeof(T));
-    const int dh = kh * p.dil, dw = kw * p.dil;
-    const int xk = (c0 + kslot) * (int)sizeof(T);
-#pragma unroll
-    for (int i = 0; i < LW; ++i) {
-      const unsigned off = c_ok ? (w_off[i] + koff) : kOOB;  // kOOB + koff stays >= 2^31 (tensors are < 2 GiB)
-      wr[i] = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, (int)off, 0, 0);
-    }
-#pragma unroll
-    for (int i = 0; i < LX; ++i) {
-      const int hv = x_h0[i] + dh, wv = x_w0[i] + dw;  // position in the (virtually zero-upsampled) input
-      const int hi = hv >> p.up_shift, wi = wv >> p.up_shift;
-      const bool ok = c_ok && (((hv | wv) & p.up_mask) == 0) && ((unsigned)hi < (unsigned)p.H) &&
-                      ((unsigned)wi < (unsigned)p.W);
-      const unsigned off = (unsigned)(x_nb[i] + hi * p.W + wi) * (unsigned)(p.ldx * (int)sizeof(T)) + (unsigned)xk;
-      xr[i] = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, (int)(ok ? off : kOOB), 0, 0);
-    }
-  };
-  // PIPE 3: global -> LDS directly (buffer_load ... lds), no VGPR staging, no ds_write; out-of-range lanes land zeros.
-  auto gdma = [&](int it, int buf) {
-    const int ti = it / p.cpt;
-    const int c0 = (it - ti * p.cpt) * BK;
-    const int tap = (int)((p.taps >> (4 * ti)) & 15ull);
-    const int kh = tap / p.KW, kw = tap - kh * p.KW;
-    const bool c_ok = (c0 + kslot) < p.Cin;
-    const unsigned koff = (unsigned)((tap * p.Cin + c0) * (int)sizeof(T));
-    const int dh = kh * p.dil, dw = kw * p.dil;
-    const int xk = (c0 + kslot) * (int)sizeof(T);
+    const unsigned wk = (unsigned)(p.tap_woff[ti] + c0 * (int)sizeof(T));
     char* base = smem + buf * TILE_BYTES + wave * 1024;
 #pragma unroll
     for (int i = 0; i < LW; ++i) {
       if (BC % 32 == 0 || 8 * wave + 32 * i < BC) {
-        const unsigned off = c_ok ? (w_off[i] + koff) : kOOB;
+        const unsigned off = c_ok ? (w_off[i] + wk) : kOOB;  // kOOB + wk stays >= 2^31 (tensors are < 2 GiB)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (__attribute__((address_space(3))) void*)(base + i * 4096), 16,
                                                  (int)off, 0, 0, 0);
       }
     }
+    if constexpr (UP) {
+      const int dh = p.tap_dh[ti], dw = p.tap_dw[ti];
+      const int xk = c0 * (int)sizeof(T) + kbyte;
 #pragma unroll
-    for (int i = 0; i < LX; ++i) {
-      if (BP % 32 == 0 || 8 * wave + 32 * i < BP) {
-        const int hv = x_h0[i] + dh, wv = x_w0[i] + dw;
-        const int hi = hv >> p.up_shift, wi = wv >> p.up_shift;
-        const bool ok = c_ok && (((hv | wv) & p.up_mask) == 0) && ((unsigned)hi < (unsigned)p.H) &&
-                        ((unsigned)wi < (unsigned)p.W);
-        const unsigned off = (unsigned)(x_nb[i] + hi * p.W + wi) * (unsigned)(p.ldx * (int)sizeof(T)) + (unsigned)xk;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc,
-                                                 (__attribute__((address_space(3))) void*)(base + BC * 128 + i * 4096),
-                                                 16, (int)(ok ? off : kOOB), 0, 0, 0);
+      for (int i = 0; i < LX; ++i) {
+        if (BP % 32 == 0 || 8 * wave + 32 * i < BP) {
+          const int hv = x_h0[i] + dh, wv = x_w0[i] + dw;  // position in the (virtually zero-upsampled) input
+          const int hi = hv >> p.up_shift, wi = wv >> p.up_shift;
+          const bool ok = c_ok && (((hv | wv) & p.up_mask) == 0) && ((unsigned)hi < (unsigned)p.H) &&
+                          ((unsigned)wi < (unsigned)p.W);
+          const unsigned off = (unsigned)(x_nb[i] + hi * p.W + wi) * (unsigned)(p.ldx * (int)sizeof(T)) + (unsigned)xk;
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(
+              xrsrc, (__attribute__((address_space(3))) void*)(base + BC * 128 + i * 4096), 16, (int)(ok ? off : kOOB), 0, 0, 0);
+        }
+      }
+    } else {
+      const unsigned xk = (unsigned)(p.tap_xoff[ti] + c0 * (int)sizeof(T));
+#pragma unroll
+      for (int i = 0; i < LX; ++i) {
+        if (BP % 32 == 0 || 8 * wave + 32 * i < BP) {
+          const bool ok = c_ok && ((x_mask[i] >> ti) & 1u);
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(
+              xrsrc, (__attribute__((address_space(3))) void*)(base + BC * 128 + i * 4096), 16,
+              (int)(ok ? x_off[i] + xk : kOOB), 0, 0, 0);
+        }
       }
     }
-  };
-  auto lstore = [&](const u32x4_t (&wr)[LW], const u32x4_t (&xr)[LX], int buf) {
-    char* base = smem + buf * TILE_BYTES;
-#pragma unroll
-    for (int i = 0; i < LW; ++i)
-      if (NVW % 256 == 0 || tid + i * 256 < NVW) *(u32x4_t*)(base + lds0 + i * 4096) = wr[i];
-#pragma unroll
-    for (int i = 0; i < LX; ++i)
-      if (NVX % 256 == 0 || tid + i * 256 < NVX) *(u32x4_t*)(base + BC * 128 + lds0 + i * 4096) = xr[i];
+    if (++g_cc == p.cpt) { g_cc = 0; ++g_ti; }
   };
 
   const int wc0 = (wave % WC) * TC, wp0 = (wave / WC) * TP;
@@ -290,45 +283,14 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p) {
   };
 
   if (it_begin < it_end) {
-    if constexpr (PIPE == 1) {
-      gload(wregA, xregA, it_begin);
-      lstore(wregA, xregA, 0);
+    gdma(0);
+    __syncthreads();  // (drains the DMA: hipcc emits vmcnt(0) before the barrier while an LDS-DMA is in flight)
+    int buf = 0;
+    for (int it = it_begin; it < it_end; ++it) {
+      if (it + 1 < it_end) gdma(buf ^ 1);
+      compute(buf);
       __syncthreads();
-      int buf = 0;
-      for (int it = it_begin; it < it_end; ++it) {
-        const bool more = (it + 1) < it_end;
-        if (more) gload(wregA, xregA, it + 1);
-        compute(buf);
-        if (more) lstore(wregA, xregA, buf ^ 1);
-        __syncthreads();
-        buf ^= 1;
-      }
-    } else if constexpr (PIPE == 3) {
-      gdma(it_begin, 0);
-      __syncthreads();  // (drains the DMA: hipcc emits vmcnt(0) before the barrier while an LDS-DMA is in flight)
-      int buf = 0;
-      for (int it = it_begin; it < it_end; ++it) {
-        if (it + 1 < it_end) gdma(it + 1, buf ^ 1);
-        compute(buf);
-        __syncthreads();
-        buf ^= 1;
-      }
-    } else {
-      gload(wregA, xregA, it_begin);
-      if (it_begin + 1 < it_end) gload(wregB, xregB, it_begin + 1);
-      lstore(wregA, xregA, 0);
-      __syncthreads();
-      for (int it = it_begin; it < it_end; it += 2) {
-        if (it + 2 < it_end) gload(wregA, xregA, it + 2);
-        compute(0);
-        if (it + 1 < it_end) lstore(wregB, xregB, 1);
-        __syncthreads();
-        if (it + 1 >= it_end) break;
-        if (it + 3 < it_end) gload(wregB, xregB, it + 3);
-        compute(1);
-        if (it + 2 < it_end) lstore(wregA, xregA, 0);
-        __syncthreads();
-      }
+      buf ^= 1;
     }
   }
 
@@ -473,55 +435,35 @@ struct TileCfg {
   float eff;  // relative per-WG efficiency (bigger tiles reuse LDS operands more)
 };
 const TileCfg kTiles[] = {
-    {1, 128, 128, 1.00f}, {2, 64, 128, 0.85f}, {3, 64, 64, 0.70f}, {4, 128, 64, 0.85f},
-    {5, 128, 32, 0.55f},  {6, 16, 128, 0.35f}, {7, 32, 128, 0.60f},
+    {1, 128, 128, 1.00f}, {2, 64, 128, 0.90f}, {3, 64, 64, 0.72f}, {4, 128, 64, 0.95f},
+    {5, 128, 32, 0.55f},  {6, 16, 128, 0.30f}, {7, 32, 128, 0.55f},
 };
 constexpr int kNumTiles = sizeof(kTiles) / sizeof(kTiles[0]);
 
-template <typename T, int BC, int BP, int WC, int WP, int PIPE>
+template <typename T, int BC, int BP, int WC, int WP, bool UP>
 hipError_t launch_cfg(const IgemmParams& p, int nblk, hipStream_t s) {
   constexpr int lds = 2 * (BC + BP) * 128;
   static_assert(BP * BC * 4 <= lds, "epilogue staging must fit in the K-loop LDS");
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)igemm_kernel<T, BC, BP, WC, WP, PIPE>,
+    (void)hipFuncSetAttribute((const void*)igemm_kernel<T, BC, BP, WC, WP, UP>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr_set = true;
   }
-  igemm_kernel<T, BC, BP, WC, WP, PIPE><<<dim3(nblk), dim3(256), lds, s>>>(p);
+  igemm_kernel<T, BC, BP, WC, WP, UP><<<dim3(nblk), dim3(256), lds, s>>>(p);
   return hipGetLastError();
 }
 
-template <typename T>
-hipError_t launch_tile(int id, int pipe, const IgemmParams& p, int nblk, hipStream_t s) {
-  if (pipe == 1) {
-    switch (id) {
-      case 1: return launch_cfg<T, 128, 128, 2, 2, 1>(p, nblk, s);
-      case 2: return launch_cfg<T, 64, 128, 2, 2, 1>(p, nblk, s);
-      case 3: return launch_cfg<T, 64, 64, 2, 2, 1>(p, nblk, s);
-      case 4: return launch_cfg<T, 128, 64, 2, 2, 1>(p, nblk, s);
-      case 5: return launch_cfg<T, 128, 32, 4, 1, 1>(p, nblk, s);
-      case 6: return launch_cfg<T, 16, 128, 1, 4, 1>(p, nblk, s);
-      case 7: return launch_cfg<T, 32, 128, 1, 4, 1>(p, nblk, s);
-      default: return hipErrorInvalidValue;
-    }
-  }
-  if (pipe == 2) {
-    switch (id) {
-      case 1: return launch_cfg<T, 128, 128, 2, 2, 2>(p, nblk, s);
-      case 2: return launch_cfg<T, 64, 128, 2, 2, 2>(p, nblk, s);
-      case 3: return launch_cfg<T, 64, 64, 2, 2, 2>(p, nblk, s);
-      default: return hipErrorInvalidValue;
-    }
-  }
+template <typename T, bool UP>
+hipError_t launch_tile(int id, const IgemmParams& p, int nblk, hipStream_t s) {
   switch (id) {
-    case 1: return launch_cfg<T, 128, 128, 2, 2, 3>(p, nblk, s);
-    case 2: return launch_cfg<T, 64, 128, 2, 2, 3>(p, nblk, s);
-    case 3: return launch_cfg<T, 64, 64, 2, 2, 3>(p, nblk, s);
-    case 4: return launch_cfg<T, 128, 64, 2, 2, 3>(p, nblk, s);
-    case 5: return launch_cfg<T, 128, 32, 4, 1, 3>(p, nblk, s);
-    case 6: return launch_cfg<T, 16, 128, 1, 4, 3>(p, nblk, s);
-    case 7: return launch_cfg<T, 32, 128, 1, 4, 3>(p, nblk, s);
+    case 1: return launch_cfg<T, 128, 128, 2, 2, UP>(p, nblk, s);
+    case 2: return launch_cfg<T, 64, 128, 2, 2, UP>(p, nblk, s);
+    case 3: return launch_cfg<T, 64, 64, 2, 2, UP>(p, nblk, s);
+    case 4: return launch_cfg<T, 128, 64, 2, 2, UP>(p, nblk, s);
+    case 5: return launch_cfg<T, 128, 32, 4, 1, UP>(p, nblk, s);
+    case 6: return launch_cfg<T, 16, 128, 1, 4, UP>(p, nblk, s);
+    case 7: return launch_cfg<T, 32, 128, 1, 4, UP>(p, nblk, s);
     default: return hipErrorInvalidValue;
   }
 }
@@ -529,7 +471,6 @@ hipError_t launch_tile(int id, int pipe, const IgemmParams& p, int nblk, hipStre
 struct Plan {
   IgemmParams p;
   int tile_id;
-  int pipe;      // software-pipeline depth of the K loop (1 or 2 tiles of loads in flight)
   int direct_epi;  // testing: force the direct (MFMA-layout) epilogue
   int nblk;
   size_t ws_bytes;
@@ -586,7 +527,12 @@ Plan make_plan(const cavp_conv_desc* d) {
         wlive = wi >= 0 && (wi % up) == 0 && wi / up < d->W;
       }
       if (hlive && wlive) {
+        const int es_ = d->dtype == CAVP_F32 ? 4 : 2;
         p.taps |= (unsigned long long)(kh * d->KW + kw) << (4 * p.ntaps);
+        p.tap_dh[p.ntaps] = kh * d->dil;
+        p.tap_dw[p.ntaps] = kw * d->dil;
+        p.tap_xoff[p.ntaps] = (kh * d->dil * d->W + kw * d->dil) * d->ldx * es_;
+        p.tap_woff[p.ntaps] = (kh * d->KW + kw) * d->Cin * es_;
         ++p.ntaps;
       }
     }
@@ -594,50 +540,46 @@ Plan make_plan(const cavp_conv_desc* d) {
   const int BK = 8 * VE;
   p.cpt = cdiv(d->Cin, BK);
   p.iters = p.ntaps * p.cpt;
-  // ---- tile choice ----
-  int best = -1;
-  // d->tile = id + 100 * (pipe==1) + 1000 * (direct epilogue): testing / A-B knobs
-  {  // hundreds digit of the knob: 0 = default pipeline, 1/2 = register staging depth 1/2, 3 = LDS-DMA
-    const int pk = (d->tile / 100) % 10;
-    pl.pipe = pk == 0 ? 3 : pk;
-    if (pl.pipe < 1 || pl.pipe > 3) { pl.status = CAVP_ERR_BAD_ARG; return pl; }
-  }
-  pl.direct_epi = (d->tile / 1000) % 10;
+  // ---- tile + split-K choice: a small time model, fitted to tools/bench_conv.py on MI355X ----
+  //   t = rounds * (flops of one padded workgroup) / (rate per resident slot)  +  split-K slab traffic
+  // rate: the 2-stage LDS-DMA structure tops out at ~600 TF/s (bf16) / ~100 TF/s (f32) with 128x128 tiles, because
+  // the operand fill rate of the chip (~9 TB/s global->LDS), not the MFMA pipe, is its ceiling; smaller tiles move
+  // more operand bytes per flop (eff below).  Resident workgroups per CU follow from the tile's LDS footprint.
+  int best = -1, best_sk = 1;
+  pl.direct_epi = (d->tile / 1000) % 10;  // d->tile = id + 1000 * (direct epilogue): testing / A-B knobs
   const int want_tile = d->tile % 100;
-  if (want_tile > 0) {
-    for (int i = 0; i < kNumTiles; ++i)
-      if (kTiles[i].id == want_tile) best = i;
-    if (best < 0) { pl.status = CAVP_ERR_BAD_ARG; return pl; }
-  } else {
-    double best_score = -1.0;
-    for (int i = 0; i < kNumTiles; ++i) {
-      const TileCfg& t = kTiles[i];
-      const long long nwg = (long long)cdiv(p.Cout, t.BC) * cdiv(p.M, t.BP);
-      const double useful = ((double)p.Cout * p.M) / ((double)nwg * t.BC * t.BP);
-      // 256 CUs x 2 resident workgroups; the last partial "wave" of workgroups is the quantisation loss
-      const double slots = 512.0;
-      const double rounds = (double)((nwg + 511) / 512);
-      const double fill = (double)nwg / (rounds * slots);
-      const double score = useful * t.eff * (0.25 + 0.75 * fill);
-      if (score > best_score) { best_score = score; best = i; }
+  const double peak = d->dtype == CAVP_F32 ? 100e12 : 600e12;
+  const int sk_opts[] = {1, 2, 3, 4, 6, 8, 12, 16, 24, 32};
+  double best_t = 1e30;
+  for (int i = 0; i < kNumTiles; ++i) {
+    const TileCfg& t = kTiles[i];
+    if (want_tile > 0 && t.id != want_tile) continue;
+    const long long nwg = (long long)cdiv(p.Cout, t.BC) * cdiv(p.M, t.BP);
+    int bpc = (160 * 1024) / (2 * (t.BC + t.BP) * 128);
+    if (bpc > 4) bpc = 4;
+    const double slots = 256.0 * bpc;
+    for (int sk : sk_opts) {
+      if (d->splitk > 0 && sk != 1) continue;
+      int use_sk = d->splitk > 0 ? d->splitk : sk;
+      if (use_sk > 1 && (use_sk > p.iters / 4)) continue;
+      if (use_sk > p.iters) use_sk = p.iters > 0 ? p.iters : 1;
+      const double blocks = (double)nwg * use_sk;
+      const double rounds = (double)((long long)((blocks + slots - 1) / slots));
+      const double wg_flops = 2.0 * t.BC * t.BP * (double)BK * ((double)p.iters / use_sk);
+      double tt = rounds * wg_flops / (peak * t.eff / slots) + 2e-6;
+      if (use_sk > 1) tt += (2.0 * use_sk + 1.0) * p.M * p.Cout * 4.0 / 3e12 + 4e-6;
+      if (tt < best_t) { best_t = tt; best = i; best_sk = use_sk; }
     }
   }
+  if (best < 0) { pl.status = CAVP_ERR_BAD_ARG; return pl; }
   const TileCfg& t = kTiles[best];
   pl.tile_id = t.id;
   p.tiles_c = cdiv(p.Cout, t.BC);
   p.tiles_p = cdiv(p.M, t.BP);
   const int nwg = p.tiles_c * p.tiles_p;
-  int sk = d->splitk;
-  if (sk <= 0) {
-    sk = 1;
-    if (nwg < 256 && p.iters >= 16) {
-      sk = cdiv(512, nwg);
-      if (sk > p.iters / 8) sk = p.iters / 8;
-      if (sk > 32) sk = 32;
-      if (sk < 1) sk = 1;
-    }
-  }
+  int sk = best_sk;
   if (sk > p.iters) sk = p.iters > 0 ? p.iters : 1;
+  if (sk < 1) sk = 1;
   p.splitk = sk;
   pl.nblk = nwg * sk;
   pl.ws_bytes = sk > 1 ? (size_t)sk * p.M * p.Cout * sizeof(float) : 0;
@@ -699,8 +641,10 @@ extern "C" int cavp_conv2d_nhwc(const cavp_conv_desc* d, const void* x, const vo
   p.tile_stats = tile_stats;
   if (tile_stats && !p.coalesced) return CAVP_ERR_UNSUPPORTED;   // see cavp_conv2d_tile_stats_layout
   hipStream_t s = (hipStream_t)stream;
-  hipError_t e = d->dtype == CAVP_F32 ? launch_tile<float>(pl.tile_id, pl.pipe, p, pl.nblk, s)
-                                      : launch_tile<bf16_t>(pl.tile_id, pl.pipe, p, pl.nblk, s);
+  const bool upm = p.up_mask != 0;
+  hipError_t e = d->dtype == CAVP_F32
+                     ? (upm ? launch_tile<float, true>(pl.tile_id, p, pl.nblk, s) : launch_tile<float, false>(pl.tile_id, p, pl.nblk, s))
+                     : (upm ? launch_tile<bf16_t, true>(pl.tile_id, p, pl.nblk, s) : launch_tile<bf16_t, false>(pl.tile_id, p, pl.nblk, s));
   if (e != hipSuccess) return CAVP_ERR_LAUNCH;
   if (p.splitk > 1) {
     const long long total = (long long)p.M * ((p.Cout + 3) / 4);

@@ -65,35 +65,57 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
   const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.dy, 0, p.dy_bytes, 0x00020000);
 
   // DMA geometry: wave-instruction g (= wave + 4 i, i < 4) fills rows 4g .. 4g+3 of a tile; lane l lands at byte
-  // 16 l of that 1 KiB, i.e. row 4g + (l >> 4), physical 16-byte slot l & 15.
+  // 16 l of that 1 KiB, i.e. row 4g + (l >> 4), physical 16-byte slot l & 15.  The swizzle key of row drow0 + 16 i
+  // does not depend on i, so the lane's channel offset is fixed; the pixel coordinates of its 4 rows are advanced
+  // incrementally (+64 pixels per K tile) instead of being re-derived with integer divisions every iteration.
   const int drow0 = 4 * wave + (lane >> 4);  // + 16 i
   const int HoWo = p.Ho * p.Wo;
   auto swz_key = [](int row) { return (row & 3) | (((row >> 3) & 1) << 2); };
+  const int cel = ((((lane & 15) >> 1) ^ swz_key(drow0)) * 32 + (lane & 1) * 16) / ES;  // logical channel of this lane
+  const bool ci_ok = ci_base + cel < p.Cin, co_ok = co_base + cel < p.Cout;
+  const unsigned xcb = (unsigned)((ci_base + cel) * ES), ycb = (unsigned)((co_base + cel) * ES);
+  const bool pointwise = (p.ntaps_all == 1) && p.stride == 1 && p.pad == 0;
+  int pixr[4], pn[4], ph[4], pw[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    pixr[i] = r_begin + drow0 + 16 * i;
+    const int pp = pixr[i] < p.M ? pixr[i] : 0;
+    pn[i] = pp / HoWo;
+    const int rr = pp - pn[i] * HoWo;
+    ph[i] = rr / p.Wo;
+    pw[i] = rr - ph[i] * p.Wo;
+  }
+  const int dh = kh * p.dil - p.pad, dw = kw * p.dil - p.pad;
 
-  auto gdma = [&](int r0, int buf) {
+  auto gdma = [&](int buf) {
     char* base = smem + buf * STAGE + wave * 1024;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int row = drow0 + 16 * i;
-      const int pix = r0 + row;
-      // logical channel byte offset of this lane inside the 256-byte row (inverse swizzle on the source)
-      const int chunk = ((lane & 15) >> 1) ^ swz_key(row);
-      const int cbyte = chunk * 32 + (lane & 1) * 16;
-      const int cel = cbyte / ES;
+      const int pix = pixr[i];
       const bool pok = pix < r_end;
-      const int pp = pok ? pix : 0;
-      const int n = pp / HoWo, rr = pp - n * HoWo;
-      const int ho = rr / p.Wo, wo = rr - ho * p.Wo;
-      const int hi = ho * p.stride - p.pad + kh * p.dil, wi = wo * p.stride - p.pad + kw * p.dil;
-      const bool xok = pok && ((unsigned)hi < (unsigned)p.H) && ((unsigned)wi < (unsigned)p.W) && (ci_base + cel < p.Cin);
-      const unsigned xoff = (unsigned)((n * p.H + hi) * p.W + wi) * (unsigned)(p.ldx * ES) + (unsigned)((ci_base + cel) * ES);
+      unsigned xoff;
+      bool xok = pok && ci_ok;
+      if (pointwise) {
+        xoff = (unsigned)pix * (unsigned)(p.ldx * ES) + xcb;
+      } else {
+        const int hi = ph[i] * p.stride + dh, wi = pw[i] * p.stride + dw;
+        xok = xok && ((unsigned)hi < (unsigned)p.H) && ((unsigned)wi < (unsigned)p.W);
+        xoff = (unsigned)((pn[i] * p.H + hi) * p.W + wi) * (unsigned)(p.ldx * ES) + xcb;
+      }
       __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (__attribute__((address_space(3))) void*)(base + i * 4096), 16,
                                                (int)(xok ? xoff : kOOB), 0, 0, 0);
-      const bool yok = pok && (co_base + cel < p.Cout);
-      const unsigned yoff = (unsigned)pp * (unsigned)(p.ldy * ES) + (unsigned)((co_base + cel) * ES);
+      const unsigned yoff = (unsigned)pix * (unsigned)(p.ldy * ES) + ycb;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(yrsrc,
                                                (__attribute__((address_space(3))) void*)(base + BK * 256 + i * 4096), 16,
-                                               (int)(yok ? yoff : kOOB), 0, 0, 0);
+                                               (int)((pok && co_ok) ? yoff : kOOB), 0, 0, 0);
+      // advance this row by one K tile (64 pixels)
+      pixr[i] = pix + BK;
+      if (!pointwise) {
+        int w2 = pw[i] + BK, h2 = ph[i], n2 = pn[i];
+        while (w2 >= p.Wo) { w2 -= p.Wo; ++h2; }
+        while (h2 >= p.Ho) { h2 -= p.Ho; ++n2; }
+        pw[i] = w2; ph[i] = h2; pn[i] = n2;
+      }
     }
   };
 
@@ -170,11 +192,11 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
   };
 
   if (r_begin < r_end) {
-    gdma(r_begin, 0);
+    gdma(0);
     __syncthreads();
     int buf = 0;
     for (int r0 = r_begin; r0 < r_end; r0 += BK) {
-      if (r0 + BK < r_end) gdma(r0 + BK, buf ^ 1);
+      if (r0 + BK < r_end) gdma(buf ^ 1);
       compute(buf);
       __syncthreads();
       buf ^= 1;
