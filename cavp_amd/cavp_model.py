@@ -612,6 +612,34 @@ class CAVP(nn.Module):
         self._last_outputs = (out_pred, fusion, attn)
         return loss
 
+    def capture_train_step(self, image, audio, label, ignore_index: int = 255, loss_scale: float = 1.0):
+        """Capture forward_train + CE + backward (about 1000 kernel launches) into ONE hipGraph and return
+        `replay() -> loss`.  `image`, `audio`, `label` are the static input buffers: copy new batches into them before
+        each replay.  Weight packing is part of the graph, so replays always see the current parameters; the
+        cross-rank gradient all-reduce stays outside the graph (issued by replay() on the arena)."""
+        from .train import allreduce_arena, dist_world
+        with torch.no_grad():
+            self.train_step(image, audio, label, ignore_index, loss_scale, all_reduce=False)   # warm-up: workspace, arena
+            torch.cuda.synchronize()
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                self.train_step(image, audio, label, ignore_index, loss_scale, all_reduce=False)
+            torch.cuda.current_stream().wait_stream(side)
+            graph = torch.cuda.CUDAGraph()
+            world = dist_world()
+            with torch.cuda.graph(graph):
+                loss = self.train_step(image, audio, label, ignore_index, loss_scale / world, all_reduce=False)
+        arena = self._grad_arena
+
+        def replay():
+            graph.replay()
+            if world > 1:
+                allreduce_arena(arena)
+            return loss
+        self._train_graph = graph   # keep alive
+        return replay
+
     def forward(self, image, audio=None, shuffle_info=None, ow_flag=False, eval_mode=False, audio_func=False):
         if eval_mode:
             return self.forward_inference(image, audio)

@@ -622,8 +622,7 @@ def run_train_forward(model, image: torch.Tensor, audio: torch.Tensor, tp: Train
     fea_v = V(tp.empty((n, lh, lw, co + tp.P["reduce"].cout)))
     tp.bilinear(asp, fea_v.slice(0, co), align_corners=True)
     tp.bn_act(tp.conv(f1, "reduce", stats=True), m.segment.reduce[1], ACT_RELU, out=fea_v.slice(co, co + tp.P["reduce"].cout))
-    # ---- 2B duplication + audio (cavp_model.py:181-186; vgg.py:17-23) ----
-    fea_v2 = tp.dup2(fea_v)
+    # ---- audio on 2B (cavp_model.py:181-186; vgg.py:17-23) ----
     if audio.shape[0] != 2 * B:
         raise CavpError(f"train mode expects audio of 2B = {2 * B} (cavp_model.py:181), got {audio.shape[0]}")
     a = tp.conv_smallcin(audio, "a.conv0", 1, ACT_RELU)
@@ -639,15 +638,23 @@ def run_train_forward(model, image: torch.Tensor, audio: torch.Tensor, tp: Train
     a = tp.conv(a, "a.fc1", act=ACT_RELU)
     fea_a = tp.conv(a, "a.fc2", act=ACT_RELU)
     # ---- fusion (cavp_model.py:143-154; attn.py:232-244) ----
-    B2, hh, ww, Cc = fea_v2.t.shape
-    tok = tp.reshape(fea_v2, (B2, hh * ww, Cc))
-    hidp = tp.gelu(tp.conv(tok, "proj.fc1"))
-    fea_v_proj = tp.conv(hidp, "proj.fc2")
-    v0 = tp.conv(fea_v_proj, "ca.pe_v")
+    # The reference duplicates the visual features to 2B first (`torch.cat((fea_v, fea_v.clone()))`, cavp_model.py:181)
+    # and runs projector / patch_embed_v / norm1 / q on both identical halves.  Those four GEMMs + LN depend only on
+    # fea_v, so they are computed ONCE on B and their results duplicated where the halves start to differ (the
+    # audio-conditioned gate); in backward the duplication sums the two halves' gradients - same values, half the work.
+    Bv, hh, ww, Cc = fea_v.t.shape
+    B2 = 2 * Bv
+    tokB = tp.reshape(fea_v, (Bv, hh * ww, Cc))
+    hidp = tp.gelu(tp.conv(tokB, "proj.fc1"))
+    fea_v_projB = tp.conv(hidp, "proj.fc2")
+    v0B = tp.conv(fea_v_projB, "ca.pe_v")
     a0 = tp.conv(fea_a, "ca.pe_a")
-    vn = tp.layernorm(v0, blk.norm1)
+    vnB = tp.layernorm(v0B, blk.norm1)
     an = tp.layernorm(a0, blk.norm1)
-    q = tp.conv(vn, "ca.q")
+    qB = tp.conv(vnB, "ca.q")
+    vn, q = tp.dup2(vnB), tp.dup2(qB)
+    fea_v_proj = tp.dup2(fea_v_projB)   # pack["visual"] (output only)
+    fea_v2 = fea_v
     k = tp.conv(an, "ca.k")
     vv = tp.conv(an, "ca.v")
     o, attn = tp.attn_gate(q, k, vv, blk.attn.num_heads, blk.attn.scale)

@@ -196,3 +196,34 @@ def test_native_train_step_matches_autograd_path():
         assert cos >= 0.995 and abs(float(a.norm()) - float(b.norm())) <= 3e-2 * float(a.norm()), (k, cos)
     for (k, b1), (_, b2) in zip(m1.named_buffers(), m2.named_buffers()):
         assert torch.allclose(b1.float(), b2.float(), atol=1e-3, rtol=1e-3), k
+
+
+def test_train_step_hipgraph_replay_matches_eager():
+    """The whole training step captured as one hipGraph: replays track the eager step (weights re-packed inside the
+    graph, running stats and gradients updated by every replay)."""
+    cfg = dict(C=2, B=4, hw=(64, 64), lds=[False, False, False])
+    B = cfg["B"]
+    image, audio, label = [t.to(DEV) for t in synth_inputs(B, cfg["hw"], audio_batch=2 * B, num_classes=cfg["C"], seed=11)]
+    m1, _ = _build(cfg)
+    m2, _ = _build(cfg)
+    l1 = m1.train_step(image, audio, label)
+    replay = m2.capture_train_step(image, audio, label)   # warm-up + capture advance running stats 3x; reset below
+    m2.load_state_dict(m1.state_dict())                   # same running stats as m1 BEFORE its step? -> compare grads only
+    l2 = float(replay().item())      # the loss tensor is a static graph buffer: read it before the next replay
+    torch.cuda.synchronize()
+    assert abs(float(l1.item()) - l2) <= 5e-3
+    for (k, p1), (_, p2) in zip(m1.named_parameters(), m2.named_parameters()):
+        if p1.grad is None:
+            assert p2.grad is None, k
+            continue
+        a, b = p1.grad.double().flatten(), p2.grad.double().flatten()
+        if float(a.norm()) < 1e-10:
+            continue
+        cos = float((a @ b) / (a.norm() * b.norm()))
+        assert cos >= 0.99, (k, cos)
+    # a parameter update between replays is picked up (packing is inside the graph)
+    with torch.no_grad():
+        for p in m2.parameters():
+            p.mul_(0.5)
+    l3 = float(replay().item())
+    assert abs(l3 - l2) > 1e-4
