@@ -1,0 +1,158 @@
+"""MI355X path of the reference's live contrastive loss, `loss/contrastive_aud.py::ContrastLoss` (SURVEY.md §8a row a13,
+config #5).  Same constructor and `forward(embeds_match, gt_match, embeds_shuffle, gt_shuffle)`.
+
+Split of work:
+  host   - nearest-downsampling of the label maps and the class-balanced sampling (contrastive_aud.py:18-22,76-141):
+           pure index bookkeeping on the (small) label tensors, done on the CPU with the SAME sequence of
+           `torch.randperm` calls on the default CPU generator as the reference, so the sampled anchors are identical
+           for an identical RNG state;
+  device - L2-normalise + gather of the N anchors, S = A A^T / T on the f32 MFMA igemm, the row-wise InfoNCE, and the
+           whole backward (dS, (dS + dS^T) A via the wgrad GEMM, normalisation backward, scatter into the feature
+           gradient) - libcavp_hip.so only, no torch arithmetic.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional, Tuple
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import _lib, ops
+from . import train_ops as T
+from .ops import _ptr, _stream
+
+
+def nearest_indices(n_in: int, n_out: int) -> np.ndarray:
+    """F.interpolate(mode='nearest') source index: min(floor(dst * float32(in / out)), in - 1)."""
+    scale = np.float32(n_in) / np.float32(n_out)
+    return np.minimum(np.floor(np.arange(n_out, dtype=np.float32) * scale).astype(np.int64), n_in - 1)
+
+
+def downsample_labels(gt: torch.Tensor, size: Tuple[int, int]) -> np.ndarray:
+    """[B, H, W] int labels -> [B, h*w] (nearest), on the host."""
+    g = gt.detach().cpu().numpy()
+    hi, wi = nearest_indices(g.shape[1], size[0]), nearest_indices(g.shape[2], size[1])
+    return g[:, hi][:, :, wi].reshape(g.shape[0], -1)
+
+
+class SamplePlan:
+    """Anchors chosen by `extraction_samples`: first `n_match` rows come from embeds_match, the rest from embeds_shuffle."""
+    __slots__ = ("b", "p", "labels", "n_match", "n")
+
+    def __init__(self, b, p, labels, n_match):
+        self.b, self.p, self.labels, self.n_match, self.n = b, p, labels, n_match, len(b)
+
+
+def sample_anchors(gt_match: np.ndarray, gt_shuffle: np.ndarray, ignore_idx: int, max_views: int) -> Optional[SamplePlan]:
+    """contrastive_aud.py:76-141 on [B, hw] label arrays; consumes torch.randperm exactly like the reference."""
+    B, HW = gt_match.shape
+    bb, pp = np.divmod(np.arange(B * HW), HW)
+    gm = gt_match.reshape(-1)
+    fg = (gm > 0) & (gm != ignore_idx)
+    fg_b, fg_p, fg_l = bb[fg], pp[fg], gm[fg]
+    sel_b: List[np.ndarray] = []
+    sel_p: List[np.ndarray] = []
+    sel_l: List[np.ndarray] = []
+    for item in np.unique(fg_l):                       # torch.unique: sorted ascending
+        cur = np.nonzero(fg_l == item)[0]
+        if cur.shape[0] < max_views:
+            continue
+        r = torch.randperm(cur.shape[0]).numpy()[:max_views]
+        sel_b.append(fg_b[cur][r]); sel_p.append(fg_p[cur][r]); sel_l.append(fg_l[cur][r])
+    if not sel_b:
+        return None
+    bg = gm == 0
+    bg_b, bg_p = bb[bg], pp[bg]
+    sh_l = gt_shuffle.reshape(-1)[fg]                   # shuffle-branch candidates live at the MATCH foreground pixels
+    sample_num = int(min(max_views, fg_b.shape[0], bg_b.shape[0]))
+    i1 = torch.randperm(bg_b.shape[0]).numpy()[:sample_num]
+    i2 = torch.randperm(fg_b.shape[0]).numpy()[:sample_num]
+    b = np.concatenate(sel_b + [bg_b[i1], fg_b[i2]])
+    p = np.concatenate(sel_p + [bg_p[i1], fg_p[i2]])
+    lab = np.concatenate(sel_l + [np.zeros(sample_num, dtype=gm.dtype), sh_l[i2]])
+    return SamplePlan(b.astype(np.int32), p.astype(np.int32), lab.astype(np.int32), len(b) - sample_num)
+
+
+def _strides_bcp(x: torch.Tensor) -> Tuple[int, int, int]:
+    """element strides (batch, channel, pixel) of a [B, C, H, W] tensor whose (H, W) plane is a uniform pixel grid."""
+    sb, sc, sh, sw = x.stride()
+    if x.shape[3] > 1 and x.shape[2] > 1 and sh != sw * x.shape[3]:
+        raise _lib.CavpError("feature map must have a uniform pixel stride (NCHW-contiguous or channels-last)")
+    return sb, sc, sw
+
+
+class _InfoNCEFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, em, es, plan: SamplePlan, temperature: float, eps: float):
+        lib = _lib.load()
+        dev = em.device
+        st = C.c_void_p(_stream())
+        Cc = em.shape[1]
+        n, npad = plan.n, (plan.n + 3) // 4 * 4
+        ib = torch.from_numpy(plan.b).to(dev)
+        ip = torch.from_numpy(plan.p).to(dev)
+        lab = torch.from_numpy(plan.labels).to(dev)
+        A = torch.zeros((npad, Cc), dtype=torch.float32, device=dev)
+        norms = torch.empty(npad, dtype=torch.float32, device=dev)
+        for x, lo, hi in ((em, 0, plan.n_match), (es, plan.n_match, n)):
+            if hi > lo:
+                sb, sc, sp = _strides_bcp(x)
+                _lib.check(lib.cavp_gather_l2norm(_ptr(x), sb, sc, sp, _ptr(ib[lo:]), _ptr(ip[lo:]), hi - lo, Cc,
+                                                  C.c_float(1e-12), _ptr(A[lo:]), _ptr(norms[lo:]), st), "cavp_gather_l2norm")
+        S = torch.empty((npad, npad), dtype=torch.float32, device=dev)
+        inv_t = torch.full((npad,), 1.0 / temperature, dtype=torch.float32, device=dev)
+        ops.linear(A, A.view(npad, 1, 1, Cc), S, scale=inv_t)          # S = A A^T / T on the f32 MFMA path
+        rows = torch.empty(npad, dtype=torch.float32, device=dev)
+        loss = torch.empty(1, dtype=torch.float32, device=dev)
+        need_grad = em.requires_grad or es.requires_grad
+        dS = torch.empty_like(S) if need_grad else None
+        _lib.check(lib.cavp_infonce_rows(_ptr(S), _ptr(lab), n, npad, C.c_float(eps), _ptr(rows), _ptr(loss), _ptr(dS),
+                                         C.c_float(1.0), st), "cavp_infonce_rows")
+        ctx.saved = (A, norms, dS, ib, ip, plan, em, es, temperature)
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, gout):
+        lib = _lib.load()
+        A, norms, dS, ib, ip, plan, em, es, temperature = ctx.saved
+        st = C.c_void_p(_stream())
+        npad, Cc = A.shape
+        n = plan.n
+        G = torch.empty_like(dS)
+        # dL/dA = (dS + dS^T) A / T  (anchors and contrasts are the same tensor), scaled by the incoming gradient
+        _lib.check(lib.cavp_symm_add(_ptr(dS), _ptr(G), npad, C.c_float(float(gout) / temperature), st), "cavp_symm_add")
+        dA = torch.zeros((npad, Cc), dtype=torch.float32, device=A.device)
+        T.linear_wgrad(A, G, dA)
+        grads = []
+        for x, lo, hi in ((em, 0, plan.n_match), (es, plan.n_match, n)):
+            b, c, h, w = x.shape
+            g = torch.zeros((b, h, w, c), dtype=torch.float32, device=x.device)   # NHWC memory, returned as an NCHW view
+            if hi > lo:
+                _lib.check(lib.cavp_l2norm_bwd_scatter(_ptr(dA[lo:]), _ptr(A[lo:]), _ptr(norms[lo:]), _ptr(ib[lo:]), _ptr(ip[lo:]),
+                                                       hi - lo, Cc, _ptr(g), h * w * c, 1, c, st), "cavp_l2norm_bwd_scatter")
+            grads.append(g.permute(0, 3, 1, 2))
+        return grads[0], grads[1], None, None, None
+
+
+class ContrastLoss(nn.Module):
+    def __init__(self, temperature, ignore_idx, max_views):
+        super().__init__()
+        self.ignore_idx = ignore_idx
+        self.ood_idx = 254
+        self.eps = 1e-12
+        self.temperature = temperature
+        self.max_views = max_views
+
+    def forward(self, embeds_match, gt_match, embeds_shuffle, gt_shuffle):
+        if not embeds_match.is_cuda:
+            raise _lib.CavpError("ContrastLoss (MI355X path) needs HIP device tensors: there is no CPU fallback")
+        if embeds_match.dtype != torch.float32 or embeds_shuffle.dtype != torch.float32:
+            raise _lib.CavpError("ContrastLoss expects the f32 out_fusion features")
+        size = tuple(embeds_match.shape[2:])
+        plan = sample_anchors(downsample_labels(gt_match, size), downsample_labels(gt_shuffle, size), self.ignore_idx,
+                              self.max_views)
+        if plan is None:
+            return torch.tensor([0.0], device=gt_match.device)          # contrastive_aud.py:35-36
+        return _InfoNCEFn.apply(embeds_match, embeds_shuffle, plan, float(self.temperature), float(self.eps))

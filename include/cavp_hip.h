@@ -212,6 +212,22 @@ int cavp_ce_loss_nchw(const float* logits, const int64_t* labels, int32_t n_img,
                       int32_t ignore_index, float grad_scale, float* loss, float* dlogits, float* scratch2,
                       void* stream);
 
+/* ---- pixel-level audio-visual InfoNCE (loss/contrastive_aud.py::ContrastLoss, config #5 / SURVEY.md §8a row a13) ----
+ * The class-balanced sampling (torch.randperm on the CPU generator, contrastive_aud.py:76-141) stays on the host; these
+ * are the device stages for the N sampled anchors.  S = A A^T / T and dA = G A run on cavp_conv2d_nhwc / _wgrad. */
+/* A[i] = x[b_i, :, p_i] / max(||.||, eps); x addressed by element strides (works for NCHW memory and for the NHWC
+ * memory behind out_fusion); also saves the norms (F.normalize, contrastive_aud.py:25-26 + gathers :97-139). */
+int cavp_gather_l2norm(const float* x, int64_t stride_b, int64_t stride_c, int64_t stride_p, const int32_t* idx_b,
+                       const int32_t* idx_p, int32_t N, int32_t C, float eps, float* A, float* norms, void* stream);
+/* info_nce (contrastive_aud.py:41-74) on S[ld][ld] (already / temperature): row_mlpp[i], loss[0] = -mean(row_mlpp);
+ * optional dS = grad_scale * dloss/dS (zero in the padding rows / columns >= N). */
+int cavp_infonce_rows(const float* S, const int32_t* labels, int32_t N, int32_t ld, float eps, float* row_mlpp,
+                      float* loss, float* dS, float grad_scale, void* stream);
+int cavp_symm_add(const float* d, float* g, int32_t n, float scale, void* stream); /* g = (d + d^T) * scale */
+int cavp_l2norm_bwd_scatter(const float* dA, const float* A, const float* norms, const int32_t* idx_b,
+                            const int32_t* idx_p, int32_t N, int32_t C, float* dx, int64_t stride_b, int64_t stride_c,
+                            int64_t stride_p, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -142,6 +142,41 @@ def run_case(name, cfg, out_dir):
           + " ".join(f"{k}:{taps[k].std().item():.2f}" for k in ("layer1", "layer2", "layer3", "layer4", "aspp")))
 
 
+def contrast_inputs(seed=7, B=2, C=304, hw=(56, 56), full=(224, 224), num_classes=4):
+    """Synthetic ContrastLoss inputs: blocky label maps so that several classes keep >= max_views pixels at 56x56."""
+    g = torch.Generator().manual_seed(seed)
+    em = torch.randn((B, C) + hw, generator=g)
+    es = em * 0.5 + torch.randn((B, C) + hw, generator=g)
+    gt = torch.zeros((B,) + full, dtype=torch.long)
+    for b in range(B):
+        for k in range(1, num_classes):
+            h0 = int(torch.randint(0, full[0] - 100, (1,), generator=g)); w0 = int(torch.randint(0, full[1] - 120, (1,), generator=g))
+            gt[b, h0:h0 + 60 + 20 * k, w0:w0 + 120] = k
+        gt[b, :8, :] = 255
+    gs = gt.clone()
+    gs[1:] = 0                       # image >= 1: shuffled audio does not match -> background (trainer :176-179)
+    return em, gt, es, gs
+
+
+def run_contrast(out_dir):
+    from loss.contrastive_aud import ContrastLoss
+    em, gt, es, gs = contrast_inputs()
+    em.requires_grad_(True); es.requires_grad_(True)
+    crit = ContrastLoss(temperature=0.1, ignore_idx=255, max_views=512)
+    torch.manual_seed(1234)
+    loss = crit(em, gt, es, gs)
+    loss.backward()
+    store = {"loss": np.array([loss.item()], dtype=np.float64)}
+    for k, t in (("d_match", em.grad), ("d_shuffle", es.grad)):
+        s_, c_ = sample(t)
+        store["sample/" + k], store["cksum/" + k] = s_, c_
+        nz = t.abs().sum(1).flatten().nonzero().flatten()
+        store["nnz_pixels/" + k] = np.array([nz.numel()], dtype=np.int64)
+    path = os.path.join(out_dir, "contrast.npz")
+    np.savez_compressed(path, **store)
+    print(f"contrast: wrote {path}; loss={loss.item():.6f}; |d_match|={em.grad.norm().item():.4e} |d_shuffle|={es.grad.norm().item():.4e}")
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(REPO, "tests", "golden"))
@@ -153,3 +188,5 @@ if __name__ == "__main__":
         if a.only and name != a.only:
             continue
         run_case(name, cfg, a.out)
+    if not a.only or a.only == "contrast":
+        run_contrast(a.out)
