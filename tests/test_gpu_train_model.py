@@ -227,3 +227,48 @@ def test_train_step_hipgraph_replay_matches_eager():
             p.mul_(0.5)
     l3 = float(replay().item())
     assert abs(l3 - l2) > 1e-4
+
+
+def test_ce_plus_contrast_through_autograd_path():
+    """The reference trainer's loss (trainer_cavp_vpo_mono.py:183-189): CE on `out[:B] + out[B:]*0` PLUS ContrastLoss on
+    out_fusion halves - gradients enter the HIP backward through BOTH out_pred and out_fusion.  Checked against the
+    CPU oracle's autograd over the same graph (same RNG state for the anchor sampling)."""
+    from cavp_amd.contrast import ContrastLoss
+    from oracle import cavp_oracle as O
+    from oracle.contrast_oracle import contrast_loss
+    cfg = dict(C=3, B=4, hw=(64, 64), lds=[False, False, False])
+    B = cfg["B"]
+    m, sd = _build(cfg)
+    image, audio, label = synth_inputs(B, cfg["hw"], audio_batch=2 * B, num_classes=cfg["C"], seed=21)
+    label[:, 8:40, 8:48] = 1
+    label[:, 44:60, 4:60] = 2
+    label[:, :4] = 255
+    shuf = label.clone()
+    shuf[2:] = 0
+    crit = ContrastLoss(temperature=0.1, ignore_idx=255, max_views=32)
+    out, fus, _ = m(image.to(DEV), audio.to(DEV), None, False)
+    torch.manual_seed(77)
+    l_ctr = crit(fus[:B], label.to(DEV), fus[B:], shuf.to(DEV))
+    l_ce = F.cross_entropy(out[:B] + out[B:] * 0.0, label.to(DEV), ignore_index=255)
+    (l_ce + l_ctr).backward()
+    torch.cuda.synchronize()
+    params = {k: v.clone().requires_grad_(True) for k, v in sd.items() if v.is_floating_point() and "running_" not in k}
+    sd2 = dict(sd)
+    sd2.update(params)
+    ro, rf, _ = O.cavp_forward(sd2, image, audio, cfg["lds"], eval_mode=False)
+    torch.manual_seed(77)
+    r_ctr = contrast_loss(rf[:B], label, rf[B:], shuf, 0.1, 255, 32)
+    r_ce = O.ce_loss_train(ro, label, B)
+    (r_ce + r_ctr).backward()
+    assert abs(float(l_ctr.item()) - float(r_ctr.item())) <= 1e-3 * max(1.0, abs(float(r_ctr.item())))
+    assert abs(float(l_ce.item()) - float(r_ce.item())) <= 1e-4 * max(1.0, abs(float(r_ce.item())))
+    mine = dict(m.named_parameters())
+    coss = []
+    for k, p in params.items():
+        if p.grad is None or float(p.grad.norm()) < 1e-9:
+            continue
+        a, b = mine[k].grad.double().cpu().flatten(), p.grad.double().flatten()
+        coss.append(float((a @ b) / (a.norm() * b.norm() + 1e-30)))
+    coss = np.array(coss)
+    print(f"CE+contrast: l_ctr {float(l_ctr.item()):.5f} (oracle {float(r_ctr.item()):.5f}); grad cosine min {coss.min():.5f} median {np.median(coss):.6f}")
+    assert np.median(coss) >= 0.9995 and coss.min() >= 0.99
