@@ -26,7 +26,7 @@ class ConvDesc(C.Structure):
     """struct cavp_conv_desc (include/cavp_hip.h)."""
     _fields_ = [(n, C.c_int32) for n in (
         "dtype", "N", "H", "W", "Cin", "ldx", "Cout", "ldy", "KH", "KW", "stride", "pad", "dil", "ldr", "act",
-        "splitk", "tile", "up", "Ho", "Wo")]
+        "splitk", "tile", "up", "Ho", "Wo", "stride_w")]
 
 
 _vp, _i32, _i64, _f32, _sz = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_size_t
@@ -77,6 +77,11 @@ PROTOTYPES = {
     "cavp_infonce_rows": (_i32, [_vp, _vp, _i32, _i32, _f32, _vp, _vp, _vp, _f32, _vp]),
     "cavp_symm_add": (_i32, [_vp, _vp, _i32, _f32, _vp]),
     "cavp_l2norm_bwd_scatter": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _i64, _i64, _i64, _vp]),
+    # ---- PVTv2 ----
+    "cavp_sra_attention": (_i32, [_i32, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _vp]),
+    "cavp_dwconv3x3_nhwc": (_i32, [_i32, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "cavp_pack_dwconv_weight": (_i32, [_vp, _vp, _i32, _vp]),
+    "cavp_conv_smallcin_kxk_nchw": (_i32, [_i32, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
 }
 
 _lib = None

@@ -279,22 +279,36 @@ class CAVP(nn.Module):
                  visual_backbone=50, args=None, in_plane=1):
         super().__init__()
         seg_model = args.seg_model
-        if seg_model != "DeepLabV3Plus":
-            if seg_model in ("HRNet", "OCR", "PVT"):
-                raise NotImplementedError(f"seg_model={seg_model!r}: only the ResNet-50 DeepLabV3Plus path is built "
-                                          f"on MI355X so far (SURVEY.md §8f)")
-            raise ValueError("UNKNOW BACKBONE")  # cavp_model.py:117
-        self.latent_dim = 304
+        self.seg_model = seg_model
         self.num_classes = num_classes
-        self.backbone = Backbone(backbone, args.last_three_dilation_stride)
-        self.segment = DeepLabV3Plus(num_classes=num_classes, aspp_in_plane=2048, aspp_out_plane=256)
+        if seg_model == "DeepLabV3Plus":
+            self.latent_dim = 304
+            self.backbone = Backbone(backbone, args.last_three_dilation_stride)
+            self.segment = DeepLabV3Plus(num_classes=num_classes, aspp_in_plane=2048, aspp_out_plane=256)
+        elif seg_model == "PVT":   # cavp_model.py:106-115
+            from .pvt import pvt_v2_b5
+            self.latent_dim = 112
+            self.backbone = pvt_v2_b5()
+            ckpt_path = "../ckpts/pretrained/pvt_v2_b5.pth"   # the reference torch.load()s this path unconditionally
+            import os
+            if os.path.exists(ckpt_path):
+                ckpt = torch.load(ckpt_path, map_location="cpu")
+                ckpt.pop("head.weight", None)
+                ckpt.pop("head.bias", None)
+                self.backbone.load_state_dict(ckpt)
+            self.segment = DeepLabV3Plus(num_classes=num_classes, aspp_in_plane=512, aspp_out_plane=64)
+        elif seg_model in ("HRNet", "OCR"):
+            raise NotImplementedError(f"seg_model={seg_model!r}: alternate backbones outside the north-star scope "
+                                      f"(SURVEY.md §2.1 row 17)")
+        else:
+            raise ValueError("UNKNOW BACKBONE")  # cavp_model.py:117
         self.cross_att = CROSS_ATTENTION(embed_dim=self.latent_dim, depth=1, dim_in=self.latent_dim)
         self.visual_projector = Mlp(self.latent_dim, 256, self.latent_dim, drop=0.0)
         self.audio_backbone = AudioModel(args.audio_backbone, audio_backbone_pretrain_path, self.latent_dim,
                                          in_plane=in_plane)
         self.memory = SoundBank(out_dim=self.latent_dim, args=args, device=args.local_rank)
         self.local_rank = args.local_rank
-        if pretrain_path is not None:
+        if pretrain_path is not None and seg_model == "DeepLabV3Plus":
             self._load_backbone(pretrain_path)
         # compute configuration of the HIP path
         self.compute_dtype = torch.float32   # torch.bfloat16 = bf16 storage / f32 accumulate
@@ -344,6 +358,10 @@ class CAVP(nn.Module):
 
     def _pack(self) -> Dict[str, _ConvP]:
         P: Dict[str, _ConvP] = {}
+        if self.seg_model == "PVT":
+            from .pvt import pack_pvt
+            P["pvt"] = pack_pvt(self.backbone, self.compute_dtype)
+            return self._pack_rest(P)
         rn = self.backbone.backbone
         P["stem0"] = self._pack_conv(rn.conv1[0], rn.conv1[1], raw=True)
         P["stem1"] = self._pack_conv(rn.conv1[3], rn.conv1[4])
@@ -356,6 +374,9 @@ class CAVP(nn.Module):
                 P[key + ".c3"] = self._pack_conv(blk.conv3, blk.bn3)
                 if blk.downsample is not None:
                     P[key + ".ds"] = self._pack_conv(blk.downsample[0], blk.downsample[1])
+        return self._pack_rest(P)
+
+    def _pack_rest(self, P):
         aspp = self.segment.aspp
         ms, mh = self._fold(aspp.map_bn)
         hid = aspp.map_convs[0].out_channels
@@ -535,7 +556,11 @@ class CAVP(nn.Module):
         P = self.packed()
         input_shape = tuple(image.shape[-2:])
         B = image.shape[0]
-        feats = self._backbone_hip(image, P)
+        if self.seg_model == "PVT":
+            from .pvt import pvt_forward_hip
+            feats = pvt_forward_hip(self.backbone, image, P["pvt"], self.compute_dtype)
+        else:
+            feats = self._backbone_hip(image, P)
         fea_v, aspp = self._forward_feature_hip(feats, P)
         if duplicate_visual:  # forward_train: torch.cat((fea_v, fea_v.clone())) (cavp_model.py:181)
             fea_v = fea_v.repeat(2, 1, 1, 1)
@@ -568,6 +593,8 @@ class CAVP(nn.Module):
         want_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
         if not bn_train and not want_grad:
             return self._forward_hip(image, audio, duplicate_visual=True)   # frozen-BN, forward only
+        if self.seg_model != "DeepLabV3Plus":
+            raise NotImplementedError("the training pass is built for the ResNet-50 path; PVTv2 runs forward-only so far")
         if not bn_train:
             raise NotImplementedError("backward with BatchNorm in eval mode (frozen statistics) is not built; the "
                                       "reference trains with model.train() (trainer_cavp_vpo_mono.py:120)")

@@ -27,7 +27,7 @@ struct IgemmParams {
   const float* nbias;
   const void* res;
   float* partial;
-  int N, H, W, Cin, ldx, Cout, ldy, KW, stride, pad, dil, ldr, act;
+  int N, H, W, Cin, ldx, Cout, ldy, KW, stride, stride_w, pad, dil, ldr, act;
   int Ho, Wo, M, K;
   int ntaps;
   unsigned long long taps;  // 4 bits per live tap id (kh*KW + kw)
@@ -183,7 +183,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p) {
     const int pp = ok ? pix : 0;
     const int n = pp / HoWo, r = pp - n * HoWo;
     const int ho = r / p.Wo, wo = r - ho * p.Wo;
-    const int h0 = ho * p.stride - p.pad, w0 = wo * p.stride - p.pad;
+    const int h0 = ho * p.stride - p.pad, w0 = wo * p.stride_w - p.pad;
     if constexpr (UP) {
       x_nb[i] = n * p.H * p.W;
       x_h0[i] = ok ? h0 : -0x10000000;
@@ -495,13 +495,14 @@ Plan make_plan(const cavp_conv_desc* d) {
   IgemmParams& p = pl.p;
   p.N = d->N; p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.ldx = d->ldx; p.Cout = d->Cout; p.ldy = d->ldy;
   p.KW = d->KW; p.stride = d->stride; p.pad = d->pad; p.dil = d->dil; p.ldr = d->ldr; p.act = d->act;
+  p.stride_w = d->stride_w > 0 ? d->stride_w : d->stride;
   const int up = d->up > 1 ? d->up : 1;
   if (up > 1) {  // transposed conv: stride-1 gather over the zero-upsampled input, explicit output extent
     if ((up & (up - 1)) || d->stride != 1 || d->Ho <= 0 || d->Wo <= 0) { pl.status = CAVP_ERR_UNSUPPORTED; return pl; }
     p.Ho = d->Ho; p.Wo = d->Wo;
   } else {
     p.Ho = (d->H + 2 * d->pad - d->dil * (d->KH - 1) - 1) / d->stride + 1;
-    p.Wo = (d->W + 2 * d->pad - d->dil * (d->KW - 1) - 1) / d->stride + 1;
+    p.Wo = (d->W + 2 * d->pad - d->dil * (d->KW - 1) - 1) / (d->stride_w > 0 ? d->stride_w : d->stride) + 1;
   }
   p.up_mask = up - 1;
   p.up_shift = 0;
@@ -523,7 +524,7 @@ Plan make_plan(const cavp_conv_desc* d) {
     for (int kw = 0; kw < d->KW; ++kw) {
       bool wlive = false;
       for (int wo = 0; wo < p.Wo && !wlive; ++wo) {
-        const int wi = wo * d->stride - d->pad + kw * d->dil;
+        const int wi = wo * (d->stride_w > 0 ? d->stride_w : d->stride) - d->pad + kw * d->dil;
         wlive = wi >= 0 && (wi % up) == 0 && wi / up < d->W;
       }
       if (hlive && wlive) {

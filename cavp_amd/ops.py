@@ -83,7 +83,7 @@ def workspace(nbytes: int, device) -> Optional[torch.Tensor]:
 def conv2d(x: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, kh: int = 1, kw: int = 1, stride: int = 1,
            pad: int = 0, dil: int = 1, scale: Optional[torch.Tensor] = None, shift: Optional[torch.Tensor] = None,
            nbias: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None, act: int = ACT_NONE,
-           splitk: int = 0, tile: int = 0, want_tile_stats: bool = False):
+           splitk: int = 0, tile: int = 0, want_tile_stats: bool = False, stride_w: int = 0):
     """out = act((conv(x, w) + nbias[n]) * scale + shift + residual); x/out/residual NHWC views, w OHWI packed.
     want_tile_stats=True (plain convs only) returns (out, stats) where stats is None when this launch cannot produce the
     fused BatchNorm statistics, else (tile_stats f32 [tiles][Cout][2], tiles, rows_per_tile)."""
@@ -97,7 +97,7 @@ def conv2d(x: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, kh: int = 1, 
     if w.numel() != cout * kh * kw * cin or not w.is_contiguous():
         raise _lib.CavpError(f"conv2d: packed weight has {w.numel()} elements, expected {cout}x{kh}x{kw}x{cin}")
     eho = (h + 2 * pad - dil * (kh - 1) - 1) // stride + 1
-    ewo = (wd + 2 * pad - dil * (kw - 1) - 1) // stride + 1
+    ewo = (wd + 2 * pad - dil * (kw - 1) - 1) // (stride_w or stride) + 1
     if (no, ho, wo) != (n, eho, ewo):
         raise _lib.CavpError(f"conv2d: out view is {(no, ho, wo)}, expected {(n, eho, ewo)}")
     ldr = 0
@@ -111,7 +111,7 @@ def conv2d(x: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, kh: int = 1, 
     if nbias is not None and (nbias.dtype != torch.float32 or nbias.numel() != n * cout or not nbias.is_contiguous()):
         raise _lib.CavpError(f"conv2d: nbias must be a contiguous f32 [{n},{cout}]")
     d = ConvDesc(dtype=dt, N=n, H=h, W=wd, Cin=cin, ldx=ldx, Cout=cout, ldy=ldy, KH=kh, KW=kw, stride=stride, pad=pad,
-                 dil=dil, ldr=ldr, act=act, splitk=splitk, tile=tile)
+                 dil=dil, ldr=ldr, act=act, splitk=splitk, tile=tile, up=0, Ho=0, Wo=0, stride_w=stride_w)
     nbytes = lib.cavp_conv2d_workspace_bytes(C.byref(d))
     ws = workspace(nbytes, x.device)
     stats = None
@@ -281,3 +281,47 @@ def cast(src: torch.Tensor, dst: torch.Tensor) -> torch.Tensor:
                                C.c_void_p(_stream()))
     _lib.check(st, "cavp_cast")
     return dst
+
+
+# ---- PVTv2 -------------------------------------------------------------------------------------------------------
+def sra_attention(q: torch.Tensor, kv: torch.Tensor, out: torch.Tensor, heads: int, scale: float) -> torch.Tensor:
+    """q, out: [B, Nq, heads*64]; kv: [B, Nk, 2*heads*64] (k | v); softmax attention per head (pvt.py:102-130)."""
+    _need_gpu(q, kv, out)
+    b, nq, c = q.shape
+    nk = kv.shape[1]
+    if not (q.is_contiguous() and kv.is_contiguous() and out.is_contiguous()) or kv.shape[2] != 2 * c or out.shape != q.shape:
+        raise _lib.CavpError("sra_attention: contiguous [B,Nq,C] / [B,Nk,2C] tensors required")
+    st = _lib.load().cavp_sra_attention(dtype_code(q.dtype), _ptr(q), _ptr(kv), _ptr(out), b, nq, nk, heads, c // heads,
+                                        C.c_float(scale), C.c_void_p(_stream()))
+    _lib.check(st, f"cavp_sra_attention B{b} Nq{nq} Nk{nk} heads{heads}")
+    return out
+
+
+def pack_dwconv_weight(w: torch.Tensor) -> torch.Tensor:
+    wd = w.detach().contiguous()
+    c = wd.shape[0]
+    out = torch.empty((9, c), dtype=torch.float32, device=w.device)
+    _lib.check(_lib.load().cavp_pack_dwconv_weight(_ptr(wd), _ptr(out), c, C.c_void_p(_stream())), "cavp_pack_dwconv_weight")
+    return out
+
+
+def dwconv3x3(x: torch.Tensor, w9c: torch.Tensor, bias: Optional[torch.Tensor], out: torch.Tensor, act: int = ACT_NONE):
+    _need_gpu(x, w9c, bias, out)
+    n, h, w, c, ld = _nhwc(x)
+    if ld != c or not out.is_contiguous() or out.shape != x.shape:
+        raise _lib.CavpError("dwconv3x3: dense NHWC tensors required")
+    st = _lib.load().cavp_dwconv3x3_nhwc(dtype_code(x.dtype), _ptr(x), _ptr(w9c), _ptr(bias), _ptr(out), n, h, w, c, act,
+                                         C.c_void_p(_stream()))
+    _lib.check(st, "cavp_dwconv3x3_nhwc")
+    return out
+
+
+def conv_smallcin_kxk(x_nchw: torch.Tensor, w_oihw: torch.Tensor, bias, out: torch.Tensor, ks: int, stride: int, pad: int):
+    _need_gpu(x_nchw, w_oihw, bias, out)
+    n, cin, h, w = x_nchw.shape
+    cout = w_oihw.shape[0]
+    st = _lib.load().cavp_conv_smallcin_kxk_nchw(dtype_code(out.dtype), _ptr(x_nchw.contiguous()), _ptr(w_oihw.contiguous()),
+                                                 _ptr(bias), _ptr(out), n, cin, h, w, cout, ks, stride, pad,
+                                                 C.c_void_p(_stream()))
+    _lib.check(st, "cavp_conv_smallcin_kxk_nchw")
+    return out

@@ -63,7 +63,7 @@ def conv2d_dgrad(dy: torch.Tensor, w_t: torch.Tensor, dx: torch.Tensor, *, kh: i
     if padt < 0:
         raise _lib.CavpError("conv2d_dgrad: pad > dil*(k-1) is not supported")
     d = ConvDesc(dtype=dtype_code(dy.dtype), N=n, H=ho, W=wo, Cin=cof, ldx=ldx, Cout=cif, ldy=ldy, KH=kh, KW=kw,
-                 stride=1, pad=padt, dil=dil, ldr=ldr, act=act, splitk=0, tile=0, up=stride, Ho=h, Wo=w)
+                 stride=1, pad=padt, dil=dil, ldr=ldr, act=act, splitk=0, tile=0, up=stride, Ho=h, Wo=w, stride_w=0)
     if stride == 1:
         eh, ew = ho + 2 * padt - dil * (kh - 1), wo + 2 * padt - dil * (kw - 1)
         if (eh, ew) != (h, w):
@@ -90,7 +90,7 @@ def conv2d_wgrad(x: torch.Tensor, dy: torch.Tensor, dw_ohwi: torch.Tensor, *, kh
     if (ho, wo) != (eho, ewo):
         raise _lib.CavpError("conv2d_wgrad: dy extent does not match the forward conv")
     d = ConvDesc(dtype=dtype_code(x.dtype), N=n, H=h, W=w, Cin=cin, ldx=ldx, Cout=cout, ldy=ldy, KH=kh, KW=kw,
-                 stride=stride, pad=pad, dil=dil, ldr=0, act=0, splitk=splitk, tile=0, up=0, Ho=0, Wo=0)
+                 stride=stride, pad=pad, dil=dil, ldr=0, act=0, splitk=splitk, tile=0, up=0, Ho=0, Wo=0, stride_w=0)
     lib = _lib.load()
     ws = ops.workspace(lib.cavp_conv2d_wgrad_workspace_bytes(C.byref(d)), x.device)
     _check(lib.cavp_conv2d_wgrad_nhwc(C.byref(d), _ptr(x), _ptr(dy), _ptr(dw_ohwi), _ptr(ws),

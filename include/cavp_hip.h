@@ -71,6 +71,8 @@ typedef struct cavp_conv_desc {
   int32_t up;         /* 0/1 = ordinary conv.  up = s > 1 (power of two): x is read as if zero-upsampled by s, i.e. the
                          data-gradient of a stride-s conv (transposed conv); Ho/Wo below then give the output size */
   int32_t Ho, Wo;     /* only read when up > 1 (the forward conv's input extent) */
+  int32_t stride_w;   /* 0 = same as `stride`; otherwise the horizontal stride (PVT spatial-reduction convs are run as
+                         KH = sr, KW = 1 convs over the input viewed as [N][H][W/sr][sr*C] with stride (sr, 1)) */
 } cavp_conv_desc;
 
 size_t cavp_conv2d_workspace_bytes(const cavp_conv_desc* d);
@@ -227,6 +229,20 @@ int cavp_symm_add(const float* d, float* g, int32_t n, float scale, void* stream
 int cavp_l2norm_bwd_scatter(const float* dA, const float* A, const float* norms, const int32_t* idx_b,
                             const int32_t* idx_p, int32_t N, int32_t C, float* dx, int64_t stride_b, int64_t stride_c,
                             int64_t stride_p, void* stream);
+
+/* ---- PVTv2-B5 visual backbone (models/visual/backbones/pvt/pvt.py, config #4 / SURVEY.md §8a row a12) ---- */
+/* Attention.forward (pvt.py:102-130): softmax(q k^T * scale) v per head with the spatially-reduced K/V (Nk <= 256,
+ * head_dim 64).  q, o: [B][Nq][heads*64]; kv: [B][Nk][2*heads*64] (k then v, as written by the `kv` Linear). */
+int cavp_sra_attention(int32_t dtype, const void* q, const void* kv, void* o, int32_t B, int32_t Nq, int32_t Nk,
+                       int32_t heads, int32_t head_dim, float scale, void* stream);
+/* DWConv (pvt.py:315-326): depth-wise 3x3 pad 1 + bias on NHWC, optional fused act (GELU of Mlp.forward :46-55). */
+int cavp_dwconv3x3_nhwc(int32_t dtype, const void* x, const float* w9c, const float* bias, void* y, int32_t N, int32_t H,
+                        int32_t W, int32_t C, int32_t act, void* stream);
+int cavp_pack_dwconv_weight(const float* w_c133, float* w9c, int32_t C, void* stream); /* [C][1][3][3] -> [9][C] */
+/* OverlapPatchEmbed.proj of stage 1 (pvt.py:187-188): KSxKS conv, Cin <= 3, NCHW f32 in, NHWC out, + bias. */
+int cavp_conv_smallcin_kxk_nchw(int32_t dtype, const float* x_nchw, const float* w_oihw, const float* bias, void* y_nhwc,
+                                int32_t N, int32_t Cin, int32_t H, int32_t W, int32_t Cout, int32_t KS, int32_t stride,
+                                int32_t pad, void* stream);
 
 #ifdef __cplusplus
 }

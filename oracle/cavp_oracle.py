@@ -117,6 +117,56 @@ def backbone_forward(image, sd, last_three_dilation_stride, train=False, p="back
 
 
 # --------------------------------------------------------------------------------------------------------------
+# PVTv2-B5 (models/visual/backbones/pvt/pvt.py:413-421: dims 64/128/320/512, heads 1/2/5/8, depths 3/6/40/3, sr 8/4/2/1)
+# --------------------------------------------------------------------------------------------------------------
+PVT_DIMS, PVT_HEADS, PVT_DEPTHS, PVT_SR = (64, 128, 320, 512), (1, 2, 5, 8), (3, 6, 40, 3), (8, 4, 2, 1)
+
+
+def _lne(x, sd, p, eps):
+    return F.layer_norm(x, (x.shape[-1],), sd[p + ".weight"], sd[p + ".bias"], eps)
+
+
+def pvt_forward(image, sd, p="backbone"):
+    """PyramidVisionTransformerV2.forward_features (pvt.py:291-306); Block :166-170; Attention :102-130 (softmax);
+    Mlp :46-55 with DWConv :320-326; OverlapPatchEmbed :209-215.  Block / stage norms use eps 1e-6, the patch-embed
+    norm and the attention's sr norm the LayerNorm default 1e-5."""
+    x = image
+    feats = []
+    B = image.shape[0]
+    for i in range(4):
+        k, s_, pad = (7, 4, 3) if i == 0 else (3, 2, 1)
+        x = F.conv2d(x, sd[f"{p}.patch_embed{i + 1}.proj.weight"], sd[f"{p}.patch_embed{i + 1}.proj.bias"], s_, pad)
+        H, W = x.shape[-2:]
+        x = _lne(x.flatten(2).transpose(1, 2), sd, f"{p}.patch_embed{i + 1}.norm", 1e-5)
+        C, nh, sr = PVT_DIMS[i], PVT_HEADS[i], PVT_SR[i]
+        for j in range(PVT_DEPTHS[i]):
+            b = f"{p}.block{i + 1}.{j}"
+            n1 = _lne(x, sd, b + ".norm1", 1e-6)
+            N = n1.shape[1]
+            q = _linear(n1, sd, b + ".attn.q").reshape(B, N, nh, C // nh).permute(0, 2, 1, 3)
+            if sr > 1:
+                x_ = n1.permute(0, 2, 1).reshape(B, C, H, W)
+                x_ = F.conv2d(x_, sd[b + ".attn.sr.weight"], sd[b + ".attn.sr.bias"], sr).reshape(B, C, -1).permute(0, 2, 1)
+                x_ = _lne(x_, sd, b + ".attn.norm", 1e-5)
+            else:
+                x_ = n1
+            kv = _linear(x_, sd, b + ".attn.kv").reshape(B, -1, 2, nh, C // nh).permute(2, 0, 3, 1, 4)
+            attn = ((q @ kv[0].transpose(-2, -1)) * (C // nh) ** -0.5).softmax(dim=-1)
+            o = (attn @ kv[1]).transpose(1, 2).reshape(B, N, C)
+            x = x + _linear(o, sd, b + ".attn.proj")
+            n2 = _lne(x, sd, b + ".norm2", 1e-6)
+            h = _linear(n2, sd, b + ".mlp.fc1")
+            hc = h.shape[-1]
+            h = F.conv2d(h.transpose(1, 2).reshape(B, hc, H, W), sd[b + ".mlp.dwconv.dwconv.weight"],
+                         sd[b + ".mlp.dwconv.dwconv.bias"], 1, 1, 1, hc).flatten(2).transpose(1, 2)
+            x = x + _linear(F.gelu(h), sd, b + ".mlp.fc2")
+        x = _lne(x, sd, f"{p}.norm{i + 1}", 1e-6)
+        x = x.reshape(B, H, W, -1).permute(0, 3, 1, 2).contiguous()
+        feats.append(x)
+    return feats
+
+
+# --------------------------------------------------------------------------------------------------------------
 # DeepLabV3+ encoder side (encoder_decoder.py:97-105, ASPP :137-156)
 # --------------------------------------------------------------------------------------------------------------
 def aspp_forward(x, sd, train=False, p="segment.aspp", rates=(6, 12, 18)):
@@ -235,7 +285,8 @@ def forward_cls(x, sd, input_shape, train=False, taps=None):
 # CAVP.forward (cavp_model.py:199-205; forward_inference :190-197; forward_train :175-188)
 # --------------------------------------------------------------------------------------------------------------
 def cavp_forward(sd: Dict[str, torch.Tensor], image, audio, last_three_dilation_stride=(False, False, False),
-                 eval_mode: bool = True, bn_train: Optional[bool] = None, taps: Optional[dict] = None):
+                 eval_mode: bool = True, bn_train: Optional[bool] = None, taps: Optional[dict] = None,
+                 seg_model: str = "DeepLabV3Plus"):
     """Returns (out_pred, out_fusion, {"audio","visual","attn_v"}).
 
     eval_mode=True  -> forward_inference: image [B], audio [B].
@@ -244,10 +295,13 @@ def cavp_forward(sd: Dict[str, torch.Tensor], image, audio, last_three_dilation_
     if bn_train is None:
         bn_train = not eval_mode
     input_shape = tuple(image.shape[-2:])
-    feats = backbone_forward(image, sd, last_three_dilation_stride, bn_train)
+    if seg_model == "PVT":   # cavp_model.py:106-115
+        feats = pvt_forward(image, sd)
+    else:
+        feats = backbone_forward(image, sd, last_three_dilation_stride, bn_train)
     if taps is not None:
         for i, f in enumerate(feats):
-            taps[f"layer{i + 1}"] = f
+            taps[("stage" if seg_model == "PVT" else "layer") + str(i + 1)] = f
     fea_v = forward_feature(feats, sd, bn_train, taps)
     if not eval_mode:
         fea_v = torch.cat((fea_v, fea_v.clone()), 0)

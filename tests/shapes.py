@@ -6,7 +6,8 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-def cavp_state_shapes(num_classes):
-    with open(os.path.join(_HERE, "golden", "state_dict_shapes.json")) as f:
+def cavp_state_shapes(num_classes, seg_model="DeepLabV3Plus"):
+    name = "state_dict_shapes_pvt.json" if seg_model == "PVT" else "state_dict_shapes.json"
+    with open(os.path.join(_HERE, "golden", name)) as f:
         raw = json.load(f)
     return {k: tuple(num_classes if d == "C" else d for d in v) for k, v in raw.items()}

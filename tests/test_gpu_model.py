@@ -108,3 +108,36 @@ def test_cpu_tensors_fail_loudly():
     image, audio, _ = synth_inputs(1, (32, 32), seed=0)
     with pytest.raises(CavpError):
         m(image, audio, eval_mode=True)
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-3), (torch.bfloat16, None)], ids=["f32", "bf16"])
+def test_pvt_forward_matches_reference_golden(dtype, tol):
+    """config #4: PVTv2-B5 backbone (MFMA softmax attention, SR convs, depth-wise MLP) + 112-d fusion + decoder."""
+    from cavp_amd.cavp_model import CAVP
+    z, cfg = load_case("pvt_eval")
+    a = _args(cfg)
+    a.seg_model = "PVT"
+    m = CAVP(50, None, num_classes=cfg["C"], args=a)
+    sd = synth_state_dict({k: tuple(v.shape) for k, v in m.state_dict().items()}, seed=1)
+    m.load_state_dict(sd, strict=True)
+    m.eval().to(DEV).set_compute_dtype(dtype)
+    image, audio, _ = synth_inputs(cfg["B"], cfg["hw"], num_classes=cfg["C"], seed=0)
+    taps = {}
+    with torch.no_grad():
+        out, fus, pack = m._forward_hip(image.to(DEV), audio.to(DEV), duplicate_visual=False, taps=taps)
+    torch.cuda.synchronize()
+    got = {f"stage{i + 1}": taps[f"layer{i + 1}"] for i in range(4)}
+    got.update(out_pred=out, out_fusion=fus, pack_visual=pack["visual"], pack_attn_v=pack["attn_v"])
+    rep = {}
+    for k, t in got.items():
+        ref = z["sample/" + k]
+        scale = max(1.0, float(np.abs(ref).max()))
+        if tol is not None:
+            rep[k] = check_tap(z, k, t, (tol if k == "out_pred" else 3e-4) * scale, what="pvt:")
+        else:
+            from tests._golden_util import sample
+            s, _ = sample(t)
+            rel = float(np.abs(s - ref).max() / scale)
+            rep[k] = rel
+            assert rel <= 0.12, (k, rel)
+    print("pvt", dtype, {k: f"{v:.2e}" for k, v in rep.items()})

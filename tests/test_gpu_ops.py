@@ -262,3 +262,47 @@ def test_errors_are_loud():
         ops.conv2d(x, w, torch.zeros((1, 4, 4, 8), device=DEV))
     with pytest.raises(_lib.CavpError):
         ops.conv2d(torch.zeros((1, 4, 4, 8)), torch.zeros((8, 1, 1, 8)), torch.zeros((1, 4, 4, 8)))  # CPU tensors
+
+
+# ---- PVTv2 kernels ----------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+@pytest.mark.parametrize("B,Nq,Nk,heads", [(2, 1024, 256, 5), (1, 4096, 64, 1), (2, 100, 256, 8), (1, 256, 200, 2)])
+def test_sra_attention(B, Nq, Nk, heads, dtype):
+    ops = _ops()
+    C = heads * 64
+    q, kv = _rand(B, Nq, C, seed=50), _rand(B, Nk, 2 * C, seed=51)
+    qq, kk = _q(q, dtype), _q(kv, dtype)
+    qh = qq.view(B, Nq, heads, 64).permute(0, 2, 1, 3)
+    kh = kk[..., :C].reshape(B, Nk, heads, 64).permute(0, 2, 1, 3)
+    vh = kk[..., C:].reshape(B, Nk, heads, 64).permute(0, 2, 1, 3)
+    ref = ((qh @ kh.transpose(-2, -1)) * 0.125).softmax(-1) @ vh
+    ref = ref.transpose(1, 2).reshape(B, Nq, C)
+    out = torch.empty((B, Nq, C), dtype=dtype, device=DEV)
+    ops.sra_attention(q.to(dtype).to(DEV), kv.to(dtype).to(DEV), out, heads, 0.125)
+    _check(out, ref, dtype, "sra_attention")
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+def test_dwconv_and_patch_embed_and_sr_conv(dtype):
+    ops = _ops()
+    x, w, b = _rand(2, 64, 13, 17, seed=52), _rand(64, 1, 3, 3, seed=53, scale=0.3), _rand(64, seed=54)
+    ref = F.gelu(F.conv2d(_q(x, dtype), w, b, 1, 1, 1, 64))
+    xv, _ = _to_nhwc_dev(x, dtype)
+    out = torch.empty((2, 13, 17, 64), dtype=dtype, device=DEV)
+    ops.dwconv3x3(xv.contiguous(), ops.pack_dwconv_weight(w.to(DEV)), b.to(DEV), out, act=ops.ACT_GELU)
+    _check(out.permute(0, 3, 1, 2), ref, dtype, "dwconv3x3+gelu")
+    # 7x7 stride-4 overlapping patch embedding (Cin = 3)
+    img, w7, b7 = _rand(2, 3, 64, 96, seed=55), _rand(64, 3, 7, 7, seed=56, scale=0.1), _rand(64, seed=57)
+    ref = F.conv2d(img, w7, b7, 4, 3)
+    out = torch.empty((2, ref.shape[2], ref.shape[3], 64), dtype=dtype, device=DEV)
+    ops.conv_smallcin_kxk(img.to(DEV), w7.to(DEV), b7.to(DEV), out, 7, 4, 3)
+    _check(out.permute(0, 3, 1, 2), ref, dtype, "patch_embed7x7")
+    # spatial-reduction conv k = s = sr as a (KH = sr, KW = 1) conv over [N, H, W/sr, sr*C], stride (sr, 1)
+    for sr, C in ((8, 64), (4, 128), (2, 320)):
+        xs, ws, bs = _rand(2, C, 16, 32, seed=58), _rand(C, C, sr, sr, seed=59, scale=(C * sr * sr) ** -0.5), _rand(C, seed=60)
+        ref = F.conv2d(_q(xs, dtype), _q(ws, dtype), bs, sr)
+        xv, _ = _to_nhwc_dev(xs, dtype)
+        xin = xv.contiguous().view(2, 16, 32 // sr, sr * C)
+        out = torch.empty((2, 16 // sr, 32 // sr, C), dtype=dtype, device=DEV)
+        ops.conv2d(xin, ops.pack_weight(ws.to(DEV), dtype), out, kh=sr, kw=1, stride=sr, stride_w=1, shift=bs.to(DEV))
+        _check(out.permute(0, 3, 1, 2), ref, dtype, f"sr_conv{sr}")

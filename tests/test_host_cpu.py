@@ -87,3 +87,16 @@ def test_product_never_imports_oracle():
                 src = open(os.path.join(root, f)).read()
                 assert "oracle" not in src.replace("oracle/", "").replace("the oracle", "") or f == "synth.py" or True
                 assert "import oracle" not in src and "from oracle" not in src, f
+
+
+def test_pvt_state_dict_key_tree_matches_reference():
+    from cavp_amd.cavp_model import CAVP
+    from tests.shapes import cavp_state_shapes
+    a = _args(71)
+    a.seg_model = "PVT"
+    m = CAVP(50, None, num_classes=71, args=a)
+    mine = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+    ref = cavp_state_shapes(71, "PVT")
+    assert set(mine) == set(ref), sorted(set(mine) ^ set(ref))[:10]
+    assert mine == ref
+    assert m.latent_dim == 112

@@ -64,3 +64,18 @@ def test_oracle_train_matches_reference():
         n = g.numel()
         s = g.flatten()[:: max(1, n // 4096)][:4096].numpy()
         assert np.abs(s - ref).max() <= 1e-5 * max(1.0, np.abs(ref).max()), k
+
+
+def test_oracle_pvt_matches_reference():
+    """config #4: seg_model="PVT" (PVTv2-B5 backbone, latent 112) eval forward."""
+    z, cfg = load_case("pvt_eval")
+    sd = synth_state_dict(cavp_state_shapes(cfg["C"], "PVT"), seed=1)
+    image, audio, _ = synth_inputs(cfg["B"], cfg["hw"], num_classes=cfg["C"], seed=0)
+    taps = {}
+    with torch.no_grad():
+        out, fus, pack = O.cavp_forward(sd, image, audio, cfg["lds"], eval_mode=True, taps=taps, seg_model="PVT")
+    taps = {k: v for k, v in taps.items() if k.startswith("stage")}
+    taps.update(out_pred=out, out_fusion=fus, pack_visual=pack["visual"], pack_attn_v=pack["attn_v"])
+    for k in sorted(taps):
+        scale = max(1.0, float(np.abs(z["sample/" + k]).max()))
+        check_tap(z, k, taps[k], 2 * ATOL * scale, what="pvt:")

@@ -142,6 +142,60 @@ def run_case(name, cfg, out_dir):
           + " ".join(f"{k}:{taps[k].std().item():.2f}" for k in ("layer1", "layer2", "layer3", "layer4", "aspp")))
 
 
+def run_pvt(out_dir, hw=(256, 256), C=71, B=1):
+    """config #4 (seg_model="PVT", config_avss.py shape family): reference forward with the hard-coded
+    `torch.load("../ckpts/pretrained/pvt_v2_b5.pth")` (cavp_model.py:109) patched to a fresh random state."""
+    import models.cavp_model as CM
+    from models.visual.backbones.pvt.pvt import pvt_v2_b5
+    real_load = torch.load
+
+    def fake_load(path, *a, **k):
+        if "pvt_v2_b5" in str(path):
+            sd = pvt_v2_b5().state_dict()
+            sd["head.weight"], sd["head.bias"] = torch.zeros(1), torch.zeros(1)
+            return sd
+        return real_load(path, *a, **k)
+    torch.load = fake_load
+    try:
+        args = EasyDict(seg_model="PVT", last_three_dilation_stride=[False, False, False], audio_backbone="vgg",
+                        num_classes=C, batch_size=B, local_rank="cpu")
+        m = CAVP(50, None, num_classes=C, audio_backbone_pretrain_path=None, visual_backbone=50, args=args)
+    finally:
+        torch.load = real_load
+    sd = synth_state_dict({k: tuple(v.shape) for k, v in m.state_dict().items()}, seed=1)
+    m.load_state_dict(sd, strict=True)
+    import json
+    with open(os.path.join(out_dir, "state_dict_shapes_pvt.json"), "w") as f:
+        json.dump({k: ["C" if (k.startswith("segment.upsample.classifier") and i == 0) else int(d) for i, d in enumerate(v.shape)]
+                   for k, v in m.state_dict().items()}, f, indent=0)
+    image, audio, _ = synth_inputs(B, hw, num_classes=C, seed=0)
+    taps = {}
+    orig = m.backbone.forward_features
+
+    def ff(x):
+        outs = orig(x)
+        for i, o in enumerate(outs):
+            taps[f"stage{i + 1}"] = o
+        return outs
+    m.backbone.forward_features = ff
+    m.eval()
+    with torch.no_grad():
+        out, fus, pack = m(image, audio, eval_mode=True)
+    taps.update(out_pred=out, out_fusion=fus, pack_visual=pack["visual"], pack_attn_v=pack["attn_v"])
+    store = {}
+    for k, t in taps.items():
+        s_, c_ = sample(t)
+        store["sample/" + k], store["cksum/" + k] = s_, c_
+        store["shape/" + k] = np.array(t.shape, dtype=np.int64)
+    store["cfg/CBHW"] = np.array([C, B, hw[0], hw[1]], dtype=np.int64)
+    store["cfg/lds"] = np.array([0, 0, 0], dtype=np.int64)
+    store["cfg/train"] = np.array([0], dtype=np.int64)
+    path = os.path.join(out_dir, "pvt_eval.npz")
+    np.savez_compressed(path, **store)
+    print(f"pvt_eval: wrote {path}; |out|max={out.abs().max().item():.3f} " +
+          " ".join(f"{k}:{taps[k].std().item():.2f}" for k in ("stage1", "stage2", "stage3", "stage4")))
+
+
 def contrast_inputs(seed=7, B=2, C=304, hw=(56, 56), full=(224, 224), num_classes=4):
     """Synthetic ContrastLoss inputs: blocky label maps so that several classes keep >= max_views pixels at 56x56."""
     g = torch.Generator().manual_seed(seed)
@@ -190,3 +244,5 @@ if __name__ == "__main__":
         run_case(name, cfg, a.out)
     if not a.only or a.only == "contrast":
         run_contrast(a.out)
+    if not a.only or a.only == "pvt":
+        run_pvt(a.out)
