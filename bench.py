@@ -43,6 +43,8 @@ def parse():
     ap.add_argument("--mode", choices=["train", "eval"], default="train",
                     help="train = forward_train + CE + backward (+ gradient all-reduce when N > 1): the BASELINE.json "
                          "metric; eval = inference forward only")
+    ap.add_argument("--config", choices=["c1p", "c4"], default="c1p",
+                    help="c1p = ResNet-50 224x224 (the BASELINE metric); c4 = PVTv2-B5 512x512, inference only (config #4)")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -50,15 +52,17 @@ def parse():
     return ap.parse_args()
 
 
-def model_cfg():
+def model_cfg(name="c1p"):
+    if name == "c4":   # config_avss.py shape: PVTv2-B5, 512x512, 71 classes
+        return dict(C=71, lds=[False, False, False], hw=(512, 512), seg_model="PVT")
     # C1' (SURVEY.md §8d): config_avss_binary.py shape — 224x224, OS16, VGGish audio, num_classes=2
-    return dict(C=2, lds=[False, False, False], hw=(224, 224))
+    return dict(C=2, lds=[False, False, False], hw=(224, 224), seg_model="DeepLabV3Plus")
 
 
 def build_model(cfg, B, dtype, device):
     from cavp_amd.cavp_model import CAVP
     from cavp_amd.synth import synth_state_dict
-    args = types.SimpleNamespace(seg_model="DeepLabV3Plus", last_three_dilation_stride=cfg["lds"], audio_backbone="vgg",
+    args = types.SimpleNamespace(seg_model=cfg.get("seg_model", "DeepLabV3Plus"), last_three_dilation_stride=cfg["lds"], audio_backbone="vgg",
                                  num_classes=cfg["C"], batch_size=B, local_rank="cpu")
     m = CAVP(50, None, num_classes=cfg["C"], audio_backbone_pretrain_path=None, visual_backbone=50, args=args)
     sd = synth_state_dict({k: tuple(v.shape) for k, v in m.state_dict().items()}, seed=1)
@@ -284,7 +288,9 @@ def main():
     if world > 1:
         dist.init_process_group("nccl", device_id=dev)
     dtype = torch.bfloat16 if a.dtype == "bf16" else torch.float32
-    cfg = model_cfg()
+    cfg = model_cfg(a.config)
+    if a.config == "c4":
+        a.mode = "eval"
     B = a.batch
     from cavp_amd.synth import synth_inputs
     model, sd = build_model(cfg, B, dtype, dev)
@@ -346,8 +352,8 @@ def main():
     if rank == 0:
         value = world * B * a.steps / elapsed
         line = {
-            "metric": ("frames/sec end-to-end CAVP fwd+bwd, B=32 224x224" if train
-                       else "frames/sec end-to-end CAVP forward (inference), B=32 224x224"),
+            "metric": ("frames/sec end-to-end CAVP fwd+bwd, B=32 224x224" if train else
+                       f"frames/sec end-to-end CAVP forward (inference), B={B} {cfg['hw'][0]}x{cfg['hw'][1]}"),
             "value": round(value, 2), "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(elapsed / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
@@ -356,16 +362,19 @@ def main():
                                     f"full backward" + (" + one flat RCCL gradient all-reduce" if world > 1 else "") +
                                     ", 224x224 RGB + 96x64 mel, num_classes=2, random-init (synthetic) weights"
                                     if train else
-                                    f"C1' (config_avss_binary shape): CAVP ResNet-50 OS16 + VGGish, eval forward, "
-                                    f"B={B}/GPU, 224x224 RGB + 96x64 mel, num_classes=2, random-init (synthetic) weights"),
+                                    (f"C4 (config_avss shape): CAVP PVTv2-B5 + VGGish, eval forward, B={B}/GPU, 512x512 RGB + 96x64 "
+                                     f"mel, num_classes=71, random-init (synthetic) weights" if a.config == "c4" else
+                                     f"C1' (config_avss_binary shape): CAVP ResNet-50 OS16 + VGGish, eval forward, "
+                                     f"B={B}/GPU, 224x224 RGB + 96x64 mel, num_classes=2, random-init (synthetic) weights")),
                        "global_batch": world * B, "per_gpu_batch": B, "parallelism": f"dp{world}",
                        "launch": "eager" if a.no_graph else "hipGraph replay"},
         }
         if not a.no_roofline:
             line["roofline"] = measure_roofline(model, run_step, image, a.dtype)
         if world == 1 and not a.no_cpu_baseline:
-            line["cpu_baseline"] = (cpu_baseline_train(sd, cfg, max(2, a.cpu_sample_batch // 2)) if train
-                                    else cpu_baseline(sd, cfg, a.cpu_sample_batch))
+            if a.config == "c1p":
+                line["cpu_baseline"] = (cpu_baseline_train(sd, cfg, max(2, a.cpu_sample_batch // 2)) if train
+                                        else cpu_baseline(sd, cfg, a.cpu_sample_batch))
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
