@@ -11,9 +11,12 @@
 // * One K step consumes 4 slots: lane l reads slot j*4 + (l >> 4) of row (l & 15) for BOTH operands.  For bf16
 //   that is exactly the 16x16x32 fragment; for f32 it is a K-permutation shared by A and B (sum order only), fed
 //   to four exact-f32 v_mfma_f32_16x16x4_f32.
-// * Global -> register -> LDS software pipeline with two LDS buffers and one barrier per K tile; loads of tile
-//   k+1 are in flight while tile k is multiplied.  Out-of-image taps, K tails (Cin not a multiple of the tile)
-//   and M / Cout tails are zero-filled at load time (unconditional load from a clamped address + select).
+// * Global -> LDS directly (buffer_load ... lds, no VGPR staging) through a ring of NS LDS stages with ONE barrier
+//   per K tile: tile k is multiplied while tiles k+1 .. k+NS-1 are in flight (counted s_waitcnt vmcnt, raw
+//   s_barrier).  The 4-wave / 2-stage tiles keep two workgroups per CU; the 8-wave 256x128 / 128x256 tiles hold one
+//   144 KiB 3-stage workgroup per CU (96 KiB of operands in flight per CU and 1.36x fewer operand bytes per flop).
+//   Out-of-image taps, K tails (Cin not a multiple of the tile) and M / Cout tails are zero-filled by the buffer
+//   descriptor's bounds check (the lane is pointed past num_records instead of branching).
 // * Taps that cannot touch the image for any output pixel (dilation >= extent, e.g. ASPP d=18 on 14x14) are
 //   removed on the host; split-K writes f32 slabs that a small epilogue kernel reduces deterministically.
 #include "common.h"
@@ -42,6 +45,7 @@ struct IgemmParams {
   int tap_xoff[9];          // per live tap: byte displacement (dh*W + dw)*ldx*sizeof(T) in x (ordinary conv only)
   int tap_woff[9];          // per live tap: byte offset tap*Cin*sizeof(T) inside a weight row
   float* tile_stats;        // optional [tiles_p][Cout][2] per-tile (mean, M2) of the raw outputs (BatchNorm statistics)
+  int dbg;                  // profiling only (tile knob, hundreds digit): 1 = skip the operand loads, 2 = skip the MFMAs
   int coalesced;            // LDS-staged, fully coalesced 16-byte epilogue (needs Cout, ldy, ldr % VE == 0, 16-B aligned)
 };
 
@@ -123,16 +127,22 @@ __device__ __forceinline__ void epilogue_store4(const IgemmParams& p, float v0, 
   }
 }
 
-template <typename T, int BC, int BP, int WC, int WP, bool UP>
-__global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p) {
+// s_waitcnt immediate that only waits for vmcnt <= n (gfx9 encoding: vmcnt[3:0] | expcnt[6:4] | lgkmcnt[11:8] | vmcnt[15:14])
+constexpr int vmcnt_imm(int n) { return (n & 15) | ((n >> 4) << 14) | (7 << 4) | (15 << 8); }
+
+template <typename T, int BC, int BP, int WC, int WP, bool UP, int NS>
+__global__ __launch_bounds__(64 * WC * WP, (WC * WP == 4 ? 2 : 1)) void igemm_kernel(const IgemmParams p) {
   constexpr int VE = Elem<T>::VE;
   constexpr int BK = 8 * VE;  // one 128-byte LDS row of K
   constexpr int TC = BC / WC, TP = BP / WP;
   constexpr int MC = TC / 16, MP = TP / 16;
+  constexpr int NW = WC * WP, NT = 64 * NW;
   constexpr int NVW = BC * 8, NVX = BP * 8;
-  constexpr int LW = (NVW + 255) / 256, LX = (NVX + 255) / 256;
+  constexpr int LW = (NVW + NT - 1) / NT, LX = (NVX + NT - 1) / NT;
   constexpr int TILE_BYTES = (BC + BP) * 128;
-  static_assert(WC * WP == 4, "4 waves per workgroup");
+  constexpr int RSTEP = 8 * NW;  // LDS rows covered by one DMA instruction of the whole workgroup
+  static_assert(NW == 4 || NW == 8, "4 or 8 waves per workgroup");
+  static_assert(NS >= 2 && (NS - 2) * (LW + LX) < 64, "vmcnt is a 6-bit counter");
   static_assert(TC % 16 == 0 && TP % 16 == 0, "wave tile must be a multiple of the 16x16 MFMA block");
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -155,7 +165,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p) {
   const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.w_bytes, 0x00020000);
 
   // ---- per-thread load descriptors (fixed for the whole K loop) ----
-  // LDS-DMA geometry: a wave-instruction writes 1 KiB = rows 8g..8g+7 LINEARLY (lane l -> byte 16 l), g = wave + 4 i,
+  // LDS-DMA geometry: a wave-instruction writes 1 KiB = rows 8g..8g+7 LINEARLY (lane l -> byte 16 l), g = wave + NW i,
   // so the bank swizzle moves to the SOURCE: lane l fetches logical slot (l & 7) ^ ((row >> 1) & 7) of its row.
   // Everything that does not change over the K loop is folded into one byte offset + one tap-validity bitmask per
   // row, so a K iteration costs ~4 VALU per load (the first version redid the bounds tests and two integer
@@ -166,38 +176,40 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p) {
   unsigned w_off[LW];  // byte offset of (cout row, k = kslot) or kOOB
 #pragma unroll
   for (int i = 0; i < LW; ++i) {
-    const int row = row0 + 32 * i;
+    const int row = row0 + RSTEP * i;
     const int c = c_base + row;
     const bool ok = (row < BC) && (c < p.Cout);
     w_off[i] = ok ? (unsigned)(((size_t)c * p.K + kslot) * sizeof(T)) : kOOB;
   }
   unsigned x_off[LX];   // byte offset of (pixel @ tap displacement 0, channel kslot); wraps are harmless (masked)
   unsigned x_mask[LX];  // bit ti = live tap ti reads inside the image for this row
-  int x_h0[LX], x_w0[LX], x_nb[LX];  // UP only
+  int x_h0[LX], x_w0[LX], x_nb[LX];  // x_nb: UP only
   const int HoWo = p.Ho * p.Wo;
 #pragma unroll
   for (int i = 0; i < LX; ++i) {
-    const int row = row0 + 32 * i;
+    const int row = row0 + RSTEP * i;
     const int pix = p_base + row;
     const bool ok = (row < BP) && (pix < p.M);
     const int pp = ok ? pix : 0;
     const int n = pp / HoWo, r = pp - n * HoWo;
     const int ho = r / p.Wo, wo = r - ho * p.Wo;
     const int h0 = ho * p.stride - p.pad, w0 = wo * p.stride_w - p.pad;
+    x_h0[i] = ok ? h0 : -0x10000000;  // a dead row fails every bounds test below
+    x_w0[i] = w0;
+    x_mask[i] = 0;
     if constexpr (UP) {
       x_nb[i] = n * p.H * p.W;
-      x_h0[i] = ok ? h0 : -0x10000000;
-      x_w0[i] = w0;
       x_off[i] = 0;
-      x_mask[i] = 0;
     } else {
       x_off[i] = (unsigned)((n * p.H + h0) * p.W + w0) * (unsigned)(p.ldx * (int)sizeof(T)) + (unsigned)kbyte;
-      unsigned m = 0;
-      for (int t = 0; t < p.ntaps; ++t) {
-        const int hi = h0 + p.tap_dh[t], wi = w0 + p.tap_dw[t];
-        m |= (ok && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W) ? (1u << t) : 0u;
-      }
-      x_mask[i] = m;
+    }
+  }
+  if constexpr (!UP) {
+    for (int t = 0; t < p.ntaps; ++t) {  // tap outermost: its two scalar table loads are shared by the LX rows
+      const int dh = p.tap_dh[t], dw = p.tap_dw[t];
+#pragma unroll
+      for (int i = 0; i < LX; ++i)
+        x_mask[i] |= ((unsigned)(x_h0[i] + dh) < (unsigned)p.H && (unsigned)(x_w0[i] + dw) < (unsigned)p.W) ? (1u << t) : 0u;
     }
   }
 
@@ -206,16 +218,19 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p) {
   int g_cc = it_begin - g_ti * p.cpt;
 
   // global -> LDS directly (buffer_load ... lds), no VGPR staging, no ds_write; out-of-range lanes land zeros.
-  auto gdma = [&](int buf) {
-    const int ti = g_ti, c0 = g_cc * BK;
-    const bool c_ok = (c0 + kslot) < p.Cin;
+  // `live` = false issues the same number of DMA instructions with every lane out of range (zero fill, no memory
+  // traffic): the ring's tail keeps the per-iteration vmcnt arithmetic uniform.
+  auto gdma = [&](int buf, bool live) {
+    const int ti = g_ti < p.ntaps ? g_ti : p.ntaps - 1, c0 = g_cc * BK;
+    const bool c_ok = live && (c0 + kslot) < p.Cin;
+    const unsigned oobm = c_ok ? 0u : kOOB;  // OR-ed into the offset: any offset >= 2^31 is out of range (tensors < 2 GiB)
     const unsigned wk = (unsigned)(p.tap_woff[ti] + c0 * (int)sizeof(T));
     char* base = smem + buf * TILE_BYTES + wave * 1024;
 #pragma unroll
     for (int i = 0; i < LW; ++i) {
-      if (BC % 32 == 0 || 8 * wave + 32 * i < BC) {
-        const unsigned off = c_ok ? (w_off[i] + wk) : kOOB;  // kOOB + wk stays >= 2^31 (tensors are < 2 GiB)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (__attribute__((address_space(3))) void*)(base + i * 4096), 16,
+      if (BC % RSTEP == 0 || 8 * wave + RSTEP * i < BC) {
+        const unsigned off = (w_off[i] + wk) | oobm;  // (a kOOB row + wk stays >= 2^31)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (__attribute__((address_space(3))) void*)(base + i * (NW * 1024)), 16,
                                                  (int)off, 0, 0, 0);
       }
     }
@@ -224,25 +239,24 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p) {
       const int xk = c0 * (int)sizeof(T) + kbyte;
 #pragma unroll
       for (int i = 0; i < LX; ++i) {
-        if (BP % 32 == 0 || 8 * wave + 32 * i < BP) {
+        if (BP % RSTEP == 0 || 8 * wave + RSTEP * i < BP) {
           const int hv = x_h0[i] + dh, wv = x_w0[i] + dw;  // position in the (virtually zero-upsampled) input
           const int hi = hv >> p.up_shift, wi = wv >> p.up_shift;
-          const bool ok = c_ok && (((hv | wv) & p.up_mask) == 0) && ((unsigned)hi < (unsigned)p.H) &&
-                          ((unsigned)wi < (unsigned)p.W);
+          const bool ok = (((hv | wv) & p.up_mask) == 0) && ((unsigned)hi < (unsigned)p.H) && ((unsigned)wi < (unsigned)p.W);
           const unsigned off = (unsigned)(x_nb[i] + hi * p.W + wi) * (unsigned)(p.ldx * (int)sizeof(T)) + (unsigned)xk;
           __builtin_amdgcn_raw_ptr_buffer_load_lds(
-              xrsrc, (__attribute__((address_space(3))) void*)(base + BC * 128 + i * 4096), 16, (int)(ok ? off : kOOB), 0, 0, 0);
+              xrsrc, (__attribute__((address_space(3))) void*)(base + BC * 128 + i * (NW * 1024)), 16, (int)((ok ? off : kOOB) | oobm), 0, 0, 0);
         }
       }
     } else {
       const unsigned xk = (unsigned)(p.tap_xoff[ti] + c0 * (int)sizeof(T));
 #pragma unroll
       for (int i = 0; i < LX; ++i) {
-        if (BP % 32 == 0 || 8 * wave + 32 * i < BP) {
-          const bool ok = c_ok && ((x_mask[i] >> ti) & 1u);
+        if (BP % RSTEP == 0 || 8 * wave + RSTEP * i < BP) {
+          const unsigned tapm = ((~(x_mask[i] >> ti)) & 1u) << 31;  // tap outside the image for this pixel
           __builtin_amdgcn_raw_ptr_buffer_load_lds(
-              xrsrc, (__attribute__((address_space(3))) void*)(base + BC * 128 + i * 4096), 16,
-              (int)(ok ? x_off[i] + xk : kOOB), 0, 0, 0);
+              xrsrc, (__attribute__((address_space(3))) void*)(base + BC * 128 + i * (NW * 1024)), 16,
+              (int)((x_off[i] + xk) | tapm | oobm), 0, 0, 0);
         }
       }
     }
@@ -258,43 +272,90 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p) {
 #pragma unroll
     for (int b = 0; b < MP; ++b) acc[a][b] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
-  auto compute = [&](int buf) {
+  // fragment loads of K sub-step j (32 bf16 / 16 f32 of K) of one stage, and the MFMA block that consumes them
+  auto read_frag = [&](u32x4_t (&af)[MC], u32x4_t (&bfv)[MP], int buf, int j) {
     const char* wb = smem + buf * TILE_BYTES;
     const char* xb = wb + BC * 128;
+    const int s = j * 4 + lgrp;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      u32x4_t af[MC], bfv[MP];
-      const int s = j * 4 + lgrp;
-#pragma unroll
-      for (int a = 0; a < MC; ++a) {
-        const int r = wc0 + a * 16 + lrow;
-        af[a] = *(const u32x4_t*)(wb + r * 128 + ((s ^ ((r >> 1) & 7)) << 4));
-      }
-#pragma unroll
-      for (int b = 0; b < MP; ++b) {
-        const int r = wp0 + b * 16 + lrow;
-        bfv[b] = *(const u32x4_t*)(xb + r * 128 + ((s ^ ((r >> 1) & 7)) << 4));
-      }
-#pragma unroll
-      for (int a = 0; a < MC; ++a)
-#pragma unroll
-        for (int b = 0; b < MP; ++b) Mma<T>::run(acc[a][b], af[a], bfv[b]);
+    for (int a = 0; a < MC; ++a) {
+      const int r = wc0 + a * 16 + lrow;
+      af[a] = *(const u32x4_t*)(wb + r * 128 + ((s ^ ((r >> 1) & 7)) << 4));
     }
+#pragma unroll
+    for (int b = 0; b < MP; ++b) {
+      const int r = wp0 + b * 16 + lrow;
+      bfv[b] = *(const u32x4_t*)(xb + r * 128 + ((s ^ ((r >> 1) & 7)) << 4));
+    }
+  };
+  auto mma_block = [&](const u32x4_t (&af)[MC], const u32x4_t (&bfv)[MP]) {
+#pragma unroll
+    for (int a = 0; a < MC; ++a)
+#pragma unroll
+      for (int b = 0; b < MP; ++b) Mma<T>::run(acc[a][b], af[a], bfv[b]);
   };
 
   if (it_begin < it_end) {
-    gdma(0);
-    __syncthreads();  // (drains the DMA: hipcc emits vmcnt(0) before the barrier while an LDS-DMA is in flight)
-    int buf = 0;
-    for (int it = it_begin; it < it_end; ++it) {
-      if (it + 1 < it_end) gdma(buf ^ 1);
-      compute(buf);
-      __syncthreads();
-      buf ^= 1;
+    if constexpr (NS == 2) {
+      // two stages, two workgroups per CU.  Iteration `it`: wait for MY loads of tile `it`, barrier (=> everybody's
+      // tile `it` landed and everybody finished multiplying tile it-1), issue tile it+1 into the stage tile it-1
+      // vacated, multiply tile `it`.
+      gdma(0, true);
+      int buf = 0;
+      for (int it = it_begin; it < it_end; ++it) {
+        __builtin_amdgcn_s_waitcnt(vmcnt_imm(0));
+        __builtin_amdgcn_s_barrier();
+        if (!(p.dbg & 8)) gdma(buf ^ 1, it + 1 < it_end && !(p.dbg & 1));
+        if (!(p.dbg & 2)) {
+          u32x4_t af[MC], bfv[MP];
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            read_frag(af, bfv, buf, j);
+            mma_block(af, bfv);
+          }
+        }
+        buf ^= 1;
+      }
+    } else {
+      // three stages, one 8-wave workgroup per CU, software-pipelined through two fragment register sets so that no
+      // ds_read latency is exposed: the barrier sits in the MIDDLE of a K tile.
+      //   top:   issue the j=1 fragment reads of tile `it`; multiply its j=0 fragments (loaded during tile it-1)
+      //   mid:   wait: my DMA of tile it+1 landed (tile it+2 may still fly) and my j=1 reads returned; barrier
+      //          => tile it+1 is complete for everybody and stage it%3 is not read any more
+      //          issue the DMA of tile it+3 into stage it%3, issue the j=0 fragment reads of tile it+1
+      //   tail:  multiply the j=1 fragments of tile `it`
+      static_assert(NS == 3, "ring arithmetic below is written for 3 stages");
+      constexpr int LD = LW + LX;
+      const int n = it_end - it_begin;
+      gdma(0, true);
+      gdma(1, 1 < n);
+      gdma(2, 2 < n);
+      u32x4_t a0[MC] = {}, b0[MP] = {}, a1[MC] = {}, b1[MP] = {};
+      __builtin_amdgcn_s_waitcnt(vmcnt_imm(2 * LD));
+      __builtin_amdgcn_s_barrier();
+      read_frag(a0, b0, 0, 0);
+      int buf = 0;
+      for (int it = 0; it < n; ++it) {
+        const int nb = buf == 2 ? 0 : buf + 1;
+        if (!(p.dbg & 4)) read_frag(a1, b1, buf, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (!(p.dbg & 2)) mma_block(a0, b0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_waitcnt((LD & 15) | ((LD >> 4) << 14) | (7 << 4) | (0 << 8));  // vmcnt(LD) & lgkmcnt(0)
+        __builtin_amdgcn_s_barrier();
+        if (!(p.dbg & 8)) gdma(buf, it + 3 < n && !(p.dbg & 1));
+        if (!(p.dbg & 4)) read_frag(a0, b0, nb, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (!(p.dbg & 2)) mma_block(a1, b1);
+        __builtin_amdgcn_sched_barrier(0);
+        buf = nb;
+      }
     }
+    __syncthreads();  // drains the (empty) tail DMAs and fences the K-loop LDS reads before the epilogue reuses LDS
   }
 
   // ---- epilogue ----
+  if (p.dbg & 16) return;
   if (p.coalesced) {
     // Stage the f32 accumulators in LDS as [pixel][cout] (16-byte slots XOR-swizzled by pixel & 7), then let each
     // thread finish VE consecutive channels of one pixel: scale/shift/bias/residual are 16-byte vector loads and the
@@ -303,6 +364,35 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p) {
     float* st = (float*)smem;
     constexpr int SLOTS = BC / 4;  // 16-byte f32 slots per pixel row
     constexpr int SWZ = SLOTS >= 8 ? 7 : SLOTS - 1;
+    constexpr int CH = BC / VE;    // output chunks (16 B of T) per pixel row
+    constexpr int NCH = BP * CH;
+    constexpr int ITER = NCH / NT;  // chunks per thread
+    constexpr int RSTR = NT / CH;   // pixel rows between a thread's consecutive chunks
+    static_assert(NCH % NT == 0 && NT % CH == 0, "a thread keeps one channel group for all its chunks");
+    // the thread's channel group is the same for every chunk it finishes: fetch its scale / shift ONCE, before the
+    // staging barrier hides the latency (the first version re-loaded 2 x VE scalars per chunk inside a serial loop
+    // whose every iteration waited on them: 11 us per 128x128 tile, 35 us of a 230 us launch)
+    const int ecc = (tid % CH) * VE, ec = c_base + ecc, eprow0 = tid / CH;
+    const bool ec_ok = ec < p.Cout;
+    float sc[VE], sh[VE];
+#pragma unroll
+    for (int e = 0; e < VE; ++e) { sc[e] = 1.f; sh[e] = 0.f; }
+    if (ec_ok) {
+      if (p.scale) {
+#pragma unroll
+        for (int q = 0; q < VE / 4; ++q) {
+          const float4 t = *(const float4*)(p.scale + ec + 4 * q);
+          sc[4 * q] = t.x; sc[4 * q + 1] = t.y; sc[4 * q + 2] = t.z; sc[4 * q + 3] = t.w;
+        }
+      }
+      if (p.shift) {
+#pragma unroll
+        for (int q = 0; q < VE / 4; ++q) {
+          const float4 t = *(const float4*)(p.shift + ec + 4 * q);
+          sh[4 * q] = t.x; sh[4 * q + 1] = t.y; sh[4 * q + 2] = t.z; sh[4 * q + 3] = t.w;
+        }
+      }
+    }
 #pragma unroll
     for (int a = 0; a < MC; ++a)
 #pragma unroll
@@ -312,7 +402,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p) {
         *(f32x4_t*)(st + (size_t)prow * BC + ((slot ^ (prow & SWZ)) << 2)) = acc[a][b];
       }
     __syncthreads();
-    if (p.tile_stats && tid < BC && c_base + tid < p.Cout) {
+    if (p.tile_stats && tid < BC && c_base + tid < p.Cout) {  // (BC <= NT for every tile)
       // BatchNorm batch statistics for free: per-channel mean and centred second moment of this tile's rows, straight
       // from the f32 accumulators in LDS (two passes over <= BP values; combined across tiles with Chan's formula in
       // cavp_bn_finalize_tiles - no extra pass over the activation, no atomics, no E[x^2]-E[x]^2 cancellation)
@@ -330,55 +420,57 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p) {
       o[0] = mean;
       o[1] = m2;
     }
-    constexpr int CH = BC / VE;                 // output chunks (16 B of T) per pixel row
-    constexpr int NCH = BP * CH;
-    for (int ch = tid; ch < NCH; ch += 256) {
-      const int prow = ch / CH, cc = (ch - prow * CH) * VE;
-      const int pix = p_base + prow, c = c_base + cc;
-      if (pix >= p.M || c >= p.Cout) continue;
-      float v[VE];
+    constexpr int G = ITER < 8 ? ITER : 8;  // chunks finished per batch: all residual loads of a batch fly together
+    static_assert(ITER % G == 0, "chunk batches");
+    for (int i0 = 0; i0 < ITER; i0 += G) {
+      u32x4_t rr[G];
+      bool okk[G];
 #pragma unroll
-      for (int q = 0; q < VE / 4; ++q) {
-        const int slot = cc / 4 + q;
-        const f32x4_t t = *(const f32x4_t*)(st + (size_t)prow * BC + ((slot ^ (prow & SWZ)) << 2));
-        v[4 * q] = t[0]; v[4 * q + 1] = t[1]; v[4 * q + 2] = t[2]; v[4 * q + 3] = t[3];
+      for (int g = 0; g < G; ++g) {
+        const int pix = p_base + eprow0 + (i0 + g) * RSTR;
+        okk[g] = ec_ok && pix < p.M;
+        rr[g] = (u32x4_t){0u, 0u, 0u, 0u};
+        if (p.res && okk[g]) rr[g] = *(const u32x4_t*)((const T*)p.res + (size_t)pix * p.ldr + ec);
       }
-      if (p.nbias) {
-        const float* nb = p.nbias + (size_t)(pix / HoWo) * p.Cout + c;
 #pragma unroll
-        for (int e = 0; e < VE; ++e) v[e] += nb[e];
-      }
-      if (p.scale) {
+      for (int g = 0; g < G; ++g) {
+        const int prow = eprow0 + (i0 + g) * RSTR, pix = p_base + prow;
+        if (!okk[g]) continue;
+        float v[VE];
 #pragma unroll
-        for (int e = 0; e < VE; ++e) v[e] *= p.scale[c + e];
-      }
-      if (p.shift) {
+        for (int q = 0; q < VE / 4; ++q) {
+          const int slot = ecc / 4 + q;
+          const f32x4_t t = *(const f32x4_t*)(st + (size_t)prow * BC + ((slot ^ (prow & SWZ)) << 2));
+          v[4 * q] = t[0]; v[4 * q + 1] = t[1]; v[4 * q + 2] = t[2]; v[4 * q + 3] = t[3];
+        }
+        if (p.nbias) {
+          const float* nb = p.nbias + (size_t)(pix / HoWo) * p.Cout + ec;
 #pragma unroll
-        for (int e = 0; e < VE; ++e) v[e] += p.shift[c + e];
-      }
-      if (p.res) {
-        const u32x4_t r = *(const u32x4_t*)((const T*)p.res + (size_t)pix * p.ldr + c);
+          for (int e = 0; e < VE; ++e) v[e] += nb[e];
+        }
+#pragma unroll
+        for (int e = 0; e < VE; ++e) v[e] = __fadd_rn(__fmul_rn(v[e], sc[e]), sh[e]);  // two roundings, as every other epilogue path
         if constexpr (sizeof(T) == 4) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] += __uint_as_float(r[e]);
+          for (int e = 0; e < 4; ++e) v[e] += __uint_as_float(rr[g][e]);
         } else {
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            v[2 * e] += __uint_as_float(r[e] << 16);
-            v[2 * e + 1] += __uint_as_float(r[e] & 0xffff0000u);
+            v[2 * e] += __uint_as_float(rr[g][e] << 16);
+            v[2 * e + 1] += __uint_as_float(rr[g][e] & 0xffff0000u);
           }
         }
-      }
-      u32x4_t o;
-      if constexpr (sizeof(T) == 4) {
+        u32x4_t o;
+        if constexpr (sizeof(T) == 4) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = __float_as_uint(apply_act(v[e], p.act));
-      } else {
+          for (int e = 0; e < 4; ++e) o[e] = __float_as_uint(apply_act(v[e], p.act));
+        } else {
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
-          o[e] = (unsigned)f2bf(apply_act(v[2 * e], p.act)) | ((unsigned)f2bf(apply_act(v[2 * e + 1], p.act)) << 16);
+          for (int e = 0; e < 4; ++e)
+            o[e] = (unsigned)f2bf(apply_act(v[2 * e], p.act)) | ((unsigned)f2bf(apply_act(v[2 * e + 1], p.act)) << 16);
+        }
+        *(u32x4_t*)((T*)p.y + (size_t)pix * p.ldy + ec) = o;
       }
-      *(u32x4_t*)((T*)p.y + (size_t)pix * p.ldy + c) = o;
     }
     return;
   }
@@ -437,20 +529,23 @@ struct TileCfg {
 const TileCfg kTiles[] = {
     {1, 128, 128, 1.00f}, {2, 64, 128, 0.90f}, {3, 64, 64, 0.72f}, {4, 128, 64, 0.95f},
     {5, 128, 32, 0.55f},  {6, 16, 128, 0.30f}, {7, 32, 128, 0.55f},
+    {8, 256, 128, 1.00f}, {9, 128, 256, 1.00f},  // 8 waves, 3 stages (eff set to 1.0 until measured: kBigEff below)
 };
+inline int tile_stages(int id) { return id >= 8 ? 3 : 2; }
 constexpr int kNumTiles = sizeof(kTiles) / sizeof(kTiles[0]);
 
-template <typename T, int BC, int BP, int WC, int WP, bool UP>
+template <typename T, int BC, int BP, int WC, int WP, bool UP, int NS = 2>
 hipError_t launch_cfg(const IgemmParams& p, int nblk, hipStream_t s) {
-  constexpr int lds = 2 * (BC + BP) * 128;
+  constexpr int lds = NS * (BC + BP) * 128;
   static_assert(BP * BC * 4 <= lds, "epilogue staging must fit in the K-loop LDS");
+  static_assert(BC <= 64 * WC * WP, "tile_stats: one thread per output channel of the tile");
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)igemm_kernel<T, BC, BP, WC, WP, UP>,
+    (void)hipFuncSetAttribute((const void*)igemm_kernel<T, BC, BP, WC, WP, UP, NS>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr_set = true;
   }
-  igemm_kernel<T, BC, BP, WC, WP, UP><<<dim3(nblk), dim3(256), lds, s>>>(p);
+  igemm_kernel<T, BC, BP, WC, WP, UP, NS><<<dim3(nblk), dim3(64 * WC * WP), lds, s>>>(p);
   return hipGetLastError();
 }
 
@@ -464,6 +559,8 @@ hipError_t launch_tile(int id, const IgemmParams& p, int nblk, hipStream_t s) {
     case 5: return launch_cfg<T, 128, 32, 4, 1, UP>(p, nblk, s);
     case 6: return launch_cfg<T, 16, 128, 1, 4, UP>(p, nblk, s);
     case 7: return launch_cfg<T, 32, 128, 1, 4, UP>(p, nblk, s);
+    case 8: return launch_cfg<T, 256, 128, 4, 2, UP, 3>(p, nblk, s);
+    case 9: return launch_cfg<T, 128, 256, 2, 4, UP, 3>(p, nblk, s);
     default: return hipErrorInvalidValue;
   }
 }
@@ -547,7 +644,8 @@ Plan make_plan(const cavp_conv_desc* d) {
   // the operand fill rate of the chip (~9 TB/s global->LDS), not the MFMA pipe, is its ceiling; smaller tiles move
   // more operand bytes per flop (eff below).  Resident workgroups per CU follow from the tile's LDS footprint.
   int best = -1, best_sk = 1;
-  pl.direct_epi = (d->tile / 1000) % 10;  // d->tile = id + 1000 * (direct epilogue): testing / A-B knobs
+  pl.direct_epi = (d->tile / 1000) % 10;
+  p.dbg = (d->tile / 100) % 10 + ((d->tile / 10000) % 10) * 8 + ((d->tile / 100000) % 10) * 16;  // ten-thousands digit: issue no DMA at all  // d->tile = id + 1000 * (direct epilogue): testing / A-B knobs
   const int want_tile = d->tile % 100;
   const double peak = d->dtype == CAVP_F32 ? 100e12 : 600e12;
   const int sk_opts[] = {1, 2, 3, 4, 6, 8, 12, 16, 24, 32};
@@ -556,8 +654,9 @@ Plan make_plan(const cavp_conv_desc* d) {
     const TileCfg& t = kTiles[i];
     if (want_tile > 0 && t.id != want_tile) continue;
     const long long nwg = (long long)cdiv(p.Cout, t.BC) * cdiv(p.M, t.BP);
-    int bpc = (160 * 1024) / (2 * (t.BC + t.BP) * 128);
+    int bpc = (160 * 1024) / (tile_stages(t.id) * (t.BC + t.BP) * 128);
     if (bpc > 4) bpc = 4;
+    if (t.id >= 8 && want_tile != t.id) continue;  // big tiles: explicit request only until the time model is refitted
     const double slots = 256.0 * bpc;
     for (int sk : sk_opts) {
       if (d->splitk > 0 && sk != 1) continue;
@@ -638,7 +737,8 @@ extern "C" int cavp_conv2d_nhwc(const cavp_conv_desc* d, const void* x, const vo
              (!shift || aligned(shift, 16)) && (!nbias || aligned(nbias, 16));
   const int VE = d->dtype == CAVP_F32 ? 4 : 8;
   p.coalesced = !pl.direct_epi && p.splitk == 1 && (d->Cout % VE == 0) && (d->ldy % VE == 0) && aligned(y, 16) &&
-                (!residual || (d->ldr % VE == 0 && aligned(residual, 16)));
+                (!residual || (d->ldr % VE == 0 && aligned(residual, 16))) && (!scale || aligned(scale, 16)) &&
+                (!shift || aligned(shift, 16));
   p.tile_stats = tile_stats;
   if (tile_stats && !p.coalesced) return CAVP_ERR_UNSUPPORTED;   // see cavp_conv2d_tile_stats_layout
   hipStream_t s = (hipStream_t)stream;

@@ -72,7 +72,7 @@ CONV_CASES = [
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
 @pytest.mark.parametrize("case", CONV_CASES, ids=[c[0] for c in CONV_CASES])
-@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5, 6, 7])
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9])
 def test_conv_igemm_tiles(case, tile, dtype):
     ops = _ops()
     name, n, h, w, cin, cout, k, s, p, d = case

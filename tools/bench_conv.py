@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Micro-benchmark of cavp_conv2d_nhwc on the CAVP layer shapes (B=32, C1').  GPU box only.
 usage: python tools/bench_conv.py [--dtype bf16|f32] [--variants 0,101,1001,...] [--shapes name,...]
-A variant is the `tile` knob of cavp_conv_desc: tile id + 100*(pipe depth 1) + 1000*(direct epilogue); 0 = auto."""
+A variant is the `tile` knob of cavp_conv_desc: tile id + 100*(profiling: 1 = no operand loads, 2 = no MFMAs) + 1000*(direct epilogue); 0 = auto."""
 import argparse
 import os
 import sys

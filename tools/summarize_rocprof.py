@@ -37,6 +37,19 @@ def main():
         lines.append(f"{'calls':>7} {'total_us':>12} {'avg_us':>10} {'min_us':>9} {'max_us':>9} {'%':>6}  kernel")
         for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1]):
             lines.append(f"{v[0]:7d} {v[1]:12.1f} {v[1] / v[0]:10.2f} {v[2]:9.2f} {v[3]:9.2f} {100 * v[1] / tot:6.2f}  {k}")
+    for t in glob.glob(os.path.join(a.dir, "**", "*_results.db"), recursive=True):   # rocprofv3 default (rocpd sqlite)
+        import sqlite3
+        con = sqlite3.connect(t)
+        agg = defaultdict(lambda: [0, 0.0, 1e30, 0.0])
+        for name, dur in con.execute("select name, duration from kernels"):
+            d = dur / 1e3
+            g = agg[short(name)]
+            g[0] += 1; g[1] += d; g[2] = min(g[2], d); g[3] = max(g[3], d)
+        tot = sum(v[1] for v in agg.values())
+        lines.append(f"# kernel trace: {os.path.relpath(t, a.dir)}  total kernel time {tot / 1e3:.3f} ms")
+        lines.append(f"{'calls':>7} {'total_us':>12} {'avg_us':>10} {'min_us':>9} {'max_us':>9} {'%':>6}  kernel")
+        for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+            lines.append(f"{v[0]:7d} {v[1]:12.1f} {v[1] / v[0]:10.2f} {v[2]:9.2f} {v[3]:9.2f} {100 * v[1] / tot:6.2f}  {k}")
     for t in glob.glob(os.path.join(a.dir, "**", "*counter_collection.csv"), recursive=True):
         agg = defaultdict(lambda: defaultdict(lambda: [0, 0.0]))
         with open(t) as f:
