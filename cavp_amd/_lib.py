@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(HERE, "libcavp_hip.so")
 
 F32, BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_LEAKY, ACT_GELU = 0, 1, 2, 3
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 class CavpError(RuntimeError):
@@ -53,6 +53,7 @@ PROTOTYPES = {
     "cavp_conv2d_wgrad_workspace_bytes": (_sz, [C.POINTER(ConvDesc)]),
     "cavp_conv2d_wgrad_nhwc": (_i32, [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _sz, _vp]),
     "cavp_pack_weight_dgrad": (_i32, [_i32, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
+    "cavp_pack_weights_multi": (_i32, [_i32, _vp, _i32, _vp]),
     "cavp_unpack_weight_grad": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
     "cavp_conv3x3_smallcin_wgrad": (_i32, [_i32, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "cavp_colstats": (_i32, [_i32, _vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp]),

@@ -18,6 +18,8 @@
 // * f32: v_mfma_f32_16x16x4_f32 fragments are plain ds_read_b32 (lanes 0-15 = 16 consecutive channels of one row).
 // * X (rows = ci) is the MFMA A operand and dY (cols = co) the B operand, so a lane's 4 accumulators are 4
 //   consecutive ci of one co = 16 contiguous bytes of dW.
+#include <stdlib.h>
+
 #include "common.h"
 
 struct WgradParams {
@@ -31,6 +33,7 @@ struct WgradParams {
   int tiles_co, tiles_ci, ksplit;
   int rows_per_split;  // multiple of 64
   int x_bytes, dy_bytes;
+  int dbg;             // profiling only (env CAVP_WGRAD_DBG): 1 = loads out of range, 2 = no MFMAs, 4 = no DMA, 8 = no epilogue
   float* slabs;        // ksplit > 1: per-split partial gradients [ksplit][Cout][taps][Cin] (plain stores, then reduced)
 };
 
@@ -92,7 +95,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int pix = pixr[i];
-      const bool pok = pix < r_end;
+      const bool pok = pix < r_end && !(p.dbg & 1);
       unsigned xoff;
       bool xok = pok && ci_ok;
       if (pointwise) {
@@ -196,8 +199,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
     __syncthreads();
     int buf = 0;
     for (int r0 = r_begin; r0 < r_end; r0 += BK) {
-      if (r0 + BK < r_end) gdma(buf ^ 1);
-      compute(buf);
+      if (r0 + BK < r_end && !(p.dbg & 4)) gdma(buf ^ 1);
+      if (!(p.dbg & 2)) compute(buf);
       __syncthreads();
       buf ^= 1;
     }
@@ -206,6 +209,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
   // D[i = ci][j = co]: lane holds ci = 4*lgrp + {0..3} (rows) of co = lrow (col) in each 16x16 block = 16 contiguous
   // bytes of dW.  ksplit == 1: this workgroup owns the tile -> plain read-modify-write; otherwise plain stores into
   // this split's slab (reduced afterwards, deterministic, no atomics).
+  if (p.dbg & 8) return;
   float* out = p.ksplit > 1 ? p.slabs + (size_t)z * p.Cout * p.ntaps_all * p.Cin : p.dw;
 #pragma unroll
   for (int a = 0; a < MB; ++a) {
@@ -317,6 +321,10 @@ extern "C" int cavp_conv2d_wgrad_nhwc(const cavp_conv_desc* d, const void* x, co
   if (pl.ws_bytes > 0 && (!workspace || workspace_bytes < pl.ws_bytes || ((uintptr_t)workspace & 15))) return CAVP_ERR_WORKSPACE;
   WgradParams& p = pl.p;
   p.x = x; p.dy = dy; p.dw = dw; p.slabs = (float*)workspace;
+  {
+    static const int dbg = getenv("CAVP_WGRAD_DBG") ? atoi(getenv("CAVP_WGRAD_DBG")) : 0;
+    p.dbg = dbg;
+  }
   const int lds = 2 * 2 * 64 * 256;
   hipStream_t s = (hipStream_t)stream;
   static bool attr = false;

@@ -700,7 +700,10 @@ __global__ __launch_bounds__(256) void bcast_add_kernel(T* __restrict__ x, const
 // cross entropy (ignore_index) on NCHW f32 logits: pass 1 = per-pixel loss + valid count; pass 2 = gradient
 // ------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void ce_fwd_kernel(const float* __restrict__ logits, const long long* __restrict__ label,
-                                                     int n_img, int C, long long HW, int ignore, float* __restrict__ acc) {
+                                                     int n_img, int C, long long HW, int ignore, float* __restrict__ part) {
+  // one (loss, count) partial per workgroup, no atomics: 32 K same-address float atomics (two per wave of a 4096-block
+  // grid) serialised at ~12 ns each and made this 25 MB pass take 420 us
+  __shared__ float red[8];
   const long long total = (long long)n_img * HW;
   float loss = 0.f, cnt = 0.f;
   for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
@@ -717,9 +720,12 @@ __global__ __launch_bounds__(256) void ce_fwd_kernel(const float* __restrict__ l
   }
   loss = wave_sum(loss);
   cnt = wave_sum(cnt);
-  if ((threadIdx.x & 63) == 0) {
-    atomicAdd(acc, loss);
-    atomicAdd(acc + 1, cnt);
+  const int wv = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) { red[wv] = loss; red[4 + wv] = cnt; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    part[2 + 2 * blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+    part[3 + 2 * blockIdx.x] = (red[4] + red[5]) + (red[6] + red[7]);
   }
 }
 __global__ __launch_bounds__(256) void ce_bwd_kernel(const float* __restrict__ logits, const long long* __restrict__ label,
@@ -749,7 +755,22 @@ __global__ __launch_bounds__(256) void ce_bwd_kernel(const float* __restrict__ l
     }
   }
 }
-__global__ void ce_finish_kernel(const float* acc, float* loss) { loss[0] = acc[1] > 0.f ? acc[0] / acc[1] : 0.f; }
+__global__ __launch_bounds__(256) void ce_finish_kernel(float* acc, int nparts, float* loss) {
+  __shared__ float red[8];
+  float l = 0.f, c = 0.f;
+  for (int i = threadIdx.x; i < nparts; i += 256) { l += acc[2 + 2 * i]; c += acc[3 + 2 * i]; }
+  l = wave_sum(l);
+  c = wave_sum(c);
+  const int wv = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) { red[wv] = l; red[4 + wv] = c; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float lt = (red[0] + red[1]) + (red[2] + red[3]), ct = (red[4] + red[5]) + (red[6] + red[7]);
+    acc[0] = lt;
+    acc[1] = ct;
+    loss[0] = ct > 0.f ? lt / ct : 0.f;
+  }
+}
 
 // ------------------------------------------------------------------------------------------------------------
 // weight gradient of the small-Cin 3x3 conv (NCHW f32 input): dw[co][ci][kh][kw] += sum_p dy[p][co] * x[p @ tap]
@@ -844,7 +865,97 @@ __global__ void pack_dgrad_kernel(const float* __restrict__ w, T* __restrict__ o
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------
+// multi-tensor weight re-pack: OIHW f32 -> OHWI and/or dgrad ([Cin][rot180 taps][Cout]) in the compute dtype, every
+// job of a launch described in the kernel arguments (no device-side table, hipGraph-capturable as is).
+// A workgroup moves a 64 co x TCI ci x all-taps tile through LDS: the source is read as 64 contiguous runs of
+// TCI*KHW floats, both destinations are written in runs of >= 32 contiguous elements (the per-tensor dgrad pack read
+// its source with a Cin*KHW*4-byte stride per lane).
+// ------------------------------------------------------------------------------------------------------------
+constexpr int kPackMaxJobs = 48;
+constexpr int kPackTCO = 64, kPackRL = 144;   // co rows per tile, max floats per row (TCI * KHW <= kPackRL)
+struct PackJobDev {
+  const float* src;
+  void* ohwi;
+  void* dgrad;
+  int Cout, Cin, KHW, TCI, tiles_ci, blk0;
+};
+struct PackArgs {
+  PackJobDev j[kPackMaxJobs];
+  int njobs;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void pack_multi_kernel(const PackArgs a) {
+  __shared__ float tile[kPackTCO][kPackRL + 1];
+  int ji = 0;
+  while (ji + 1 < a.njobs && (int)blockIdx.x >= a.j[ji + 1].blk0) ++ji;   // uniform scan over <= 48 prefix sums
+  const PackJobDev& J = a.j[ji];
+  const int b = blockIdx.x - J.blk0;
+  const int tci = b % J.tiles_ci, tco = b / J.tiles_ci;
+  const int co0 = tco * kPackTCO, ci0 = tci * J.TCI;
+  const int nco = min(kPackTCO, J.Cout - co0), nci = min(J.TCI, J.Cin - ci0);
+  const int KHW = J.KHW, rl = nci * KHW;
+  // read: row r (co0 + r) = rl contiguous floats starting at (co*Cin + ci0)*KHW
+  for (int idx = threadIdx.x; idx < nco * rl; idx += 256) {
+    const int r = idx / rl, c = idx - r * rl;
+    tile[r][c] = J.src[((size_t)(co0 + r) * J.Cin + ci0) * KHW + c];
+  }
+  __syncthreads();
+  if (J.ohwi) {  // dst[(co*KHW + t)*Cin + ci]: runs of nci contiguous ci
+    T* o = (T*)J.ohwi;
+    for (int idx = threadIdx.x; idx < nco * rl; idx += 256) {
+      const int ci = idx % nci;
+      const int q = idx / nci;
+      const int t = q % KHW, r = q / KHW;
+      Elem<T>::st(o + ((size_t)(co0 + r) * KHW + t) * J.Cin + ci0 + ci, tile[r][ci * KHW + t]);
+    }
+  }
+  if (J.dgrad) {  // dst[(ci*KHW + (KHW-1-t))*Cout + co]: runs of nco contiguous co
+    T* o = (T*)J.dgrad;
+    for (int idx = threadIdx.x; idx < nco * rl; idx += 256) {
+      const int r = idx % nco;
+      const int q = idx / nco;   // = ci*KHW + t
+      const int t = q % KHW, ci = q / KHW;
+      Elem<T>::st(o + ((size_t)(ci0 + ci) * KHW + (KHW - 1 - t)) * J.Cout + co0 + r, tile[r][q]);
+    }
+  }
+}
+
 }  // namespace
+
+extern "C" int cavp_pack_weights_multi(int32_t dtype, const cavp_pack_job* jobs, int32_t njobs, void* stream) {
+  if (!jobs || njobs <= 0) return CAVP_ERR_BAD_ARG;
+  if (!dt_ok(dtype)) return CAVP_ERR_UNSUPPORTED;
+  hipStream_t s = (hipStream_t)stream;
+  for (int j0 = 0; j0 < njobs; j0 += kPackMaxJobs) {
+    PackArgs a{};
+    a.njobs = njobs - j0 < kPackMaxJobs ? njobs - j0 : kPackMaxJobs;
+    long long blk = 0;
+    for (int i = 0; i < a.njobs; ++i) {
+      const cavp_pack_job& jb = jobs[j0 + i];
+      if (!jb.w_oihw || jb.Cout <= 0 || jb.Cin <= 0 || jb.KH <= 0 || jb.KW <= 0) return CAVP_ERR_BAD_ARG;
+      PackJobDev& d = a.j[i];
+      d.src = jb.w_oihw; d.ohwi = jb.ohwi; d.dgrad = jb.dgrad;
+      d.Cout = jb.Cout; d.Cin = jb.Cin; d.KHW = jb.KH * jb.KW;
+      if (d.KHW > kPackRL) return CAVP_ERR_UNSUPPORTED;
+      int tci = kPackRL / d.KHW;
+      if (tci > 64) tci = 64;
+      d.TCI = tci;
+      d.tiles_ci = (jb.Cin + tci - 1) / tci;
+      d.blk0 = (int)blk;
+      blk += (long long)d.tiles_ci * ((jb.Cout + kPackTCO - 1) / kPackTCO);
+      if (blk > 0x7fffffffll) return CAVP_ERR_UNSUPPORTED;
+    }
+    if (dtype == CAVP_F32)
+      pack_multi_kernel<float><<<(int)blk, 256, 0, s>>>(a);
+    else
+      pack_multi_kernel<bf16_t><<<(int)blk, 256, 0, s>>>(a);
+    if (hipGetLastError() != hipSuccess) return CAVP_ERR_LAUNCH;
+  }
+  return CAVP_OK;
+}
 
 extern "C" int cavp_scale_f32(const float* in, float alpha, float* out, int32_t n, void* stream) {
   if (!in || !out || n <= 0) return CAVP_ERR_BAD_ARG;
@@ -1107,11 +1218,10 @@ extern "C" int cavp_ce_loss_nchw(const float* logits, const int64_t* labels, int
   if (!logits || !labels || !loss || !scratch2 || n_img <= 0 || n_total < n_img || C <= 0 || HW <= 0)
     return CAVP_ERR_BAD_ARG;
   hipStream_t s = (hipStream_t)stream;
-  if (hipMemsetAsync(scratch2, 0, 2 * sizeof(float), s) != hipSuccess) return CAVP_ERR_LAUNCH;
   long long nb = ((long long)n_img * HW + 255) / 256;
-  if (nb > 4096) nb = 4096;
+  if (nb > 1024) nb = 1024;   // = (CAVP_CE_SCRATCH_FLOATS - 2) / 2 partials
   ce_fwd_kernel<<<(int)nb, 256, 0, s>>>(logits, (const long long*)labels, n_img, C, HW, ignore_index, scratch2);
-  ce_finish_kernel<<<1, 1, 0, s>>>(scratch2, loss);
+  ce_finish_kernel<<<1, 256, 0, s>>>(scratch2, (int)nb, loss);
   if (dlogits) {
     long long nb2 = ((long long)n_total * HW + 255) / 256;
     if (nb2 > 8192) nb2 = 8192;

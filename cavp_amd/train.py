@@ -118,6 +118,8 @@ class TrainPass:
         self.tape: List[Callable[[], None]] = []
         self.grads: Dict[int, torch.Tensor] = {}
         self.P: Dict[str, _P] = {}
+        self._pack_jobs = []
+        self._nbt = []   # BatchNorm num_batches_tracked counters bumped once, together, at the end of the forward
         self.dev = next(model.parameters()).device
         self.named: Dict[str, V] = {}   # debug taps (activations + their gradients after backward)
 
@@ -148,10 +150,19 @@ class TrainPass:
                 ops.cast(p.bias.detach().contiguous(), bpad[:p.cout])
                 p.real_bias, p.bias = p.bias, bpad
             p.cout = cp
-        p.w = p.weight.detach() if raw else ops.pack_weight(p.weight, self.dt)
-        p.wT = T.pack_weight_dgrad(p.weight, self.dt) if (need_dgrad and not raw) else None
+        # the re-packs themselves are deferred to flush_packs(): one multi-tensor launch instead of two per layer
+        if raw:
+            p.w, p.wT = p.weight.detach(), None
+        else:
+            p.w = torch.empty((p.cout, p.kh, p.kw, p.cin), dtype=self.dt, device=self.dev)
+            p.wT = torch.empty((p.cin, p.kh, p.kw, p.cout), dtype=self.dt, device=self.dev) if need_dgrad else None
+            self._pack_jobs.append((p.weight, p.w, p.wT))
         self.P[key] = p
         return p
+
+    def flush_packs(self) -> None:
+        T.pack_weights_multi(self._pack_jobs, self.dt)
+        self._pack_jobs = []
 
     def finish_padded(self) -> None:
         for p in self.P.values():
@@ -355,7 +366,7 @@ class TrainPass:
                           bn.running_mean if track else None, bn.running_var if track else None, scale, shift, mean,
                           rstd, stat_shift=m0)
         if track and bn.num_batches_tracked is not None:
-            bn.num_batches_tracked.add_(1)
+            self._nbt.append(bn.num_batches_tracked)
         y = out if out is not None else V(self.empty(z.t.shape, z.t.dtype))
         T.scale_shift_act(z.t, scale, shift, y.t, act, residual=residual.t if residual is not None else None)
 
@@ -585,6 +596,7 @@ def run_train_forward(model, image: torch.Tensor, audio: torch.Tensor, tp: Train
         tp.pack("ca." + nme, getattr(blk.attn, nme))
     tp.pack("ca.fc1", blk.mlp.fc1)
     tp.pack("ca.fc2", blk.mlp.fc2)
+    tp.flush_packs()
 
     dt = tp.dt
     # ---- backbone (resnet.py:186-201) ----
@@ -672,6 +684,9 @@ def run_train_forward(model, image: torch.Tensor, audio: torch.Tensor, tp: Train
     lo = tp.conv(c2, "cls")   # [2B, h, w, Cpad]; channels >= num_classes are exact zeros
     tp.named.update(fusion=fusion, z0h=z0h, c1=c1, z1h=z1h, c2=c2, lo=lo, r2=r2, r1=r1, vn=vn, q=q, o=o, fea_v2=fea_v2,
                     fea_v=fea_v, f4=f4, f1=f1, fea_a=fea_a, asp=asp, cat=cat, zcat=zcat)
+    if tp._nbt:
+        torch._foreach_add_(tp._nbt, 1)   # 61 counters, one launch
+        tp._nbt = []
     return lo, fusion, fea_v_proj, fea_a, attn
 
 

@@ -107,6 +107,38 @@ def linear_wgrad(x: torch.Tensor, dy: torch.Tensor, dw: torch.Tensor) -> torch.T
     return conv2d_wgrad(xv, yv, dw, kh=1, kw=1, stride=1, pad=0, dil=1)
 
 
+CE_SCRATCH_FLOATS = 2 + 2 * 1024   # CAVP_CE_SCRATCH_FLOATS (include/cavp_hip.h)
+
+
+class PackJob(C.Structure):
+    """struct cavp_pack_job (include/cavp_hip.h)."""
+    _fields_ = [("w_oihw", C.c_void_p), ("ohwi", C.c_void_p), ("dgrad", C.c_void_p),
+                ("Cout", C.c_int32), ("Cin", C.c_int32), ("KH", C.c_int32), ("KW", C.c_int32)]
+
+
+def pack_weights_multi(jobs, dtype: torch.dtype) -> None:
+    """jobs: list of (w f32 OIHW / [out, in] contiguous, ohwi_out or None, dgrad_out or None).  One launch per 48 tensors."""
+    if not jobs:
+        return
+    arr = (PackJob * len(jobs))()
+    for i, (w, o, g) in enumerate(jobs):
+        wd = w.detach()
+        _need_gpu(wd)
+        if wd.dtype != torch.float32 or not wd.is_contiguous():
+            raise _lib.CavpError("pack_weights_multi: contiguous f32 parameters required")
+        if wd.dim() == 2:
+            cout, cin, kh, kw = wd.shape[0], wd.shape[1], 1, 1
+        else:
+            cout, cin, kh, kw = wd.shape
+        for t in (o, g):
+            if t is not None and (t.dtype != dtype or not t.is_contiguous() or t.numel() != wd.numel()):
+                raise _lib.CavpError("pack_weights_multi: destination dtype / size mismatch")
+        arr[i] = PackJob(wd.data_ptr(), o.data_ptr() if o is not None else None, g.data_ptr() if g is not None else None,
+                         cout, cin, kh, kw)
+    _check(_lib.load().cavp_pack_weights_multi(dtype_code(dtype), C.cast(arr, C.c_void_p), len(jobs), _s()),
+           "cavp_pack_weights_multi")
+
+
 def pack_weight_dgrad(w: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
     wd = w.detach()
     _need_gpu(wd)
@@ -299,7 +331,7 @@ def ce_loss(logits_nchw, labels, n_img: int, ignore_index: int = 255, grad_scale
             or not labels.is_contiguous():
         raise _lib.CavpError("ce_loss: contiguous f32 NCHW logits and int64 labels required")
     loss = torch.empty(1, dtype=torch.float32, device=logits_nchw.device)
-    scratch = torch.empty(2, dtype=torch.float32, device=logits_nchw.device)
+    scratch = torch.empty(CE_SCRATCH_FLOATS, dtype=torch.float32, device=logits_nchw.device)
     dl = torch.empty_like(logits_nchw) if want_grad else None
     _check(_lib.load().cavp_ce_loss_nchw(_ptr(logits_nchw), _ptr(labels), n_img, nt, c, h * w, ignore_index,
                                          C.c_float(grad_scale), _ptr(loss), _ptr(dl), _ptr(scratch), _s()), "cavp_ce_loss_nchw")

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define CAVP_ABI_VERSION 3
+#define CAVP_ABI_VERSION 4
 
 typedef enum { CAVP_F32 = 0, CAVP_BF16 = 1 } cavp_dtype_t;
 typedef enum { CAVP_ACT_NONE = 0, CAVP_ACT_RELU = 1, CAVP_ACT_LEAKY = 2, CAVP_ACT_GELU = 3 } cavp_act_t;
@@ -143,6 +143,17 @@ int cavp_conv2d_wgrad_nhwc(const cavp_conv_desc* d, const void* x, const void* d
                            size_t workspace_bytes, void* stream);
 
 /* OIHW f32 -> [Cin][KH][KW][Cout] (dtype), taps rotated by 180 degrees: the OHWI weight of the transposed conv. */
+/* All weight re-packs of one training step in one launch per <= 48 tensors (the per-tensor entry points cost ~170
+ * launches of ~8 us each per step, profiles/r01_notes.md): for every job, w_oihw f32 [Cout][Cin][KH][KW] ->
+ * ohwi (cavp_pack_weight_ohwi layout, may be NULL) and dgrad (cavp_pack_weight_dgrad layout, may be NULL), both `dtype`.
+ * `jobs` is a HOST array; device pointers inside. */
+typedef struct cavp_pack_job {
+  const float* w_oihw;
+  void* ohwi;
+  void* dgrad;
+  int32_t Cout, Cin, KH, KW;
+} cavp_pack_job;
+int cavp_pack_weights_multi(int32_t dtype, const cavp_pack_job* jobs, int32_t njobs, void* stream);
 int cavp_pack_weight_dgrad(int32_t dtype, const float* w_oihw, void* w_t, int32_t Cout, int32_t Cin, int32_t KH,
                            int32_t KW, void* stream);
 /* OHWI f32 gradient -> OIHW f32 (.grad layout); accumulate != 0 adds into the destination. */
@@ -209,9 +220,11 @@ int cavp_bcast_add_nhwc(int32_t dtype, void* x, const float* v, float alpha, int
                         int32_t ld, void* stream);
 /* nn.CrossEntropyLoss(ignore_index) on NCHW f32 logits of the first n_img images (loss/losser.py:60-62 applied to
  * `out[:B] + out[B:]*0`, trainer_cavp_vpo_mono.py:171,187): loss[0] = mean over valid pixels; dlogits (optional,
- * [n_total][C][HW]) = grad_scale * dloss/dlogits, zero for images >= n_img.  scratch2: 2 floats. */
+ * [n_total][C][HW]) = grad_scale * dloss/dlogits, zero for images >= n_img.  scratch: CAVP_CE_SCRATCH_FLOATS floats
+ * (per-workgroup partial sums, combined in a fixed order: the loss is bit-reproducible run to run). */
+#define CAVP_CE_SCRATCH_FLOATS (2 + 2 * 1024)
 int cavp_ce_loss_nchw(const float* logits, const int64_t* labels, int32_t n_img, int32_t n_total, int32_t C, int64_t HW,
-                      int32_t ignore_index, float grad_scale, float* loss, float* dlogits, float* scratch2,
+                      int32_t ignore_index, float grad_scale, float* loss, float* dlogits, float* scratch,
                       void* stream);
 
 /* ---- pixel-level audio-visual InfoNCE (loss/contrastive_aud.py::ContrastLoss, config #5 / SURVEY.md §8a row a13) ----

@@ -279,3 +279,32 @@ def test_fused_bn_statistics_from_conv_epilogue(shape, dt):
     _check(shift, b - m_ref * g / torch.sqrt(v_ref + 1e-5), torch.float32, "shift", 1e-4)
     _check(rm, 0.1 * m_ref, torch.float32, "running_mean", 1e-4)
     _check(rv, 0.9 + 0.1 * z.var((0, 2, 3), unbiased=True), torch.float32, "running_var", 1e-4)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_pack_weights_multi_matches_single(dtype):
+    """cavp_pack_weights_multi == cavp_pack_weight_ohwi + cavp_pack_weight_dgrad per tensor, bit for bit (ragged shapes,
+    more tensors than one launch holds)."""
+    ops, T = _mods()
+    g = torch.Generator().manual_seed(3)
+    shapes = [(64, 3, 3, 3), (70, 50, 3, 3), (256, 304, 3, 3), (304, 1216), (1216, 304), (8, 256, 1, 1), (130, 66, 1, 1),
+              (24, 40, 7, 7)] * 7   # 56 tensors > 48 per launch
+    ws = [torch.randn(s, generator=g).to(DEV) for s in shapes]
+    jobs, outs = [], []
+    for i, w in enumerate(ws):
+        if w.dim() == 2:
+            co, ci, kh, kw = w.shape[0], w.shape[1], 1, 1
+        else:
+            co, ci, kh, kw = w.shape
+        o = torch.empty((co, kh, kw, ci), dtype=dtype, device=DEV) if i % 3 != 2 else None
+        d = torch.empty((ci, kh, kw, co), dtype=dtype, device=DEV) if i % 3 != 1 else None
+        jobs.append((w, o, d))
+        outs.append((o, d))
+    T.pack_weights_multi(jobs, dtype)
+    torch.cuda.synchronize()
+    for w, (o, d) in zip(ws, outs):
+        if o is not None:
+            assert torch.equal(o, ops.pack_weight(w, dtype))
+        if d is not None:
+            assert torch.equal(d, T.pack_weight_dgrad(w, dtype))
