@@ -291,10 +291,26 @@ WgradPlan make_wgrad_plan(const cavp_conv_desc* d) {
   p.tiles_ci = (d->Cin + TCH - 1) / TCH;
   const int base = p.tiles_co * p.tiles_ci * p.ntaps;
   const int chunks = (p.M + 63) / 64;
-  // ~2 workgroups per CU, but at least 4 K iterations (256 pixel rows) per workgroup: the split count multiplies the
-  // slab traffic (ksplit x |dW| written + read), so small outputs get many splits and big outputs few.
-  int ks = d->splitk > 0 ? d->splitk : (512 + base - 1) / base;
-  if (ks > chunks / 4) ks = chunks / 4;
+  // Split count from a small time model fitted to tools/bench_wgrad.py on MI355X (profiles/r01_notes.md):
+  //   t(ks) = rounds * steps * 1.7 us  +  ks * |dW| * 8 B / 2.5 TB/s  (+ reduce launch)
+  // rounds = ceil(base * ks / 512 resident workgroups), steps = K tiles per workgroup.  The first version aimed at
+  // "about 512 workgroups" with a ceil: 540 or 513 workgroups = a second, nearly empty round (head conv 951 -> 600 us).
+  int ks = 1;
+  if (d->splitk > 0) {
+    ks = d->splitk;
+  } else {
+    const double dw_bytes = (double)d->Cout * p.ntaps * d->Cin * 4.0;
+    double best = 1e30;
+    const int ks_max = chunks / 2 > 1 ? chunks / 2 : 1;
+    for (int k = 1; k <= ks_max && k <= 512; ++k) {
+      const int steps = (chunks + k - 1) / k;
+      const int kk = (chunks + steps - 1) / steps;   // effective split count for this step count
+      const long long rounds = ((long long)base * kk + 511) / 512;
+      double t = (double)rounds * steps * 1.7e-6 + (kk > 1 ? kk * dw_bytes * 2.0 / 2.5e12 + 6e-6 : 0.0);
+      if (t < best) { best = t; ks = kk; }
+    }
+  }
+  if (ks > chunks) ks = chunks;
   if (ks < 1) ks = 1;
   const int cps = (chunks + ks - 1) / ks;
   ks = (chunks + cps - 1) / cps;
