@@ -33,6 +33,37 @@ template <> struct Elem<bf16_t> {
   __device__ static __forceinline__ void st(bf16_t* p, float v) { *p = f2bf(v); }
 };
 
+// 16-byte vector load / store of VE elements as f32
+template <typename T> struct VecT;
+template <> struct VecT<float> {
+  static constexpr int VE = 4;
+  __device__ static __forceinline__ void load(const float* p, float* v) {
+    const float4 t = *(const float4*)p;
+    v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+  }
+  __device__ static __forceinline__ void store(float* p, const float* v) { *(float4*)p = make_float4(v[0], v[1], v[2], v[3]); }
+};
+template <> struct VecT<bf16_t> {
+  static constexpr int VE = 8;
+  __device__ static __forceinline__ void load(const bf16_t* p, float* v) {
+    const uint4 t = *(const uint4*)p;
+    const unsigned u[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      v[2 * i] = __uint_as_float(u[i] << 16);
+      v[2 * i + 1] = __uint_as_float(u[i] & 0xffff0000u);
+    }
+  }
+  __device__ static __forceinline__ void store(bf16_t* p, const float* v) {
+    uint4 t;
+    t.x = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16);
+    t.y = (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
+    t.z = (unsigned)f2bf(v[4]) | ((unsigned)f2bf(v[5]) << 16);
+    t.w = (unsigned)f2bf(v[6]) | ((unsigned)f2bf(v[7]) << 16);
+    *(uint4*)p = t;
+  }
+};
+
 // activation codes = cavp_act_t in include/cavp_hip.h
 __device__ __forceinline__ float apply_act(float v, int act) {
   switch (act) {

@@ -1,0 +1,283 @@
+// nn.LayerNorm forward / backward over the last dim of [rows][C] for gfx950 (attn.py:130,136,229; pvt.py norm layers).
+//
+// HBM-bound: the forward reads x once and writes y once, the backward reads x and dy once and writes dx once.
+// * G lanes cooperate on a row (G = 8 / 16 / 32 / 64, the smallest power of two that covers C with 16-byte vectors),
+//   so a wave holds 64 / G rows: C = 64 (PVT stage 1) keeps all 64 lanes busy instead of 8.
+// * Every lane owns PLV 16-byte vectors of the row (channel (l + G i) * VE): one wide load per operand and one wide
+//   store per row instead of the 2-byte accesses of the first version (5 loads + 5 loads + 5 stores per lane per row
+//   at C = 304: 210 us per call against a 90 us HBM floor).
+// * Two-pass statistics (mean, then centred variance) in registers, reductions by xor-shuffles inside the G-lane group.
+// * gamma / beta of the lane's channels are loaded once, before the row loop.
+// * backward: dgamma / dbeta are accumulated in registers over the workgroup's rows, combined across the row groups of
+//   the wave by shuffles, across the 4 waves through LDS, and leave as one f32 atomic per channel per workgroup.
+#include "common.h"
+
+namespace {
+
+template <int G>
+__device__ __forceinline__ float group_sum(float v) {
+#pragma unroll
+  for (int o = G / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+template <typename T, int G, int PLV>
+__global__ __launch_bounds__(256) void layernorm_vec_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, T* __restrict__ y, int rows,
+                                                            int C, int ldx, int ldy, float eps) {
+  constexpr int VE = VecT<T>::VE, RW = 64 / G;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int l = lane % G, g = lane / G;
+  float ga[PLV][VE], be[PLV][VE];
+  bool ok[PLV];
+#pragma unroll
+  for (int i = 0; i < PLV; ++i) {
+    const int c = (l + G * i) * VE;
+    ok[i] = c < C;
+#pragma unroll
+    for (int q = 0; q < VE / 4; ++q) {   // 16-byte parameter loads (gamma / beta are 16-byte aligned, C % VE == 0)
+      const float4 gq = ok[i] ? *(const float4*)(gamma + c + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+      const float4 bq = ok[i] ? *(const float4*)(beta + c + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+      ga[i][4 * q] = gq.x; ga[i][4 * q + 1] = gq.y; ga[i][4 * q + 2] = gq.z; ga[i][4 * q + 3] = gq.w;
+      be[i][4 * q] = bq.x; be[i][4 * q + 1] = bq.y; be[i][4 * q + 2] = bq.z; be[i][4 * q + 3] = bq.w;
+    }
+  }
+  const float invC = 1.f / (float)C;
+  for (long long row = ((long long)blockIdx.x * 4 + wv) * RW + g; row < rows; row += (long long)gridDim.x * 4 * RW) {
+    float v[PLV][VE];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < PLV; ++i) {
+      if (ok[i]) {
+        VecT<T>::load(x + (size_t)row * ldx + (l + G * i) * VE, v[i]);
+      } else {
+#pragma unroll
+        for (int e = 0; e < VE; ++e) v[i][e] = 0.f;
+      }
+#pragma unroll
+      for (int e = 0; e < VE; ++e) s += v[i][e];
+    }
+    const float mean = group_sum<G>(s) * invC;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < PLV; ++i)
+#pragma unroll
+      for (int e = 0; e < VE; ++e) {
+        const float d = ok[i] ? v[i][e] - mean : 0.f;
+        v[i][e] = d;
+        q += d * d;
+      }
+    const float rstd = rsqrtf(group_sum<G>(q) * invC + eps);
+#pragma unroll
+    for (int i = 0; i < PLV; ++i) {
+      if (ok[i]) {
+        float o[VE];
+#pragma unroll
+        for (int e = 0; e < VE; ++e) o[e] = v[i][e] * rstd * ga[i][e] + be[i][e];
+        VecT<T>::store(y + (size_t)row * ldy + (l + G * i) * VE, o);
+      }
+    }
+  }
+}
+
+// dx = rstd * (dyg - mean(dyg) - xhat * mean(dyg * xhat)), dyg = dy * gamma;  dgamma += sum dy * xhat, dbeta += sum dy
+template <typename T, int G, int PLV>
+__global__ __launch_bounds__(256) void layernorm_bwd_vec_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+                                                                const float* __restrict__ gamma, T* __restrict__ dx,
+                                                                float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                                int rows, int C, int ld_dy, int ld_x, int ld_dx, float eps,
+                                                                int rows_per_block) {
+  constexpr int VE = VecT<T>::VE, RW = 64 / G, CW = G * PLV * VE;  // channels covered by a row group
+  __shared__ float part[2][4][CW];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int l = lane % G, g = lane / G;
+  float ga[PLV][VE], ag[PLV][VE], ab[PLV][VE];
+  bool ok[PLV];
+#pragma unroll
+  for (int i = 0; i < PLV; ++i) {
+    const int c = (l + G * i) * VE;
+    ok[i] = c < C;
+#pragma unroll
+    for (int q = 0; q < VE / 4; ++q) {
+      const float4 gq = ok[i] ? *(const float4*)(gamma + c + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+      ga[i][4 * q] = gq.x; ga[i][4 * q + 1] = gq.y; ga[i][4 * q + 2] = gq.z; ga[i][4 * q + 3] = gq.w;
+    }
+#pragma unroll
+    for (int e = 0; e < VE; ++e) ag[i][e] = ab[i][e] = 0.f;
+  }
+  const float invC = 1.f / (float)C;
+  const int r_begin = blockIdx.x * rows_per_block;
+  int r_end = r_begin + rows_per_block;
+  if (r_end > rows) r_end = rows;
+  for (int row = r_begin + wv * RW + g; row < r_end; row += 4 * RW) {
+    float xv[PLV][VE], dv[PLV][VE];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < PLV; ++i) {
+      if (ok[i]) {
+        VecT<T>::load(x + (size_t)row * ld_x + (l + G * i) * VE, xv[i]);
+        VecT<T>::load(dy + (size_t)row * ld_dy + (l + G * i) * VE, dv[i]);
+      } else {
+#pragma unroll
+        for (int e = 0; e < VE; ++e) xv[i][e] = dv[i][e] = 0.f;
+      }
+#pragma unroll
+      for (int e = 0; e < VE; ++e) s += xv[i][e];
+    }
+    const float mean = group_sum<G>(s) * invC;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < PLV; ++i)
+#pragma unroll
+      for (int e = 0; e < VE; ++e) {
+        const float d = ok[i] ? xv[i][e] - mean : 0.f;
+        xv[i][e] = d;
+        q += d * d;
+      }
+    const float rstd = rsqrtf(group_sum<G>(q) * invC + eps);
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < PLV; ++i)
+#pragma unroll
+      for (int e = 0; e < VE; ++e) {
+        const float xh = xv[i][e] * rstd;       // (padding lanes: 0)
+        const float dg = dv[i][e] * ga[i][e];
+        s1 += dg;
+        s2 += dg * xh;
+        ag[i][e] += dv[i][e] * xh;
+        ab[i][e] += dv[i][e];
+        xv[i][e] = xh;
+        dv[i][e] = dg;
+      }
+    s1 = group_sum<G>(s1) * invC;
+    s2 = group_sum<G>(s2) * invC;
+#pragma unroll
+    for (int i = 0; i < PLV; ++i) {
+      if (ok[i]) {
+        float o[VE];
+#pragma unroll
+        for (int e = 0; e < VE; ++e) o[e] = rstd * (dv[i][e] - s1 - xv[i][e] * s2);
+        VecT<T>::store(dx + (size_t)row * ld_dx + (l + G * i) * VE, o);
+      }
+    }
+  }
+  // combine the RW row groups of the wave (lanes l, l+G, l+2G ... hold the same channels), then the 4 waves
+#pragma unroll
+  for (int i = 0; i < PLV; ++i)
+#pragma unroll
+    for (int e = 0; e < VE; ++e) {
+      float a = ag[i][e], b = ab[i][e];
+#pragma unroll
+      for (int o = G; o < 64; o <<= 1) {
+        a += __shfl_xor(a, o, 64);
+        b += __shfl_xor(b, o, 64);
+      }
+      if (g == 0) {
+        part[0][wv][(l + G * i) * VE + e] = a;
+        part[1][wv][(l + G * i) * VE + e] = b;
+      }
+    }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * C; i += 256) {
+    const int st = i / C, c = i - st * C;
+    const float s = (part[st][0][c] + part[st][1][c]) + (part[st][2][c] + part[st][3][c]);
+    atomicAdd((st == 0 ? dgamma : dbeta) + c, s);
+  }
+}
+
+inline bool dt_ok(int dt) { return dt == CAVP_F32 || dt == CAVP_BF16; }
+inline bool al16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+
+// (G, PLV) for C channels of VE-element vectors; 0 if C is too wide
+inline bool ln_geometry(int C, int VE, int* G, int* PLV) {
+  const int vecs = (C + VE - 1) / VE;
+  int plv = (vecs + 63) / 64;
+  if (plv == 4) plv = 5;
+  if (plv > 5) return false;
+  int need = (vecs + plv - 1) / plv, g = 8;
+  while (g < need) g <<= 1;
+  if (plv > 1) g = 64;
+  *G = g;
+  *PLV = plv;
+  return true;
+}
+
+}  // namespace
+
+#define LN_DISPATCH(KERNEL_CALL)                                                     \
+  switch (G * 10 + PLV) {                                                            \
+    case 81: KERNEL_CALL(8, 1); break;                                               \
+    case 161: KERNEL_CALL(16, 1); break;                                             \
+    case 321: KERNEL_CALL(32, 1); break;                                             \
+    case 641: KERNEL_CALL(64, 1); break;                                             \
+    case 642: KERNEL_CALL(64, 2); break;                                             \
+    case 643: KERNEL_CALL(64, 3); break;                                             \
+    case 645: KERNEL_CALL(64, 5); break;                                             \
+    default: return CAVP_ERR_UNSUPPORTED;                                            \
+  }
+
+// bf16: 5 vectors per lane would need an 80 KiB LDS partial array in the backward; C <= 1536 covers every norm layer
+#define LN_DISPATCH_BF16(KERNEL_CALL)                                                \
+  switch (G * 10 + PLV) {                                                            \
+    case 81: KERNEL_CALL(8, 1); break;                                               \
+    case 161: KERNEL_CALL(16, 1); break;                                             \
+    case 321: KERNEL_CALL(32, 1); break;                                             \
+    case 641: KERNEL_CALL(64, 1); break;                                             \
+    case 642: KERNEL_CALL(64, 2); break;                                             \
+    case 643: KERNEL_CALL(64, 3); break;                                             \
+    default: return CAVP_ERR_UNSUPPORTED;                                            \
+  }
+
+extern "C" int cavp_layernorm(int32_t dtype, const void* x, const float* gamma, const float* beta, void* y,
+                              int32_t rows, int32_t C, int32_t ldx, int32_t ldy, float eps, void* stream) {
+  if (!x || !gamma || !beta || !y || rows <= 0 || C <= 0 || ldx < C || ldy < C) return CAVP_ERR_BAD_ARG;
+  if (!dt_ok(dtype)) return CAVP_ERR_UNSUPPORTED;
+  const int VE = dtype == CAVP_F32 ? 4 : 8;
+  if (C % VE || ldx % VE || ldy % VE) return CAVP_ERR_UNSUPPORTED;
+  if (!al16(x) || !al16(y) || !al16(gamma) || !al16(beta)) return CAVP_ERR_ALIGN;
+  int G, PLV;
+  if (!ln_geometry(C, VE, &G, &PLV)) return CAVP_ERR_UNSUPPORTED;
+  const int rpb = 4 * (64 / G);
+  long long nbl = ((long long)rows + rpb - 1) / rpb;
+  if (nbl > 8192) nbl = 8192;
+  const int nb = (int)nbl;
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == CAVP_F32) {
+#define CALL(g, p) layernorm_vec_kernel<float, g, p><<<nb, 256, 0, s>>>((const float*)x, gamma, beta, (float*)y, rows, C, ldx, ldy, eps)
+    LN_DISPATCH(CALL)
+#undef CALL
+  } else {
+#define CALL(g, p) layernorm_vec_kernel<bf16_t, g, p><<<nb, 256, 0, s>>>((const bf16_t*)x, gamma, beta, (bf16_t*)y, rows, C, ldx, ldy, eps)
+    LN_DISPATCH_BF16(CALL)
+#undef CALL
+  }
+  return hipGetLastError() == hipSuccess ? CAVP_OK : CAVP_ERR_LAUNCH;
+}
+
+extern "C" int cavp_layernorm_bwd(int32_t dtype, const void* dy, const void* x, const float* gamma, void* dx,
+                                  float* dgamma, float* dbeta, int32_t rows, int32_t C, int32_t ld_dy, int32_t ld_x,
+                                  int32_t ld_dx, float eps, void* stream) {
+  if (!dy || !x || !gamma || !dx || !dgamma || !dbeta || rows <= 0 || C <= 0) return CAVP_ERR_BAD_ARG;
+  if (!dt_ok(dtype)) return CAVP_ERR_UNSUPPORTED;
+  const int VE = dtype == CAVP_F32 ? 4 : 8;
+  if (C % VE || ld_dy % VE || ld_x % VE || ld_dx % VE) return CAVP_ERR_UNSUPPORTED;
+  if (!al16(x) || !al16(dy) || !al16(dx) || !al16(gamma)) return CAVP_ERR_ALIGN;
+  int G, PLV;
+  if (!ln_geometry(C, VE, &G, &PLV)) return CAVP_ERR_UNSUPPORTED;
+  const int rpi = 4 * (64 / G);  // rows per workgroup iteration
+  int gx = 1024;
+  int rpb = (rows + gx - 1) / gx;
+  rpb = (rpb + rpi - 1) / rpi * rpi;
+  gx = (rows + rpb - 1) / rpb;
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == CAVP_F32) {
+#define CALL(g, p) layernorm_bwd_vec_kernel<float, g, p><<<gx, 256, 0, s>>>((const float*)dy, (const float*)x, gamma, (float*)dx, dgamma, dbeta, rows, C, ld_dy, ld_x, ld_dx, eps, rpb)
+    LN_DISPATCH(CALL)
+#undef CALL
+  } else {
+#define CALL(g, p) layernorm_bwd_vec_kernel<bf16_t, g, p><<<gx, 256, 0, s>>>((const bf16_t*)dy, (const bf16_t*)x, gamma, (bf16_t*)dx, dgamma, dbeta, rows, C, ld_dy, ld_x, ld_dx, eps, rpb)
+    LN_DISPATCH_BF16(CALL)
+#undef CALL
+  }
+  return hipGetLastError() == hipSuccess ? CAVP_OK : CAVP_ERR_LAUNCH;
+}

@@ -233,34 +233,6 @@ __global__ __launch_bounds__(256) void bilinear_to_nchw_kernel(const T* __restri
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// LayerNorm: one wave per row, two-pass statistics (mean, then centred variance) with wave shuffles
-// ------------------------------------------------------------------------------------------------------------
-template <typename T>
-__global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
-                                                        const float* __restrict__ beta, T* __restrict__ y, int rows,
-                                                        int C, int ldx, int ldy, float eps) {
-  const int lane = threadIdx.x & 63;
-  const int wpb = 4;
-  for (long long row = blockIdx.x * (long long)wpb + (threadIdx.x >> 6); row < rows; row += (long long)gridDim.x * wpb) {
-    const T* xp = x + (size_t)row * ldx;
-    float s = 0.f;
-    for (int c = lane; c < C; c += 64) s += Elem<T>::ld(xp + c);
-    const float mean = wave_sum(s) / (float)C;
-    float q = 0.f;
-    for (int c = lane; c < C; c += 64) {
-      const float d = Elem<T>::ld(xp + c) - mean;
-      q += d * d;
-    }
-    const float rstd = rsqrtf(wave_sum(q) / (float)C + eps);
-    T* yp = y + (size_t)row * ldy;
-    for (int c = lane; c < C; c += 64) {
-      const float v = (Elem<T>::ld(xp + c) - mean) * rstd * gamma[c] + beta[c];
-      Elem<T>::st(yp + c, v);
-    }
-  }
-}
-
-// ------------------------------------------------------------------------------------------------------------
 // sigmoid attention gate with a single key/value token: one wave per (b, t)
 // ------------------------------------------------------------------------------------------------------------
 template <typename T>
@@ -418,19 +390,6 @@ extern "C" int cavp_bilinear_nhwc_to_nchw(int32_t dtype, const void* x, float* y
     bilinear_to_nchw_kernel<float><<<nb, 256, 0, s>>>((const float*)x, y, N, Hi, Wi, C, ldx, Ho, Wo, align_corners);
   else
     bilinear_to_nchw_kernel<bf16_t><<<nb, 256, 0, s>>>((const bf16_t*)x, y, N, Hi, Wi, C, ldx, Ho, Wo, align_corners);
-  CHECK_LAUNCH();
-}
-
-extern "C" int cavp_layernorm(int32_t dtype, const void* x, const float* gamma, const float* beta, void* y,
-                              int32_t rows, int32_t C, int32_t ldx, int32_t ldy, float eps, void* stream) {
-  if (!x || !gamma || !beta || !y || rows <= 0 || C <= 0 || ldx < C || ldy < C) return CAVP_ERR_BAD_ARG;
-  if (!dtype_ok(dtype)) return CAVP_ERR_UNSUPPORTED;
-  const int nb = nblocks(rows, 4, 16384);
-  hipStream_t s = (hipStream_t)stream;
-  if (dtype == CAVP_F32)
-    layernorm_kernel<float><<<nb, 256, 0, s>>>((const float*)x, gamma, beta, (float*)y, rows, C, ldx, ldy, eps);
-  else
-    layernorm_kernel<bf16_t><<<nb, 256, 0, s>>>((const bf16_t*)x, gamma, beta, (bf16_t*)y, rows, C, ldx, ldy, eps);
   CHECK_LAUNCH();
 }
 

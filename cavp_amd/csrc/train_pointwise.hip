@@ -7,36 +7,6 @@
 
 namespace {
 
-template <typename T> struct VecT;
-template <> struct VecT<float> {
-  static constexpr int VE = 4;
-  __device__ static __forceinline__ void load(const float* p, float* v) {
-    const float4 t = *(const float4*)p;
-    v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
-  }
-  __device__ static __forceinline__ void store(float* p, const float* v) { *(float4*)p = make_float4(v[0], v[1], v[2], v[3]); }
-};
-template <> struct VecT<bf16_t> {
-  static constexpr int VE = 8;
-  __device__ static __forceinline__ void load(const bf16_t* p, float* v) {
-    const uint4 t = *(const uint4*)p;
-    const unsigned u[4] = {t.x, t.y, t.z, t.w};
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      v[2 * i] = __uint_as_float(u[i] << 16);
-      v[2 * i + 1] = __uint_as_float(u[i] & 0xffff0000u);
-    }
-  }
-  __device__ static __forceinline__ void store(bf16_t* p, const float* v) {
-    uint4 t;
-    t.x = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16);
-    t.y = (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
-    t.z = (unsigned)f2bf(v[4]) | ((unsigned)f2bf(v[5]) << 16);
-    t.w = (unsigned)f2bf(v[6]) | ((unsigned)f2bf(v[7]) << 16);
-    *(uint4*)p = t;
-  }
-};
-
 __device__ __forceinline__ float act_grad_from_out(float y, int act) {  // d act(x)/dx expressed through y = act(x)
   switch (act) {
     case CAVP_ACT_RELU: return y > 0.f ? 1.f : 0.f;
@@ -364,80 +334,6 @@ __global__ __launch_bounds__(256) void add_kernel(const T* __restrict__ a, const
 #pragma unroll
     for (int e = 0; e < VE; ++e) x[e] += y[e];
     VecT<T>::store(o + i, x);
-  }
-}
-
-// ------------------------------------------------------------------------------------------------------------
-// LayerNorm backward: one wave per row.  dx = rstd * (dyg - mean(dyg) - xhat * mean(dyg * xhat)), dyg = dy * gamma
-// dgamma += sum_rows dy * xhat, dbeta += sum_rows dy  (per-block LDS partials, one atomic per channel per block)
-// ------------------------------------------------------------------------------------------------------------
-template <typename T, int MAXC>
-__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
-                                                            const float* __restrict__ gamma, T* __restrict__ dx,
-                                                            float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                            int rows, int C, int ld_dy, int ld_x, int ld_dx, float eps,
-                                                            int rows_per_block) {
-  constexpr int PL = MAXC / 64;  // channels per lane
-  __shared__ float part[2][4][MAXC];
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  float ag[PL], ab[PL];
-#pragma unroll
-  for (int i = 0; i < PL; ++i) ag[i] = ab[i] = 0.f;
-  const int r_begin = blockIdx.x * rows_per_block;
-  int r_end = r_begin + rows_per_block;
-  if (r_end > rows) r_end = rows;
-  for (int r = r_begin + wv; r < r_end; r += 4) {
-    float xv[PL], dv[PL];
-    float s = 0.f;
-#pragma unroll
-    for (int i = 0; i < PL; ++i) {
-      const int c = lane + 64 * i;
-      xv[i] = c < C ? Elem<T>::ld(x + (size_t)r * ld_x + c) : 0.f;
-      dv[i] = c < C ? Elem<T>::ld(dy + (size_t)r * ld_dy + c) : 0.f;
-      s += xv[i];
-    }
-    const float mean = wave_sum(s) / (float)C;
-    float q = 0.f;
-#pragma unroll
-    for (int i = 0; i < PL; ++i) {
-      const int c = lane + 64 * i;
-      const float d = c < C ? xv[i] - mean : 0.f;
-      q += d * d;
-    }
-    const float rstd = rsqrtf(wave_sum(q) / (float)C + eps);
-    float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-    for (int i = 0; i < PL; ++i) {
-      const int c = lane + 64 * i;
-      if (c < C) {
-        const float xh = (xv[i] - mean) * rstd;
-        const float dg = dv[i] * gamma[c];
-        s1 += dg;
-        s2 += dg * xh;
-        ag[i] += dv[i] * xh;
-        ab[i] += dv[i];
-        xv[i] = xh;
-        dv[i] = dg;
-      }
-    }
-    s1 = wave_sum(s1) / (float)C;
-    s2 = wave_sum(s2) / (float)C;
-#pragma unroll
-    for (int i = 0; i < PL; ++i) {
-      const int c = lane + 64 * i;
-      if (c < C) Elem<T>::st(dx + (size_t)r * ld_dx + c, rstd * (dv[i] - s1 - xv[i] * s2));
-    }
-  }
-#pragma unroll
-  for (int i = 0; i < PL; ++i) {
-    part[0][wv][lane + 64 * i] = ag[i];
-    part[1][wv][lane + 64 * i] = ab[i];
-  }
-  __syncthreads();
-  for (int i = threadIdx.x; i < 2 * C; i += 256) {
-    const int st = i / C, c = i - st * C;
-    const float s = part[st][0][c] + part[st][1][c] + part[st][2][c] + part[st][3][c];
-    atomicAdd((st == 0 ? dgamma : dbeta) + c, s);
   }
 }
 
@@ -1098,27 +994,6 @@ extern "C" int cavp_colsum(int32_t dtype, const void* x, int64_t rows, int32_t C
   ColArgs a{};
   a.a = x; a.out0 = out; a.out1 = out; a.rows = (int)rows; a.C = C; a.lda = ldx;
   return launch_col_reduce<2>(dtype, a, (hipStream_t)stream);
-}
-
-extern "C" int cavp_layernorm_bwd(int32_t dtype, const void* dy, const void* x, const float* gamma, void* dx,
-                                  float* dgamma, float* dbeta, int32_t rows, int32_t C, int32_t ld_dy, int32_t ld_x,
-                                  int32_t ld_dx, float eps, void* stream) {
-  if (!dy || !x || !gamma || !dx || !dgamma || !dbeta || rows <= 0 || C <= 0) return CAVP_ERR_BAD_ARG;
-  if (!dt_ok(dtype) || C > 1280) return CAVP_ERR_UNSUPPORTED;
-  int gx = 1024;
-  int rpb = (rows + gx - 1) / gx;
-  if (rpb < 4) rpb = 4;
-  rpb = (rpb + 3) / 4 * 4;
-  gx = (rows + rpb - 1) / rpb;
-  hipStream_t s = (hipStream_t)stream;
-#define LN_BWD(T, MAXC) layernorm_bwd_kernel<T, MAXC><<<gx, 256, 0, s>>>((const T*)dy, (const T*)x, gamma, (T*)dx, dgamma, dbeta, rows, C, ld_dy, ld_x, ld_dx, eps, rpb)
-  if (dtype == CAVP_F32) {
-    if (C <= 320) LN_BWD(float, 320); else LN_BWD(float, 1280);
-  } else {
-    if (C <= 320) LN_BWD(bf16_t, 320); else LN_BWD(bf16_t, 1280);
-  }
-#undef LN_BWD
-  CHECK_LAUNCH();
 }
 
 extern "C" int cavp_attn_gate_bwd(int32_t dtype, const void* dout, const void* q, const void* k, const void* v,

@@ -208,7 +208,7 @@ def test_bilinear_to_nchw(C, dtype):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
-@pytest.mark.parametrize("rows,C", [(3136, 304), (2, 304), (17, 1216), (5, 64)])
+@pytest.mark.parametrize("rows,C", [(3136, 304), (2, 304), (17, 1216), (5, 64), (1031, 64), (77, 128), (9, 112), (33, 320), (130, 512)])
 def test_layernorm(rows, C, dtype):
     ops = _ops()
     x = _rand(rows, C, seed=26) * 3 + 1

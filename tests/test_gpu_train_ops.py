@@ -148,7 +148,7 @@ def test_act_bwd_colsum_add(dt):
 
 
 @pytest.mark.parametrize("dt", DTYPES, ids=IDS)
-@pytest.mark.parametrize("rows,C", [(3136 * 2, 304), (3, 304), (50, 1216)])
+@pytest.mark.parametrize("rows,C", [(3136 * 2, 304), (3, 304), (50, 1216), (1031, 64), (77, 128), (130, 512)])
 def test_layernorm_bwd(rows, C, dt):
     ops, T = _mods()
     x = _q(_rand(rows, C, seed=16) * 2 + 0.3, dt).requires_grad_(True)
