@@ -232,34 +232,6 @@ __global__ __launch_bounds__(256) void bilinear_to_nchw_kernel(const T* __restri
   }
 }
 
-// ------------------------------------------------------------------------------------------------------------
-// sigmoid attention gate with a single key/value token: one wave per (b, t)
-// ------------------------------------------------------------------------------------------------------------
-template <typename T>
-__global__ __launch_bounds__(256) void attn_gate_kernel(const T* __restrict__ q, const T* __restrict__ k,
-                                                        const T* __restrict__ v, T* __restrict__ o,
-                                                        float* __restrict__ attn, int B, int Tn, int heads, int hd,
-                                                        float scale) {
-  const int lane = threadIdx.x & 63;
-  const int C = heads * hd;
-  const long long rows = (long long)B * Tn;
-  for (long long row = blockIdx.x * 4ll + (threadIdx.x >> 6); row < rows; row += (long long)gridDim.x * 4) {
-    const int b = (int)(row / Tn), t = (int)(row - (long long)b * Tn);
-    const T* qp = q + (size_t)row * C;
-    const T* kp = k + (size_t)b * C;
-    const T* vp = v + (size_t)b * C;
-    T* op = o + (size_t)row * C;
-    for (int h = 0; h < heads; ++h) {
-      float s = 0.f;
-      for (int d = lane; d < hd; d += 64) s += Elem<T>::ld(qp + h * hd + d) * Elem<T>::ld(kp + h * hd + d);
-      s = wave_sum(s) * scale;
-      const float g = 1.f / (1.f + expf(-s));
-      if (lane == 0) attn[((size_t)b * heads + h) * Tn + t] = g;
-      for (int d = lane; d < hd; d += 64) Elem<T>::st(op + h * hd + d, g * Elem<T>::ld(vp + h * hd + d));
-    }
-  }
-}
-
 __global__ void bn_fold_kernel(const float* gamma, const float* beta, const float* mean, const float* var, float eps,
                                float* scale, float* shift, int C) {
   const int c = blockIdx.x * 256 + threadIdx.x;
@@ -390,19 +362,6 @@ extern "C" int cavp_bilinear_nhwc_to_nchw(int32_t dtype, const void* x, float* y
     bilinear_to_nchw_kernel<float><<<nb, 256, 0, s>>>((const float*)x, y, N, Hi, Wi, C, ldx, Ho, Wo, align_corners);
   else
     bilinear_to_nchw_kernel<bf16_t><<<nb, 256, 0, s>>>((const bf16_t*)x, y, N, Hi, Wi, C, ldx, Ho, Wo, align_corners);
-  CHECK_LAUNCH();
-}
-
-extern "C" int cavp_attn_gate(int32_t dtype, const void* q, const void* k, const void* v, void* o, float* attn,
-                              int32_t B, int32_t T, int32_t heads, int32_t hd, float scale, void* stream) {
-  if (!q || !k || !v || !o || !attn || B <= 0 || T <= 0 || heads <= 0 || hd <= 0) return CAVP_ERR_BAD_ARG;
-  if (!dtype_ok(dtype)) return CAVP_ERR_UNSUPPORTED;
-  const int nb = nblocks((long long)B * T, 4, 16384);
-  hipStream_t s = (hipStream_t)stream;
-  if (dtype == CAVP_F32)
-    attn_gate_kernel<float><<<nb, 256, 0, s>>>((const float*)q, (const float*)k, (const float*)v, (float*)o, attn, B, T, heads, hd, scale);
-  else
-    attn_gate_kernel<bf16_t><<<nb, 256, 0, s>>>((const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)o, attn, B, T, heads, hd, scale);
   CHECK_LAUNCH();
 }
 

@@ -338,81 +338,6 @@ __global__ __launch_bounds__(256) void add_kernel(const T* __restrict__ a, const
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// attention-gate backward (single key/value token).  grid = (chunks, B); one wave per token.
-//   ds_h = <do_h, v_h> (+ dattn);  da = ds * s (1 - s);  dq = da * scale * k;  dk += da * scale * q;  dv += s * do
-// ------------------------------------------------------------------------------------------------------------
-template <typename T, int MAXC>
-__global__ __launch_bounds__(256) void attn_gate_bwd_kernel(const T* __restrict__ dout, const T* __restrict__ q,
-                                                            const T* __restrict__ k, const T* __restrict__ v,
-                                                            const float* __restrict__ attn,
-                                                            const float* __restrict__ dattn, T* __restrict__ dq,
-                                                            float* __restrict__ dk, float* __restrict__ dv, int Tn,
-                                                            int heads, int hd, float scale, int tok_per_block) {
-  constexpr int PL = MAXC / 64;
-  __shared__ float part[2][4][MAXC];
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, b = blockIdx.y;
-  const int C = heads * hd;
-  float kk[PL], vv[PL], adk[PL], adv[PL];
-  int hh[PL];
-#pragma unroll
-  for (int i = 0; i < PL; ++i) {
-    const int c = lane + 64 * i;
-    kk[i] = c < C ? Elem<T>::ld(k + (size_t)b * C + c) : 0.f;
-    vv[i] = c < C ? Elem<T>::ld(v + (size_t)b * C + c) : 0.f;
-    hh[i] = c < C ? c / hd : -1;
-    adk[i] = adv[i] = 0.f;
-  }
-  const int t_begin = blockIdx.x * tok_per_block;
-  int t_end = t_begin + tok_per_block;
-  if (t_end > Tn) t_end = Tn;
-  for (int t = t_begin + wv; t < t_end; t += 4) {
-    const size_t row = ((size_t)b * Tn + t) * C;
-    float dd[PL], qq[PL];
-#pragma unroll
-    for (int i = 0; i < PL; ++i) {
-      const int c = lane + 64 * i;
-      dd[i] = c < C ? Elem<T>::ld(dout + row + c) : 0.f;
-      qq[i] = c < C ? Elem<T>::ld(q + row + c) : 0.f;
-    }
-    float da_h[8];
-    for (int h = 0; h < heads; ++h) {
-      float s = 0.f;
-#pragma unroll
-      for (int i = 0; i < PL; ++i) s += (hh[i] == h) ? dd[i] * vv[i] : 0.f;
-      s = wave_sum(s);
-      const size_t ai = ((size_t)b * heads + h) * Tn + t;
-      if (dattn) s += dattn[ai];
-      const float g = attn[ai];
-      da_h[h] = s * g * (1.f - g) * scale;
-#pragma unroll
-      for (int i = 0; i < PL; ++i)
-        if (hh[i] == h) adv[i] += g * dd[i];
-    }
-#pragma unroll
-    for (int i = 0; i < PL; ++i) {
-      const int c = lane + 64 * i;
-      if (c < C) {
-        float da = 0.f;
-        for (int h = 0; h < heads; ++h) da = (hh[i] == h) ? da_h[h] : da;
-        Elem<T>::st(dq + row + c, da * kk[i]);
-        adk[i] += da * qq[i];
-      }
-    }
-  }
-#pragma unroll
-  for (int i = 0; i < PL; ++i) {
-    part[0][wv][lane + 64 * i] = adk[i];
-    part[1][wv][lane + 64 * i] = adv[i];
-  }
-  __syncthreads();
-  for (int i = threadIdx.x; i < 2 * C; i += 256) {
-    const int st = i / C, c = i - st * C;
-    const float s = part[st][0][c] + part[st][1][c] + part[st][2][c] + part[st][3][c];
-    atomicAdd((st == 0 ? dk : dv) + (size_t)b * C + c, s);
-  }
-}
-
-// ------------------------------------------------------------------------------------------------------------
 // max pool backward (gather form, deterministic): dx[p] = sum over windows containing p whose first arg-max is p
 // ------------------------------------------------------------------------------------------------------------
 template <typename T>
@@ -994,26 +919,6 @@ extern "C" int cavp_colsum(int32_t dtype, const void* x, int64_t rows, int32_t C
   ColArgs a{};
   a.a = x; a.out0 = out; a.out1 = out; a.rows = (int)rows; a.C = C; a.lda = ldx;
   return launch_col_reduce<2>(dtype, a, (hipStream_t)stream);
-}
-
-extern "C" int cavp_attn_gate_bwd(int32_t dtype, const void* dout, const void* q, const void* k, const void* v,
-                                  const float* attn, const float* dattn, void* dq, float* dk, float* dv, int32_t B,
-                                  int32_t T, int32_t heads, int32_t hd, float scale, void* stream) {
-  if (!dout || !q || !k || !v || !attn || !dq || !dk || !dv || B <= 0 || T <= 0 || heads <= 0 || hd <= 0)
-    return CAVP_ERR_BAD_ARG;
-  if (!dt_ok(dtype) || heads > 8 || heads * hd > 320) return CAVP_ERR_UNSUPPORTED;
-  int gx = 2048 / B;
-  if (gx < 1) gx = 1;
-  int tpb = (T + gx - 1) / gx;
-  if (tpb < 4) tpb = 4;
-  tpb = (tpb + 3) / 4 * 4;
-  gx = (T + tpb - 1) / tpb;
-  hipStream_t s = (hipStream_t)stream;
-  if (dtype == CAVP_F32)
-    attn_gate_bwd_kernel<float, 320><<<dim3(gx, B), 256, 0, s>>>((const float*)dout, (const float*)q, (const float*)k, (const float*)v, attn, dattn, (float*)dq, dk, dv, T, heads, hd, scale, tpb);
-  else
-    attn_gate_bwd_kernel<bf16_t, 320><<<dim3(gx, B), 256, 0, s>>>((const bf16_t*)dout, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, attn, dattn, (bf16_t*)dq, dk, dv, T, heads, hd, scale, tpb);
-  CHECK_LAUNCH();
 }
 
 extern "C" int cavp_maxpool_bwd_nhwc(int32_t dtype, const void* x, const void* dy, void* dx, int32_t N, int32_t H,
