@@ -40,7 +40,7 @@ PROTOTYPES = {
     "cavp_conv2d_tile_stats_layout": (_i32, [C.POINTER(ConvDesc), C.POINTER(_i32), C.POINTER(_i32)]),
     "cavp_bn_finalize_tiles": (_i32, [_vp, _i32, _i32, _i64, _vp, _vp, _f32, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp]),
     "cavp_conv3x3_smallcin_nchw": (_i32, [_i32, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
-    "cavp_maxpool_nhwc": (_i32, [_i32, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "cavp_maxpool_nhwc": (_i32, [_i32, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "cavp_global_avgpool_nhwc": (_i32, [_i32, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "cavp_bilinear_nhwc": (_i32, [_i32, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "cavp_bilinear_nhwc_to_nchw": (_i32, [_i32, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
@@ -55,7 +55,8 @@ PROTOTYPES = {
     "cavp_pack_weight_dgrad": (_i32, [_i32, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "cavp_pack_weights_multi": (_i32, [_i32, _vp, _i32, _vp]),
     "cavp_unpack_weight_grad": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
-    "cavp_conv3x3_smallcin_wgrad": (_i32, [_i32, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "cavp_conv3x3_smallcin_wgrad": (_i32, [_i32, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, C.c_size_t, _vp]),
+    "cavp_conv3x3_smallcin_wgrad_workspace_bytes": (C.c_size_t, [_i32, _i32, _i32, _i32, _i32, _i32, _i32]),
     "cavp_colstats": (_i32, [_i32, _vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp]),
     "cavp_scale_f32": (_i32, [_vp, _f32, _vp, _i32, _vp]),
     "cavp_bn_finalize": (_i32, [_vp, _vp, _vp, _i64, _vp, _vp, _f32, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp]),

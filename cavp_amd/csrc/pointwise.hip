@@ -105,7 +105,8 @@ __global__ __launch_bounds__(256) void conv3x3_smallcin_kernel(const float* __re
 // max pool NHWC.  thread = (output pixel, 16-byte channel vector)
 // ------------------------------------------------------------------------------------------------------------
 template <typename T>
-__global__ __launch_bounds__(256) void maxpool_kernel(const T* __restrict__ x, T* __restrict__ y, int N, int H, int W,
+__global__ __launch_bounds__(256) void maxpool_kernel(const T* __restrict__ x, T* __restrict__ y,
+                                                      unsigned char* __restrict__ argmax, int N, int H, int W,
                                                       int C, int k, int stride, int pad, int Ho, int Wo) {
   constexpr int VE = Vec<T>::VE;
   const int CV = C / VE;
@@ -117,8 +118,10 @@ __global__ __launch_bounds__(256) void maxpool_kernel(const T* __restrict__ x, T
     const int ho = (int)((pix / Wo) % Ho);
     const int n = (int)(pix / ((long long)Wo * Ho));
     float m[VE];
+    int am[VE];   // window-relative position kh * k + kw of the FIRST maximum (strict >, scan order: as ATen)
+    bool first = true;
 #pragma unroll
-    for (int j = 0; j < VE; ++j) m[j] = -INFINITY;
+    for (int j = 0; j < VE; ++j) { m[j] = -INFINITY; am[j] = 0; }
     for (int kh = 0; kh < k; ++kh) {
       const int hi = ho * stride - pad + kh;
       if ((unsigned)hi >= (unsigned)H) continue;
@@ -128,10 +131,26 @@ __global__ __launch_bounds__(256) void maxpool_kernel(const T* __restrict__ x, T
         float v[VE];
         Vec<T>::load(x + ((size_t)(n * H + hi) * W + wi) * C + cv * VE, v);
 #pragma unroll
-        for (int j = 0; j < VE; ++j) m[j] = fmaxf(m[j], v[j]);
+        for (int j = 0; j < VE; ++j) {
+          const bool take = first || v[j] > m[j];
+          am[j] = take ? kh * k + kw : am[j];
+          m[j] = take ? v[j] : m[j];
+        }
+        first = false;
       }
     }
     Vec<T>::store(y + (size_t)pix * C + cv * VE, m);
+    if (argmax) {
+      unsigned char* ap = argmax + (size_t)pix * C + cv * VE;
+      if constexpr (VE == 8) {
+        uint2 o;
+        o.x = (unsigned)am[0] | ((unsigned)am[1] << 8) | ((unsigned)am[2] << 16) | ((unsigned)am[3] << 24);
+        o.y = (unsigned)am[4] | ((unsigned)am[5] << 8) | ((unsigned)am[6] << 16) | ((unsigned)am[7] << 24);
+        *(uint2*)ap = o;
+      } else {
+        *(unsigned*)ap = (unsigned)am[0] | ((unsigned)am[1] << 8) | ((unsigned)am[2] << 16) | ((unsigned)am[3] << 24);
+      }
+    }
   }
 }
 
@@ -299,9 +318,10 @@ extern "C" int cavp_conv3x3_smallcin_nchw(int32_t dtype, const float* x, const f
   CHECK_LAUNCH();
 }
 
-extern "C" int cavp_maxpool_nhwc(int32_t dtype, const void* x, void* y, int32_t N, int32_t H, int32_t W, int32_t C,
-                                 int32_t k, int32_t stride, int32_t pad, void* stream) {
-  if (!x || !y || N <= 0 || H <= 0 || W <= 0 || C <= 0 || k <= 0 || stride <= 0 || pad < 0) return CAVP_ERR_BAD_ARG;
+extern "C" int cavp_maxpool_nhwc(int32_t dtype, const void* x, void* y, uint8_t* argmax, int32_t N, int32_t H, int32_t W,
+                                 int32_t C, int32_t k, int32_t stride, int32_t pad, void* stream) {
+  if (!x || !y || N <= 0 || H <= 0 || W <= 0 || C <= 0 || k <= 0 || k > 15 || stride <= 0 || pad < 0) return CAVP_ERR_BAD_ARG;
+  if (argmax && ((uintptr_t)argmax & 7)) return CAVP_ERR_ALIGN;
   if (!dtype_ok(dtype)) return CAVP_ERR_UNSUPPORTED;
   const int VE = dtype == CAVP_F32 ? 4 : 8;
   if (C % VE) return CAVP_ERR_UNSUPPORTED;
@@ -312,9 +332,9 @@ extern "C" int cavp_maxpool_nhwc(int32_t dtype, const void* x, void* y, int32_t 
   const int nb = nblocks(total, 256, 16384);
   hipStream_t s = (hipStream_t)stream;
   if (dtype == CAVP_F32)
-    maxpool_kernel<float><<<nb, 256, 0, s>>>((const float*)x, (float*)y, N, H, W, C, k, stride, pad, Ho, Wo);
+    maxpool_kernel<float><<<nb, 256, 0, s>>>((const float*)x, (float*)y, (unsigned char*)argmax, N, H, W, C, k, stride, pad, Ho, Wo);
   else
-    maxpool_kernel<bf16_t><<<nb, 256, 0, s>>>((const bf16_t*)x, (bf16_t*)y, N, H, W, C, k, stride, pad, Ho, Wo);
+    maxpool_kernel<bf16_t><<<nb, 256, 0, s>>>((const bf16_t*)x, (bf16_t*)y, (unsigned char*)argmax, N, H, W, C, k, stride, pad, Ho, Wo);
   CHECK_LAUNCH();
 }
 

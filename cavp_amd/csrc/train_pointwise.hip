@@ -338,10 +338,13 @@ __global__ __launch_bounds__(256) void add_kernel(const T* __restrict__ a, const
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// max pool backward (gather form, deterministic): dx[p] = sum over windows containing p whose first arg-max is p
+// max pool backward (gather form, deterministic): dx[p] = sum of dy over the windows whose recorded arg-max is p.
+// The forward stores the window-relative arg-max (one byte per output element), so the backward reads dy and the
+// index only - the first version re-derived every window's winner from x: 36 vector loads per input element for the
+// 3x3 / stride-2 stem pool (500 us for a 232 MB problem).
 // ------------------------------------------------------------------------------------------------------------
 template <typename T>
-__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy,
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const unsigned char* __restrict__ argmax, const T* __restrict__ dy,
                                                           T* __restrict__ dx, int N, int H, int W, int C, int k,
                                                           int stride, int pad, int Ho, int Wo) {
   constexpr int VE = VecT<T>::VE;
@@ -353,8 +356,7 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* __restrict__ 
     const int wi = (int)(pix % W);
     const int hi = (int)((pix / W) % H);
     const int n = (int)(pix / ((long long)W * H));
-    float xc[VE], acc[VE];
-    VecT<T>::load(x + (size_t)pix * C + cv * VE, xc);
+    float acc[VE];
 #pragma unroll
     for (int e = 0; e < VE; ++e) acc[e] = 0.f;
     // windows (ho, wo) with ho*stride - pad <= hi < ho*stride - pad + k
@@ -368,28 +370,22 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* __restrict__ 
     if (wo_hi > Wo - 1) wo_hi = Wo - 1;
     for (int ho = ho_lo; ho <= ho_hi; ++ho) {
       for (int wo = wo_lo; wo <= wo_hi; ++wo) {
-        // does (hi, wi) win this window?  first maximum in (kh, kw) scan order wins (strict >), as in ATen
-        bool win[VE];
+        const unsigned code = (unsigned)((hi - (ho * stride - pad)) * k + (wi - (wo * stride - pad)));
+        const size_t o = ((size_t)(n * Ho + ho) * Wo + wo) * C + cv * VE;
+        unsigned am[VE];
+        if constexpr (VE == 8) {
+          const uint2 t = *(const uint2*)(argmax + o);
 #pragma unroll
-        for (int e = 0; e < VE; ++e) win[e] = true;
-        for (int kh = 0; kh < k; ++kh) {
-          const int h2 = ho * stride - pad + kh;
-          if ((unsigned)h2 >= (unsigned)H) continue;
-          for (int kw = 0; kw < k; ++kw) {
-            const int w2 = wo * stride - pad + kw;
-            if ((unsigned)w2 >= (unsigned)W) continue;
-            if (h2 == hi && w2 == wi) continue;
-            float o[VE];
-            VecT<T>::load(x + ((size_t)(n * H + h2) * W + w2) * C + cv * VE, o);
-            const bool before = (h2 < hi) || (h2 == hi && w2 < wi);
+          for (int e = 0; e < 4; ++e) { am[e] = (t.x >> (8 * e)) & 255u; am[4 + e] = (t.y >> (8 * e)) & 255u; }
+        } else {
+          const unsigned t = *(const unsigned*)(argmax + o);
 #pragma unroll
-            for (int e = 0; e < VE; ++e) win[e] = win[e] && (before ? (xc[e] > o[e]) : (xc[e] >= o[e]));
-          }
+          for (int e = 0; e < 4; ++e) am[e] = (t >> (8 * e)) & 255u;
         }
         float g[VE];
-        VecT<T>::load(dy + ((size_t)(n * Ho + ho) * Wo + wo) * C + cv * VE, g);
+        VecT<T>::load(dy + o, g);
 #pragma unroll
-        for (int e = 0; e < VE; ++e) acc[e] += win[e] ? g[e] : 0.f;
+        for (int e = 0; e < VE; ++e) acc[e] += am[e] == code ? g[e] : 0.f;
       }
     }
     VecT<T>::store(dx + (size_t)pix * C + cv * VE, acc);
@@ -595,63 +591,35 @@ __global__ __launch_bounds__(256) void ce_finish_kernel(float* acc, int nparts, 
 
 // ------------------------------------------------------------------------------------------------------------
 // weight gradient of the small-Cin 3x3 conv (NCHW f32 input): dw[co][ci][kh][kw] += sum_p dy[p][co] * x[p @ tap]
-// A workgroup walks a pixel range in chunks of 64: the dY rows and the <= 27 gathered input taps of the chunk are
-// staged in LDS once, thread (co, tap lane) accumulates its taps over the chunk (dY read conflict-free, the tap
-// value is a wave-wide broadcast), one f32 atomic per (workgroup, weight) at the end.
+// = a TN GEMM over the pixels with K-operand "im2col(x)": the <= 27 taps of a pixel are gathered once into a
+// [pixels][KP] matrix of the compute dtype (KP = 32 bf16 / 28 f32 columns, 26 MB for the 224x224 stem) and the MFMA
+// weight-gradient kernel (conv_wgrad.hip) does the reduction as a 1x1 "conv" - the first version (LDS-staged
+// scalar FMAs + one atomic per workgroup and weight) took 500 us for 1.4 GFLOP.
 // ------------------------------------------------------------------------------------------------------------
-template <typename T, int COUT>
-__global__ __launch_bounds__(256) void smallcin_wgrad_kernel(const float* __restrict__ x, const T* __restrict__ dy,
-                                                             float* __restrict__ dw, int N, int Cin, int H, int W,
-                                                             int stride, int Ho, int Wo, int pix_per_block) {
-  constexpr int P = 64, KMAX = 27, NPL = 256 / COUT, TPT = (KMAX + NPL - 1) / NPL;
-  __shared__ float sdy[P][COUT];
-  __shared__ float sx[P][KMAX + 1];
-  const int K = Cin * 9;
+template <typename T, int KP>
+__global__ __launch_bounds__(256) void smallcin_im2col_kernel(const float* __restrict__ x, T* __restrict__ col, int N,
+                                                              int Cin, int H, int W, int stride, int Ho, int Wo) {
+  constexpr int VE = VecT<T>::VE;
   const long long M = (long long)N * Ho * Wo;
-  const long long p0 = (long long)blockIdx.x * pix_per_block;
-  long long p1 = p0 + pix_per_block;
-  if (p1 > M) p1 = M;
-  const int co = threadIdx.x % COUT, tl = threadIdx.x / COUT;
-  float acc[TPT];
+  for (long long pix = blockIdx.x * 256ll + threadIdx.x; pix < M; pix += (long long)gridDim.x * 256) {
+    const int wo = (int)(pix % Wo);
+    const int ho = (int)((pix / Wo) % Ho);
+    const int n = (int)(pix / ((long long)Wo * Ho));
+    float v[KP];
 #pragma unroll
-  for (int j = 0; j < TPT; ++j) acc[j] = 0.f;
-  for (long long pc = p0; pc < p1; pc += P) {
-    for (int i = threadIdx.x; i < P * COUT; i += 256) {
-      const int pp = i / COUT, c = i - pp * COUT;
-      const long long p = pc + pp;
-      sdy[pp][c] = p < p1 ? Elem<T>::ld(dy + (size_t)p * COUT + c) : 0.f;
+    for (int j = 0; j < KP; ++j) {
+      const int ci = j / 9, kh = (j % 9) / 3, kw = j % 3;
+      const int hi = ho * stride - 1 + kh, wi = wo * stride - 1 + kw;
+      const bool ok = ci < Cin && (unsigned)hi < (unsigned)H && (unsigned)wi < (unsigned)W;
+      v[j] = ok ? x[(((size_t)n * Cin + ci) * H + hi) * W + wi] : 0.f;
     }
-    for (int i = threadIdx.x; i < P * K; i += 256) {
-      const int pp = i / K, k = i - pp * K;
-      const long long p = pc + pp;
-      float v = 0.f;
-      if (p < p1) {
-        const int wo = (int)(p % Wo);
-        const int ho = (int)((p / Wo) % Ho);
-        const int n = (int)(p / ((long long)Wo * Ho));
-        const int ci = k / 9, kh = (k % 9) / 3, kw = k % 3;
-        const int hi = ho * stride - 1 + kh, wi = wo * stride - 1 + kw;
-        if ((unsigned)hi < (unsigned)H && (unsigned)wi < (unsigned)W) v = x[(((size_t)n * Cin + ci) * H + hi) * W + wi];
-      }
-      sx[pp][k] = v;
-    }
-    __syncthreads();
-#pragma unroll 4
-    for (int pp = 0; pp < P; ++pp) {
-      const float d = sdy[pp][co];
 #pragma unroll
-      for (int j = 0; j < TPT; ++j) {
-        const int t = tl + NPL * j;
-        if (t < K) acc[j] = fmaf(d, sx[pp][t], acc[j]);
-      }
-    }
-    __syncthreads();
+    for (int q = 0; q < KP / VE; ++q) VecT<T>::store(col + (size_t)pix * KP + q * VE, v + q * VE);
   }
-#pragma unroll
-  for (int j = 0; j < TPT; ++j) {
-    const int t = tl + NPL * j;
-    if (t < K) atomicAdd(dw + (size_t)co * K + t, acc[j]);
-  }
+}
+__global__ void smallcin_scatter_kernel(const float* __restrict__ t, float* __restrict__ dw, int Cout, int K, int KP) {
+  const int i = blockIdx.x * 256 + threadIdx.x;   // dw[co][ci][kh][kw] flat = co * K + j
+  if (i < Cout * K) dw[i] += t[(i / K) * KP + (i % K)];
 }
 
 // OHWI f32 gradient -> OIHW f32 parameter gradient (accumulate = add into existing .grad)
@@ -921,21 +889,22 @@ extern "C" int cavp_colsum(int32_t dtype, const void* x, int64_t rows, int32_t C
   return launch_col_reduce<2>(dtype, a, (hipStream_t)stream);
 }
 
-extern "C" int cavp_maxpool_bwd_nhwc(int32_t dtype, const void* x, const void* dy, void* dx, int32_t N, int32_t H,
+extern "C" int cavp_maxpool_bwd_nhwc(int32_t dtype, const uint8_t* argmax, const void* dy, void* dx, int32_t N, int32_t H,
                                      int32_t W, int32_t C, int32_t k, int32_t stride, int32_t pad, void* stream) {
-  if (!x || !dy || !dx || N <= 0 || H <= 0 || W <= 0 || C <= 0 || k <= 0 || stride <= 0 || pad < 0) return CAVP_ERR_BAD_ARG;
+  const void* x = argmax;
+  if (!x || !dy || !dx || N <= 0 || H <= 0 || W <= 0 || C <= 0 || k <= 0 || k > 15 || stride <= 0 || pad < 0) return CAVP_ERR_BAD_ARG;
   if (!dt_ok(dtype)) return CAVP_ERR_UNSUPPORTED;
   const int VE = dtype == CAVP_F32 ? 4 : 8;
   if (C % VE) return CAVP_ERR_UNSUPPORTED;
-  if (!al16(x) || !al16(dy) || !al16(dx)) return CAVP_ERR_ALIGN;
+  if (((uintptr_t)x & 7) || !al16(dy) || !al16(dx)) return CAVP_ERR_ALIGN;
   const int Ho = (H + 2 * pad - k) / stride + 1, Wo = (W + 2 * pad - k) / stride + 1;
   long long nb = ((long long)N * H * W * (C / VE) + 255) / 256;
   if (nb > 32768) nb = 32768;
   hipStream_t s = (hipStream_t)stream;
   if (dtype == CAVP_F32)
-    maxpool_bwd_kernel<float><<<(int)nb, 256, 0, s>>>((const float*)x, (const float*)dy, (float*)dx, N, H, W, C, k, stride, pad, Ho, Wo);
+    maxpool_bwd_kernel<float><<<(int)nb, 256, 0, s>>>(argmax, (const float*)dy, (float*)dx, N, H, W, C, k, stride, pad, Ho, Wo);
   else
-    maxpool_bwd_kernel<bf16_t><<<(int)nb, 256, 0, s>>>((const bf16_t*)x, (const bf16_t*)dy, (bf16_t*)dx, N, H, W, C, k, stride, pad, Ho, Wo);
+    maxpool_bwd_kernel<bf16_t><<<(int)nb, 256, 0, s>>>(argmax, (const bf16_t*)dy, (bf16_t*)dx, N, H, W, C, k, stride, pad, Ho, Wo);
   CHECK_LAUNCH();
 }
 
@@ -1011,22 +980,56 @@ extern "C" int cavp_ce_loss_nchw(const float* logits, const int64_t* labels, int
   CHECK_LAUNCH();
 }
 
+namespace {
+struct SmallcinPlan { cavp_conv_desc d; size_t col_bytes, tmp_bytes, ws_bytes; int KP; long long M; int Ho, Wo; };
+inline bool smallcin_plan(int dtype, int N, int Cin, int H, int W, int Cout, int stride, SmallcinPlan* pl) {
+  if (!dt_ok(dtype) || Cin < 1 || Cin > 3 || Cout % 8 || N <= 0 || H <= 0 || W <= 0 || stride <= 0) return false;
+  pl->Ho = (H - 1) / stride + 1; pl->Wo = (W - 1) / stride + 1;
+  pl->M = (long long)N * pl->Ho * pl->Wo;
+  pl->KP = dtype == CAVP_F32 ? 28 : 32;
+  const size_t es = dtype == CAVP_F32 ? 4 : 2;
+  if (pl->M * pl->KP * (long long)es >= 0x7fffffffll) return false;
+  cavp_conv_desc d{};
+  d.dtype = dtype; d.N = 1; d.H = 1; d.W = (int)pl->M; d.Cin = pl->KP; d.ldx = pl->KP; d.Cout = Cout; d.ldy = Cout;
+  d.KH = d.KW = 1; d.stride = 1; d.pad = 0; d.dil = 1;
+  pl->d = d;
+  pl->col_bytes = ((size_t)pl->M * pl->KP * es + 255) / 256 * 256;
+  pl->tmp_bytes = ((size_t)Cout * pl->KP * 4 + 255) / 256 * 256;
+  pl->ws_bytes = cavp_conv2d_wgrad_workspace_bytes(&pl->d);
+  return true;
+}
+}  // namespace
+
+extern "C" size_t cavp_conv3x3_smallcin_wgrad_workspace_bytes(int32_t dtype, int32_t N, int32_t Cin, int32_t H, int32_t W,
+                                                              int32_t Cout, int32_t stride) {
+  SmallcinPlan pl;
+  if (!smallcin_plan(dtype, N, Cin, H, W, Cout, stride, &pl)) return 0;
+  return pl.col_bytes + pl.tmp_bytes + pl.ws_bytes;
+}
+
 extern "C" int cavp_conv3x3_smallcin_wgrad(int32_t dtype, const float* x_nchw, const void* dy_nhwc, float* dw_oihw,
                                            int32_t N, int32_t Cin, int32_t H, int32_t W, int32_t Cout, int32_t stride,
-                                           void* stream) {
-  if (!x_nchw || !dy_nhwc || !dw_oihw || N <= 0 || H <= 0 || W <= 0 || stride <= 0) return CAVP_ERR_BAD_ARG;
-  if (!dt_ok(dtype) || Cin < 1 || Cin > 3 || Cout != 64) return CAVP_ERR_UNSUPPORTED;
-  const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
-  const long long M = (long long)N * Ho * Wo;
-  int gx = 512;
-  long long ppb = (M + gx - 1) / gx;
-  ppb = (ppb + 63) / 64 * 64;
-  gx = (int)((M + ppb - 1) / ppb);
+                                           void* workspace, size_t workspace_bytes, void* stream) {
+  if (!x_nchw || !dy_nhwc || !dw_oihw || !workspace) return CAVP_ERR_BAD_ARG;
+  SmallcinPlan pl;
+  if (!smallcin_plan(dtype, N, Cin, H, W, Cout, stride, &pl)) return CAVP_ERR_UNSUPPORTED;
+  if (workspace_bytes < pl.col_bytes + pl.tmp_bytes + pl.ws_bytes || !al16(workspace)) return CAVP_ERR_WORKSPACE;
+  char* col = (char*)workspace;
+  float* tmp = (float*)(col + pl.col_bytes);
+  void* ws = (char*)tmp + pl.tmp_bytes;
   hipStream_t s = (hipStream_t)stream;
+  long long nb = (pl.M + 255) / 256;
+  if (nb > 16384) nb = 16384;
   if (dtype == CAVP_F32)
-    smallcin_wgrad_kernel<float, 64><<<gx, 256, 0, s>>>(x_nchw, (const float*)dy_nhwc, dw_oihw, N, Cin, H, W, stride, Ho, Wo, (int)ppb);
+    smallcin_im2col_kernel<float, 28><<<(int)nb, 256, 0, s>>>(x_nchw, (float*)col, N, Cin, H, W, stride, pl.Ho, pl.Wo);
   else
-    smallcin_wgrad_kernel<bf16_t, 64><<<gx, 256, 0, s>>>(x_nchw, (const bf16_t*)dy_nhwc, dw_oihw, N, Cin, H, W, stride, Ho, Wo, (int)ppb);
+    smallcin_im2col_kernel<bf16_t, 32><<<(int)nb, 256, 0, s>>>(x_nchw, (bf16_t*)col, N, Cin, H, W, stride, pl.Ho, pl.Wo);
+  if (hipGetLastError() != hipSuccess) return CAVP_ERR_LAUNCH;
+  if (hipMemsetAsync(tmp, 0, (size_t)Cout * pl.KP * 4, s) != hipSuccess) return CAVP_ERR_LAUNCH;
+  const int st = cavp_conv2d_wgrad_nhwc(&pl.d, col, dy_nhwc, tmp, ws, pl.ws_bytes, stream);
+  if (st != CAVP_OK) return st;
+  const int K = Cin * 9;
+  smallcin_scatter_kernel<<<(Cout * K + 255) / 256, 256, 0, s>>>(tmp, dw_oihw, Cout, K, pl.KP);
   CHECK_LAUNCH();
 }
 

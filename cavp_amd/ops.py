@@ -163,7 +163,9 @@ def conv3x3_smallcin_nchw(x_nchw: torch.Tensor, w_oihw: torch.Tensor, out: torch
     return out
 
 
-def maxpool(x: torch.Tensor, out: torch.Tensor, k: int, stride: int, pad: int) -> torch.Tensor:
+def maxpool(x: torch.Tensor, out: torch.Tensor, k: int, stride: int, pad: int,
+            argmax: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """argmax (optional): uint8 tensor of out's shape receiving the window-relative arg-max (for maxpool_bwd)."""
     _need_gpu(x, out)
     n, h, w, c, ld = _nhwc(x)
     no, ho, wo, co, ldo = _nhwc(out)
@@ -171,7 +173,10 @@ def maxpool(x: torch.Tensor, out: torch.Tensor, k: int, stride: int, pad: int) -
         raise _lib.CavpError("maxpool: dense NHWC tensors of one dtype required")
     if (no, ho, wo) != (n, (h + 2 * pad - k) // stride + 1, (w + 2 * pad - k) // stride + 1):
         raise _lib.CavpError("maxpool: bad output shape")
-    st = _lib.load().cavp_maxpool_nhwc(dtype_code(x.dtype), _ptr(x), _ptr(out), n, h, w, c, k, stride, pad,
+    if argmax is not None and (argmax.dtype != torch.uint8 or not argmax.is_contiguous() or argmax.numel() != out.numel()
+                               or argmax.device != x.device):
+        raise _lib.CavpError("maxpool: argmax must be a dense uint8 tensor of the output's shape")
+    st = _lib.load().cavp_maxpool_nhwc(dtype_code(x.dtype), _ptr(x), _ptr(out), _ptr(argmax), n, h, w, c, k, stride, pad,
                                        C.c_void_p(_stream()))
     _lib.check(st, "cavp_maxpool_nhwc")
     return out

@@ -422,13 +422,14 @@ class TrainPass:
     def maxpool(self, x: V, k: int, stride: int, pad: int) -> V:
         n, h, w, c = x.t.shape
         y = V(self.empty((n, (h + 2 * pad - k) // stride + 1, (w + 2 * pad - k) // stride + 1, c)))
-        ops.maxpool(x.t, y.t, k, stride, pad)
+        am = torch.empty(y.t.shape, dtype=torch.uint8, device=self.dev)
+        ops.maxpool(x.t, y.t, k, stride, pad, argmax=am)
 
         def bwd():
             if y.g is None:
                 return
             dx = self.empty(x.t.shape, x.t.dtype)
-            T.maxpool_bwd(x.t, y.g if y.g.is_contiguous() else self._dense_copy(y.g), dx, k, stride, pad)
+            T.maxpool_bwd(am, y.g if y.g.is_contiguous() else self._dense_copy(y.g), dx, k, stride, pad)
             self.acc_add(x, dx)
         self.tape.append(bwd)
         return y

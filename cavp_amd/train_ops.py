@@ -172,8 +172,13 @@ def smallcin_wgrad(x_nchw: torch.Tensor, dy: torch.Tensor, dw_oihw: torch.Tensor
     cout = dy.shape[-1]
     if dw_oihw.dtype != torch.float32 or tuple(dw_oihw.shape) != (cout, cin, 3, 3) or not dy.is_contiguous():
         raise _lib.CavpError("smallcin_wgrad: bad shapes")
-    _check(_lib.load().cavp_conv3x3_smallcin_wgrad(dtype_code(dy.dtype), _ptr(x_nchw), _ptr(dy), _ptr(dw_oihw), n, cin, h, w,
-                                                   cout, stride, _s()), "cavp_conv3x3_smallcin_wgrad")
+    lib = _lib.load()
+    ws = ops.workspace(lib.cavp_conv3x3_smallcin_wgrad_workspace_bytes(dtype_code(dy.dtype), n, cin, h, w, cout, stride),
+                       x_nchw.device)
+    if ws is None:
+        raise _lib.CavpError("smallcin_wgrad: unsupported shape")
+    _check(lib.cavp_conv3x3_smallcin_wgrad(dtype_code(dy.dtype), _ptr(x_nchw), _ptr(dy), _ptr(dw_oihw), n, cin, h, w, cout,
+                                           stride, _ptr(ws), C.c_size_t(ws.numel()), _s()), "cavp_conv3x3_smallcin_wgrad")
     return dw_oihw
 
 
@@ -287,10 +292,13 @@ def attn_gate_bwd(dout, q, k, v, attn, dattn, dq, dk, dv, heads: int, scale: flo
            "cavp_attn_gate_bwd")
 
 
-def maxpool_bwd(x, dy, dx, k: int, stride: int, pad: int) -> torch.Tensor:
-    n, h, w, c, _ = _nhwc(x)
-    _need_gpu(x, dy, dx)
-    _check(_lib.load().cavp_maxpool_bwd_nhwc(dtype_code(x.dtype), _ptr(x), _ptr(dy), _ptr(dx), n, h, w, c, k, stride, pad, _s()),
+def maxpool_bwd(argmax, dy, dx, k: int, stride: int, pad: int) -> torch.Tensor:
+    """argmax: uint8 [N][Ho][Wo][C] written by ops.maxpool; dy: same shape (dtype); dx: [N][H][W][C]."""
+    n, h, w, c, _ = _nhwc(dx)
+    _need_gpu(argmax, dy, dx)
+    if argmax.dtype != torch.uint8 or argmax.numel() != dy.numel() or not argmax.is_contiguous() or not dy.is_contiguous():
+        raise _lib.CavpError("maxpool_bwd: dense uint8 argmax of dy's shape required")
+    _check(_lib.load().cavp_maxpool_bwd_nhwc(dtype_code(dx.dtype), _ptr(argmax), _ptr(dy), _ptr(dx), n, h, w, c, k, stride, pad, _s()),
            "cavp_maxpool_bwd_nhwc")
     return dx
 

@@ -91,9 +91,11 @@ int cavp_conv3x3_smallcin_nchw(int32_t dtype, const float* x_nchw, const float* 
                                const float* shift, void* y_nhwc, int32_t N, int32_t Cin, int32_t H, int32_t W,
                                int32_t Cout, int32_t stride, int32_t act, void* stream);
 
-/* nn.MaxPool2d(k, s, p) on NHWC (resnet.py:139,190: 3/2/1; vgg.py:30: 2/2/0). */
-int cavp_maxpool_nhwc(int32_t dtype, const void* x, void* y, int32_t N, int32_t H, int32_t W, int32_t C,
-                      int32_t k, int32_t stride, int32_t pad, void* stream);
+/* nn.MaxPool2d(k, s, p) on NHWC (resnet.py:139,190: 3/2/1; vgg.py:30: 2/2/0).  argmax (optional, u8 [N][Ho][Wo][C]):
+ * window-relative position kh*k + kw of the first maximum in scan order (the element ATen routes the gradient to),
+ * consumed by cavp_maxpool_bwd_nhwc. */
+int cavp_maxpool_nhwc(int32_t dtype, const void* x, void* y, uint8_t* argmax, int32_t N, int32_t H, int32_t W,
+                      int32_t C, int32_t k, int32_t stride, int32_t pad, void* stream);
 
 /* x.view(N, C, -1).mean(-1) for NHWC x; output f32 [N][C] (ASPP._global_pooling, encoder_decoder.py:158-161). */
 int cavp_global_avgpool_nhwc(int32_t dtype, const void* x, float* y, int32_t N, int32_t HW, int32_t C, int32_t ldx,
@@ -159,9 +161,13 @@ int cavp_pack_weight_dgrad(int32_t dtype, const float* w_oihw, void* w_t, int32_
 /* OHWI f32 gradient -> OIHW f32 (.grad layout); accumulate != 0 adds into the destination. */
 int cavp_unpack_weight_grad(const float* g_ohwi, float* g_oihw, int32_t Cout, int32_t Cin, int32_t KH, int32_t KW,
                             int32_t accumulate, void* stream);
-/* Weight gradient of cavp_conv3x3_smallcin_nchw (OIHW f32, atomically accumulated; caller zeroes). */
+/* Weight gradient of cavp_conv3x3_smallcin_nchw: dw_oihw (f32) += im2col(x)^T dy on the MFMA weight-gradient kernel
+ * (deterministic).  workspace: cavp_conv3x3_smallcin_wgrad_workspace_bytes(...) bytes, 16-byte aligned. */
+size_t cavp_conv3x3_smallcin_wgrad_workspace_bytes(int32_t dtype, int32_t N, int32_t Cin, int32_t H, int32_t W,
+                                                   int32_t Cout, int32_t stride);
 int cavp_conv3x3_smallcin_wgrad(int32_t dtype, const float* x_nchw, const void* dy_nhwc, float* dw_oihw, int32_t N,
-                                int32_t Cin, int32_t H, int32_t W, int32_t Cout, int32_t stride, void* stream);
+                                int32_t Cin, int32_t H, int32_t W, int32_t Cout, int32_t stride, void* workspace,
+                                size_t workspace_bytes, void* stream);
 
 /* nn.BatchNorm2d in training mode (resnet.py / encoder_decoder.py BN layers under model.train()):
  *   cavp_colstats     sum[c] += sum_rows (x - s_c), sumsq[c] += sum_rows (x - s_c)^2 with an optional per-channel
@@ -207,7 +213,8 @@ int cavp_layernorm_bwd(int32_t dtype, const void* dy, const void* x, const float
 int cavp_attn_gate_bwd(int32_t dtype, const void* dout, const void* q, const void* k, const void* v, const float* attn,
                        const float* dattn, void* dq, float* dk, float* dv, int32_t B, int32_t T, int32_t heads,
                        int32_t hd, float scale, void* stream);
-int cavp_maxpool_bwd_nhwc(int32_t dtype, const void* x, const void* dy, void* dx, int32_t N, int32_t H, int32_t W,
+/* dx [N][H][W][C] = gradient routed to the recorded arg-max of every window (argmax from cavp_maxpool_nhwc) */
+int cavp_maxpool_bwd_nhwc(int32_t dtype, const uint8_t* argmax, const void* dy, void* dx, int32_t N, int32_t H, int32_t W,
                           int32_t C, int32_t k, int32_t stride, int32_t pad, void* stream);
 int cavp_bilinear_bwd_nhwc(int32_t dtype, const void* dy, void* dx, int32_t N, int32_t Hi, int32_t Wi, int32_t C,
                            int32_t ld_dx, int32_t Ho, int32_t Wo, int32_t ld_dy, int32_t align_corners, void* stream);

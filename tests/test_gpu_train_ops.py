@@ -191,12 +191,17 @@ def test_attn_gate_bwd(dt):
 @pytest.mark.parametrize("k,s,p,hw", [(3, 2, 1, (28, 30)), (2, 2, 0, (12, 8)), (3, 2, 1, (15, 9))])
 def test_maxpool_bwd(k, s, p, hw, dt):
     ops, T = _mods()
-    x = _q(_rand(2, 64, *hw, seed=25), dt).requires_grad_(True)
+    # post-ReLU style input: exact ties (zeros) inside windows exercise the first-maximum rule
+    x = _q(torch.relu(_rand(2, 64, *hw, seed=25)), dt).requires_grad_(True)
     y = F.max_pool2d(x, k, s, p)
     dy = _q(_rand(*y.shape, seed=26), dt)
     y.backward(dy)
     dx = torch.empty((2, hw[0], hw[1], 64), dtype=dt, device=DEV)
-    T.maxpool_bwd(_nhwc(x.detach(), dt), _nhwc(dy, dt), dx, k, s, p)
+    yo = torch.empty((2, y.shape[2], y.shape[3], 64), dtype=dt, device=DEV)
+    am = torch.empty(yo.shape, dtype=torch.uint8, device=DEV)
+    ops.maxpool(_nhwc(x.detach(), dt), yo, k, s, p, argmax=am)
+    _check(yo.permute(0, 3, 1, 2), y.detach(), dt, "maxpool fwd (argmax variant)", 1e-6, 1e-2)
+    T.maxpool_bwd(am, _nhwc(dy, dt), dx, k, s, p)
     _check(dx.permute(0, 3, 1, 2), x.grad, dt, "maxpool bwd", 1e-6, 1e-2)
 
 
