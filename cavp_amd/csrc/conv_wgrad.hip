@@ -6,7 +6,8 @@
 //   second kernel reduces the slabs in a fixed order (deterministic; f32 atomics on a 32 K-element dW from 512
 //   workgroups were 2.3x slower - profiles/r01_notes.md).
 // * Both operands are streamed global -> LDS with LDS-DMA (buffer_load ... lds) exactly as they lie in memory:
-//   64 pixel rows x 256 bytes of channels per stage (128 bf16 / 64 f32 channels), two stages.  Rows that fall
+//   32 pixel rows x 256 bytes of channels per stage (128 bf16 / 64 f32 channels), two stages = 32 KiB per workgroup,
+//   four workgroups per CU (64-row stages are kept behind CAVP_WGRAD_BK=64 for A/B runs).  Rows that fall
 //   outside the image (padding taps), beyond the pixel range or beyond Cin/Cout are zero-filled by the buffer
 //   descriptor's bounds check.
 // * bf16: the MFMA 16x16x32 fragment (8 consecutive k = pixels for one channel) is gathered with the gfx950 LDS
@@ -39,11 +40,11 @@ struct WgradParams {
 
 typedef short s16x4_t __attribute__((ext_vector_type(4)));
 
-template <typename T>
-__global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
+template <typename T, int BK>   // BK = pixel rows per stage (64: two 64 KiB workgroups per CU; 32: four 32 KiB ones)
+__global__ __launch_bounds__(256, (BK == 32 ? 4 : 2)) void wgrad_kernel(const WgradParams p) {
   constexpr int ES = (int)sizeof(T);
   constexpr int TCH = 256 / ES;      // channels per tile row (256 bytes)
-  constexpr int BK = 64;             // pixel rows per stage
+  constexpr int NI = BK / 16;        // DMA instructions per operand per thread and stage
   constexpr int STAGE = 2 * BK * 256;  // X tile + dY tile
   constexpr int WT = TCH / 2;        // per-wave tile edge (2 x 2 waves)
   constexpr int MB = WT / 16;        // 16x16 blocks per wave edge
@@ -78,9 +79,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
   const bool ci_ok = ci_base + cel < p.Cin, co_ok = co_base + cel < p.Cout;
   const unsigned xcb = (unsigned)((ci_base + cel) * ES), ycb = (unsigned)((co_base + cel) * ES);
   const bool pointwise = (p.ntaps_all == 1) && p.stride == 1 && p.pad == 0;
-  int pixr[4], pn[4], ph[4], pw[4];
+  int pixr[NI], pn[NI], ph[NI], pw[NI];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < NI; ++i) {
     pixr[i] = r_begin + drow0 + 16 * i;
     const int pp = pixr[i] < p.M ? pixr[i] : 0;
     pn[i] = pp / HoWo;
@@ -93,7 +94,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
   auto gdma = [&](int buf) {
     char* base = smem + buf * STAGE + wave * 1024;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NI; ++i) {
       const int pix = pixr[i];
       const bool pok = pix < r_end && !(p.dbg & 1);
       unsigned xoff;
@@ -230,24 +231,51 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
   }
 }
 
-// dw += sum_z slabs[z] over the live taps only (dead-tap regions of the slabs are never written)
+// dw += sum_z slabs[z] over the live taps only (dead-tap regions of the slabs are never written).
+// 256 threads = QPB output quads x ZG split groups: group zg sums the splits zg, zg + ZG, ... and the groups are
+// combined through LDS in a fixed order (deterministic).  Small dW (16 K elements from 392 splits) needs the split
+// dimension spread over threads: one thread per quad walking all splits left 16 workgroups each chasing 392
+// dependent-latency loads (50 us of an 83 us launch).
+template <int ZG>
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradParams p) {
+  constexpr int QPB = 256 / ZG;
+  __shared__ float4 part[ZG][QPB];
   const int cq = p.Cin >> 2;
   const long long total = (long long)p.Cout * p.ntaps * cq;
   const size_t slab = (size_t)p.Cout * p.ntaps_all * p.Cin;
-  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-    const int c4 = (int)(i % cq);
-    const long long r = i / cq;
-    const int ti = (int)(r % p.ntaps);
-    const int co = (int)(r / p.ntaps);
-    const int tap = (int)((p.taps >> (4 * ti)) & 15ull);
-    const size_t off = ((size_t)co * p.ntaps_all + tap) * p.Cin + (size_t)c4 * 4;
-    float4 s = *(const float4*)(p.dw + off);
-    for (int z = 0; z < p.ksplit; ++z) {
-      const float4 v = *(const float4*)(p.slabs + (size_t)z * slab + off);
-      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+  const int ql = threadIdx.x % QPB, zg = threadIdx.x / QPB;
+  for (long long i0 = (long long)blockIdx.x * QPB; i0 < total; i0 += (long long)gridDim.x * QPB) {
+    const long long i = i0 + ql;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    size_t off = 0;
+    if (i < total) {
+      const int c4 = (int)(i % cq);
+      const long long r = i / cq;
+      const int ti = (int)(r % p.ntaps);
+      const int co = (int)(r / p.ntaps);
+      const int tap = (int)((p.taps >> (4 * ti)) & 15ull);
+      off = ((size_t)co * p.ntaps_all + tap) * p.Cin + (size_t)c4 * 4;
+      for (int z = zg; z < p.ksplit; z += ZG) {
+        const float4 v = *(const float4*)(p.slabs + (size_t)z * slab + off);
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+      }
     }
-    *(float4*)(p.dw + off) = s;
+    if constexpr (ZG > 1) {
+      part[zg][ql] = s;
+      __syncthreads();
+      if (zg == 0 && i < total) {
+#pragma unroll
+        for (int g = 1; g < ZG; ++g) {
+          const float4 v = part[g][ql];
+          s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+      }
+      __syncthreads();
+    }
+    if (zg == 0 && i < total) {
+      const float4 o = *(const float4*)(p.dw + off);
+      *(float4*)(p.dw + off) = make_float4(o.x + s.x, o.y + s.y, o.z + s.z, o.w + s.w);
+    }
   }
 }
 
@@ -292,9 +320,11 @@ WgradPlan make_wgrad_plan(const cavp_conv_desc* d) {
   const int base = p.tiles_co * p.tiles_ci * p.ntaps;
   const int chunks = (p.M + 63) / 64;
   // Split count from a small time model fitted to tools/bench_wgrad.py on MI355X (profiles/r01_notes.md):
-  //   t(ks) = rounds * steps * 1.7 us  +  ks * |dW| * 8 B / 2.5 TB/s  (+ reduce launch)
-  // rounds = ceil(base * ks / 512 resident workgroups), steps = K tiles per workgroup.  The first version aimed at
-  // "about 512 workgroups" with a ceil: 540 or 513 workgroups = a second, nearly empty round (head conv 951 -> 600 us).
+  //   t(ks) = rounds * steps * 1.08 us  +  ks * |dW| * 8 B / 2.5 TB/s  (+ reduce launch)
+  // rounds = ceil(base * ks / 1024 resident workgroups: four 32 KiB workgroups per CU), steps = 32-row K tiles per
+  // workgroup.  The first version aimed at "about 512 workgroups" with a ceil: 540 or 513 workgroups = a second, nearly
+  // empty round (head conv 951 -> 600 us); 64-row stages (two workgroups per CU, 1.7 us per tile) -> 32-row stages:
+  // head conv 580 -> 415 us (the K loop is bound by DMA latency per workgroup, more resident workgroups hide it).
   int ks = 1;
   if (d->splitk > 0) {
     ks = d->splitk;
@@ -305,8 +335,8 @@ WgradPlan make_wgrad_plan(const cavp_conv_desc* d) {
     for (int k = 1; k <= ks_max && k <= 512; ++k) {
       const int steps = (chunks + k - 1) / k;
       const int kk = (chunks + steps - 1) / steps;   // effective split count for this step count
-      const long long rounds = ((long long)base * kk + 511) / 512;
-      double t = (double)rounds * steps * 1.7e-6 + (kk > 1 ? kk * dw_bytes * 2.0 / 2.5e12 + 6e-6 : 0.0);
+      const long long rounds = ((long long)base * kk + 1023) / 1024;
+      double t = (double)rounds * (2 * steps) * 1.08e-6 + (kk > 1 ? kk * dw_bytes * 2.0 / 2.5e12 + 6e-6 : 0.0);
       if (t < best) { best = t; ks = kk; }
     }
   }
@@ -341,23 +371,34 @@ extern "C" int cavp_conv2d_wgrad_nhwc(const cavp_conv_desc* d, const void* x, co
     static const int dbg = getenv("CAVP_WGRAD_DBG") ? atoi(getenv("CAVP_WGRAD_DBG")) : 0;
     p.dbg = dbg;
   }
-  const int lds = 2 * 2 * 64 * 256;
+  static const int bk = getenv("CAVP_WGRAD_BK") ? atoi(getenv("CAVP_WGRAD_BK")) : 32;   // A/B knob (profiling)
+  const int lds = 2 * 2 * bk * 256;
   hipStream_t s = (hipStream_t)stream;
   static bool attr = false;
   if (!attr) {
-    (void)hipFuncSetAttribute((const void*)wgrad_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    (void)hipFuncSetAttribute((const void*)wgrad_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute((const void*)wgrad_kernel<float, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 2 * 64 * 256);
+    (void)hipFuncSetAttribute((const void*)wgrad_kernel<bf16_t, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 2 * 64 * 256);
     attr = true;
   }
-  if (d->dtype == CAVP_F32)
-    wgrad_kernel<float><<<pl.nblk, 256, lds, s>>>(p);
-  else
-    wgrad_kernel<bf16_t><<<pl.nblk, 256, lds, s>>>(p);
+  if (d->dtype == CAVP_F32) {
+    if (bk == 32) wgrad_kernel<float, 32><<<pl.nblk, 256, lds, s>>>(p); else wgrad_kernel<float, 64><<<pl.nblk, 256, lds, s>>>(p);
+  } else {
+    if (bk == 32) wgrad_kernel<bf16_t, 32><<<pl.nblk, 256, lds, s>>>(p); else wgrad_kernel<bf16_t, 64><<<pl.nblk, 256, lds, s>>>(p);
+  }
   if (hipGetLastError() != hipSuccess) return CAVP_ERR_LAUNCH;
   if (p.ksplit > 1) {
-    long long nb = ((long long)p.Cout * p.ntaps * (p.Cin / 4) + 255) / 256;
+    const long long quads = (long long)p.Cout * p.ntaps * (p.Cin / 4);
+    int zgrp = 1;   // split groups per workgroup: spread the split dimension when there are few output quads
+    while (zgrp < 16 && zgrp * 2 <= p.ksplit && quads * zgrp < 131072) zgrp *= 2;
+    long long nb = (quads + (256 / zgrp) - 1) / (256 / zgrp);
     if (nb > 8192) nb = 8192;
-    wgrad_reduce_kernel<<<(int)nb, 256, 0, s>>>(p);
+    switch (zgrp) {
+      case 1: wgrad_reduce_kernel<1><<<(int)nb, 256, 0, s>>>(p); break;
+      case 2: wgrad_reduce_kernel<2><<<(int)nb, 256, 0, s>>>(p); break;
+      case 4: wgrad_reduce_kernel<4><<<(int)nb, 256, 0, s>>>(p); break;
+      case 8: wgrad_reduce_kernel<8><<<(int)nb, 256, 0, s>>>(p); break;
+      default: wgrad_reduce_kernel<16><<<(int)nb, 256, 0, s>>>(p); break;
+    }
     if (hipGetLastError() != hipSuccess) return CAVP_ERR_LAUNCH;
   }
   return CAVP_OK;
