@@ -234,6 +234,15 @@ int cavp_ce_loss_nchw(const float* logits, const int64_t* labels, int32_t n_img,
                       int32_t ignore_index, float grad_scale, float* loss, float* dlogits, float* scratch,
                       void* stream);
 
+/* ---- log-mel front-end = trainers' preprocess_audio (trainer_cavp_vpo_mono.py:43-52,59-69;
+ * utils/sourcesep.py:23-47): STFT(n_fft 512, hop, centred window, reflect padding) -> |.|^2 -> mel filterbank ->
+ * 20 log10(max(amin, x)) -> 2 (x - spec_min) / (spec_max - spec_min) - 1.
+ * wave: f32 [N][A]; window: f32 [n_fft] (Hann of win_length, zero-padded to the frame centre); fb: f32 [n_fft/2+1][n_mels];
+ * out: f32 [N][n_frames][n_mels] (n_frames <= 1 + A / hop). */
+int cavp_mel_frontend(const float* wave, int32_t N, int32_t A, const float* window, const float* fb, float* out,
+                      int32_t n_fft, int32_t hop, int32_t n_frames, int32_t n_mels, float amin, float spec_min,
+                      float spec_max, void* stream);
+
 /* ---- pixel-level audio-visual InfoNCE (loss/contrastive_aud.py::ContrastLoss, config #5 / SURVEY.md §8a row a13) ----
  * The class-balanced sampling (torch.randperm on the CPU generator, contrastive_aud.py:76-141) stays on the host; these
  * are the device stages for the N sampled anchors.  S = A A^T / T and dA = G A run on cavp_conv2d_nhwc / _wgrad. */
