@@ -54,6 +54,9 @@ PROTOTYPES = {
     "cavp_conv2d_wgrad_nhwc": (_i32, [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _sz, _vp]),
     "cavp_pack_weight_dgrad": (_i32, [_i32, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "cavp_pack_weights_multi": (_i32, [_i32, _vp, _i32, _vp]),
+    "cavp_optimizer_blocks": (_i32, [C.c_int64]),
+    "cavp_optimizer_step": (_i32, [_vp, _i32, _i32, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
+                                   C.c_int64, _vp]),
     "cavp_mel_frontend": (_i32, [_vp, _i32, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _i32, C.c_float, C.c_float, C.c_float, _vp]),
     "cavp_unpack_weight_grad": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
     "cavp_conv3x3_smallcin_wgrad": (_i32, [_i32, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, C.c_size_t, _vp]),

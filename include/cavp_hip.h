@@ -234,6 +234,28 @@ int cavp_ce_loss_nchw(const float* logits, const int64_t* labels, int32_t n_img,
                       int32_t ignore_index, float grad_scale, float* loss, float* dlogits, float* scratch,
                       void* stream);
 
+/* ---- fused optimiser step (harness row of SURVEY.md §8c): torch.optim.SGD(momentum, weight_decay) on the visual groups +
+ * torch.optim.Adam on the audio encoder (main_vpo_mono.py:45-65,118-125), all tensors in one launch.
+ * jobs_device: DEVICE array (built once; blk0 = running sum of cavp_optimizer_blocks(n) over the preceding jobs, ascending).
+ * kind 0 = SGD (m = momentum buffer, v unused), 1 = Adam (m, v = first / second moments, zero-initialised).
+ * lr of a job = lr_sgd (or lr_adam) * lr_mult; step = 1 for the first call (SGD: buf = d; Adam bias corrections). */
+typedef struct cavp_opt_job {
+  float* p;
+  const float* g;
+  float* m;
+  float* v;
+  int64_t n;
+  float lr_mult;
+  float weight_decay;
+  int32_t blk0;
+  int32_t kind;
+  int32_t vec;   /* p, g, m 16-byte aligned: float4 path */
+  int32_t pad_;
+} cavp_opt_job;
+int32_t cavp_optimizer_blocks(int64_t n);
+int cavp_optimizer_step(const cavp_opt_job* jobs_device, int32_t njobs, int32_t total_blocks, float lr_sgd, float lr_adam,
+                        float momentum, float beta1, float beta2, float eps, int64_t step, void* stream);
+
 /* ---- log-mel front-end = trainers' preprocess_audio (trainer_cavp_vpo_mono.py:43-52,59-69;
  * utils/sourcesep.py:23-47): STFT(n_fft 512, hop, centred window, reflect padding) -> |.|^2 -> mel filterbank ->
  * 20 log10(max(amin, x)) -> 2 (x - spec_min) / (spec_max - spec_min) - 1.

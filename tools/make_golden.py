@@ -231,6 +231,73 @@ def run_contrast(out_dir):
     print(f"contrast: wrote {path}; loss={loss.item():.6f}; |d_match|={em.grad.norm().item():.4e} |d_shuffle|={es.grad.norm().item():.4e}")
 
 
+def run_optstep(out_dir, steps=2, hw=(96, 96), B=4, C=3):
+    """Harness row of SURVEY.md §8c: (inputs, labels, seed) -> loss, and the sentinel WEIGHTS after each optimiser step.
+    Uses the reference's own `engine.utils.group_weight` and `engine.lr_policy.WarmUpPolyLR`; `set_group_lr` and the
+    optimiser construction are restated from main_vpo_mono.py:45-65,118-125 (that file drags in the whole trainer), the
+    learning-rate update from trainer_cavp_vpo_mono.py:73-85; hyper-parameters = config/config_avss_binary.py:52-57."""
+    from engine.lr_policy import WarmUpPolyLR
+    from engine.utils import group_weight
+    hyp = EasyDict(lr=1e-3, lr_power=0.9, momentum=0.9, weight_decay=1e-4, use_baseline=False)
+    args = EasyDict(seg_model="DeepLabV3Plus", last_three_dilation_stride=[False, False, False], audio_backbone="vgg",
+                    num_classes=C, batch_size=B, local_rank="cpu")
+    m = CAVP(50, None, num_classes=C, audio_backbone_pretrain_path=None, visual_backbone=50, args=args)
+    sd = synth_state_dict({k: tuple(v.shape) for k, v in m.state_dict().items()}, seed=1)
+    m.load_state_dict(sd, strict=True)
+    groups = []
+    groups = group_weight(groups, m.backbone, norm_layer=torch.nn.BatchNorm2d, lr=hyp.lr)
+    groups.append({"params": m.visual_projector.parameters(), "lr": hyp.lr * 1})
+    groups.append({"params": m.cross_att.parameters(), "lr": hyp.lr * 1})
+    for module in m.segment.business_layer:
+        groups = group_weight(groups, module, torch.nn.BatchNorm2d, hyp.lr * 10.0)
+    names = {id(p): k for k, p in m.named_parameters()}
+    group_names = [[names[id(p)] for p in (list(g["params"]))] for g in groups]
+    for g, gn in zip(groups, group_names):   # generators were consumed above
+        g["params"] = [dict(m.named_parameters())[k] for k in gn]
+    opt_v = torch.optim.SGD(groups, lr=hyp.lr, momentum=hyp.momentum, weight_decay=hyp.weight_decay)
+    opt_a = torch.optim.Adam(params=m.audio_backbone.parameters(), lr=hyp.lr)
+    total_iters = 50
+    sched = WarmUpPolyLR(hyp.lr, hyp.lr_power, total_iters, 0)
+    import json
+    with open(os.path.join(out_dir, "optim_groups.json"), "w") as f:
+        json.dump({"groups": group_names,
+                   "lr_mult": [g["lr"] / hyp.lr for g in opt_v.param_groups],
+                   "weight_decay": [g["weight_decay"] for g in opt_v.param_groups],
+                   "audio": [k for k, _ in m.audio_backbone.named_parameters()]}, f, indent=0)
+    image, audio, label = synth_inputs(B, hw, audio_batch=2 * B, num_classes=C, seed=4)
+    store = {"cfg/CBHW": np.array([C, B, hw[0], hw[1]], dtype=np.int64), "cfg/total_iters": np.array([total_iters]),
+             "cfg/hyp": np.array([hyp.lr, hyp.lr_power, hyp.momentum, hyp.weight_decay], dtype=np.float64)}
+    m.train()
+    params = dict(m.named_parameters())
+    for k in SENTINELS:
+        store["w0/" + k], _ = sample(params[k])
+    losses, lrs = [], []
+    for it in range(steps):
+        lr = float(sched.get_lr(it))
+        for g in opt_v.param_groups[:4]:            # trainer_cavp_vpo_mono.py:73-79
+            g["lr"] = lr
+        for g in opt_v.param_groups[4:]:
+            g["lr"] = lr * 10.0
+        opt_v.zero_grad()
+        opt_a.zero_grad()
+        out, fus, pack = m(image, audio, None, False)
+        output = out[:B] + out[B:] * 0.0
+        loss = F.cross_entropy(output, label, ignore_index=255)
+        loss.backward()
+        opt_v.step()
+        opt_a.step()
+        losses.append(loss.item())
+        lrs.append(lr)
+        for k in SENTINELS:
+            s, c = sample(params[k])
+            store[f"w{it + 1}/" + k], store[f"wck{it + 1}/" + k] = s, c
+    store["loss"] = np.array(losses, dtype=np.float64)
+    store["lr"] = np.array(lrs, dtype=np.float64)
+    path = os.path.join(out_dir, "optstep.npz")
+    np.savez_compressed(path, **store)
+    print(f"optstep: wrote {path}; losses={losses}; lrs={lrs}; groups={[len(g) for g in group_names]}")
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(REPO, "tests", "golden"))
@@ -246,3 +313,5 @@ if __name__ == "__main__":
         run_contrast(a.out)
     if not a.only or a.only == "pvt":
         run_pvt(a.out)
+    if not a.only or a.only == "optstep":
+        run_optstep(a.out)
