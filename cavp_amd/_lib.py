@@ -51,7 +51,7 @@ PROTOTYPES = {
     "cavp_cast": (_i32, [_i32, _vp, _i32, _vp, _i64, _vp]),
     # ---- training side ----
     "cavp_conv2d_wgrad_workspace_bytes": (_sz, [C.POINTER(ConvDesc)]),
-    "cavp_conv2d_wgrad_nhwc": (_i32, [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _sz, _vp]),
+    "cavp_conv2d_wgrad_nhwc": (_i32, [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "cavp_pack_weight_dgrad": (_i32, [_i32, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "cavp_pack_weights_multi": (_i32, [_i32, _vp, _i32, _vp]),
     "cavp_optimizer_blocks": (_i32, [C.c_int64]),

@@ -35,12 +35,14 @@ struct WgradParams {
   int rows_per_split;  // multiple of 64
   int x_bytes, dy_bytes;
   int dbg;             // profiling only (env CAVP_WGRAD_DBG): 1 = loads out of range, 2 = no MFMAs, 4 = no DMA, 8 = no epilogue
+  float* dbias;        // optional: dbias[co] += sum_pix dY[pix][co] (bias gradient), taken from the dY tiles streamed anyway
+  float* bias_slabs;   // ksplit > 1: [ksplit][Cout] partial column sums
   float* slabs;        // ksplit > 1: per-split partial gradients [ksplit][Cout][taps][Cin] (plain stores, then reduced)
 };
 
 typedef short s16x4_t __attribute__((ext_vector_type(4)));
 
-template <typename T, int BK>   // BK = pixel rows per stage (64: two 64 KiB workgroups per CU; 32: four 32 KiB ones)
+template <typename T, int BK, bool BIAS>   // BK = pixel rows per stage; BIAS: also the bias gradient (column sums of dY) (64: two 64 KiB workgroups per CU; 32: four 32 KiB ones)
 __global__ __launch_bounds__(256, (BK == 32 ? 4 : 2)) void wgrad_kernel(const WgradParams p) {
   constexpr int ES = (int)sizeof(T);
   constexpr int TCH = 256 / ES;      // channels per tile row (256 bytes)
@@ -132,6 +134,13 @@ __global__ __launch_bounds__(256, (BK == 32 ? 4 : 2)) void wgrad_kernel(const Wg
 #pragma unroll
     for (int b = 0; b < MB; ++b) acc[a][b] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
+  // bias gradient: the workgroups of the first ci tile and first live tap see every dY element exactly once; their
+  // waves with wci0 == 0 add up the dY fragments they load for the MFMAs anyway (no extra pass over dY).
+  const bool do_bias = BIAS && tci == 0 && ti == 0 && (wave & 1) == 0;
+  float bsum[MB];
+#pragma unroll
+  for (int b = 0; b < MB; ++b) bsum[b] = 0.f;
+
   auto compute = [&](int buf) {
     const char* xb = smem + buf * STAGE;
     const char* yb = xb + BK * 256;
@@ -163,6 +172,11 @@ __global__ __launch_bounds__(256, (BK == 32 ? 4 : 2)) void wgrad_kernel(const Wg
               (__attribute__((address_space(3))) s16x4_t*)(yb + rb * 256 + ((ch ^ kb) << 5) + sub));
           const uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
           bfv[b] = (u32x4_t){l2.x, l2.y, h2.x, h2.y};
+          if (BIAS && do_bias) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              bsum[b] += __uint_as_float(bfv[b][e] << 16) + __uint_as_float(bfv[b][e] & 0xffff0000u);
+          }
         }
 #pragma unroll
         for (int a = 0; a < MB; ++a)
@@ -186,6 +200,7 @@ __global__ __launch_bounds__(256, (BK == 32 ? 4 : 2)) void wgrad_kernel(const Wg
         for (int b = 0; b < MB; ++b) {
           const int cb = (wco0 + b * 16 + lrow) * 4;
           bfv[b] = *(const float*)(yb + r * 256 + ((((cb >> 5) ^ key) << 5) | (cb & 31)));
+          if (BIAS && do_bias) bsum[b] += bfv[b];
         }
 #pragma unroll
         for (int a = 0; a < MB; ++a)
@@ -211,6 +226,17 @@ __global__ __launch_bounds__(256, (BK == 32 ? 4 : 2)) void wgrad_kernel(const Wg
   // bytes of dW.  ksplit == 1: this workgroup owns the tile -> plain read-modify-write; otherwise plain stores into
   // this split's slab (reduced afterwards, deterministic, no atomics).
   if (p.dbg & 8) return;
+  if (BIAS && do_bias) {   // lanes (lrow, lgrp) hold 4 disjoint pixel subsets of column co = wco0 + 16 b + lrow
+    float* bo = p.ksplit > 1 ? p.bias_slabs + (size_t)z * p.Cout : p.dbias;
+#pragma unroll
+    for (int b = 0; b < MB; ++b) {
+      float v = bsum[b];
+      v += __shfl_xor(v, 16, 64);
+      v += __shfl_xor(v, 32, 64);
+      const int co = co_base + wco0 + b * 16 + lrow;
+      if (lgrp == 0 && co < p.Cout) bo[co] = p.ksplit > 1 ? v : bo[co] + v;   // one writer per (split, co)
+    }
+  }
   float* out = p.ksplit > 1 ? p.slabs + (size_t)z * p.Cout * p.ntaps_all * p.Cin : p.dw;
 #pragma unroll
   for (int a = 0; a < MB; ++a) {
@@ -275,6 +301,13 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradParams p) 
     if (zg == 0 && i < total) {
       const float4 o = *(const float4*)(p.dw + off);
       *(float4*)(p.dw + off) = make_float4(o.x + s.x, o.y + s.y, o.z + s.z, o.w + s.w);
+    }
+  }
+  if (p.dbias) {   // bias partials: one thread per output channel, splits in order
+    for (int c = blockIdx.x * 256 + threadIdx.x; c < p.Cout; c += gridDim.x * 256) {
+      float s = 0.f;
+      for (int z = 0; z < p.ksplit; ++z) s += p.bias_slabs[(size_t)z * p.Cout + c];
+      p.dbias[c] += s;
     }
   }
 }
@@ -347,7 +380,7 @@ WgradPlan make_wgrad_plan(const cavp_conv_desc* d) {
   p.ksplit = ks;
   p.rows_per_split = cps * 64;
   pl.nblk = base * ks;
-  pl.ws_bytes = ks > 1 ? (size_t)ks * d->Cout * p.ntaps_all * d->Cin * sizeof(float) : 0;
+  pl.ws_bytes = ks > 1 ? ((size_t)ks * d->Cout * p.ntaps_all * d->Cin + (size_t)ks * d->Cout) * sizeof(float) : 0;   // dW slabs + bias slabs
   return pl;
 }
 }  // namespace
@@ -357,8 +390,8 @@ extern "C" size_t cavp_conv2d_wgrad_workspace_bytes(const cavp_conv_desc* d) {
   return pl.status == CAVP_OK ? pl.ws_bytes : 0;
 }
 
-extern "C" int cavp_conv2d_wgrad_nhwc(const cavp_conv_desc* d, const void* x, const void* dy, float* dw, void* workspace,
-                                      size_t workspace_bytes, void* stream) {
+extern "C" int cavp_conv2d_wgrad_nhwc(const cavp_conv_desc* d, const void* x, const void* dy, float* dw, float* dbias,
+                                      void* workspace, size_t workspace_bytes, void* stream) {
   if (!d || !x || !dy || !dw) return CAVP_ERR_BAD_ARG;
   WgradPlan pl = make_wgrad_plan(d);
   if (pl.status != CAVP_OK) return pl.status;
@@ -366,7 +399,8 @@ extern "C" int cavp_conv2d_wgrad_nhwc(const cavp_conv_desc* d, const void* x, co
   if (((uintptr_t)x & 15) || ((uintptr_t)dy & 15) || ((uintptr_t)dw & 15)) return CAVP_ERR_ALIGN;
   if (pl.ws_bytes > 0 && (!workspace || workspace_bytes < pl.ws_bytes || ((uintptr_t)workspace & 15))) return CAVP_ERR_WORKSPACE;
   WgradParams& p = pl.p;
-  p.x = x; p.dy = dy; p.dw = dw; p.slabs = (float*)workspace;
+  p.x = x; p.dy = dy; p.dw = dw; p.slabs = (float*)workspace; p.dbias = dbias;
+  p.bias_slabs = p.slabs ? p.slabs + (size_t)p.ksplit * d->Cout * p.ntaps_all * d->Cin : nullptr;
   {
     static const int dbg = getenv("CAVP_WGRAD_DBG") ? atoi(getenv("CAVP_WGRAD_DBG")) : 0;
     p.dbg = dbg;
@@ -376,15 +410,22 @@ extern "C" int cavp_conv2d_wgrad_nhwc(const cavp_conv_desc* d, const void* x, co
   hipStream_t s = (hipStream_t)stream;
   static bool attr = false;
   if (!attr) {
-    (void)hipFuncSetAttribute((const void*)wgrad_kernel<float, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 2 * 64 * 256);
-    (void)hipFuncSetAttribute((const void*)wgrad_kernel<bf16_t, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 2 * 64 * 256);
+    (void)hipFuncSetAttribute((const void*)wgrad_kernel<float, 64, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 2 * 64 * 256);
+    (void)hipFuncSetAttribute((const void*)wgrad_kernel<bf16_t, 64, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 2 * 64 * 256);
+    (void)hipFuncSetAttribute((const void*)wgrad_kernel<float, 64, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 2 * 64 * 256);
+    (void)hipFuncSetAttribute((const void*)wgrad_kernel<bf16_t, 64, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 2 * 64 * 256);
     attr = true;
   }
+#define WG_LAUNCH(T, B, BI) wgrad_kernel<T, B, BI><<<pl.nblk, 256, lds, s>>>(p)
+  const bool bi = dbias != nullptr;
   if (d->dtype == CAVP_F32) {
-    if (bk == 32) wgrad_kernel<float, 32><<<pl.nblk, 256, lds, s>>>(p); else wgrad_kernel<float, 64><<<pl.nblk, 256, lds, s>>>(p);
+    if (bk == 32) { if (bi) WG_LAUNCH(float, 32, true); else WG_LAUNCH(float, 32, false); }
+    else { if (bi) WG_LAUNCH(float, 64, true); else WG_LAUNCH(float, 64, false); }
   } else {
-    if (bk == 32) wgrad_kernel<bf16_t, 32><<<pl.nblk, 256, lds, s>>>(p); else wgrad_kernel<bf16_t, 64><<<pl.nblk, 256, lds, s>>>(p);
+    if (bk == 32) { if (bi) WG_LAUNCH(bf16_t, 32, true); else WG_LAUNCH(bf16_t, 32, false); }
+    else { if (bi) WG_LAUNCH(bf16_t, 64, true); else WG_LAUNCH(bf16_t, 64, false); }
   }
+#undef WG_LAUNCH
   if (hipGetLastError() != hipSuccess) return CAVP_ERR_LAUNCH;
   if (p.ksplit > 1) {
     const long long quads = (long long)p.Cout * p.ntaps * (p.Cin / 4);

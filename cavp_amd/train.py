@@ -287,15 +287,13 @@ class TrainPass:
                 g = dy
             if residual is not None:
                 self.acc_add(residual, g)
-            if p.bias is not None:
-                T.colsum(g, self.grad_buffer(p.bias))
             if nbias is not None:
                 nb = self.zeros_f32(*nbias.t.shape)
                 g4 = _as4(g)
                 for i in range(g4.shape[0]):
                     T.colsum(g4[i], nb[i])
                 self.acc_add(nbias, nb)
-            self.wgrad(p, x4, _as4(g))
+            self.wgrad(p, x4, _as4(g))      # (+ the bias gradient: column sums of g taken inside the same kernel)
             if x.needs_grad:
                 def dg(o, r):
                     T.conv2d_dgrad(_as4(g), p.wT, _as4(o), kh=p.kh, kw=p.kw, stride=p.stride, pad=p.pad, dil=p.dil,
@@ -305,12 +303,13 @@ class TrainPass:
         return y
 
     def wgrad(self, p: _P, x4: torch.Tensor, g4: torch.Tensor) -> None:
+        db = self.grad_buffer(p.bias) if p.bias is not None else None
         if p.kh * p.kw == 1:
             dw = self.grad_buffer(p.weight)   # OHWI == OIHW for 1x1 / linear: accumulate in place
-            T.conv2d_wgrad(x4, g4, dw.view(p.cout, 1, 1, p.cin), kh=1, kw=1, stride=p.stride, pad=p.pad, dil=p.dil)
+            T.conv2d_wgrad(x4, g4, dw.view(p.cout, 1, 1, p.cin), kh=1, kw=1, stride=p.stride, pad=p.pad, dil=p.dil, dbias=db)
         else:
             tmp = self.zeros_f32(p.cout, p.kh, p.kw, p.cin)
-            T.conv2d_wgrad(x4, g4, tmp, kh=p.kh, kw=p.kw, stride=p.stride, pad=p.pad, dil=p.dil)
+            T.conv2d_wgrad(x4, g4, tmp, kh=p.kh, kw=p.kw, stride=p.stride, pad=p.pad, dil=p.dil, dbias=db)
             T.unpack_weight_grad(tmp, self.grad_buffer(p.weight), accumulate=True)   # buffer starts at zero
 
     def conv_smallcin(self, x_nchw: torch.Tensor, key: str, stride: int, act: int) -> V:

@@ -77,9 +77,9 @@ def conv2d_dgrad(dy: torch.Tensor, w_t: torch.Tensor, dx: torch.Tensor, *, kh: i
 
 
 def conv2d_wgrad(x: torch.Tensor, dy: torch.Tensor, dw_ohwi: torch.Tensor, *, kh: int, kw: int, stride: int, pad: int,
-                 dil: int, splitk: int = 0) -> torch.Tensor:
-    """dw_ohwi (f32 [Cout][kh][kw][Cin], pre-zeroed) += wgrad(x, dy)."""
-    _need_gpu(x, dy, dw_ohwi)
+                 dil: int, splitk: int = 0, dbias: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """dw_ohwi (f32 [Cout][kh][kw][Cin], pre-zeroed) += wgrad(x, dy); dbias (optional f32 [Cout]) += column sums of dy."""
+    _need_gpu(x, dy, dw_ohwi, dbias)
     n, h, w, cin, ldx = _nhwc(x)
     n2, ho, wo, cout, ldy = _nhwc(dy)
     if n2 != n or x.dtype != dy.dtype or dw_ohwi.dtype != torch.float32 or dw_ohwi.numel() != cout * kh * kw * cin \
@@ -93,18 +93,20 @@ def conv2d_wgrad(x: torch.Tensor, dy: torch.Tensor, dw_ohwi: torch.Tensor, *, kh
                  stride=stride, pad=pad, dil=dil, ldr=0, act=0, splitk=splitk, tile=0, up=0, Ho=0, Wo=0, stride_w=0)
     lib = _lib.load()
     ws = ops.workspace(lib.cavp_conv2d_wgrad_workspace_bytes(C.byref(d)), x.device)
-    _check(lib.cavp_conv2d_wgrad_nhwc(C.byref(d), _ptr(x), _ptr(dy), _ptr(dw_ohwi), _ptr(ws),
+    if dbias is not None and (dbias.dtype != torch.float32 or dbias.numel() != cout or not dbias.is_contiguous()):
+        raise _lib.CavpError("conv2d_wgrad: dbias must be a dense f32 [Cout] tensor")
+    _check(lib.cavp_conv2d_wgrad_nhwc(C.byref(d), _ptr(x), _ptr(dy), _ptr(dw_ohwi), _ptr(dbias), _ptr(ws),
                                       C.c_size_t(ws.numel() if ws is not None else 0), _s()), "cavp_conv2d_wgrad_nhwc")
     return dw_ohwi
 
 
-def linear_wgrad(x: torch.Tensor, dy: torch.Tensor, dw: torch.Tensor) -> torch.Tensor:
+def linear_wgrad(x: torch.Tensor, dy: torch.Tensor, dw: torch.Tensor, dbias: Optional[torch.Tensor] = None) -> torch.Tensor:
     """x: [..., Cin], dy: [..., Cout] -> dw f32 [Cout][Cin] (pre-zeroed) += dy^T x."""
     rx, cin, ldx = _rows(x)
     ry, cout, ldy = _rows(dy)
     xv = torch.as_strided(x, (1, 1, rx, cin), (rx * ldx, rx * ldx, ldx, 1))
     yv = torch.as_strided(dy, (1, 1, ry, cout), (ry * ldy, ry * ldy, ldy, 1))
-    return conv2d_wgrad(xv, yv, dw, kh=1, kw=1, stride=1, pad=0, dil=1)
+    return conv2d_wgrad(xv, yv, dw, kh=1, kw=1, stride=1, pad=0, dil=1, dbias=dbias)
 
 
 CE_SCRATCH_FLOATS = 2 + 2 * 1024   # CAVP_CE_SCRATCH_FLOATS (include/cavp_hip.h)

@@ -139,10 +139,12 @@ int cavp_cast(int32_t src_dtype, const void* src, int32_t dst_dtype, void* dst, 
 /* Weight gradient of a conv / linear: dw[co][kh][kw][ci] += sum_pixels dy[pix][co] * x[pix @ tap][ci] (f32, OHWI; the
  * result is ADDED to dw).  Fields of `d` describe the FORWARD conv (x is its input, dy its output gradient with pixel
  * stride d->ldy).  The pixel reduction is split over workgroups; partial slabs go to `workspace`
- * (cavp_conv2d_wgrad_workspace_bytes) and are reduced in a fixed order: deterministic, no atomics. */
+ * (cavp_conv2d_wgrad_workspace_bytes) and are reduced in a fixed order: deterministic, no atomics.
+ * dbias (optional, f32 [Cout]): dbias[co] += sum_pixels dy[pix][co], the bias gradient, summed from the dY tiles the kernel
+ * streams anyway (saves the separate column-sum pass over dY). */
 size_t cavp_conv2d_wgrad_workspace_bytes(const cavp_conv_desc* d);
-int cavp_conv2d_wgrad_nhwc(const cavp_conv_desc* d, const void* x, const void* dy, float* dw_ohwi, void* workspace,
-                           size_t workspace_bytes, void* stream);
+int cavp_conv2d_wgrad_nhwc(const cavp_conv_desc* d, const void* x, const void* dy, float* dw_ohwi, float* dbias,
+                           void* workspace, size_t workspace_bytes, void* stream);
 
 /* OIHW f32 -> [Cin][KH][KW][Cout] (dtype), taps rotated by 180 degrees: the OHWI weight of the transposed conv. */
 /* All weight re-packs of one training step in one launch per <= 48 tensors (the per-tensor entry points cost ~170

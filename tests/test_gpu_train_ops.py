@@ -69,7 +69,9 @@ def test_conv_dgrad_wgrad(case, dt):
     _check(dx.permute(0, 3, 1, 2), x.grad + prev, dt, name + ".dgrad")
     # wgrad
     dw = torch.zeros((cout, k, k, cin), dtype=torch.float32, device=DEV)
-    T.conv2d_wgrad(_nhwc(x.detach(), dt), dyv, dw, kh=k, kw=k, stride=s, pad=p, dil=d)
+    db = torch.full((cout,), 0.5, dtype=torch.float32, device=DEV)     # the fused bias gradient ACCUMULATES
+    T.conv2d_wgrad(_nhwc(x.detach(), dt), dyv, dw, kh=k, kw=k, stride=s, pad=p, dil=d, dbias=db)
+    _check(db, dy.sum(dim=(0, 2, 3)) + 0.5, dt, name + ".dbias", f32_tol=5e-5, bf16_tol=2e-2)
     g = torch.zeros((cout, cin, k, k), dtype=torch.float32, device=DEV)
     T.unpack_weight_grad(dw, g, accumulate=False)
     _check(g, wt.grad, dt, name + ".wgrad", f32_tol=5e-5, bf16_tol=2e-2)
@@ -83,8 +85,10 @@ def test_linear_wgrad(rows, cin, cout, dt):
     ops, T = _mods()
     x, dy = _q(_rand(rows, cin, seed=5), dt), _q(_rand(rows, cout, seed=6), dt)
     dw = torch.zeros((cout, cin), dtype=torch.float32, device=DEV)
-    T.linear_wgrad(x.to(dt).to(DEV), dy.to(dt).to(DEV), dw)
+    db = torch.zeros(cout, dtype=torch.float32, device=DEV)
+    T.linear_wgrad(x.to(dt).to(DEV), dy.to(dt).to(DEV), dw, dbias=db)
     _check(dw, dy.t() @ x, dt, "linear_wgrad", f32_tol=5e-5, bf16_tol=2e-2)
+    _check(db, dy.sum(0), dt, "linear_wgrad.dbias", f32_tol=5e-5, bf16_tol=2e-2)
 
 
 @pytest.mark.parametrize("dt", DTYPES, ids=IDS)
