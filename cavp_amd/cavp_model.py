@@ -671,3 +671,22 @@ class CAVP(nn.Module):
         if eval_mode:
             return self.forward_inference(image, audio)
         return self.forward_train(image, audio, shuffle_info, ow_flag, audio_func=audio_func)
+
+
+def load_reference_checkpoint(model: "CAVP", ckpt, strict: bool = False):
+    """Load a checkpoint written by the reference's engine (engine/engine.py:91-99: {"model": model_v.state_dict(), ...},
+    saved from the DDP / DataParallel-wrapped model, hence `module.`-prefixed keys) the way its evaluation scripts do
+    (test_avs_semantic.py:204-205: `model_v.load_state_dict(torch.load(path)["model"], strict=False)` on the wrapped
+    model).  `ckpt`: a path, the full checkpoint dict, or a bare state_dict; prefixes `module.` are stripped so the
+    unwrapped MI355X model can take it.  Returns torch's (missing_keys, unexpected_keys) record."""
+    if isinstance(ckpt, (str, bytes)) or hasattr(ckpt, "__fspath__"):
+        ckpt = torch.load(ckpt, map_location="cpu")
+    sd = ckpt["model"] if isinstance(ckpt, dict) and "model" in ckpt and not torch.is_tensor(ckpt["model"]) else ckpt
+    clean = {}
+    for k, v in sd.items():
+        while k.startswith("module."):
+            k = k[len("module."):]
+        clean[k] = v
+    res = model.load_state_dict(clean, strict=strict)
+    model._packed = None   # kernel-ready (packed / BN-folded) parameters are rebuilt on the next forward
+    return res

@@ -100,3 +100,26 @@ def test_pvt_state_dict_key_tree_matches_reference():
     assert set(mine) == set(ref), sorted(set(mine) ^ set(ref))[:10]
     assert mine == ref
     assert m.latent_dim == 112
+
+
+def test_load_reference_checkpoint_strips_module_prefix(tmp_path):
+    """engine/engine.py:91 saves the wrapped model (`module.` keys); test_avs_semantic.py:204-205 loads with strict=False."""
+    import types
+    from cavp_amd.cavp_model import CAVP, load_reference_checkpoint
+    from cavp_amd.synth import synth_state_dict
+    args = types.SimpleNamespace(seg_model="DeepLabV3Plus", last_three_dilation_stride=[False, False, False],
+                                 audio_backbone="vgg", num_classes=2, batch_size=2, local_rank="cpu")
+    m = CAVP(50, None, num_classes=2, args=args)
+    sd = synth_state_dict({k: tuple(v.shape) for k, v in m.state_dict().items()}, seed=3)
+    wrapped = {"module." + k: v for k, v in sd.items()}
+    wrapped["module.some_dropped_head.weight"] = torch.zeros(1)
+    del wrapped["module.segment.upsample.classifier.bias"]
+    path = tmp_path / "ckpt.pth"
+    torch.save({"model": wrapped, "epoch": 3}, path)
+    res = load_reference_checkpoint(m, str(path))
+    assert res.missing_keys == ["segment.upsample.classifier.bias"] and res.unexpected_keys == ["some_dropped_head.weight"]
+    got = m.state_dict()
+    for k in ("backbone.backbone.conv1.0.weight", "cross_att.pos_embed_v", "audio_backbone.backbone.embeddings.4.weight"):
+        assert torch.equal(got[k], sd[k])
+    res2 = load_reference_checkpoint(m, {"module.module." + k: v for k, v in sd.items()}, strict=True)   # DDP over DataParallel
+    assert not res2.missing_keys and not res2.unexpected_keys
