@@ -67,7 +67,7 @@ typedef struct cavp_conv_desc {
   int32_t ldr;        /* residual pixel stride (ignored when residual == NULL) */
   int32_t act;        /* cavp_act_t */
   int32_t splitk;     /* 0 = let the library choose; >= 1 forces that many K slices */
-  int32_t tile;       /* 0 = auto; otherwise a tile-config id (testing / tuning) */
+  int32_t tile;       /* 0 = auto; otherwise id (1..9) + profiling digits (tools/bench_conv.py): testing / tuning only */
   int32_t up;         /* 0/1 = ordinary conv.  up = s > 1 (power of two): x is read as if zero-upsampled by s, i.e. the
                          data-gradient of a stride-s conv (transposed conv); Ho/Wo below then give the output size */
   int32_t Ho, Wo;     /* only read when up > 1 (the forward conv's input extent) */
