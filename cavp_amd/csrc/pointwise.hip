@@ -280,6 +280,26 @@ __global__ void cast_kernel(const S* __restrict__ s, D* __restrict__ d, long lon
     Elem<D>::st(d + i, Elem<S>::ld(s + i));
 }
 
+// 8 elements per thread (16 bytes of bf16 / 2 x 16 bytes of f32) when the tensors allow it
+template <typename S, typename D>
+__global__ __launch_bounds__(256) void cast_vec8_kernel(const S* __restrict__ s, D* __restrict__ d, long long n8) {
+  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n8; i += (long long)gridDim.x * 256) {
+    float v[8];
+    if constexpr (sizeof(S) == 2) {
+      VecT<bf16_t>::load((const bf16_t*)s + i * 8, v);
+    } else {
+      VecT<float>::load((const float*)s + i * 8, v);
+      VecT<float>::load((const float*)s + i * 8 + 4, v + 4);
+    }
+    if constexpr (sizeof(D) == 2) {
+      VecT<bf16_t>::store((bf16_t*)d + i * 8, v);
+    } else {
+      VecT<float>::store((float*)d + i * 8, v);
+      VecT<float>::store((float*)d + i * 8 + 4, v + 4);
+    }
+  }
+}
+
 inline bool al16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 inline bool dtype_ok(int dt) { return dt == CAVP_F32 || dt == CAVP_BF16; }
 #define CHECK_LAUNCH() return hipGetLastError() == hipSuccess ? CAVP_OK : CAVP_ERR_LAUNCH
@@ -409,8 +429,21 @@ extern "C" int cavp_pack_weight_ohwi(int32_t dtype, const float* w, void* o, int
 extern "C" int cavp_cast(int32_t sdt, const void* src, int32_t ddt, void* dst, int64_t n, void* stream) {
   if (!src || !dst || n <= 0) return CAVP_ERR_BAD_ARG;
   if (!dtype_ok(sdt) || !dtype_ok(ddt)) return CAVP_ERR_UNSUPPORTED;
-  const int nb = nblocks(n, 256, 8192);
   hipStream_t s = (hipStream_t)stream;
+  if (n % 8 == 0 && al16(src) && al16(dst)) {
+    const long long n8 = n / 8;
+    const int nb8 = nblocks(n8, 256, 16384);
+    if (sdt == CAVP_F32 && ddt == CAVP_BF16)
+      cast_vec8_kernel<float, bf16_t><<<nb8, 256, 0, s>>>((const float*)src, (bf16_t*)dst, n8);
+    else if (sdt == CAVP_BF16 && ddt == CAVP_F32)
+      cast_vec8_kernel<bf16_t, float><<<nb8, 256, 0, s>>>((const bf16_t*)src, (float*)dst, n8);
+    else if (sdt == CAVP_F32)
+      cast_vec8_kernel<float, float><<<nb8, 256, 0, s>>>((const float*)src, (float*)dst, n8);
+    else
+      cast_vec8_kernel<bf16_t, bf16_t><<<nb8, 256, 0, s>>>((const bf16_t*)src, (bf16_t*)dst, n8);
+    CHECK_LAUNCH();
+  }
+  const int nb = nblocks(n, 256, 8192);
   if (sdt == CAVP_F32 && ddt == CAVP_BF16)
     cast_kernel<float, bf16_t><<<nb, 256, 0, s>>>((const float*)src, (bf16_t*)dst, n);
   else if (sdt == CAVP_BF16 && ddt == CAVP_F32)
