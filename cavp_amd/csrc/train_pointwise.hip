@@ -963,6 +963,15 @@ extern "C" int cavp_scale_shift_act(int32_t dtype, const void* x, const float* s
   if (C % VE || ldx % VE || ldy % VE || (residual && ldr % VE)) return CAVP_ERR_UNSUPPORTED;
   if (!al16(x) || !al16(y) || (residual && !al16(residual))) return CAVP_ERR_ALIGN;
   hipStream_t s = (hipStream_t)stream;
+  if (!scale && !shift && ldx == C && ldy == C && (!residual || ldr == C)) {
+    // coefficient-free pass over dense tensors (the GELU of the token MLP, C = 1216): any power-of-two row length will do
+    const long long vecs = rows * (long long)(C / VE);
+    int cv2 = 256;
+    while (cv2 > 1 && vecs % cv2) cv2 >>= 1;
+    rows = vecs / cv2;
+    C = cv2 * VE;
+    ldx = ldy = ldr = C;
+  }
   if (flat_ok(C, VE, scale, shift)) {
     const int CV = C / VE;
     const int rpb = flat_rows_per_block(rows, C, 16 / VE, CV, 16 << 10, 1 << 20);
