@@ -46,6 +46,8 @@ def parse():
     ap.add_argument("--config", choices=["c1p", "c4"], default="c1p",
                     help="c1p = ResNet-50 224x224 (the BASELINE metric); c4 = PVTv2-B5 512x512, inference only (config #4)")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
+    ap.add_argument("--split-graph", action="store_true",
+                    help="force the two-graph replay of the data-parallel path (cut where the early gradients are final) on one GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-sample-batch", type=int, default=8)
@@ -310,7 +312,7 @@ def main():
         run_step()      # eager warm-up: packs weights, sizes the workspace
         torch.cuda.synchronize()
         if train and not a.no_graph:
-            step = model.capture_train_step(image, audio, label)   # ~1000 launches replayed as one hipGraph
+            step = model.capture_train_step(image, audio, label, split=True if a.split_graph else None)   # ~1000 launches as hipGraph(s)
         elif train:
             step = run_step
         elif a.no_graph:

@@ -605,19 +605,29 @@ class CAVP(nn.Module):
         out_pred, out_fusion, visual, audio_f, attn_v = CAVPTrainFunction.apply(self, image, audio, *params)
         return out_pred, out_fusion, {"audio": audio_f, "visual": visual, "attn_v": attn_v}
 
-    def train_step(self, image, audio, label, ignore_index: int = 255, loss_scale: float = 1.0, all_reduce: bool = True):
+    def _late_grad_ids(self):
+        """Parameters whose gradients the backward finishes last (see GradArena): backbone, ASPP, low-level reduce."""
+        late = list(self.backbone.parameters())
+        if hasattr(self.segment, "aspp"):
+            late += list(self.segment.aspp.parameters()) + list(self.segment.reduce.parameters())
+        return {id(p) for p in late}
+
+    def train_step(self, image, audio, label, ignore_index: int = 255, loss_scale: float = 1.0, all_reduce: bool = True,
+                   _split_hook=None):
         """MI355X-native fused training step (no torch.autograd): forward_train (batch-stat BN, audio 2B) -> HIP
         cross-entropy on `out[:B] + out[B:]*0` (trainer_cavp_vpo_mono.py:171,187) -> hand-written backward.  Every
-        gradient lands in one flat f32 arena (`p.grad` are views of it); with a torch.distributed process group the
-        arena is all-reduced once over RCCL and averaged (DDP semantics, main_vpo_mono.py:131-135).
+        gradient lands in one flat f32 arena (`p.grad` are views of it).  With a torch.distributed process group the
+        arena is all-reduced over RCCL and averaged (DDP semantics, main_vpo_mono.py:131-135) in two pieces: the range
+        the backward completes early (head, attention, audio encoder: ~75 % of the bytes) is reduced asynchronously
+        while the backbone backward still runs, the remainder at the end.
         Returns the (local) loss as a 1-element device tensor."""
         from . import train_ops as T
-        from .train import GradArena, TrainPass, allreduce_arena, dist_world, run_train_forward
+        from .train import GradArena, TrainPass, allreduce_arena_early, allreduce_arena_late, dist_world, run_train_forward
         if not image.is_cuda:
             raise CavpError("CAVP (MI355X path) needs inputs on a HIP device: there is no CPU fallback")
         arena = getattr(self, "_grad_arena", None)
         if arena is None or arena.flat.device != image.device:
-            arena = self._grad_arena = GradArena(list(self.parameters()), image.device)
+            arena = self._grad_arena = GradArena(list(self.parameters()), image.device, late_ids=self._late_grad_ids())
         arena.zero()
         tp = TrainPass(self, self.compute_dtype, arena=arena)
         B, C = image.shape[0], self.num_classes
@@ -630,21 +640,32 @@ class CAVP(nn.Module):
             g = torch.zeros(lo.t.shape, dtype=lo.t.dtype, device=lo.t.device)
             T.bilinear_bwd_from_nchw(dl, g[..., :C], n_valid=B, align_corners=False)
             lo.set_g(g)
+            early = []
+            if _split_hook is not None:
+                tp.on_early_final = _split_hook
+            elif world > 1:
+                tp.on_early_final = lambda: early.append(allreduce_arena_early(arena))
             tp.backward()
             tp.finish_padded()
             if world > 1:
-                allreduce_arena(arena)                                        # ONE collective for all 119.8 M gradients
+                allreduce_arena_late(arena, early[0] if early else None)   # + joins the early collective
             for p in arena.params:
                 p.grad = arena.views[id(p)] if id(p) in tp.touched else None   # untouched = None, as torch would leave it
         self._last_outputs = (out_pred, fusion, attn)
         return loss
 
-    def capture_train_step(self, image, audio, label, ignore_index: int = 255, loss_scale: float = 1.0):
-        """Capture forward_train + CE + backward (about 1000 kernel launches) into ONE hipGraph and return
+    def capture_train_step(self, image, audio, label, ignore_index: int = 255, loss_scale: float = 1.0,
+                           split: Optional[bool] = None):
+        """Capture forward_train + CE + backward (about 1000 kernel launches) into hipGraphs and return
         `replay() -> loss`.  `image`, `audio`, `label` are the static input buffers: copy new batches into them before
-        each replay.  Weight packing is part of the graph, so replays always see the current parameters; the
-        cross-rank gradient all-reduce stays outside the graph (issued by replay() on the arena)."""
-        from .train import allreduce_arena, dist_world
+        each replay.  Weight packing is part of the graph, so replays always see the current parameters.
+        Single process: ONE graph.  Data parallel (or `split=True`): TWO graphs cut where the early gradient range is
+        final; replay() = graph 1 -> asynchronous RCCL all-reduce of that range -> graph 2 (rest of the backward, runs
+        concurrently with the collective) -> all-reduce of the late range -> join."""
+        from .train import allreduce_arena_early, allreduce_arena_late, dist_world
+        world = dist_world()
+        if split is None:
+            split = world > 1
         with torch.no_grad():
             self.train_step(image, audio, label, ignore_index, loss_scale, all_reduce=False)   # warm-up: workspace, arena
             torch.cuda.synchronize()
@@ -653,18 +674,40 @@ class CAVP(nn.Module):
             with torch.cuda.stream(side):
                 self.train_step(image, audio, label, ignore_index, loss_scale, all_reduce=False)
             torch.cuda.current_stream().wait_stream(side)
-            graph = torch.cuda.CUDAGraph()
-            world = dist_world()
-            with torch.cuda.graph(graph):
-                loss = self.train_step(image, audio, label, ignore_index, loss_scale / world, all_reduce=False)
+            if not split:
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
+                    loss = self.train_step(image, audio, label, ignore_index, loss_scale / world, all_reduce=False)
+                graphs = (graph,)
+            else:
+                g1, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+                torch.cuda.synchronize()
+                cap = torch.cuda.Stream()
+                cap.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(cap):
+                    g1.capture_begin()
+
+                    def cut():
+                        g1.capture_end()
+                        g2.capture_begin(pool=g1.pool())   # graph 2 keeps using (and keeps alive) graph 1's allocations
+
+                    loss = self.train_step(image, audio, label, ignore_index, loss_scale / world, all_reduce=False,
+                                           _split_hook=cut)
+                    g2.capture_end()
+                torch.cuda.current_stream().wait_stream(cap)
+                graphs = (g1, g2)
         arena = self._grad_arena
 
         def replay():
-            graph.replay()
-            if world > 1:
-                allreduce_arena(arena)
+            graphs[0].replay()
+            if len(graphs) == 2:
+                work = allreduce_arena_early(arena)
+                graphs[1].replay()
+                allreduce_arena_late(arena, work)
+            elif world > 1:
+                allreduce_arena_late(arena, None)
             return loss
-        self._train_graph = graph   # keep alive
+        self._train_graph = graphs   # keep alive
         return replay
 
     def forward(self, image, audio=None, shuffle_info=None, ow_flag=False, eval_mode=False, audio_func=False):

@@ -70,13 +70,22 @@ class GradArena:
     """One flat f32 buffer holding every parameter gradient (views per parameter): a single memset per step and a
     single RCCL all-reduce over xGMI for data parallelism (C1 in SURVEY.md §2.3) instead of one per tensor/bucket."""
 
-    def __init__(self, params, device):
-        self.params = [p for p in params if p.requires_grad]
+    def __init__(self, params, device, late_ids=None):
+        """`late_ids`: ids of the parameters whose gradients become final LAST in the backward pass (backbone, ASPP,
+        low-level reduce).  They are laid out first, so that `flat[split:]` - everything the backward finishes early
+        (decoder head, cross attention, projector, the 73 M-parameter audio encoder = ~75 % of the bytes) - is one
+        contiguous range that can be all-reduced while the rest of the backward still runs."""
+        ps = [p for p in params if p.requires_grad]
+        late_ids = late_ids or set()
+        self.params = [p for p in ps if id(p) in late_ids] + [p for p in ps if id(p) not in late_ids]
         total = sum((p.numel() + 3) // 4 * 4 for p in self.params)   # keep every view 16-byte aligned
         self.flat = torch.zeros(total, dtype=torch.float32, device=device)
         self.views: Dict[int, torch.Tensor] = {}
         off = 0
+        self.split = 0
         for p in self.params:
+            if id(p) in late_ids:
+                self.split = off + (p.numel() + 3) // 4 * 4
             self.views[id(p)] = self.flat[off:off + p.numel()].view(p.shape)
             off += (p.numel() + 3) // 4 * 4
 
@@ -95,6 +104,27 @@ def allreduce_arena(arena: GradArena) -> None:
     import torch.distributed as dist
     if dist_world() > 1:
         dist.all_reduce(arena.flat)
+
+
+def allreduce_arena_early(arena: GradArena):
+    """Start the all-reduce of the early-final range `flat[split:]` without blocking the launching stream (the collective
+    runs on RCCL's own stream behind everything queued so far); returns the work handle (None for a single process)."""
+    import torch.distributed as dist
+    if dist_world() > 1 and arena.split < arena.flat.numel():
+        return dist.all_reduce(arena.flat[arena.split:], async_op=True)
+    return None
+
+
+def allreduce_arena_late(arena: GradArena, early_work) -> None:
+    """All-reduce the late range `flat[:split]` and join the early collective: afterwards the whole arena is reduced."""
+    import torch.distributed as dist
+    if dist_world() > 1:
+        if early_work is None:
+            dist.all_reduce(arena.flat)
+            return
+        if arena.split > 0:
+            dist.all_reduce(arena.flat[:arena.split])
+        early_work.wait()
 
 
 def allreduce_bn_stats(bn, buf: torch.Tensor, count: int) -> int:
@@ -120,6 +150,7 @@ class TrainPass:
         self.P: Dict[str, _P] = {}
         self._pack_jobs = []
         self._nbt = []   # BatchNorm num_batches_tracked counters bumped once, together, at the end of the forward
+        self.on_early_final: Optional[Callable[[], None]] = None   # called in backward once head / attention / audio grads are final
         self.dev = next(model.parameters()).device
         self.named: Dict[str, V] = {}   # debug taps (activations + their gradients after backward)
 
@@ -541,6 +572,15 @@ class TrainPass:
         self.tape.append(bwd)
         return y
 
+    def mark_early_grads_final(self) -> None:
+        """Tape marker: everything recorded AFTER this point in the forward (audio encoder, projector, cross attention,
+        decoder head) has its parameter gradients complete when the backward reaches it."""
+        def bwd():
+            self.finish_padded()            # the zero-padded classifier's gradient rows -> its real .grad view
+            if self.on_early_final is not None:
+                self.on_early_final()
+        self.tape.append(bwd)
+
     def backward(self) -> None:
         for fn in reversed(self.tape):
             fn()
@@ -634,6 +674,7 @@ def run_train_forward(model, image: torch.Tensor, audio: torch.Tensor, tp: Train
     fea_v = V(tp.empty((n, lh, lw, co + tp.P["reduce"].cout)))
     tp.bilinear(asp, fea_v.slice(0, co), align_corners=True)
     tp.bn_act(tp.conv(f1, "reduce", stats=True), m.segment.reduce[1], ACT_RELU, out=fea_v.slice(co, co + tp.P["reduce"].cout))
+    tp.mark_early_grads_final()   # backward: all parameter gradients of the ops below are final when this is reached
     # ---- audio on 2B (cavp_model.py:181-186; vgg.py:17-23) ----
     if audio.shape[0] != 2 * B:
         raise CavpError(f"train mode expects audio of 2B = {2 * B} (cavp_model.py:181), got {audio.shape[0]}")

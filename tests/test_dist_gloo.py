@@ -36,6 +36,24 @@ def _worker(rank, world, port, q):
         for i, p in enumerate(params):
             expect = sum((r + 1) * (i + 1) for r in range(world)) / world
             assert torch.allclose(arena.views[id(p)], torch.full(p.shape, expect)), (rank, i)
+        # 1b) two-piece reduction used to overlap the collective with the backward: parameters flagged "late" are laid out
+        #     first, `flat[split:]` (early-final gradients) is reduced asynchronously, `flat[:split]` at the end
+        from cavp_amd.train import allreduce_arena_early, allreduce_arena_late
+        late = {id(params[1])}
+        ar2 = GradArena(params + [frozen], "cpu", late_ids=late)
+        assert ar2.params[0] is params[1] and ar2.split == 8 and ar2.flat.numel() == arena.flat.numel()
+        for i, p in enumerate(params):
+            ar2.views[id(p)].fill_((rank + 1) * (i + 1) / world)
+        work = allreduce_arena_early(ar2)
+        assert work is not None
+        allreduce_arena_late(ar2, work)
+        for i, p in enumerate(params):
+            expect = sum((r + 1) * (i + 1) for r in range(world)) / world
+            assert torch.allclose(ar2.views[id(p)], torch.full(p.shape, expect)), (rank, i, "split")
+        for i, p in enumerate(params):
+            ar2.views[id(p)].fill_(float(rank + i))
+        allreduce_arena_late(ar2, None)          # no early piece started: one collective over everything
+        assert torch.allclose(ar2.views[id(params[2])], torch.full(params[2].shape, float(sum(r + 2 for r in range(world)))))
         # views alias the flat buffer (p.grad = view => the optimiser sees the reduced values with no copy)
         arena.zero()
         assert float(arena.views[id(params[0])].abs().sum()) == 0.0

@@ -231,6 +231,37 @@ def test_train_step_hipgraph_replay_matches_eager():
     assert abs(l3 - l2) > 1e-4
 
 
+def test_split_graph_capture_matches_single_graph():
+    """Data-parallel replay = two hipGraphs cut where the early gradient range (head, attention, audio encoder) is final, so
+    that its all-reduce overlaps the rest of the backward.  On one GPU the cut must not change anything: same loss and the
+    same flat gradient arena as the single-graph replay (up to the f32 atomics of the BN column reductions, whose order
+    varies from run to run); the arena puts the late parameters first."""
+    cfg = dict(C=2, B=4, hw=(64, 64), lds=[False, False, False])
+    B = cfg["B"]
+    image, audio, label = [t.to(DEV) for t in synth_inputs(B, cfg["hw"], audio_batch=2 * B, num_classes=cfg["C"], seed=12)]
+    m1, _ = _build(cfg)
+    m2, _ = _build(cfg)
+    r1 = m1.capture_train_step(image, audio, label, split=False)
+    r2 = m2.capture_train_step(image, audio, label, split=True)
+    assert len(m2._train_graph) == 2 and len(m1._train_graph) == 1
+    sd = {k: v.clone() for k, v in m1.state_dict().items()}
+    for it in range(2):
+        m1.load_state_dict(sd)
+        m2.load_state_dict(sd)
+        l1, l2 = float(r1().item()), float(r2().item())
+        torch.cuda.synchronize()
+        assert abs(l1 - l2) <= 1e-4 * abs(l1), (it, l1, l2)
+        a, b = m1._grad_arena.flat.double(), m2._grad_arena.flat.double()
+        cos = float((a @ b) / (a.norm() * b.norm()))
+        assert cos >= 0.9995 and abs(float(a.norm() / b.norm()) - 1.0) <= 5e-3, (it, cos)
+    ar = m2._grad_arena
+    late = m2._late_grad_ids()
+    assert 0 < ar.split < ar.flat.numel()
+    assert all(id(p) in late for p in ar.params[:len(late)]) and all(id(p) not in late for p in ar.params[len(late):])
+    early_bytes = (ar.flat.numel() - ar.split) / ar.flat.numel()
+    assert early_bytes > 0.6, early_bytes      # the audio encoder alone is 61 % of the parameters
+
+
 def test_ce_plus_contrast_through_autograd_path():
     """The reference trainer's loss (trainer_cavp_vpo_mono.py:183-189): CE on `out[:B] + out[B:]*0` PLUS ContrastLoss on
     out_fusion halves - gradients enter the HIP backward through BOTH out_pred and out_fusion.  Checked against the
