@@ -203,7 +203,12 @@ int launch_col_reduce(int dtype, ColArgs& a, hipStream_t s) {
     CHECK_LAUNCH();
   }
   const int gy = cdiv_h(a.C, 16 * VE);
-  int gx = 2048 / gy;
+  // workgroups per launch: every one ends with 2 x 128 device-scope f32 atomics, which are served memory-side (the L2s of
+  // the 8 XCDs are not coherent): at 2048 workgroups the atomics were 40 % of the BN backward reduce (1.60 ms per step,
+  // 0.95 without them); 512 keeps enough loads in flight and costs 1.27 ms (sweep: 2048 / 1024 / 512 / 256 -> 1.61 / 1.31 /
+  // 1.27 / 1.58 ms).  CAVP_REDUCE_BLOCKS overrides for A/B runs.
+  static const int target_blocks = getenv("CAVP_REDUCE_BLOCKS") ? atoi(getenv("CAVP_REDUCE_BLOCKS")) : 512;
+  int gx = target_blocks / gy;
   if (gx < 1) gx = 1;
   int rpb = cdiv_h(a.rows, gx);
   if (rpb < 64) rpb = 64;
