@@ -27,8 +27,8 @@ template <> struct Quad<bf16_t> {
   }
   __device__ static __forceinline__ void store(bf16_t* p, const float* v) {
     uint2 t;
-    t.x = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16);
-    t.y = (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
+    t.x = pack2bf(v[0], v[1]);
+    t.y = pack2bf(v[2], v[3]);
     *(uint2*)p = t;
   }
 };

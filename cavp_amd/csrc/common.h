@@ -14,12 +14,16 @@ typedef unsigned short bf16_t;  // raw bfloat16 bits
 #define CAVP_WAVE 64
 
 __device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float(((unsigned)h) << 16); }
-__device__ __forceinline__ bf16_t f2bf(float f) {  // round-to-nearest-even (same as torch .to(bfloat16))
-  unsigned u = __float_as_uint(f);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);  // quiet NaN
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (bf16_t)(u >> 16);
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_hw_t;
+typedef __attribute__((ext_vector_type(2))) float f32x2_hw_t;
+// f32 -> bf16, round-to-nearest-even (same as torch .to(bfloat16)): gfx950 has the conversion in hardware
+// (v_cvt_pk_bf16_f32, two values per instruction); the first version spent ~6 integer VALU ops per element on it, which
+// made the 16-byte-per-thread epilogues VALU-bound.
+__device__ __forceinline__ unsigned pack2bf(float lo, float hi) {
+  const f32x2_hw_t v = {lo, hi};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_hw_t));
 }
+__device__ __forceinline__ bf16_t f2bf(float f) { return (bf16_t)(pack2bf(f, 0.f) & 0xffffu); }
 
 template <typename T> struct Elem;
 template <> struct Elem<float> {
@@ -56,10 +60,10 @@ template <> struct VecT<bf16_t> {
   }
   __device__ static __forceinline__ void store(bf16_t* p, const float* v) {
     uint4 t;
-    t.x = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16);
-    t.y = (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
-    t.z = (unsigned)f2bf(v[4]) | ((unsigned)f2bf(v[5]) << 16);
-    t.w = (unsigned)f2bf(v[6]) | ((unsigned)f2bf(v[7]) << 16);
+    t.x = pack2bf(v[0], v[1]);
+    t.y = pack2bf(v[2], v[3]);
+    t.z = pack2bf(v[4], v[5]);
+    t.w = pack2bf(v[6], v[7]);
     *(uint4*)p = t;
   }
 };
@@ -71,6 +75,26 @@ __device__ __forceinline__ float apply_act(float v, int act) {
     case CAVP_ACT_LEAKY: return v > 0.f ? v : 0.01f * v;                      // nn.LeakyReLU() default slope
     case CAVP_ACT_GELU: return 0.5f * v * (1.f + erff(v * 0.70710678118654752f));  // exact-erf GELU
     default: return v;
+  }
+}
+
+// activation of N values with ONE (wave-uniform) dispatch on the activation code
+template <int N>
+__device__ __forceinline__ void apply_act_vec(float* v, int act) {
+  switch (act) {
+    case CAVP_ACT_RELU:
+#pragma unroll
+      for (int e = 0; e < N; ++e) v[e] = fmaxf(v[e], 0.f);
+      break;
+    case CAVP_ACT_LEAKY:
+#pragma unroll
+      for (int e = 0; e < N; ++e) v[e] = v[e] > 0.f ? v[e] : 0.01f * v[e];
+      break;
+    case CAVP_ACT_GELU:
+#pragma unroll
+      for (int e = 0; e < N; ++e) v[e] = 0.5f * v[e] * (1.f + erff(v[e] * 0.70710678118654752f));
+      break;
+    default: break;
   }
 }
 

@@ -110,8 +110,8 @@ __device__ __forceinline__ void epilogue_store4(const IgemmParams& p, float v0, 
         v[2] += bf2f((bf16_t)(r.y & 0xffff)); v[3] += bf2f((bf16_t)(r.y >> 16));
       }
       uint2 o;
-      o.x = (unsigned)f2bf(apply_act(v[0], p.act)) | ((unsigned)f2bf(apply_act(v[1], p.act)) << 16);
-      o.y = (unsigned)f2bf(apply_act(v[2], p.act)) | ((unsigned)f2bf(apply_act(v[3], p.act)) << 16);
+      o.x = pack2bf(apply_act(v[0], p.act), apply_act(v[1], p.act));
+      o.y = pack2bf(apply_act(v[2], p.act), apply_act(v[3], p.act));
       *(uint2*)yp = o;
     }
   } else {
@@ -460,14 +460,14 @@ __global__ __launch_bounds__(64 * WC * WP, (WC * WP == 4 ? 2 : 1)) void igemm_ke
             v[2 * e + 1] += __uint_as_float(rr[g][e] & 0xffff0000u);
           }
         }
+        apply_act_vec<VE>(v, p.act);
         u32x4_t o;
         if constexpr (sizeof(T) == 4) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) o[e] = __float_as_uint(apply_act(v[e], p.act));
+          for (int e = 0; e < 4; ++e) o[e] = __float_as_uint(v[e]);
         } else {
 #pragma unroll
-          for (int e = 0; e < 4; ++e)
-            o[e] = (unsigned)f2bf(apply_act(v[2 * e], p.act)) | ((unsigned)f2bf(apply_act(v[2 * e + 1], p.act)) << 16);
+          for (int e = 0; e < 4; ++e) o[e] = pack2bf(v[2 * e], v[2 * e + 1]);
         }
         *(u32x4_t*)((T*)p.y + (size_t)pix * p.ldy + ec) = o;
       }

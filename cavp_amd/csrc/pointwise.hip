@@ -35,10 +35,10 @@ template <> struct Vec<bf16_t> {
   }
   __device__ static __forceinline__ void store(bf16_t* p, const float* v) {
     uint4 t;
-    t.x = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16);
-    t.y = (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
-    t.z = (unsigned)f2bf(v[4]) | ((unsigned)f2bf(v[5]) << 16);
-    t.w = (unsigned)f2bf(v[6]) | ((unsigned)f2bf(v[7]) << 16);
+    t.x = pack2bf(v[0], v[1]);
+    t.y = pack2bf(v[2], v[3]);
+    t.z = pack2bf(v[4], v[5]);
+    t.w = pack2bf(v[6], v[7]);
     *(uint4*)p = t;
   }
 };

@@ -114,10 +114,10 @@ __global__ __launch_bounds__(256) void sra_attention_kernel(const T* __restrict_
     for (int kp = 0; kp < 8; ++kp) {  // pairs of 16-key blocks = one k-step of 32 keys
       // B operand (P^T): this lane's 8 keys = {4g + r} of block 2kp and {4g + r} of block 2kp+1
       u32x4_t pf;
-      pf[0] = (unsigned)f2bf(s[2 * kp][0]) | ((unsigned)f2bf(s[2 * kp][1]) << 16);
-      pf[1] = (unsigned)f2bf(s[2 * kp][2]) | ((unsigned)f2bf(s[2 * kp][3]) << 16);
-      pf[2] = (unsigned)f2bf(s[2 * kp + 1][0]) | ((unsigned)f2bf(s[2 * kp + 1][1]) << 16);
-      pf[3] = (unsigned)f2bf(s[2 * kp + 1][2]) | ((unsigned)f2bf(s[2 * kp + 1][3]) << 16);
+      pf[0] = pack2bf(s[2 * kp][0], s[2 * kp][1]);
+      pf[1] = pack2bf(s[2 * kp][2], s[2 * kp][3]);
+      pf[2] = pack2bf(s[2 * kp + 1][0], s[2 * kp + 1][1]);
+      pf[3] = pack2bf(s[2 * kp + 1][2], s[2 * kp + 1][3]);
 #pragma unroll
       for (int db = 0; db < 4; ++db) {
         // A operand (V^T): lane i = d, same key set: tr-read rows r0 = 32kp + 4g (+16), lane s addresses row
@@ -155,8 +155,8 @@ __global__ __launch_bounds__(256) void sra_attention_kernel(const T* __restrict_
         *(float4*)(op + d) = make_float4(acc[db][0] * inv, acc[db][1] * inv, acc[db][2] * inv, acc[db][3] * inv);
       } else {
         uint2 w;
-        w.x = (unsigned)f2bf(acc[db][0] * inv) | ((unsigned)f2bf(acc[db][1] * inv) << 16);
-        w.y = (unsigned)f2bf(acc[db][2] * inv) | ((unsigned)f2bf(acc[db][3] * inv) << 16);
+        w.x = pack2bf(acc[db][0] * inv, acc[db][1] * inv);
+        w.y = pack2bf(acc[db][2] * inv, acc[db][3] * inv);
         *(uint2*)(op + d) = w;
       }
     }
@@ -211,7 +211,7 @@ __global__ __launch_bounds__(256) void dwconv3x3_kernel(const T* __restrict__ x,
       unsigned* tu = (unsigned*)&t;
 #pragma unroll
       for (int i = 0; i < 4; ++i)
-        tu[i] = (unsigned)f2bf(apply_act(acc[2 * i], act)) | ((unsigned)f2bf(apply_act(acc[2 * i + 1], act)) << 16);
+        tu[i] = pack2bf(apply_act(acc[2 * i], act), apply_act(acc[2 * i + 1], act));
       *(uint4*)yp = t;
     }
   }
