@@ -422,42 +422,59 @@ __global__ __launch_bounds__(64 * WC * WP, (WC * WP == 4 ? 2 : 1)) void igemm_ke
     }
     constexpr int G = ITER < 8 ? ITER : 8;  // chunks finished per batch: all residual loads of a batch fly together
     static_assert(ITER % G == 0, "chunk batches");
+    static_assert(RSTR % 8 == 0, "the LDS swizzle key (row & 7) is the same for all chunks of a thread");
+    // per-thread invariants: everything that does not depend on the chunk index is computed once, the chunk loop only
+    // adds constants (this loop was VALU-bound: 64-bit multiplies and the swizzle per chunk, activation dispatch and an
+    // integer bf16 rounding per element)
+    const int key = eprow0 & SWZ;
+    const float* lds0 = st + (size_t)eprow0 * BC + (((ecc / 4) ^ key) << 2);                       // first f32x4 of chunk 0
+    const float* lds1 = VE == 8 ? st + (size_t)eprow0 * BC + (((ecc / 4 + 1) ^ key) << 2) : lds0;  // second (bf16 only)
+    T* yp = (T*)p.y + (size_t)(p_base + eprow0) * p.ldy + ec;
+    const T* rp = p.res ? (const T*)p.res + (size_t)(p_base + eprow0) * p.ldr + ec : nullptr;
+    const size_t ystep = (size_t)RSTR * p.ldy, rstep = (size_t)RSTR * p.ldr;
+    const bool has_ss = p.scale != nullptr || p.shift != nullptr;
+    const int rows_left = p.M - (p_base + eprow0);   // chunk k is in range iff k * RSTR < rows_left
     for (int i0 = 0; i0 < ITER; i0 += G) {
       u32x4_t rr[G];
-      bool okk[G];
+      if (rp) {
 #pragma unroll
-      for (int g = 0; g < G; ++g) {
-        const int pix = p_base + eprow0 + (i0 + g) * RSTR;
-        okk[g] = ec_ok && pix < p.M;
-        rr[g] = (u32x4_t){0u, 0u, 0u, 0u};
-        if (p.res && okk[g]) rr[g] = *(const u32x4_t*)((const T*)p.res + (size_t)pix * p.ldr + ec);
+        for (int g = 0; g < G; ++g) {
+          rr[g] = (u32x4_t){0u, 0u, 0u, 0u};
+          if (ec_ok && (i0 + g) * RSTR < rows_left) rr[g] = *(const u32x4_t*)(rp + (size_t)(i0 + g) * rstep);
+        }
       }
 #pragma unroll
       for (int g = 0; g < G; ++g) {
-        const int prow = eprow0 + (i0 + g) * RSTR, pix = p_base + prow;
-        if (!okk[g]) continue;
+        const int k = i0 + g;
+        if (!(ec_ok && k * RSTR < rows_left)) continue;
         float v[VE];
-#pragma unroll
-        for (int q = 0; q < VE / 4; ++q) {
-          const int slot = ecc / 4 + q;
-          const f32x4_t t = *(const f32x4_t*)(st + (size_t)prow * BC + ((slot ^ (prow & SWZ)) << 2));
-          v[4 * q] = t[0]; v[4 * q + 1] = t[1]; v[4 * q + 2] = t[2]; v[4 * q + 3] = t[3];
+        {
+          const f32x4_t t = *(const f32x4_t*)(lds0 + (size_t)k * RSTR * BC);
+          v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3];
+        }
+        if constexpr (VE == 8) {
+          const f32x4_t t = *(const f32x4_t*)(lds1 + (size_t)k * RSTR * BC);
+          v[4] = t[0]; v[5] = t[1]; v[6] = t[2]; v[7] = t[3];
         }
         if (p.nbias) {
-          const float* nb = p.nbias + (size_t)(pix / HoWo) * p.Cout + ec;
+          const float* nb = p.nbias + (size_t)((p_base + eprow0 + k * RSTR) / HoWo) * p.Cout + ec;
 #pragma unroll
           for (int e = 0; e < VE; ++e) v[e] += nb[e];
         }
+        if (has_ss) {
 #pragma unroll
-        for (int e = 0; e < VE; ++e) v[e] = __fadd_rn(__fmul_rn(v[e], sc[e]), sh[e]);  // two roundings, as every other epilogue path
-        if constexpr (sizeof(T) == 4) {
+          for (int e = 0; e < VE; ++e) v[e] = __fadd_rn(__fmul_rn(v[e], sc[e]), sh[e]);  // two roundings, as every other epilogue path
+        }
+        if (rp) {
+          if constexpr (sizeof(T) == 4) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] += __uint_as_float(rr[g][e]);
-        } else {
+            for (int e = 0; e < 4; ++e) v[e] += __uint_as_float(rr[g][e]);
+          } else {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            v[2 * e] += __uint_as_float(rr[g][e] << 16);
-            v[2 * e + 1] += __uint_as_float(rr[g][e] & 0xffff0000u);
+            for (int e = 0; e < 4; ++e) {
+              v[2 * e] += __uint_as_float(rr[g][e] << 16);
+              v[2 * e + 1] += __uint_as_float(rr[g][e] & 0xffff0000u);
+            }
           }
         }
         apply_act_vec<VE>(v, p.act);
@@ -469,7 +486,7 @@ __global__ __launch_bounds__(64 * WC * WP, (WC * WP == 4 ? 2 : 1)) void igemm_ke
 #pragma unroll
           for (int e = 0; e < 4; ++e) o[e] = pack2bf(v[2 * e], v[2 * e + 1]);
         }
-        *(u32x4_t*)((T*)p.y + (size_t)pix * p.ldy + ec) = o;
+        *(u32x4_t*)(yp + (size_t)k * ystep) = o;
       }
     }
     return;
