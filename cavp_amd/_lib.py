@@ -26,7 +26,7 @@ class ConvDesc(C.Structure):
     """struct cavp_conv_desc (include/cavp_hip.h)."""
     _fields_ = [(n, C.c_int32) for n in (
         "dtype", "N", "H", "W", "Cin", "ldx", "Cout", "ldy", "KH", "KW", "stride", "pad", "dil", "ldr", "act",
-        "splitk", "tile", "up", "Ho", "Wo", "stride_w")]
+        "splitk", "tile", "up", "Ho", "Wo", "stride_w", "dw_oihw")]
 
 
 _vp, _i32, _i64, _f32, _sz = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_size_t

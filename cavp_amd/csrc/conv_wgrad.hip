@@ -34,6 +34,7 @@ struct WgradParams {
   int tiles_co, tiles_ci, ksplit;
   int rows_per_split;  // multiple of 64
   int x_bytes, dy_bytes;
+  int oihw;            // dw layout: 0 = [Cout][taps][Cin] (OHWI), 1 = [Cout][Cin][taps] (torch .grad layout)
   int dbg;             // profiling only (env CAVP_WGRAD_DBG): 1 = loads out of range, 2 = no MFMAs, 4 = no DMA, 8 = no epilogue
   float* dbias;        // optional: dbias[co] += sum_pix dY[pix][co] (bias gradient), taken from the dY tiles streamed anyway
   float* bias_slabs;   // ksplit > 1: [ksplit][Cout] partial column sums
@@ -245,13 +246,19 @@ __global__ __launch_bounds__(256, (BK == 32 ? 4 : 2)) void wgrad_kernel(const Wg
       const int ci = ci_base + wci0 + a * 16 + lgrp * 4;
       const int co = co_base + wco0 + b * 16 + lrow;
       if (co < p.Cout && ci < p.Cin) {   // Cin % 4 == 0: a quad is in range as a whole
-        float4* dst = (float4*)(out + ((size_t)co * p.ntaps_all + tap) * p.Cin + ci);
-        float4 v = make_float4(acc[a][b][0], acc[a][b][1], acc[a][b][2], acc[a][b][3]);
-        if (p.ksplit == 1) {
-          const float4 o = *dst;
-          v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+        if (p.ksplit == 1 && p.oihw) {   // straight into the torch-layout gradient: 4 strided read-modify-writes
+          float* dst = out + ((size_t)co * p.Cin + ci) * p.ntaps_all + tap;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) dst[(size_t)e * p.ntaps_all] += acc[a][b][e];
+        } else {
+          float4* dst = (float4*)(out + ((size_t)co * p.ntaps_all + tap) * p.Cin + ci);
+          float4 v = make_float4(acc[a][b][0], acc[a][b][1], acc[a][b][2], acc[a][b][3]);
+          if (p.ksplit == 1) {
+            const float4 o = *dst;
+            v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+          }
+          *dst = v;
         }
-        *dst = v;
       }
     }
   }
@@ -299,8 +306,14 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradParams p) 
       __syncthreads();
     }
     if (zg == 0 && i < total) {
-      const float4 o = *(const float4*)(p.dw + off);
-      *(float4*)(p.dw + off) = make_float4(o.x + s.x, o.y + s.y, o.z + s.z, o.w + s.w);
+      if (p.oihw) {   // off = (co * taps_all + tap) * Cin + ci  ->  (co * Cin + ci) * taps_all + tap
+        const size_t row = off / p.Cin, ci = off - row * p.Cin, co = row / p.ntaps_all, tap = row - co * p.ntaps_all;
+        float* d = p.dw + (co * p.Cin + ci) * p.ntaps_all + tap;
+        d[0] += s.x; d[p.ntaps_all] += s.y; d[2 * (size_t)p.ntaps_all] += s.z; d[3 * (size_t)p.ntaps_all] += s.w;
+      } else {
+        const float4 o = *(const float4*)(p.dw + off);
+        *(float4*)(p.dw + off) = make_float4(o.x + s.x, o.y + s.y, o.z + s.z, o.w + s.w);
+      }
     }
   }
   if (p.dbias) {   // bias partials: one thread per output channel, splits in order
@@ -400,6 +413,7 @@ extern "C" int cavp_conv2d_wgrad_nhwc(const cavp_conv_desc* d, const void* x, co
   if (pl.ws_bytes > 0 && (!workspace || workspace_bytes < pl.ws_bytes || ((uintptr_t)workspace & 15))) return CAVP_ERR_WORKSPACE;
   WgradParams& p = pl.p;
   p.x = x; p.dy = dy; p.dw = dw; p.slabs = (float*)workspace; p.dbias = dbias;
+  p.oihw = d->dw_oihw != 0 && p.ntaps_all > 1;   // (1x1: the two layouts coincide)
   p.bias_slabs = p.slabs ? p.slabs + (size_t)p.ksplit * d->Cout * p.ntaps_all * d->Cin : nullptr;
   {
     static const int dbg = getenv("CAVP_WGRAD_DBG") ? atoi(getenv("CAVP_WGRAD_DBG")) : 0;

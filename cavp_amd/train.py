@@ -338,10 +338,9 @@ class TrainPass:
         if p.kh * p.kw == 1:
             dw = self.grad_buffer(p.weight)   # OHWI == OIHW for 1x1 / linear: accumulate in place
             T.conv2d_wgrad(x4, g4, dw.view(p.cout, 1, 1, p.cin), kh=1, kw=1, stride=p.stride, pad=p.pad, dil=p.dil, dbias=db)
-        else:
-            tmp = self.zeros_f32(p.cout, p.kh, p.kw, p.cin)
-            T.conv2d_wgrad(x4, g4, tmp, kh=p.kh, kw=p.kw, stride=p.stride, pad=p.pad, dil=p.dil, dbias=db)
-            T.unpack_weight_grad(tmp, self.grad_buffer(p.weight), accumulate=True)   # buffer starts at zero
+        else:   # k x k: the kernel accumulates straight into the torch-layout gradient (no OHWI temporary + unpack pass)
+            T.conv2d_wgrad(x4, g4, self.grad_buffer(p.weight), kh=p.kh, kw=p.kw, stride=p.stride, pad=p.pad, dil=p.dil,
+                           dbias=db, dw_oihw=True)
 
     def conv_smallcin(self, x_nchw: torch.Tensor, key: str, stride: int, act: int) -> V:
         """First stem conv (raw, BN follows) / first VGG conv (bias + ReLU fused).  Input needs no gradient."""

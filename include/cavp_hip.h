@@ -73,6 +73,7 @@ typedef struct cavp_conv_desc {
   int32_t Ho, Wo;     /* only read when up > 1 (the forward conv's input extent) */
   int32_t stride_w;   /* 0 = same as `stride`; otherwise the horizontal stride (PVT spatial-reduction convs are run as
                          KH = sr, KW = 1 convs over the input viewed as [N][H][W/sr][sr*C] with stride (sr, 1)) */
+  int32_t dw_oihw;    /* cavp_conv2d_wgrad_nhwc only: 1 = accumulate into a torch-layout [Cout][Cin][KH][KW] gradient (default 0: OHWI) */
 } cavp_conv_desc;
 
 size_t cavp_conv2d_workspace_bytes(const cavp_conv_desc* d);

@@ -77,6 +77,11 @@ def test_conv_dgrad_wgrad(case, dt):
     _check(g, wt.grad, dt, name + ".wgrad", f32_tol=5e-5, bf16_tol=2e-2)
     T.unpack_weight_grad(dw, g, accumulate=True)
     _check(g, 2 * wt.grad, dt, name + ".wgrad.acc", f32_tol=5e-5, bf16_tol=2e-2)
+    # torch-layout destination (no unpack pass): accumulates into the existing gradient, for every split count
+    for sk in (0, 1, 3):
+        g2 = torch.full((cout, cin, k, k), 0.25, dtype=torch.float32, device=DEV)
+        T.conv2d_wgrad(_nhwc(x.detach(), dt), dyv, g2, kh=k, kw=k, stride=s, pad=p, dil=d, dw_oihw=True, splitk=sk)
+        _check(g2, wt.grad + 0.25, dt, name + f".wgrad.oihw.sk{sk}", f32_tol=5e-5, bf16_tol=2e-2)
 
 
 @pytest.mark.parametrize("dt", DTYPES, ids=IDS)
