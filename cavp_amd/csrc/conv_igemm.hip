@@ -544,8 +544,10 @@ struct TileCfg {
   float eff;  // relative per-WG efficiency (bigger tiles reuse LDS operands more)
 };
 const TileCfg kTiles[] = {
-    {1, 128, 128, 1.00f}, {2, 64, 128, 0.90f}, {3, 64, 64, 0.72f}, {4, 128, 64, 0.95f},
-    {5, 128, 32, 0.55f},  {6, 16, 128, 0.30f}, {7, 32, 128, 0.55f},
+    // eff ~ operand bytes per flop relative to 128x128 (the K loop is bound by the LDS-DMA path, profiles/r01_notes.md),
+    // softened for the small tiles whose launches are dominated by fixed costs; checked against tools/bench_conv.py sweeps
+    {1, 128, 128, 1.00f}, {2, 64, 128, 0.72f}, {3, 64, 64, 0.60f}, {4, 128, 64, 0.75f},
+    {5, 128, 32, 0.45f},  {6, 16, 128, 0.25f}, {7, 32, 128, 0.45f},
     {8, 256, 128, 1.00f}, {9, 128, 256, 1.00f},  // 8 waves, 3 stages (eff set to 1.0 until measured: kBigEff below)
 };
 inline int tile_stages(int id) { return id >= 8 ? 3 : 2; }
@@ -684,6 +686,12 @@ Plan make_plan(const cavp_conv_desc* d) {
       const double rounds = (double)((long long)((blocks + slots - 1) / slots));
       const double wg_flops = 2.0 * t.BC * t.BP * (double)BK * ((double)p.iters / use_sk);
       double tt = rounds * wg_flops / (peak * t.eff / slots) + 2e-6;
+      // HBM floor (input once, output once): on bandwidth-bound layers every tile ties on it and the smaller tile (more
+      // workgroups in flight, cheaper prologue / epilogue each) wins the tie
+      const double es_ = d->dtype == CAVP_F32 ? 4.0 : 2.0;
+      const double t_mem = ((double)d->N * d->H * d->W * d->Cin + (double)p.M * p.Cout) * es_ / 3.5e12 + 2e-6;
+      if (tt < t_mem) tt = t_mem;
+      tt += 2e-7 * (double)(t.BC * t.BP) / 16384.0;
       if (use_sk > 1) tt += (2.0 * use_sk + 1.0) * p.M * p.Cout * 4.0 / 3e12 + 4e-6;
       if (tt < best_t) { best_t = tt; best = i; best_sk = use_sk; }
     }

@@ -28,6 +28,22 @@ SHAPES = {
     "ca_fc2_1216_304@3136+res": (32, 1, 3136, 1216, 304, 1, 1, 0, 1, True),
     "ca_q_304_304@3136": (32, 1, 3136, 304, 304, 1, 1, 0, 1, False),
     "a_fc0_12288_4096@1": (32, 1, 1, 12288, 4096, 1, 1, 0, 1, False),
+    # train-step batch (2B = 64 fused rows) of the decoder head / token layers, and a few more backbone shapes
+    "T_head0_3x3_304_256@56": (64, 56, 56, 304, 256, 3, 1, 1, 1, False),
+    "T_head0dg_3x3_256_304@56": (64, 56, 56, 256, 304, 3, 1, 1, 1, False),
+    "T_head1_3x3_256_256@56": (64, 56, 56, 256, 256, 3, 1, 1, 1, False),
+    "T_ca_fc1_304_1216": (64, 1, 3136, 304, 1216, 1, 1, 0, 1, False),
+    "T_ca_fc2_1216_304": (64, 1, 3136, 1216, 304, 1, 1, 0, 1, True),
+    "T_ca_q_304_304": (64, 1, 3136, 304, 304, 1, 1, 0, 1, False),
+    "T_stem1_3x3_64_64@112": (32, 112, 112, 64, 64, 3, 1, 1, 1, False),
+    "T_stem2dg_3x3_128_64@112": (32, 112, 112, 128, 64, 3, 1, 1, 1, False),
+    "T_l2_3x3_128_128@28": (32, 28, 28, 128, 128, 3, 1, 1, 1, False),
+    "T_l2_1x1_512_128@28": (32, 28, 28, 512, 128, 1, 1, 0, 1, False),
+    "T_l3_1x1_256_1024@14": (32, 14, 14, 256, 1024, 1, 1, 0, 1, True),
+    "T_l4_1x1_2048_512@14": (32, 14, 14, 2048, 512, 1, 1, 0, 1, False),
+    "T_aspp_1x1_2048_256@14": (32, 14, 14, 2048, 256, 1, 1, 0, 1, False),
+    "T_cls_1x1_256_8@56": (64, 56, 56, 256, 8, 1, 1, 0, 1, False),
+    "T_clsdg_1x1_8_256@56": (64, 56, 56, 8, 256, 1, 1, 0, 1, False),
 }
 
 
