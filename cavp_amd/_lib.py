@@ -65,9 +65,10 @@ PROTOTYPES = {
     "cavp_scale_f32": (_i32, [_vp, _f32, _vp, _i32, _vp]),
     "cavp_bn_finalize": (_i32, [_vp, _vp, _vp, _i64, _vp, _vp, _f32, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp]),
     "cavp_scale_shift_act": (_i32, [_i32, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _vp]),
-    "cavp_bn_act_bwd_reduce": (_i32, [_i32, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),
+    "cavp_bn_act_bwd_reduce": (_i32, [_i32, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp,
+                                      _vp]),
     "cavp_bn_act_bwd_apply": (_i32, [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32,
-                                     _vp, _i32, _vp, _i32, _vp]),
+                                     _vp, _i32, _vp, _i32, _vp, _vp, _vp]),
     "cavp_act_bwd": (_i32, [_i32, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _vp]),
     "cavp_add": (_i32, [_i32, _vp, _vp, _vp, _i64, _vp]),
     "cavp_colsum": (_i32, [_i32, _vp, _i64, _i32, _i32, _vp, _vp]),

@@ -37,6 +37,8 @@ struct ColArgs {
   const void* c;   // z (pre-BN conv output) or nullptr
   const float* mean;   // MODE 1: batch mean;  MODE 0: optional per-channel shift (robust variance)
   const float* rstd;
+  const float* fscale;  // MODE 1 with b == nullptr: the forward's folded scale / shift, the activation mask is re-derived
+  const float* fshift;  //   from z: y = act(z * scale + shift) > 0  <=>  z * scale + shift > 0 (no residual in that case)
   float* out0;
   float* out1;
   int rows, C, lda, ldb, ldc, act, rows_per_block;
@@ -58,9 +60,17 @@ __global__ __launch_bounds__(256) void col_reduce_kernel(const ColArgs p) {
   float mu[VE], rs[VE];
 #pragma unroll
   for (int e = 0; e < VE; ++e) { mu[e] = 0.f; rs[e] = 1.f; }
+  float fs[VE], fh[VE];
+#pragma unroll
+  for (int e = 0; e < VE; ++e) { fs[e] = 1.f; fh[e] = 0.f; }
+  const bool from_z = MODE == 1 && p.b == nullptr;   // activation mask re-derived from z (saves reading y)
   if (MODE == 1 && col_ok) {
 #pragma unroll
     for (int e = 0; e < VE; ++e) { mu[e] = p.mean[c0 + e]; rs[e] = p.rstd[c0 + e]; }
+    if (from_z && p.act != CAVP_ACT_NONE) {
+#pragma unroll
+      for (int e = 0; e < VE; ++e) { fs[e] = p.fscale[c0 + e]; fh[e] = p.fshift[c0 + e]; }
+    }
   }
   if (MODE == 0 && col_ok && p.mean) {
 #pragma unroll
@@ -78,8 +88,13 @@ __global__ __launch_bounds__(256) void col_reduce_kernel(const ColArgs p) {
         for (int e = 0; e < VE; ++e) { const float d = a[e] - mu[e]; s0[e] += d; s1[e] += d * d; }
       } else if (MODE == 1) {
         float y[VE], z[VE];
-        VecT<T>::load((const T*)p.b + r * p.ldb + c0, y);
         VecT<T>::load((const T*)p.c + r * p.ldc + c0, z);
+        if (from_z) {
+#pragma unroll
+          for (int e = 0; e < VE; ++e) y[e] = z[e] * fs[e] + fh[e];   // same expression (and contraction) as scale_shift_act
+        } else {
+          VecT<T>::load((const T*)p.b + r * p.ldb + c0, y);
+        }
 #pragma unroll
         for (int e = 0; e < VE; ++e) {
           const float g = a[e] * act_grad_from_out(y[e], p.act);
@@ -192,7 +207,7 @@ int launch_col_reduce(int dtype, ColArgs& a, hipStream_t s) {
   // (measured: the contiguous geometry helps the read + write kernels, 1.69 -> 1.23 ms per step for scale_shift_act,
   // but not the reductions - 1.59 -> 1.85 ms for the BN backward reduce - so it stays behind CAVP_FLAT_REDUCE=1)
   static const bool flat_reduce = getenv("CAVP_FLAT_REDUCE") != nullptr;
-  if (flat_reduce && flat_ok(a.C, VE, a.mean, a.rstd)) {
+  if (flat_reduce && (MODE != 1 || a.b != nullptr) && flat_ok(a.C, VE, a.mean, a.rstd)) {
     const int CV = a.C / VE;
     a.rows_per_block = flat_rows_per_block(a.rows, a.C, 16 / VE, CV, 32 << 10, 4096);   // <= 4096 atomics per channel
     const int gx = (int)((a.rows + a.rows_per_block - 1) / a.rows_per_block);
@@ -385,7 +400,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_flat_kernel(const T* __restr
                                                                 const float* __restrict__ sum_gz, float inv_m,
                                                                 T* __restrict__ dz, T* __restrict__ g_out, long long rows,
                                                                 int rows_per_block, int CV, int ld_dy, int ld_y, int ld_z,
-                                                                int ld_dz, int ld_g, int act) {
+                                                                int ld_dz, int ld_g, int act, const float* __restrict__ fscale,
+                                                                const float* __restrict__ fshift) {
   constexpr int VE = VecT<T>::VE;
   const int cv = threadIdx.x % CV, rsub = threadIdx.x / CV, RPB = 256 / CV;
   const int c = cv * VE;
@@ -397,14 +413,26 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_flat_kernel(const T* __restr
     cb[e] = -a * rs * sum_gz[c + e] * inv_m;
     cc[e] = -a * sum_g[c + e] * inv_m - cb[e] * mean[c + e];
   }
+  const bool from_z = y == nullptr;   // activation mask re-derived from z (layers without a residual): y is not read
+  float fs[VE], fh[VE];
+#pragma unroll
+  for (int e = 0; e < VE; ++e) {
+    fs[e] = (from_z && act != CAVP_ACT_NONE) ? fscale[c + e] : 1.f;
+    fh[e] = (from_z && act != CAVP_ACT_NONE) ? fshift[c + e] : 0.f;
+  }
   const long long r0 = (long long)blockIdx.x * rows_per_block;
   long long r1 = r0 + rows_per_block;
   if (r1 > rows) r1 = rows;
   for (long long r = r0 + rsub; r < r1; r += RPB) {
     float a[VE], yy[VE], zz[VE], o[VE], g[VE];
     VecT<T>::load(dy + r * ld_dy + c, a);
-    VecT<T>::load(y + r * ld_y + c, yy);
     VecT<T>::load(z + r * ld_z + c, zz);
+    if (from_z) {
+#pragma unroll
+      for (int e = 0; e < VE; ++e) yy[e] = zz[e] * fs[e] + fh[e];
+    } else {
+      VecT<T>::load(y + r * ld_y + c, yy);
+    }
 #pragma unroll
     for (int e = 0; e < VE; ++e) {
       g[e] = a[e] * act_grad_from_out(yy[e], act);
@@ -425,7 +453,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
                                                            const float* __restrict__ sum_g,
                                                            const float* __restrict__ sum_gz, float inv_m, T* __restrict__ dz,
                                                            T* __restrict__ g_out, RowLoop gm, int ld_dy, int ld_y,
-                                                           int ld_z, int ld_dz, int ld_g, int act) {
+                                                           int ld_z, int ld_dz, int ld_g, int act, const float* __restrict__ fscale,
+                                                                const float* __restrict__ fshift) {
   constexpr int VE = VecT<T>::VE;
   const int cg = threadIdx.x & 15, rl = threadIdx.x >> 4;
   const int c = (blockIdx.y * 16 + cg) * VE;
@@ -438,14 +467,26 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
     cb[e] = -a * rs * sum_gz[c + e] * inv_m;
     cc[e] = -a * sum_g[c + e] * inv_m - cb[e] * mean[c + e];
   }
+  const bool from_z = y == nullptr;   // activation mask re-derived from z (layers without a residual): y is not read
+  float fs[VE], fh[VE];
+#pragma unroll
+  for (int e = 0; e < VE; ++e) {
+    fs[e] = (from_z && act != CAVP_ACT_NONE) ? fscale[c + e] : 1.f;
+    fh[e] = (from_z && act != CAVP_ACT_NONE) ? fshift[c + e] : 0.f;
+  }
   const long long r0 = (long long)blockIdx.x * gm.rows_per_block;
   long long r1 = r0 + gm.rows_per_block;
   if (r1 > gm.rows) r1 = gm.rows;
   for (long long r = r0 + rl; r < r1; r += 16) {
     float a[VE], yy[VE], zz[VE], o[VE], g[VE];
     VecT<T>::load(dy + r * ld_dy + c, a);
-    VecT<T>::load(y + r * ld_y + c, yy);
     VecT<T>::load(z + r * ld_z + c, zz);
+    if (from_z) {
+#pragma unroll
+      for (int e = 0; e < VE; ++e) yy[e] = zz[e] * fs[e] + fh[e];
+    } else {
+      VecT<T>::load(y + r * ld_y + c, yy);
+    }
 #pragma unroll
     for (int e = 0; e < VE; ++e) {
       g[e] = a[e] * act_grad_from_out(yy[e], act);
@@ -998,14 +1039,17 @@ extern "C" int cavp_scale_shift_act(int32_t dtype, const void* x, const float* s
 
 extern "C" int cavp_bn_act_bwd_reduce(int32_t dtype, const void* dy, const void* y, const void* z, const float* mean,
                                       const float* rstd, int64_t rows, int32_t C, int32_t ld_dy, int32_t ld_y,
-                                      int32_t ld_z, int32_t act, float* sum_g, float* sum_gz, void* stream) {
-  if (!dy || !y || !z || !mean || !rstd || !sum_g || !sum_gz || rows <= 0 || C <= 0) return CAVP_ERR_BAD_ARG;
+                                      int32_t ld_z, int32_t act, float* sum_g, float* sum_gz, const float* fwd_scale,
+                                      const float* fwd_shift, void* stream) {
+  if (!dy || !z || !mean || !rstd || !sum_g || !sum_gz || rows <= 0 || C <= 0) return CAVP_ERR_BAD_ARG;
+  if (!y && act != CAVP_ACT_NONE && (!fwd_scale || !fwd_shift)) return CAVP_ERR_BAD_ARG;
   if (!dt_ok(dtype) || rows > 0x7fffffff) return CAVP_ERR_UNSUPPORTED;
   const int VE = dtype == CAVP_F32 ? 4 : 8;
-  if (C % VE || ld_dy % VE || ld_y % VE || ld_z % VE) return CAVP_ERR_UNSUPPORTED;
-  if (!al16(dy) || !al16(y) || !al16(z)) return CAVP_ERR_ALIGN;
+  if (C % VE || ld_dy % VE || (y && ld_y % VE) || ld_z % VE) return CAVP_ERR_UNSUPPORTED;
+  if (!al16(dy) || (y && !al16(y)) || !al16(z)) return CAVP_ERR_ALIGN;
   ColArgs a{};
   a.a = dy; a.b = y; a.c = z; a.mean = mean; a.rstd = rstd; a.out0 = sum_g; a.out1 = sum_gz;
+  a.fscale = fwd_scale; a.fshift = fwd_shift;
   a.rows = (int)rows; a.C = C; a.lda = ld_dy; a.ldb = ld_y; a.ldc = ld_z; a.act = act;
   return launch_col_reduce<1>(dtype, a, (hipStream_t)stream);
 }
@@ -1013,13 +1057,15 @@ extern "C" int cavp_bn_act_bwd_reduce(int32_t dtype, const void* dy, const void*
 extern "C" int cavp_bn_act_bwd_apply(int32_t dtype, const void* dy, const void* y, const void* z, const float* mean,
                                      const float* rstd, const float* gamma, const float* sum_g, const float* sum_gz,
                                      int64_t rows, int32_t C, int32_t ld_dy, int32_t ld_y, int32_t ld_z, int32_t act,
-                                     void* dz, int32_t ld_dz, void* g_out, int32_t ld_g, void* stream) {
-  if (!dy || !y || !z || !mean || !rstd || !gamma || !sum_g || !sum_gz || !dz || rows <= 0 || C <= 0)
+                                     void* dz, int32_t ld_dz, void* g_out, int32_t ld_g, const float* fwd_scale,
+                                     const float* fwd_shift, void* stream) {
+  if (!dy || !z || !mean || !rstd || !gamma || !sum_g || !sum_gz || !dz || rows <= 0 || C <= 0)
     return CAVP_ERR_BAD_ARG;
+  if (!y && act != CAVP_ACT_NONE && (!fwd_scale || !fwd_shift)) return CAVP_ERR_BAD_ARG;
   if (!dt_ok(dtype)) return CAVP_ERR_UNSUPPORTED;
   const int VE = dtype == CAVP_F32 ? 4 : 8;
-  if (C % VE || ld_dy % VE || ld_y % VE || ld_z % VE || ld_dz % VE || (g_out && ld_g % VE)) return CAVP_ERR_UNSUPPORTED;
-  if (!al16(dy) || !al16(y) || !al16(z) || !al16(dz) || (g_out && !al16(g_out))) return CAVP_ERR_ALIGN;
+  if (C % VE || ld_dy % VE || (y && ld_y % VE) || ld_z % VE || ld_dz % VE || (g_out && ld_g % VE)) return CAVP_ERR_UNSUPPORTED;
+  if (!al16(dy) || (y && !al16(y)) || !al16(z) || !al16(dz) || (g_out && !al16(g_out))) return CAVP_ERR_ALIGN;
   const float inv_m = (float)(1.0 / (double)rows);
   hipStream_t s = (hipStream_t)stream;
   if (flat_ok(C, VE, nullptr, nullptr)) {
@@ -1027,17 +1073,17 @@ extern "C" int cavp_bn_act_bwd_apply(int32_t dtype, const void* dy, const void* 
     const int rpb = flat_rows_per_block(rows, C, 16 / VE, CV, 16 << 10, 1 << 20);
     const int gx = (int)((rows + rpb - 1) / rpb);
     if (dtype == CAVP_F32)
-      bn_bwd_apply_flat_kernel<float><<<gx, 256, 0, s>>>((const float*)dy, (const float*)y, (const float*)z, mean, rstd, gamma, sum_g, sum_gz, inv_m, (float*)dz, (float*)g_out, rows, rpb, CV, ld_dy, ld_y, ld_z, ld_dz, ld_g, act);
+      bn_bwd_apply_flat_kernel<float><<<gx, 256, 0, s>>>((const float*)dy, (const float*)y, (const float*)z, mean, rstd, gamma, sum_g, sum_gz, inv_m, (float*)dz, (float*)g_out, rows, rpb, CV, ld_dy, ld_y, ld_z, ld_dz, ld_g, act, fwd_scale, fwd_shift);
     else
-      bn_bwd_apply_flat_kernel<bf16_t><<<gx, 256, 0, s>>>((const bf16_t*)dy, (const bf16_t*)y, (const bf16_t*)z, mean, rstd, gamma, sum_g, sum_gz, inv_m, (bf16_t*)dz, (bf16_t*)g_out, rows, rpb, CV, ld_dy, ld_y, ld_z, ld_dz, ld_g, act);
+      bn_bwd_apply_flat_kernel<bf16_t><<<gx, 256, 0, s>>>((const bf16_t*)dy, (const bf16_t*)y, (const bf16_t*)z, mean, rstd, gamma, sum_g, sum_gz, inv_m, (bf16_t*)dz, (bf16_t*)g_out, rows, rpb, CV, ld_dy, ld_y, ld_z, ld_dz, ld_g, act, fwd_scale, fwd_shift);
     CHECK_LAUNCH();
   }
   dim3 grid;
   const RowLoop g = row_loop_geometry(rows, C, VE, grid);
   if (dtype == CAVP_F32)
-    bn_bwd_apply_kernel<float><<<grid, 256, 0, s>>>((const float*)dy, (const float*)y, (const float*)z, mean, rstd, gamma, sum_g, sum_gz, inv_m, (float*)dz, (float*)g_out, g, ld_dy, ld_y, ld_z, ld_dz, ld_g, act);
+    bn_bwd_apply_kernel<float><<<grid, 256, 0, s>>>((const float*)dy, (const float*)y, (const float*)z, mean, rstd, gamma, sum_g, sum_gz, inv_m, (float*)dz, (float*)g_out, g, ld_dy, ld_y, ld_z, ld_dz, ld_g, act, fwd_scale, fwd_shift);
   else
-    bn_bwd_apply_kernel<bf16_t><<<grid, 256, 0, s>>>((const bf16_t*)dy, (const bf16_t*)y, (const bf16_t*)z, mean, rstd, gamma, sum_g, sum_gz, inv_m, (bf16_t*)dz, (bf16_t*)g_out, g, ld_dy, ld_y, ld_z, ld_dz, ld_g, act);
+    bn_bwd_apply_kernel<bf16_t><<<grid, 256, 0, s>>>((const bf16_t*)dy, (const bf16_t*)y, (const bf16_t*)z, mean, rstd, gamma, sum_g, sum_gz, inv_m, (bf16_t*)dz, (bf16_t*)g_out, g, ld_dy, ld_y, ld_z, ld_dz, ld_g, act, fwd_scale, fwd_shift);
   CHECK_LAUNCH();
 }
 

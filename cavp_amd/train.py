@@ -15,6 +15,7 @@ Semantics kept from the reference:
 """
 from __future__ import annotations
 
+import os
 from typing import Callable, Dict, List, Optional
 
 import torch
@@ -135,6 +136,9 @@ def allreduce_bn_stats(bn, buf: torch.Tensor, count: int) -> int:
         dist.all_reduce(buf)
         return count * dist.get_world_size()
     return count
+
+
+_BN_BWD_READ_Y = bool(int(os.environ.get("CAVP_BN_BWD_READ_Y", "0")))   # A/B knob: always read y in the BN backward
 
 
 class TrainPass:
@@ -410,7 +414,9 @@ class TrainPass:
                 sums = (self.grad_buffer(bn.bias), self.grad_buffer(bn.weight))
             else:
                 sums = self.zeros_f32(2, c)
-            T.bn_act_bwd_reduce(dy, y.t, z.t, mean, rstd, act, sums[0], sums[1])
+            # without a residual the activation mask follows from z and the folded (scale, shift): y is not re-read
+            yb = y.t if (residual is not None or _BN_BWD_READ_Y) else None
+            T.bn_act_bwd_reduce(dy, yb, z.t, mean, rstd, act, sums[0], sums[1], fwd_scale=scale, fwd_shift=shift)
             local = sums
             if count != rows:
                 # SyncBatchNorm: dz uses the GLOBAL sums / count, the affine gradients stay the LOCAL sums (DDP
@@ -420,7 +426,8 @@ class TrainPass:
                 sums = sums * (float(rows) / float(count))
             dz = self.empty(z.t.shape, z.t.dtype)
             g_out = self.empty(z.t.shape, z.t.dtype) if (residual is not None and residual.needs_grad) else None
-            T.bn_act_bwd_apply(dy, y.t, z.t, mean, rstd, bn.weight.detach(), sums[0], sums[1], act, dz, g_out=g_out)
+            T.bn_act_bwd_apply(dy, yb, z.t, mean, rstd, bn.weight.detach(), sums[0], sums[1], act, dz, g_out=g_out,
+                               fwd_scale=scale, fwd_shift=shift)
             z.set_g(dz)
             if g_out is not None:
                 self.acc_add(residual, g_out)

@@ -230,26 +230,31 @@ def scale_shift_act(x, scale, shift, y, act: int, residual=None) -> torch.Tensor
     return y
 
 
-def bn_act_bwd_reduce(dy, y, z, mean, rstd, act: int, sum_g, sum_gz) -> None:
+def bn_act_bwd_reduce(dy, y, z, mean, rstd, act: int, sum_g, sum_gz, fwd_scale=None, fwd_shift=None) -> None:
+    """y=None (BN + activation without residual): the activation mask is re-derived from z with the forward's folded
+    scale / shift, y is not read."""
     rows, c, ld_dy = _rows(dy)
-    _, _, ld_y = _rows(y)
+    ld_y = _rows(y)[2] if y is not None else 0
     _, _, ld_z = _rows(z)
-    _need_gpu(dy, y, z, mean, rstd, sum_g, sum_gz)
+    _need_gpu(dy, y, z, mean, rstd, sum_g, sum_gz, fwd_scale, fwd_shift)
     _check(_lib.load().cavp_bn_act_bwd_reduce(dtype_code(dy.dtype), _ptr(dy), _ptr(y), _ptr(z), _ptr(mean), _ptr(rstd), rows,
-                                              c, ld_dy, ld_y, ld_z, act, _ptr(sum_g), _ptr(sum_gz), _s()),
+                                              c, ld_dy, ld_y, ld_z, act, _ptr(sum_g), _ptr(sum_gz), _ptr(fwd_scale),
+                                              _ptr(fwd_shift), _s()),
            "cavp_bn_act_bwd_reduce")
 
 
-def bn_act_bwd_apply(dy, y, z, mean, rstd, gamma, sum_g, sum_gz, act: int, dz, g_out=None) -> torch.Tensor:
+def bn_act_bwd_apply(dy, y, z, mean, rstd, gamma, sum_g, sum_gz, act: int, dz, g_out=None, fwd_scale=None,
+                     fwd_shift=None) -> torch.Tensor:
     rows, c, ld_dy = _rows(dy)
-    _, _, ld_y = _rows(y)
+    ld_y = _rows(y)[2] if y is not None else 0
     _, _, ld_z = _rows(z)
     _, _, ld_dz = _rows(dz)
     ld_g = _rows(g_out)[2] if g_out is not None else 0
     _need_gpu(dy, y, z, dz, g_out)
     _check(_lib.load().cavp_bn_act_bwd_apply(dtype_code(dy.dtype), _ptr(dy), _ptr(y), _ptr(z), _ptr(mean), _ptr(rstd),
                                              _ptr(gamma), _ptr(sum_g), _ptr(sum_gz), rows, c, ld_dy, ld_y, ld_z, act, _ptr(dz),
-                                             ld_dz, _ptr(g_out), ld_g, _s()), "cavp_bn_act_bwd_apply")
+                                             ld_dz, _ptr(g_out), ld_g, _ptr(fwd_scale), _ptr(fwd_shift), _s()),
+           "cavp_bn_act_bwd_apply")
     return dz
 
 

@@ -195,13 +195,16 @@ int cavp_bn_finalize_tiles(const float* tile_stats, int32_t tiles, int32_t rows_
 int cavp_scale_shift_act(int32_t dtype, const void* x, const float* scale, const float* shift, const void* residual,
                          void* y, int64_t rows, int32_t C, int32_t ldx, int32_t ldr, int32_t ldy, int32_t act,
                          void* stream);
+/* y may be NULL for a BN + activation WITHOUT residual: the activation mask is then re-derived from z with the forward's
+ * folded fwd_scale / fwd_shift (y = act(z*scale + shift) > 0 <=> z*scale + shift > 0), which saves reading y in both passes */
 int cavp_bn_act_bwd_reduce(int32_t dtype, const void* dy, const void* y, const void* z, const float* mean,
                            const float* rstd, int64_t rows, int32_t C, int32_t ld_dy, int32_t ld_y, int32_t ld_z,
-                           int32_t act, float* sum_g, float* sum_gz, void* stream);
+                           int32_t act, float* sum_g, float* sum_gz, const float* fwd_scale, const float* fwd_shift,
+                           void* stream);
 int cavp_bn_act_bwd_apply(int32_t dtype, const void* dy, const void* y, const void* z, const float* mean,
                           const float* rstd, const float* gamma, const float* sum_g, const float* sum_gz, int64_t rows,
                           int32_t C, int32_t ld_dy, int32_t ld_y, int32_t ld_z, int32_t act, void* dz, int32_t ld_dz,
-                          void* g_out, int32_t ld_g, void* stream);
+                          void* g_out, int32_t ld_g, const float* fwd_scale, const float* fwd_shift, void* stream);
 /* dx = dy * act'(.): ReLU / LeakyReLU from the activation OUTPUT, GELU from the pre-activation (ref). */
 int cavp_act_bwd(int32_t dtype, const void* dy, const void* ref, void* dx, int64_t rows, int32_t C, int32_t ld_dy,
                  int32_t ld_ref, int32_t ld_dx, int32_t act, void* stream);

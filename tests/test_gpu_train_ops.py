@@ -134,6 +134,18 @@ def test_bn_train_fwd_bwd(act, dt):
     T.bn_act_bwd_apply(dyv, yv, zv, mean, rstd, gamma.detach().to(DEV), sg, sgz, act, dz, g_out=g)
     _check(dz.permute(0, 3, 1, 2), z.grad, dt, "dz", 1e-4, 2.5e-2)
     _check(g.permute(0, 3, 1, 2), res.grad, dt, "dres", 1e-5, 1e-2)
+    # no residual: the activation mask can be re-derived from z and the folded (scale, shift) - y is not read at all;
+    # must give exactly what the y-reading path gives on the same (no-residual) forward
+    y2 = torch.empty_like(zv)
+    T.scale_shift_act(zv, scale, shift, y2, act)
+    sg_y, sgz_y, sg_z, sgz_z = (torch.zeros(c, device=DEV) for _ in range(4))
+    T.bn_act_bwd_reduce(dyv, y2, zv, mean, rstd, act, sg_y, sgz_y)
+    T.bn_act_bwd_reduce(dyv, None, zv, mean, rstd, act, sg_z, sgz_z, fwd_scale=scale, fwd_shift=shift)
+    assert torch.allclose(sg_y, sg_z, rtol=1e-5, atol=1e-5) and torch.allclose(sgz_y, sgz_z, rtol=1e-5, atol=1e-4)
+    dz_y, dz_z = torch.empty_like(zv), torch.empty_like(zv)
+    T.bn_act_bwd_apply(dyv, y2, zv, mean, rstd, gamma.detach().to(DEV), sg_y, sgz_y, act, dz_y)
+    T.bn_act_bwd_apply(dyv, None, zv, mean, rstd, gamma.detach().to(DEV), sg_y, sgz_y, act, dz_z, fwd_scale=scale, fwd_shift=shift)
+    assert torch.equal(dz_y, dz_z)
 
 
 @pytest.mark.parametrize("dt", DTYPES, ids=IDS)
