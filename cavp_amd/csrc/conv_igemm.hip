@@ -19,6 +19,8 @@
 //   descriptor's bounds check (the lane is pointed past num_records instead of branching).
 // * Taps that cannot touch the image for any output pixel (dilation >= extent, e.g. ASPP d=18 on 14x14) are
 //   removed on the host; split-K writes f32 slabs that a small epilogue kernel reduces deterministically.
+#include <stdlib.h>
+
 #include "common.h"
 
 struct IgemmParams {
@@ -45,6 +47,7 @@ struct IgemmParams {
   int tap_xoff[9];          // per live tap: byte displacement (dh*W + dw)*ldx*sizeof(T) in x (ordinary conv only)
   int tap_woff[9];          // per live tap: byte offset tap*Cin*sizeof(T) inside a weight row
   float* tile_stats;        // optional [tiles_p][Cout][2] per-tile (mean, M2) of the raw outputs (BatchNorm statistics)
+  int nblk;                 // logical workgroups (tiles x split-K); the launch may use fewer, persistent, workgroups
   int dbg;                  // profiling only (tile knob, hundreds digit): 1 = skip the operand loads, 2 = skip the MFMAs
   int coalesced;            // LDS-staged, fully coalesced 16-byte epilogue (needs Cout, ldy, ldr % VE == 0, 16-B aligned)
 };
@@ -148,7 +151,11 @@ __global__ __launch_bounds__(64 * WC * WP, (WC * WP == 4 ? 2 : 1)) void igemm_ke
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int sid = xcd_remap(blockIdx.x, gridDim.x);
+  // persistent workgroups: gridDim.x (a multiple of 8, so a workgroup keeps its XCD) physical workgroups walk the
+  // p.nblk logical ones: launch, kernel-argument load and teardown are paid once per physical workgroup
+  for (int vb = blockIdx.x; vb < p.nblk; vb += gridDim.x) {
+  if (vb != (int)blockIdx.x) __syncthreads();   // the previous tile's epilogue is done with the LDS
+  const int sid = xcd_remap(vb, p.nblk);
   const int tiles = p.tiles_c * p.tiles_p;
   const int z = sid / tiles;
   const int rem = sid - z * tiles;
@@ -355,7 +362,7 @@ __global__ __launch_bounds__(64 * WC * WP, (WC * WP == 4 ? 2 : 1)) void igemm_ke
   }
 
   // ---- epilogue ----
-  if (p.dbg & 16) return;
+  if (p.dbg & 16) continue;
   if (p.coalesced) {
     // Stage the f32 accumulators in LDS as [pixel][cout] (16-byte slots XOR-swizzled by pixel & 7), then let each
     // thread finish VE consecutive channels of one pixel: scale/shift/bias/residual are 16-byte vector loads and the
@@ -489,7 +496,7 @@ __global__ __launch_bounds__(64 * WC * WP, (WC * WP == 4 ? 2 : 1)) void igemm_ke
         *(u32x4_t*)(yp + (size_t)k * ystep) = o;
       }
     }
-    return;
+    continue;
   }
 #pragma unroll
   for (int a = 0; a < MC; ++a) {
@@ -513,6 +520,7 @@ __global__ __launch_bounds__(64 * WC * WP, (WC * WP == 4 ? 2 : 1)) void igemm_ke
       }
     }
   }
+  }  // persistent loop
 }
 
 // Reduce split-K slabs (deterministic order) and apply the epilogue.  One thread per 4 consecutive channels.
@@ -564,7 +572,14 @@ hipError_t launch_cfg(const IgemmParams& p, int nblk, hipStream_t s) {
                               hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr_set = true;
   }
-  igemm_kernel<T, BC, BP, WC, WP, UP, NS><<<dim3(nblk), dim3(64 * WC * WP), lds, s>>>(p);
+  int bpc = (160 * 1024) / lds;   // resident workgroups per CU (LDS-limited; the 4-wave tiles use <= 128 VGPRs)
+  if (bpc > 4) bpc = 4;
+  if (bpc < 1) bpc = 1;
+  static const bool persistent = !(getenv("CAVP_IGEMM_PERSISTENT") && atoi(getenv("CAVP_IGEMM_PERSISTENT")) == 0);
+  const int grid = (persistent && nblk > bpc * 256) ? bpc * 256 : nblk;
+  IgemmParams q = p;
+  q.nblk = nblk;
+  igemm_kernel<T, BC, BP, WC, WP, UP, NS><<<dim3(grid), dim3(64 * WC * WP), lds, s>>>(q);
   return hipGetLastError();
 }
 
