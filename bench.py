@@ -327,7 +327,13 @@ def main():
         run_step()      # eager warm-up: packs weights, sizes the workspace
         torch.cuda.synchronize()
         if train and not a.no_graph:
-            step = model.capture_train_step(image, audio, label, split=True if a.split_graph else None)   # ~1000 launches as hipGraph(s)
+            try:
+                step = model.capture_train_step(image, audio, label, split=True if a.split_graph else None)   # ~1000 launches as hipGraph(s)
+            except Exception as ex:  # noqa: BLE001 - a failed capture must not cost the measurement: fall back to eager launches
+                print(f"[bench] hipGraph capture failed ({type(ex).__name__}: {ex}); timing eager launches instead", file=sys.stderr)
+                torch.cuda.synchronize()
+                a.no_graph = True
+                step = run_step
         elif train:
             step = run_step
         elif a.no_graph:
@@ -340,7 +346,7 @@ def main():
             with torch.cuda.stream(side):
                 model(image, audio, eval_mode=True)
             torch.cuda.current_stream().wait_stream(side)
-            with torch.cuda.graph(graph):
+            with torch.cuda.graph(graph, capture_error_mode="thread_local"):
                 outs = model(image, audio, eval_mode=True)
 
             def step():

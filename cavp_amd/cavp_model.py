@@ -676,7 +676,8 @@ class CAVP(nn.Module):
             torch.cuda.current_stream().wait_stream(side)
             if not split:
                 graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graph):
+                # thread_local: other threads (RCCL's watchdog polls its events) must not invalidate the capture
+                with torch.cuda.graph(graph, capture_error_mode="thread_local"):
                     loss = self.train_step(image, audio, label, ignore_index, loss_scale / world, all_reduce=False)
                 graphs = (graph,)
             else:
@@ -685,11 +686,11 @@ class CAVP(nn.Module):
                 cap = torch.cuda.Stream()
                 cap.wait_stream(torch.cuda.current_stream())
                 with torch.cuda.stream(cap):
-                    g1.capture_begin()
+                    g1.capture_begin(capture_error_mode="thread_local")
 
                     def cut():
                         g1.capture_end()
-                        g2.capture_begin(pool=g1.pool())   # graph 2 keeps using (and keeps alive) graph 1's allocations
+                        g2.capture_begin(pool=g1.pool(), capture_error_mode="thread_local")   # shares (and keeps alive) graph 1's allocations
 
                     loss = self.train_step(image, audio, label, ignore_index, loss_scale / world, all_reduce=False,
                                            _split_hook=cut)
