@@ -299,11 +299,17 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # CAVP_BENCH_SHARE_GPU=1 (plumbing check on a 1-GPU box only): every rank uses cuda:0 and the collectives run on gloo
+    share = os.environ.get("CAVP_BENCH_SHARE_GPU") == "1"
+    dev_index = 0 if share else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     import torch.distributed as dist
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if share:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
     dtype = torch.bfloat16 if a.dtype == "bf16" else torch.float32
     cfg = model_cfg(a.config)
     if a.config == "c4":
@@ -382,7 +388,7 @@ def main():
             "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
             "config": {"workload": (f"C1' (config_avss_binary shape): CAVP ResNet-50 OS16 + VGGish, training step = "
                                     f"forward_train (batch-stat BN, {B} images + {2 * B} audio clips per GPU) + cross-entropy + "
-                                    f"full backward" + (" + one flat RCCL gradient all-reduce" if world > 1 else "") +
+                                    f"full backward" + (" + gradient all-reduce over RCCL in two pieces, the first overlapped with the backbone backward" if world > 1 else "") +
                                     ", 224x224 RGB + 96x64 mel, num_classes=2, random-init (synthetic) weights"
                                     if train else
                                     (f"C4 (config_avss shape): CAVP PVTv2-B5 + VGGish, eval forward, B={B}/GPU, 512x512 RGB + 96x64 "

@@ -1,0 +1,38 @@
+"""The data-parallel bench path end to end on ONE GPU: two ranks share cuda:0 and talk over gloo
+(CAVP_BENCH_SHARE_GPU=1), which exercises everything RCCL runs would - process-group init, the two-graph capture with a
+live process group, the asynchronous early all-reduce + late all-reduce around the replays, barriers, max-over-ranks
+timing and the single JSON line - except the RCCL transport itself (multi-GPU boxes are the driver's)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.parametrize("mode", ["train", "eval"])
+def test_two_rank_bench_on_one_gpu(mode):
+    env = dict(os.environ, CAVP_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--batch", "4", "--mode", mode, "--no-cpu-baseline", "--no-roofline"]
+    r = subprocess.run(cmd, cwd=REPO, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]          # rank 0 prints ONE JSON line
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "weak" and d["value"] > 0
+    assert d["config"]["global_batch"] == 8 and d["config"]["parallelism"] == "dp2"
+    assert "capture failed" not in r.stderr
