@@ -79,6 +79,8 @@ PROTOTYPES = {
     "cavp_bilinear_bwd_nchw_to_nhwc": (_i32, [_i32, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "cavp_bcast_add_nhwc": (_i32, [_i32, _vp, _vp, _f32, _i32, _i32, _i32, _i32, _vp]),
     "cavp_ce_loss_nchw": (_i32, [_vp, _vp, _i32, _i32, _i32, _i64, _i32, _f32, _vp, _vp, _vp, _vp]),
+    "cavp_upsample_ce_head": (_i32, [_i32, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _vp, _vp,
+                              _vp, _vp, _vp]),
     # ---- contrastive loss ----
     "cavp_gather_l2norm": (_i32, [_vp, _i64, _i64, _i64, _vp, _vp, _i32, _i32, _f32, _vp, _vp, _vp]),
     "cavp_infonce_rows": (_i32, [_vp, _vp, _i32, _i32, _f32, _vp, _vp, _vp, _f32, _vp]),

@@ -16,6 +16,7 @@ Returned tensors keep the reference's logical shapes: `out_pred` is a contiguous
 from __future__ import annotations
 
 import math
+import os
 from typing import Dict, List, Optional, Sequence
 
 import torch
@@ -26,6 +27,7 @@ from ._lib import ACT_GELU, ACT_LEAKY, ACT_NONE, ACT_RELU, CavpError
 
 BN_EPS = 1e-5
 BN_MOMENTUM = 0.1
+_FUSED_HEAD = os.environ.get("CAVP_FUSED_HEAD", "1") != "0"   # A/B knob: 0 = upsample, CE, and their backward as separate ops
 
 
 class _Container(nn.Module):
@@ -613,13 +615,15 @@ class CAVP(nn.Module):
         return {id(p) for p in late}
 
     def train_step(self, image, audio, label, ignore_index: int = 255, loss_scale: float = 1.0, all_reduce: bool = True,
-                   _split_hook=None):
+                   _split_hook=None, want_pred: bool = False):
         """MI355X-native fused training step (no torch.autograd): forward_train (batch-stat BN, audio 2B) -> HIP
         cross-entropy on `out[:B] + out[B:]*0` (trainer_cavp_vpo_mono.py:171,187) -> hand-written backward.  Every
         gradient lands in one flat f32 arena (`p.grad` are views of it).  With a torch.distributed process group the
         arena is all-reduced over RCCL and averaged (DDP semantics, main_vpo_mono.py:131-135) in two pieces: the range
         the backward completes early (head, attention, audio encoder: ~75 % of the bytes) is reduced asynchronously
         while the backbone backward still runs, the remainder at the end.
+        The segmentation head is one fused op (upsample + CE + backward); `want_pred=True`
+        additionally materialises the full-resolution prediction into `self._last_outputs[0]` (otherwise None).
         Returns the (local) loss as a 1-element device tensor."""
         from . import train_ops as T
         from .train import GradArena, TrainPass, allreduce_arena_early, allreduce_arena_late, dist_world, run_train_forward
@@ -633,12 +637,20 @@ class CAVP(nn.Module):
         B, C = image.shape[0], self.num_classes
         with torch.no_grad():
             lo, fusion, fea_v_proj, fea_a, attn = run_train_forward(self, image.contiguous(), audio.contiguous(), tp)
-            out_pred = torch.empty((lo.t.shape[0], C) + tuple(image.shape[-2:]), dtype=torch.float32, device=image.device)
-            ops.bilinear_to_nchw(lo.t[..., :C], out_pred, align_corners=False)
             world = dist_world() if all_reduce else 1
-            loss, dl = T.ce_loss(out_pred, label, B, ignore_index, grad_scale=loss_scale / world)   # SUM over ranks == mean
-            g = torch.zeros(lo.t.shape, dtype=lo.t.dtype, device=lo.t.device)
-            T.bilinear_bwd_from_nchw(dl, g[..., :C], n_valid=B, align_corners=False)
+            out_pred = None
+            if tuple(label.shape[-2:]) != tuple(image.shape[-2:]):
+                raise CavpError("train_step: label and image resolution differ (the reference interpolates to the image size)")
+            if want_pred or not _FUSED_HEAD:
+                out_pred = torch.empty((lo.t.shape[0], C) + tuple(image.shape[-2:]), dtype=torch.float32, device=image.device)
+                ops.bilinear_to_nchw(lo.t[..., :C], out_pred, align_corners=False)
+            if _FUSED_HEAD:
+                # upsample + CE + their backward in one op: the full-resolution prediction never reaches HBM
+                loss, g = T.upsample_ce_head(lo.t, label, B, C, ignore_index, grad_scale=loss_scale / world)
+            else:
+                loss, dl = T.ce_loss(out_pred, label, B, ignore_index, grad_scale=loss_scale / world)   # SUM over ranks == mean
+                g = torch.zeros(lo.t.shape, dtype=lo.t.dtype, device=lo.t.device)
+                T.bilinear_bwd_from_nchw(dl, g[..., :C], n_valid=B, align_corners=False)
             lo.set_g(g)
             early = []
             if _split_hook is not None:

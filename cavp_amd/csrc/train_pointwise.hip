@@ -5,6 +5,9 @@
 // per-block partial reductions in LDS followed by one f32 atomic per (block, channel).
 #include <stdlib.h>
 
+#include <algorithm>
+#include <cmath>
+
 #include "common.h"
 
 namespace {
@@ -619,11 +622,27 @@ __device__ __forceinline__ void src_index_t(int dst, int in, int out, int align,
   i1 = i0 + (i0 < in - 1 ? 1 : 0);
   lam = src - (float)i0;
 }
-// conservative range of destination indices whose source footprint can include `src_i`
-__device__ __forceinline__ void dst_range(int src_i, int in, int out, int& lo, int& hi) {
-  const float ratio = (float)out / (float)(in > 1 ? in : 1);
-  lo = (int)floorf(((float)src_i - 1.5f) * ratio) - 2;
-  hi = (int)ceilf(((float)src_i + 1.5f) * ratio) + 2;
+// range of destination indices whose two-tap source footprint can include `src_i`: src(dst) in (src_i - 1, src_i + 1)
+// (the ends are exclusive, so floor / ceil of the bounds stay safe under float rounding; clamped sources at the borders
+// fall inside because the range is clipped to [0, out - 1])
+__device__ __forceinline__ void dst_range(int src_i, int in, int out, int align, int& lo, int& hi) {
+  float xlo, xhi;
+  if (align) {
+    if (in > 1 && out > 1) {
+      const float r = (float)(out - 1) / (float)(in - 1);
+      xlo = ((float)src_i - 1.f) * r;
+      xhi = ((float)src_i + 1.f) * r;
+    } else {
+      xlo = 0.f;
+      xhi = (float)(out - 1);
+    }
+  } else {
+    const float r = (float)out / (float)in;
+    xlo = ((float)src_i - 0.5f) * r - 0.5f;
+    xhi = ((float)src_i + 1.5f) * r - 0.5f;
+  }
+  lo = (int)floorf(xlo);
+  hi = (int)ceilf(xhi);
   if (lo < 0) lo = 0;
   if (hi > out - 1) hi = out - 1;
 }
@@ -651,8 +670,8 @@ __global__ __launch_bounds__(256) void bilinear_bwd_nhwc_kernel(const T* __restr
     const int hi = (int)((pix / Wi) % Hi);
     const int n = (int)(pix / ((long long)Wi * Hi));
     int hlo, hhi, wlo, whi;
-    dst_range(hi, Hi, Ho, hlo, hhi);
-    dst_range(wi, Wi, Wo, wlo, whi);
+    dst_range(hi, Hi, Ho, align, hlo, hhi);
+    dst_range(wi, Wi, Wo, align, wlo, whi);
     float acc[VE];
 #pragma unroll
     for (int e = 0; e < VE; ++e) acc[e] = 0.f;
@@ -687,8 +706,8 @@ __global__ __launch_bounds__(256) void bilinear_bwd_from_nchw_kernel(const float
     float acc = 0.f;
     if (n < n_valid) {
       int hlo, hhi, wlo, whi;
-      dst_range(hi, Hi, Ho, hlo, hhi);
-      dst_range(wi, Wi, Wo, wlo, whi);
+      dst_range(hi, Hi, Ho, align, hlo, hhi);
+      dst_range(wi, Wi, Wo, align, wlo, whi);
       const float* base = dy + ((size_t)n * C + c) * Ho * Wo;
       for (int ho = hlo; ho <= hhi; ++ho) {
         const float wh = tap_weight(ho, hi, Hi, Ho, align);
@@ -796,6 +815,124 @@ __global__ __launch_bounds__(256) void ce_finish_kernel(float* acc, int nparts, 
     acc[1] = ct;
     loss[0] = ct > 0.f ? lt / ct : 0.f;
   }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// fused segmentation head of the training step: bilinear upsample (low-res NHWC logits -> label resolution) +
+// cross entropy + gradient w.r.t. the low-res logits, without the [n][C][H][W] f32 prediction or its gradient in HBM
+// (224x224, B = 32: 2 x 25.7 MB written and read back; 71 classes at 512x512: 2 x 1.2 GB).
+//   pass 1 (per label pixel): interpolate the C logits, online log-sum-exp -> lse[pixel], loss / count partials
+//   pass 2 (per low-res logit): gather form of the upsample backward over the <= (2 * ratio)^2 label pixels whose
+//           footprint holds it, recomputing that pixel's class probability exp(logit_c - lse)
+// ------------------------------------------------------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ float bilerp(const T* __restrict__ img, int W, int ld, int c, int h0, int h1, int w0,
+                                        int w1, float lh, float lw) {
+  const float a = Elem<T>::ld(img + ((size_t)h0 * W + w0) * ld + c), b = Elem<T>::ld(img + ((size_t)h0 * W + w1) * ld + c);
+  const float cc = Elem<T>::ld(img + ((size_t)h1 * W + w0) * ld + c), d = Elem<T>::ld(img + ((size_t)h1 * W + w1) * ld + c);
+  return (1.f - lh) * (1.f - lw) * a + (1.f - lh) * lw * b + lh * (1.f - lw) * cc + lh * lw * d;
+}
+template <typename T>
+__global__ __launch_bounds__(256) void head_fwd_kernel(const T* __restrict__ lo, const long long* __restrict__ label,
+                                                       int n_img, int C, int Hi, int Wi, int ld, int Ho, int Wo,
+                                                       int align, int ignore, float* __restrict__ lse,
+                                                       float* __restrict__ part) {
+  __shared__ float red[8];
+  const long long HW = (long long)Ho * Wo, total = (long long)n_img * HW;
+  float loss = 0.f, cnt = 0.f;
+  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const long long lb = label[i];
+    if (lb == ignore) { lse[i] = 0.f; continue; }
+    const int wo = (int)(i % Wo);
+    const int ho = (int)((i / Wo) % Ho);
+    const int n = (int)(i / HW);
+    int h0, h1, w0, w1;
+    float lh, lw;
+    src_index_t(ho, Hi, Ho, align, h0, h1, lh);
+    src_index_t(wo, Wi, Wo, align, w0, w1, lw);
+    const T* img = lo + (size_t)n * Hi * Wi * ld;
+    float m = -INFINITY, s = 0.f, picked = 0.f;
+    for (int c = 0; c < C; ++c) {
+      const float v = bilerp<T>(img, Wi, ld, c, h0, h1, w0, w1, lh, lw);
+      if (c == lb) picked = v;
+      const float mn = fmaxf(m, v);
+      s = s * expf(m - mn) + expf(v - mn);
+      m = mn;
+    }
+    const float l = m + logf(s);
+    lse[i] = l;
+    loss += l - picked;
+    cnt += 1.f;
+  }
+  loss = wave_sum(loss);
+  cnt = wave_sum(cnt);
+  const int wv = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) { red[wv] = loss; red[4 + wv] = cnt; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    part[2 + 2 * blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+    part[3 + 2 * blockIdx.x] = (red[4] + red[5]) + (red[6] + red[7]);
+  }
+}
+// pass 2, tiled: one workgroup = (th x tw tile of low-res pixels, image, class).  Step 1 stages the class-c residual
+// r[ho][wo] = softmax_c - onehot_c (0 where ignored) of the label-resolution region under the tile in LDS - every
+// label pixel is evaluated once per class instead of once per low-res pixel it touches (4x at ratio 4), with
+// independent loads; step 2 gathers each low-res logit's footprint from LDS.  (A thread-per-logit global gather was
+// bound by its chain of dependent loads: 71 us for B = 32, two classes; 8 lanes per logit: 114 us.)
+template <typename T>
+__global__ __launch_bounds__(256) void head_bwd_kernel(const T* __restrict__ lo, const long long* __restrict__ label,
+                                                       const float* __restrict__ lse, const float* __restrict__ acc,
+                                                       float gscale, int n_img, int C, int Hi, int Wi, int ld, int Ho,
+                                                       int Wo, int align, int ignore, int th, int tw, int RW,
+                                                       int tiles_w, T* __restrict__ dlo) {
+  extern __shared__ float resid[];   // [RH][RW]
+  const int c = blockIdx.y % C, n = blockIdx.y / C;
+  const int ty0 = (blockIdx.x / tiles_w) * th, tx0 = (blockIdx.x % tiles_w) * tw;
+  const int ty1 = min(ty0 + th, Hi) - 1, tx1 = min(tx0 + tw, Wi) - 1;
+  int rh0, rh1, rw0, rw1, t0, t1;
+  dst_range(ty0, Hi, Ho, align, rh0, t1);
+  dst_range(ty1, Hi, Ho, align, t0, rh1);
+  dst_range(tx0, Wi, Wo, align, rw0, t1);
+  dst_range(tx1, Wi, Wo, align, t0, rw1);
+  const int rw = rw1 - rw0 + 1, cnt = (rh1 - rh0 + 1) * rw;
+  const T* img = lo + (size_t)n * Hi * Wi * ld;
+#pragma unroll 4
+  for (int e = threadIdx.x; e < cnt; e += 256) {
+    const int ho = rh0 + e / rw, wo = rw0 + e % rw;
+    const size_t at = ((size_t)n * Ho + ho) * Wo + wo;
+    const long long lb = label[at];
+    const float l = lse[at];
+    int h0, h1, w0, w1;
+    float lh, lw;
+    src_index_t(ho, Hi, Ho, align, h0, h1, lh);
+    src_index_t(wo, Wi, Wo, align, w0, w1, lw);
+    const float v = bilerp<T>(img, Wi, ld, c, h0, h1, w0, w1, lh, lw);
+    resid[(ho - rh0) * RW + (wo - rw0)] = lb == ignore ? 0.f : expf(v - l) - (c == lb ? 1.f : 0.f);
+  }
+  __syncthreads();
+  const int ly = threadIdx.x / tw, lx = threadIdx.x % tw;
+  const int hi = ty0 + ly, wi = tx0 + lx;
+  if (ly >= th || hi >= Hi || wi >= Wi) return;
+  const float inv = acc[1] > 0.f ? gscale / acc[1] : 0.f;
+  int hlo, hhi, wlo, whi;
+  dst_range(hi, Hi, Ho, align, hlo, hhi);
+  dst_range(wi, Wi, Wo, align, wlo, whi);
+  float g = 0.f;
+  for (int ho = hlo; ho <= hhi; ++ho) {
+    const float wh = tap_weight(ho, hi, Hi, Ho, align);
+    const float* row = resid + (ho - rh0) * RW - rw0;
+    float a = 0.f;
+    for (int wo = wlo; wo <= whi; ++wo) a += tap_weight(wo, wi, Wi, Wo, align) * row[wo];
+    g += wh * a;
+  }
+  const size_t pix = ((size_t)n * Hi + hi) * Wi + wi;
+  Elem<T>::st(dlo + pix * ld + c, g * inv);
+  if (c == 0)
+    for (int k = C; k < ld; ++k) Elem<T>::st(dlo + pix * ld + k, 0.f);
+}
+template <typename T>
+__global__ __launch_bounds__(256) void zero_tail_kernel(T* __restrict__ p, long long n) {
+  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (long long)gridDim.x * 256) Elem<T>::st(p + i, 0.f);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -1220,6 +1357,65 @@ extern "C" int cavp_ce_loss_nchw(const float* logits, const int64_t* labels, int
     ce_bwd_kernel<<<(int)nb2, 256, 0, s>>>(logits, (const long long*)labels, n_img, n_total, C, HW, ignore_index,
                                           scratch2, grad_scale, dlogits);
   }
+  CHECK_LAUNCH();
+}
+
+namespace {
+// label-resolution rows (columns) under `t` consecutive low-res rows: see dst_range
+inline int head_region(int t, int in, int out, int align) {
+  double r = (double)out / (double)in;
+  if (align && in > 1 && out > 1) r = std::max(r, (double)(out - 1) / (double)(in - 1));
+  const long long span = (long long)std::floor((t + 1) * r) + 4;
+  return (int)std::min<long long>(span, out);
+}
+template <typename T>
+int head_launch(const T* lo, const long long* lab, int n_img, int n_total, int C, int Hi, int Wi, int ld, int Ho, int Wo,
+                int align, int ignore, float gscale, float* loss, T* dlo, float* lse, float* scratch2, hipStream_t s) {
+  long long nb = ((long long)n_img * Ho * Wo + 255) / 256;
+  if (nb > 1024) nb = 1024;   // = (CAVP_CE_SCRATCH_FLOATS - 2) / 2 partials
+  head_fwd_kernel<T><<<(int)nb, 256, 0, s>>>(lo, lab, n_img, C, Hi, Wi, ld, Ho, Wo, align, ignore, lse, scratch2);
+  ce_finish_kernel<<<1, 256, 0, s>>>(scratch2, (int)nb, loss);
+  if (!dlo) return CAVP_OK;
+  int th = 16, tw = 16, RH = 0, RW = 0;
+  for (;;) {
+    RH = head_region(th, Hi, Ho, align);
+    RW = head_region(tw, Wi, Wo, align);
+    if ((long long)RH * RW * 4 <= 60 * 1024) break;
+    if (th == 1 && tw == 1) return CAVP_ERR_UNSUPPORTED;   // one low-res pixel spans > 15 K label pixels
+    if (th >= tw) th = (th + 1) / 2; else tw = (tw + 1) / 2;
+  }
+  const int tiles_h = (Hi + th - 1) / th, tiles_w = (Wi + tw - 1) / tw;
+  if ((long long)n_img * C > 65535) return CAVP_ERR_UNSUPPORTED;
+  head_bwd_kernel<T><<<dim3(tiles_h * tiles_w, n_img * C), 256, (size_t)RH * RW * 4, s>>>(
+      lo, lab, lse, scratch2, gscale, n_img, C, Hi, Wi, ld, Ho, Wo, align, ignore, th, tw, RW, tiles_w, dlo);
+  const long long tail = (long long)(n_total - n_img) * Hi * Wi * ld;   // images >= n_img contribute `* 0`
+  if (tail > 0) {
+    long long nz = (tail + 255) / 256;
+    if (nz > 4096) nz = 4096;
+    zero_tail_kernel<T><<<(int)nz, 256, 0, s>>>(dlo + (size_t)n_img * Hi * Wi * ld, tail);
+  }
+  return CAVP_OK;
+}
+}  // namespace
+
+extern "C" int cavp_upsample_ce_head(int32_t dtype, const void* lo, const int64_t* labels, int32_t n_img,
+                                     int32_t n_total, int32_t C, int32_t Hi, int32_t Wi, int32_t ld, int32_t Ho,
+                                     int32_t Wo, int32_t align_corners, int32_t ignore_index, float grad_scale,
+                                     float* loss, void* dlo, float* lse, float* scratch2, void* stream) {
+  if (!lo || !labels || !loss || !lse || !scratch2 || n_img <= 0 || n_total < n_img || C <= 0 || Hi <= 0 || Wi <= 0 ||
+      Ho <= 0 || Wo <= 0 || ld < C)
+    return CAVP_ERR_BAD_ARG;
+  if (!dt_ok(dtype)) return CAVP_ERR_UNSUPPORTED;
+  hipStream_t s = (hipStream_t)stream;
+  const long long* lab = (const long long*)labels;
+  int st;
+  if (dtype == CAVP_F32)
+    st = head_launch<float>((const float*)lo, lab, n_img, n_total, C, Hi, Wi, ld, Ho, Wo, align_corners, ignore_index,
+                            grad_scale, loss, (float*)dlo, lse, scratch2, s);
+  else
+    st = head_launch<bf16_t>((const bf16_t*)lo, lab, n_img, n_total, C, Hi, Wi, ld, Ho, Wo, align_corners,
+                             ignore_index, grad_scale, loss, (bf16_t*)dlo, lse, scratch2, s);
+  if (st != CAVP_OK) return st;
   CHECK_LAUNCH();
 }
 

@@ -353,3 +353,23 @@ def ce_loss(logits_nchw, labels, n_img: int, ignore_index: int = 255, grad_scale
     _check(_lib.load().cavp_ce_loss_nchw(_ptr(logits_nchw), _ptr(labels), n_img, nt, c, h * w, ignore_index,
                                          C.c_float(grad_scale), _ptr(loss), _ptr(dl), _ptr(scratch), _s()), "cavp_ce_loss_nchw")
     return loss, dl
+
+
+def upsample_ce_head(lo, labels, n_img: int, n_classes: int, ignore_index: int = 255, grad_scale: float = 1.0,
+                     align_corners: bool = False, want_grad: bool = True):
+    """Fused head: bilinear upsample of the NHWC low-resolution logits `lo` [n_total, h, w, ld] to the label
+    resolution + cross entropy on the first `n_img` images + gradient w.r.t. `lo`.  Returns (loss f32[1], dlo or None)."""
+    _need_gpu(lo, labels)
+    if lo.dim() != 4 or not lo.is_contiguous() or labels.dtype != torch.int64 or not labels.is_contiguous() \
+            or labels.dim() != 3 or labels.shape[0] != n_img:
+        raise _lib.CavpError("upsample_ce_head: contiguous NHWC logits and int64 [n_img, H, W] labels required")
+    nt, h, w, ld = lo.shape
+    H, W = labels.shape[1:]
+    loss = torch.empty(1, dtype=torch.float32, device=lo.device)
+    scratch = torch.empty(CE_SCRATCH_FLOATS, dtype=torch.float32, device=lo.device)
+    lse = torch.empty((n_img, H, W), dtype=torch.float32, device=lo.device)
+    dlo = torch.empty_like(lo) if want_grad else None
+    _check(_lib.load().cavp_upsample_ce_head(dtype_code(lo.dtype), _ptr(lo), _ptr(labels), n_img, nt, n_classes, h, w, ld, H, W,
+                                             int(align_corners), ignore_index, C.c_float(grad_scale), _ptr(loss),
+                                             _ptr(dlo), _ptr(lse), _ptr(scratch), _s()), "cavp_upsample_ce_head")
+    return loss, dlo

@@ -239,6 +239,18 @@ int cavp_bcast_add_nhwc(int32_t dtype, void* x, const float* v, float alpha, int
 int cavp_ce_loss_nchw(const float* logits, const int64_t* labels, int32_t n_img, int32_t n_total, int32_t C, int64_t HW,
                       int32_t ignore_index, float grad_scale, float* loss, float* dlogits, float* scratch,
                       void* stream);
+/* SURVEY.md §8f row f1 - the head of the training step in one op: F.interpolate(bilinear) of the low-resolution logits
+ * (models/cavp_model.py:143-146) + CrossEntropyLoss(ignore_index) on `out[:n_img] + out[n_img:]*0`
+ * (trainer_cavp_vpo_mono.py:171,187; loss/losser.py:60-62) + the gradient w.r.t. the low-resolution logits, without
+ * the [n_total][C][Ho][Wo] f32 prediction or its gradient ever reaching HBM.
+ *   lo, dlo: [n_total][Hi][Wi][ld] (dtype), classes in columns [0, C); dlo (optional) = grad_scale * dloss/dlo with every
+ *            column written (padding columns and images >= n_img: zero)
+ *   labels:  int64 [n_img][Ho][Wo];  lse: f32 [n_img][Ho][Wo] workspace (per-pixel log-sum-exp);
+ *   scratch: CAVP_CE_SCRATCH_FLOATS floats;  loss[0] = mean over the valid pixels (fixed summation order). */
+int cavp_upsample_ce_head(int32_t dtype, const void* lo, const int64_t* labels, int32_t n_img, int32_t n_total, int32_t C,
+                          int32_t Hi, int32_t Wi, int32_t ld, int32_t Ho, int32_t Wo, int32_t align_corners,
+                          int32_t ignore_index, float grad_scale, float* loss, void* dlo, float* lse, float* scratch,
+                          void* stream);
 
 /* ---- fused optimiser step (harness row of SURVEY.md §8c): torch.optim.SGD(momentum, weight_decay) on the visual groups +
  * torch.optim.Adam on the audio encoder (main_vpo_mono.py:45-65,118-125), all tensors in one launch.

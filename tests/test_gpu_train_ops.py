@@ -261,6 +261,45 @@ def test_bilinear_bwd_from_nchw_and_ce(C, dt):
 
 
 @pytest.mark.parametrize("dt", DTYPES, ids=IDS)
+@pytest.mark.parametrize("C,ld,hw,HW", [(2, 8, (14, 14), (56, 56)), (22, 24, (9, 13), (35, 50)), (71, 72, (8, 8), (32, 32)),
+                                        (2, 2, (7, 7), (7, 7))])
+def test_fused_upsample_ce_head(C, ld, hw, HW, dt):
+    """one op == F.interpolate(bilinear) + CrossEntropyLoss(ignore_index) on out[:B] + out[B:]*0 and
+    its gradient w.r.t. the low-resolution logits (non-integer ratios, padded channel stride, all-ignored rows)."""
+    ops, T = _mods()
+    B = 2
+    lo = _q(_rand(2 * B, C, *hw, seed=40, scale=2.0), dt).requires_grad_(True)
+    out = F.interpolate(lo, size=HW, mode="bilinear", align_corners=False)
+    label = torch.randint(0, C, (B, *HW), generator=torch.Generator().manual_seed(41))
+    label[torch.rand((B, *HW), generator=torch.Generator().manual_seed(42)) < 0.1] = 255
+    label[0, :3] = 255
+    loss = F.cross_entropy(out[:B] + out[B:] * 0.0, label, ignore_index=255)
+    (loss * 3.0).backward()
+    x = torch.full((2 * B, *hw, ld), 7.0, dtype=dt, device=DEV)     # padding columns hold junk: must not be read
+    x[..., :C] = lo.detach().permute(0, 2, 3, 1).to(dt).to(DEV)
+    l, dlo = T.upsample_ce_head(x, label.to(DEV), B, C, 255, grad_scale=3.0)
+    assert abs(float(l.item()) - float(loss.item())) <= 2e-5 * max(1.0, abs(float(loss.item())))
+    assert dlo.shape == x.shape and dlo.dtype == dt
+    assert float(dlo[..., C:].abs().max()) == 0.0 if ld > C else True
+    assert float(dlo[B:].abs().max()) == 0.0
+    _check(dlo[..., :C].permute(0, 3, 1, 2), lo.grad, dt, "fused head dlo", 5e-5, 1.5e-2)
+    # and against the three-op path it replaces
+    outp = torch.empty((2 * B, C, *HW), dtype=torch.float32, device=DEV)
+    ops.bilinear_to_nchw(x[..., :C], outp, align_corners=False)
+    l3, dl = T.ce_loss(outp, label.to(DEV), B, 255, grad_scale=3.0)
+    g3 = torch.zeros_like(x)
+    T.bilinear_bwd_from_nchw(dl, g3[..., :C], n_valid=B, align_corners=False)
+    assert abs(float(l3.item()) - float(l.item())) <= 2e-6 * max(1.0, abs(float(l.item())))
+    _check(dlo, g3.float().cpu(), dt, "fused vs three-op", 2e-5, 1.5e-2)
+    # loss only
+    l2, none = T.upsample_ce_head(x, label.to(DEV), B, C, 255, want_grad=False)
+    assert none is None and float(l2.item()) == float(l.item())
+    # everything ignored: loss 0, zero gradient (the three-op path's convention; torch returns nan)
+    l0, d0 = T.upsample_ce_head(x, torch.full_like(label, 255).to(DEV), B, C, 255)
+    assert float(l0.item()) == 0.0 and float(d0.abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("dt", DTYPES, ids=IDS)
 def test_bcast_add_and_smallcin_wgrad(dt):
     ops, T = _mods()
     x = _q(_rand(3, 64, 5, 7, seed=32), dt)
