@@ -48,6 +48,7 @@ struct IgemmParams {
   int tap_woff[9];          // per live tap: byte offset tap*Cin*sizeof(T) inside a weight row
   float* tile_stats;        // optional [tiles_p][Cout][2] per-tile (mean, M2) of the raw outputs (BatchNorm statistics)
   int nblk;                 // logical workgroups (tiles x split-K); the launch may use fewer, persistent, workgroups
+  int stagger;              // A/B knob: workgroups of the second residency slot start this many s_sleep(64) late
   int dbg;                  // profiling only (tile knob, hundreds digit): 1 = skip the operand loads, 2 = skip the MFMAs
   int coalesced;            // LDS-staged, fully coalesced 16-byte epilogue (needs Cout, ldy, ldr % VE == 0, 16-B aligned)
 };
@@ -153,6 +154,8 @@ __global__ __launch_bounds__(64 * WC * WP, (WC * WP == 4 ? 2 : 1)) void igemm_ke
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   // persistent workgroups: gridDim.x (a multiple of 8, so a workgroup keeps its XCD) physical workgroups walk the
   // p.nblk logical ones: launch, kernel-argument load and teardown are paid once per physical workgroup
+  if (p.stagger > 0 ? ((blockIdx.x >> 8) & 1) : p.stagger < 0 ? ((blockIdx.x >> 3) & 1) : 0)
+    for (int i = 0; i < (p.stagger < 0 ? -p.stagger : p.stagger); ++i) __builtin_amdgcn_s_sleep(64);
   for (int vb = blockIdx.x; vb < p.nblk; vb += gridDim.x) {
   if (vb != (int)blockIdx.x) __syncthreads();   // the previous tile's epilogue is done with the LDS
   const int sid = xcd_remap(vb, p.nblk);
@@ -406,7 +409,7 @@ __global__ __launch_bounds__(64 * WC * WP, (WC * WP == 4 ? 2 : 1)) void igemm_ke
       for (int b = 0; b < MP; ++b) {
         const int prow = wp0 + b * 16 + lrow;
         const int slot = (wc0 + a * 16) / 4 + lgrp;
-        *(f32x4_t*)(st + (size_t)prow * BC + ((slot ^ (prow & SWZ)) << 2)) = acc[a][b];
+        if (!(p.dbg & 64)) *(f32x4_t*)(st + (size_t)prow * BC + ((slot ^ (prow & SWZ)) << 2)) = acc[a][b];
       }
     __syncthreads();
     if (p.tile_stats && tid < BC && c_base + tid < p.Cout) {  // (BC <= NT for every tile)
@@ -493,7 +496,7 @@ __global__ __launch_bounds__(64 * WC * WP, (WC * WP == 4 ? 2 : 1)) void igemm_ke
 #pragma unroll
           for (int e = 0; e < 4; ++e) o[e] = pack2bf(v[2 * e], v[2 * e + 1]);
         }
-        *(u32x4_t*)(yp + (size_t)k * ystep) = o;
+        if (!(p.dbg & 32) || o[0] == 0x12345678u) *(u32x4_t*)(yp + (size_t)k * ystep) = o;
       }
     }
     continue;
@@ -577,8 +580,10 @@ hipError_t launch_cfg(const IgemmParams& p, int nblk, hipStream_t s) {
   if (bpc < 1) bpc = 1;
   static const bool persistent = !(getenv("CAVP_IGEMM_PERSISTENT") && atoi(getenv("CAVP_IGEMM_PERSISTENT")) == 0);
   const int grid = (persistent && nblk > bpc * 256) ? bpc * 256 : nblk;
+  static const int stagger = getenv("CAVP_IGEMM_STAGGER") ? atoi(getenv("CAVP_IGEMM_STAGGER")) : 0;
   IgemmParams q = p;
   q.nblk = nblk;
+  q.stagger = grid > 256 ? stagger : 0;
   igemm_kernel<T, BC, BP, WC, WP, UP, NS><<<dim3(grid), dim3(64 * WC * WP), lds, s>>>(q);
   return hipGetLastError();
 }

@@ -44,6 +44,15 @@ SHAPES = {
     "T_aspp_1x1_2048_256@14": (32, 14, 14, 2048, 256, 1, 1, 0, 1, False),
     "T_cls_1x1_256_8@56": (64, 56, 56, 256, 8, 1, 1, 0, 1, False),
     "T_clsdg_1x1_8_256@56": (64, 56, 56, 8, 256, 1, 1, 0, 1, False),
+    # K sweep at a fixed output (anatomy of the per-tile fixed costs)
+    "K_64_1216": (32, 1, 3136, 64, 1216, 1, 1, 0, 1, False),
+    "K_128_1216": (32, 1, 3136, 128, 1216, 1, 1, 0, 1, False),
+    "K_64_256": (32, 1, 3136, 64, 256, 1, 1, 0, 1, False),
+    "K_64_256hw": (32, 56, 56, 64, 256, 1, 1, 0, 1, False),
+    "K_64_1280": (32, 1, 3136, 64, 1280, 1, 1, 0, 1, False),
+    "K_64_640": (32, 1, 3136, 64, 640, 1, 1, 0, 1, False),
+    "K_640_1216": (32, 1, 3136, 640, 1216, 1, 1, 0, 1, False),
+    "K_1280_1216": (32, 1, 3136, 1280, 1216, 1, 1, 0, 1, False),
 }
 
 
