@@ -34,6 +34,7 @@ struct IgemmParams {
   float* partial;
   int N, H, W, Cin, ldx, Cout, ldy, KW, stride, stride_w, pad, dil, ldr, act;
   int Ho, Wo, M, K;
+  unsigned div_hw_m, div_hw_s, div_w_m, div_w_s, div_tc_m, div_tc_s;  // floor(n / (Ho*Wo)) and floor(n / Wo) as multiply + shift (fast_div)
   int ntaps;
   unsigned long long taps;  // 4 bits per live tap id (kh*KW + kw)
   int cpt;                  // K tiles per tap
@@ -131,6 +132,19 @@ __device__ __forceinline__ void epilogue_store4(const IgemmParams& p, float v0, 
   }
 }
 
+// floor(n / d) for 0 <= n < 2^31 by a host-prepared multiplier: m = floor(2^(31+L) / d) + 1, L = ceil(log2 d), shift = 31 + L
+// (exact: the error term n * e / 2^(31+L), e <= 1, stays below 1/d because n < 2^31 <= 2^(31+L) / d).  The tile set-up did
+// two real integer divisions per operand row (~40 VALU each, 8 per thread and tile): ~1 us of every tile at 2 waves per SIMD.
+__device__ __forceinline__ int fast_div(int n, unsigned m, unsigned shift) {
+  return (int)(((unsigned long long)(unsigned)n * m) >> shift);
+}
+inline void fast_div_prepare(int d, unsigned* m, unsigned* shift) {
+  int L = 0;
+  while ((1ll << L) < d) ++L;
+  *m = (unsigned)(((1ull << (31 + L)) / (unsigned)d) + 1ull);
+  *shift = 31u + (unsigned)L;
+}
+
 // s_waitcnt immediate that only waits for vmcnt <= n (gfx9 encoding: vmcnt[3:0] | expcnt[6:4] | lgkmcnt[11:8] | vmcnt[15:14])
 constexpr int vmcnt_imm(int n) { return (n & 15) | ((n >> 4) << 14) | (7 << 4) | (15 << 8); }
 
@@ -160,12 +174,14 @@ __global__ __launch_bounds__(64 * WC * WP, (WC * WP == 4 ? 2 : 1)) void igemm_ke
   if (vb != (int)blockIdx.x) __syncthreads();   // the previous tile's epilogue is done with the LDS
   const int sid = xcd_remap(vb, p.nblk);
   const int tiles = p.tiles_c * p.tiles_p;
-  const int z = sid / tiles;
+  // (wave-uniform, but integer division has no scalar instruction: each `/` below used to be a ~40-instruction VALU
+  // sequence, the 64-bit ones more, paid by every wave for every tile)
+  const int z = p.splitk == 1 ? 0 : sid / tiles;
   const int rem = sid - z * tiles;
-  const int tp = rem / p.tiles_c, tc = rem - tp * p.tiles_c;
+  const int tp = fast_div(rem, p.div_tc_m, p.div_tc_s), tc = rem - tp * p.tiles_c;
   const int c_base = tc * BC, p_base = tp * BP;
-  const int it_begin = (int)((long long)p.iters * z / p.splitk);
-  const int it_end = (int)((long long)p.iters * (z + 1) / p.splitk);
+  const int it_begin = p.splitk == 1 ? 0 : p.iters * z / p.splitk;   // iters * splitk < 2^31
+  const int it_end = p.splitk == 1 ? p.iters : p.iters * (z + 1) / p.splitk;
 
   // Buffer descriptors (wave-uniform, from kernel arguments): the hardware bounds check returns 0 for any offset
   // >= num_records, so padding taps / K tails / M and Cout tails are "loaded" as zeros by pointing the lane at
@@ -201,8 +217,8 @@ __global__ __launch_bounds__(64 * WC * WP, (WC * WP == 4 ? 2 : 1)) void igemm_ke
     const int pix = p_base + row;
     const bool ok = (row < BP) && (pix < p.M);
     const int pp = ok ? pix : 0;
-    const int n = pp / HoWo, r = pp - n * HoWo;
-    const int ho = r / p.Wo, wo = r - ho * p.Wo;
+    const int n = fast_div(pp, p.div_hw_m, p.div_hw_s), r = pp - n * HoWo;
+    const int ho = fast_div(r, p.div_w_m, p.div_w_s), wo = r - ho * p.Wo;
     const int h0 = ho * p.stride - p.pad, w0 = wo * p.stride_w - p.pad;
     x_h0[i] = ok ? h0 : -0x10000000;  // a dead row fails every bounds test below
     x_w0[i] = w0;
@@ -224,7 +240,7 @@ __global__ __launch_bounds__(64 * WC * WP, (WC * WP == 4 ? 2 : 1)) void igemm_ke
   }
 
   // K-loop position (tap index, channel tile) kept incrementally: no division in the loop
-  int g_ti = it_begin / p.cpt;
+  int g_ti = it_begin == 0 ? 0 : it_begin / p.cpt;
   int g_cc = it_begin - g_ti * p.cpt;
 
   // global -> LDS directly (buffer_load ... lds), no VGPR staging, no ds_write; out-of-range lanes land zeros.
@@ -467,7 +483,7 @@ __global__ __launch_bounds__(64 * WC * WP, (WC * WP == 4 ? 2 : 1)) void igemm_ke
           v[4] = t[0]; v[5] = t[1]; v[6] = t[2]; v[7] = t[3];
         }
         if (p.nbias) {
-          const float* nb = p.nbias + (size_t)((p_base + eprow0 + k * RSTR) / HoWo) * p.Cout + ec;
+          const float* nb = p.nbias + (size_t)fast_div(p_base + eprow0 + k * RSTR, p.div_hw_m, p.div_hw_s) * p.Cout + ec;
 #pragma unroll
           for (int e = 0; e < VE; ++e) v[e] += nb[e];
         }
@@ -647,6 +663,8 @@ Plan make_plan(const cavp_conv_desc* d) {
   const long long M = (long long)d->N * p.Ho * p.Wo;
   if (M > 0x7fffffffll / 4) { pl.status = CAVP_ERR_UNSUPPORTED; return pl; }
   p.M = (int)M;
+  fast_div_prepare(p.Ho * p.Wo, &p.div_hw_m, &p.div_hw_s);
+  fast_div_prepare(p.Wo, &p.div_w_m, &p.div_w_s);
   p.K = d->KH * d->KW * d->Cin;
   // live taps: tap (kh,kw) is live iff some output row/col maps it inside the image
   p.ntaps = 0;
@@ -720,6 +738,7 @@ Plan make_plan(const cavp_conv_desc* d) {
   const TileCfg& t = kTiles[best];
   pl.tile_id = t.id;
   p.tiles_c = cdiv(p.Cout, t.BC);
+  fast_div_prepare(p.tiles_c, &p.div_tc_m, &p.div_tc_s);
   p.tiles_p = cdiv(p.M, t.BP);
   const int nwg = p.tiles_c * p.tiles_p;
   int sk = best_sk;
