@@ -104,6 +104,19 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
+// floor(n / d) for 0 <= n < 2^31 by a host-prepared multiplier: m = floor(2^(31+L) / d) + 1, L = ceil(log2 d), shift = 31 + L
+// (exact: the error term n * e / 2^(31+L), e <= 1, stays below 1/d because n < 2^31 <= 2^(31+L) / d).  The tile set-up did
+// two real integer divisions per operand row (~40 VALU each, 8 per thread and tile): ~1 us of every tile at 2 waves per SIMD.
+__device__ __forceinline__ int fast_div(int n, unsigned m, unsigned shift) {
+  return (int)(((unsigned long long)(unsigned)n * m) >> shift);
+}
+inline void fast_div_prepare(int d, unsigned* m, unsigned* shift) {
+  int L = 0;
+  while ((1ll << L) < d) ++L;
+  *m = (unsigned)(((1ull << (31 + L)) / (unsigned)d) + 1ull);
+  *shift = 31u + (unsigned)L;
+}
+
 // Bijective XCD-aware block remap (8 XCDs, block b is dispatched to XCD b % 8): gives each XCD a contiguous
 // range of logical tile ids so neighbouring tiles (which share an operand panel) hit the same private L2.
 __device__ __forceinline__ int xcd_remap(int bid, int nblk) {

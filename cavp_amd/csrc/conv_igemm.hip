@@ -132,19 +132,6 @@ __device__ __forceinline__ void epilogue_store4(const IgemmParams& p, float v0, 
   }
 }
 
-// floor(n / d) for 0 <= n < 2^31 by a host-prepared multiplier: m = floor(2^(31+L) / d) + 1, L = ceil(log2 d), shift = 31 + L
-// (exact: the error term n * e / 2^(31+L), e <= 1, stays below 1/d because n < 2^31 <= 2^(31+L) / d).  The tile set-up did
-// two real integer divisions per operand row (~40 VALU each, 8 per thread and tile): ~1 us of every tile at 2 waves per SIMD.
-__device__ __forceinline__ int fast_div(int n, unsigned m, unsigned shift) {
-  return (int)(((unsigned long long)(unsigned)n * m) >> shift);
-}
-inline void fast_div_prepare(int d, unsigned* m, unsigned* shift) {
-  int L = 0;
-  while ((1ll << L) < d) ++L;
-  *m = (unsigned)(((1ull << (31 + L)) / (unsigned)d) + 1ull);
-  *shift = 31u + (unsigned)L;
-}
-
 // s_waitcnt immediate that only waits for vmcnt <= n (gfx9 encoding: vmcnt[3:0] | expcnt[6:4] | lgkmcnt[11:8] | vmcnt[15:14])
 constexpr int vmcnt_imm(int n) { return (n & 15) | ((n >> 4) << 14) | (7 << 4) | (15 << 8); }
 

@@ -33,6 +33,7 @@ struct WgradParams {
   unsigned long long taps;
   int tiles_co, tiles_ci, ksplit;
   int rows_per_split;  // multiple of 64
+  unsigned dv_co[2], dv_ci[2], dv_nt[2], dv_kw[2], dv_hw[2], dv_w[2];  // fast_div (multiplier, shift) of tiles_co, tiles_ci, ntaps, KW, Ho*Wo, Wo
   int x_bytes, dy_bytes;
   int oihw;            // dw layout: 0 = [Cout][taps][Cin] (OHWI), 1 = [Cout][Cin][taps] (torch .grad layout)
   int dbg;             // profiling only (env CAVP_WGRAD_DBG): 1 = loads out of range, 2 = no MFMAs, 4 = no DMA, 8 = no epilogue
@@ -56,13 +57,13 @@ __global__ __launch_bounds__(256, (BK == 32 ? 4 : 2)) void wgrad_kernel(const Wg
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
-  int bid = xcd_remap(blockIdx.x, gridDim.x);
-  const int tco = bid % p.tiles_co; bid /= p.tiles_co;
-  const int tci = bid % p.tiles_ci; bid /= p.tiles_ci;
-  const int ti = bid % p.ntaps;
-  const int z = bid / p.ntaps;
+  const int bid = xcd_remap(blockIdx.x, gridDim.x);
+  // (multiply + shift: integer division is a ~40-instruction VALU sequence even for wave-uniform values)
+  const int b1 = fast_div(bid, p.dv_co[0], p.dv_co[1]), tco = bid - b1 * p.tiles_co;
+  const int b2 = fast_div(b1, p.dv_ci[0], p.dv_ci[1]), tci = b1 - b2 * p.tiles_ci;
+  const int z = fast_div(b2, p.dv_nt[0], p.dv_nt[1]), ti = b2 - z * p.ntaps;
   const int tap = (int)((p.taps >> (4 * ti)) & 15ull);
-  const int kh = tap / p.KW, kw = tap - kh * p.KW;
+  const int kh = fast_div(tap, p.dv_kw[0], p.dv_kw[1]), kw = tap - kh * p.KW;
   const int co_base = tco * TCH, ci_base = tci * TCH;
   const int r_begin = z * p.rows_per_split;
   int r_end = r_begin + p.rows_per_split;
@@ -87,9 +88,9 @@ __global__ __launch_bounds__(256, (BK == 32 ? 4 : 2)) void wgrad_kernel(const Wg
   for (int i = 0; i < NI; ++i) {
     pixr[i] = r_begin + drow0 + 16 * i;
     const int pp = pixr[i] < p.M ? pixr[i] : 0;
-    pn[i] = pp / HoWo;
+    pn[i] = fast_div(pp, p.dv_hw[0], p.dv_hw[1]);
     const int rr = pp - pn[i] * HoWo;
-    ph[i] = rr / p.Wo;
+    ph[i] = fast_div(rr, p.dv_w[0], p.dv_w[1]);
     pw[i] = rr - ph[i] * p.Wo;
   }
   const int dh = kh * p.dil - p.pad, dw = kw * p.dil - p.pad;
@@ -364,6 +365,12 @@ WgradPlan make_wgrad_plan(const cavp_conv_desc* d) {
   p.tiles_co = (d->Cout + TCH - 1) / TCH;
   p.tiles_ci = (d->Cin + TCH - 1) / TCH;
   const int base = p.tiles_co * p.tiles_ci * p.ntaps;
+  fast_div_prepare(p.tiles_co, &p.dv_co[0], &p.dv_co[1]);
+  fast_div_prepare(p.tiles_ci, &p.dv_ci[0], &p.dv_ci[1]);
+  fast_div_prepare(p.ntaps, &p.dv_nt[0], &p.dv_nt[1]);
+  fast_div_prepare(p.KW, &p.dv_kw[0], &p.dv_kw[1]);
+  fast_div_prepare(p.Ho * p.Wo, &p.dv_hw[0], &p.dv_hw[1]);
+  fast_div_prepare(p.Wo, &p.dv_w[0], &p.dv_w[1]);
   const int chunks = (p.M + 63) / 64;
   // Split count from a small time model fitted to tools/bench_wgrad.py on MI355X (profiles/r01_notes.md):
   //   t(ks) = rounds * steps * 1.08 us  +  ks * |dW| * 8 B / 2.5 TB/s  (+ reduce launch)
