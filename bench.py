@@ -103,7 +103,7 @@ class KernelTimer:
         if train_mod is not None:
             for name in ("conv2d_dgrad", "conv2d_wgrad", "colstats", "colsum", "scale_shift_act", "bn_act_bwd_reduce",
                          "bn_act_bwd_apply", "act_bwd", "add", "layernorm_bwd", "attn_gate_bwd", "maxpool_bwd",
-                         "bilinear_bwd", "bilinear_bwd_from_nchw", "bcast_add", "ce_loss", "smallcin_wgrad",
+                         "bilinear_bwd", "bilinear_bwd_from_nchw", "bcast_add", "ce_loss", "upsample_ce_head", "smallcin_wgrad",
                          "unpack_weight_grad", "pack_weight_dgrad"):
                 fn = getattr(train_mod, name)
                 self._orig[(train_mod, name)] = fn
