@@ -33,7 +33,7 @@ struct WgradParams {
   unsigned long long taps;
   int tiles_co, tiles_ci, ksplit;
   int rows_per_split;  // multiple of 64
-  unsigned dv_co[2], dv_ci[2], dv_nt[2], dv_kw[2], dv_hw[2], dv_w[2];  // fast_div (multiplier, shift) of tiles_co, tiles_ci, ntaps, KW, Ho*Wo, Wo
+  unsigned dv_co[2], dv_ci[2], dv_nt[2], dv_kw[2], dv_hw[2], dv_w[2], dv_cq[2];  // fast_div (multiplier, shift) of tiles_co, tiles_ci, ntaps, KW, Ho*Wo, Wo
   int x_bytes, dy_bytes;
   int oihw;            // dw layout: 0 = [Cout][taps][Cin] (OHWI), 1 = [Cout][Cin][taps] (torch .grad layout)
   int dbg;             // profiling only (env CAVP_WGRAD_DBG): 1 = loads out of range, 2 = no MFMAs, 4 = no DMA, 8 = no epilogue
@@ -282,16 +282,30 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradParams p) 
     const long long i = i0 + ql;
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
     size_t off = 0;
-    if (i < total) {
-      const int c4 = (int)(i % cq);
-      const long long r = i / cq;
-      const int ti = (int)(r % p.ntaps);
-      const int co = (int)(r / p.ntaps);
-      const int tap = (int)((p.taps >> (4 * ti)) & 15ull);
+    int co = 0, tap = 0, c4 = 0;
+    if (i < total) {   // (total = Cout * ntaps * Cin / 4 < 2^31: checked by the planner)
+      const int r = fast_div((int)i, p.dv_cq[0], p.dv_cq[1]);
+      c4 = (int)i - r * cq;
+      co = fast_div(r, p.dv_nt[0], p.dv_nt[1]);
+      const int ti = r - co * p.ntaps;
+      tap = (int)((p.taps >> (4 * ti)) & 15ull);
       off = ((size_t)co * p.ntaps_all + tap) * p.Cin + (size_t)c4 * 4;
-      for (int z = zg; z < p.ksplit; z += ZG) {
-        const float4 v = *(const float4*)(p.slabs + (size_t)z * slab + off);
+      // the splits are summed in a fixed order (z ascending) with the loads of 8 splits in flight
+      const float* sp = p.slabs + off + (size_t)zg * slab;
+      const size_t zstep = (size_t)ZG * slab;
+      int z = zg;
+      for (; z + 7 * ZG < p.ksplit; z += 8 * ZG) {
+        float4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = *(const float4*)(sp + (size_t)u * zstep);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w; }
+        sp += 8 * zstep;
+      }
+      for (; z < p.ksplit; z += ZG) {
+        const float4 v = *(const float4*)sp;
         s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        sp += zstep;
       }
     }
     if constexpr (ZG > 1) {
@@ -308,8 +322,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradParams p) 
     }
     if (zg == 0 && i < total) {
       if (p.oihw) {   // off = (co * taps_all + tap) * Cin + ci  ->  (co * Cin + ci) * taps_all + tap
-        const size_t row = off / p.Cin, ci = off - row * p.Cin, co = row / p.ntaps_all, tap = row - co * p.ntaps_all;
-        float* d = p.dw + (co * p.Cin + ci) * p.ntaps_all + tap;
+        float* d = p.dw + ((size_t)co * p.Cin + (size_t)c4 * 4) * p.ntaps_all + tap;
         d[0] += s.x; d[p.ntaps_all] += s.y; d[2 * (size_t)p.ntaps_all] += s.z; d[3 * (size_t)p.ntaps_all] += s.w;
       } else {
         const float4 o = *(const float4*)(p.dw + off);
@@ -369,6 +382,7 @@ WgradPlan make_wgrad_plan(const cavp_conv_desc* d) {
   fast_div_prepare(p.tiles_ci, &p.dv_ci[0], &p.dv_ci[1]);
   fast_div_prepare(p.ntaps, &p.dv_nt[0], &p.dv_nt[1]);
   fast_div_prepare(p.KW, &p.dv_kw[0], &p.dv_kw[1]);
+  fast_div_prepare(p.Cin >> 2, &p.dv_cq[0], &p.dv_cq[1]);
   fast_div_prepare(p.Ho * p.Wo, &p.dv_hw[0], &p.dv_hw[1]);
   fast_div_prepare(p.Wo, &p.dv_w[0], &p.dv_w[1]);
   const int chunks = (p.M + 63) / 64;
@@ -450,6 +464,7 @@ extern "C" int cavp_conv2d_wgrad_nhwc(const cavp_conv_desc* d, const void* x, co
   if (hipGetLastError() != hipSuccess) return CAVP_ERR_LAUNCH;
   if (p.ksplit > 1) {
     const long long quads = (long long)p.Cout * p.ntaps * (p.Cin / 4);
+    if (quads > 0x7fffffffll) return CAVP_ERR_UNSUPPORTED;
     int zgrp = 1;   // split groups per workgroup: spread the split dimension when there are few output quads
     while (zgrp < 16 && zgrp * 2 <= p.ksplit && quads * zgrp < 131072) zgrp *= 2;
     long long nb = (quads + (256 / zgrp) - 1) / (256 / zgrp);
