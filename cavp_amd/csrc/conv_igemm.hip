@@ -34,7 +34,7 @@ struct IgemmParams {
   float* partial;
   int N, H, W, Cin, ldx, Cout, ldy, KW, stride, stride_w, pad, dil, ldr, act;
   int Ho, Wo, M, K;
-  unsigned div_hw_m, div_hw_s, div_w_m, div_w_s, div_tc_m, div_tc_s;  // floor(n / (Ho*Wo)) and floor(n / Wo) as multiply + shift (fast_div)
+  unsigned div_hw_m, div_hw_s, div_w_m, div_w_s, div_tc_m, div_tc_s, div_cq_m, div_cq_s;  // floor(n / (Ho*Wo)) and floor(n / Wo) as multiply + shift (fast_div)
   int ntaps;
   unsigned long long taps;  // 4 bits per live tap id (kh*KW + kw)
   int cpt;                  // K tiles per tap
@@ -81,7 +81,7 @@ __device__ __forceinline__ float epi_one(float v, int cc, int n_img, const Igemm
 template <typename T>
 __device__ __forceinline__ void epilogue_store4(const IgemmParams& p, float v0, float v1, float v2, float v3, int pix,
                                                 int c) {
-  const int n_img = p.nbias ? pix / (p.Ho * p.Wo) : 0;
+  const int n_img = p.nbias ? fast_div(pix, p.div_hw_m, p.div_hw_s) : 0;
   float v[4] = {v0, v1, v2, v3};
   T* yp = (T*)p.y + (size_t)pix * p.ldy + c;
   const T* rp = p.res ? (const T*)p.res + (size_t)pix * p.ldr + c : nullptr;
@@ -535,14 +535,24 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const IgemmParams 
   const int cq = (p.Cout + 3) >> 2;
   const long long total = (long long)p.M * cq;
   for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-    const int pix = (int)(i / cq);
+    const int pix = total <= 0x7fffffffll ? fast_div((int)i, p.div_cq_m, p.div_cq_s) : (int)(i / cq);
     const int c = (int)(i - (long long)pix * cq) * 4;
     float v[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int z = 0; z < p.splitk; ++z) {
-      const float* src = p.partial + ((size_t)z * p.M + pix) * p.Cout + c;
+    if ((p.Cout & 3) == 0) {   // slabs are 16-byte aligned rows: one vector load per split (summed in split order)
+      const float* src = p.partial + (size_t)pix * p.Cout + c;
+      const size_t zstep = (size_t)p.M * p.Cout;
+#pragma unroll 4
+      for (int z = 0; z < p.splitk; ++z) {
+        const float4 t = *(const float4*)(src + (size_t)z * zstep);
+        v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
+      }
+    } else {
+      for (int z = 0; z < p.splitk; ++z) {
+        const float* src = p.partial + ((size_t)z * p.M + pix) * p.Cout + c;
 #pragma unroll
-      for (int e = 0; e < 4; ++e)
-        if (c + e < p.Cout) v[e] += src[e];
+        for (int e = 0; e < 4; ++e)
+          if (c + e < p.Cout) v[e] += src[e];
+      }
     }
     epilogue_store4<T>(p, v[0], v[1], v[2], v[3], pix, c);
   }
@@ -652,6 +662,7 @@ Plan make_plan(const cavp_conv_desc* d) {
   p.M = (int)M;
   fast_div_prepare(p.Ho * p.Wo, &p.div_hw_m, &p.div_hw_s);
   fast_div_prepare(p.Wo, &p.div_w_m, &p.div_w_s);
+  fast_div_prepare((d->Cout + 3) >> 2, &p.div_cq_m, &p.div_cq_s);
   p.K = d->KH * d->KW * d->Cin;
   // live taps: tap (kh,kw) is live iff some output row/col maps it inside the image
   p.ntaps = 0;
