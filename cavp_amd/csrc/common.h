@@ -117,6 +117,35 @@ inline void fast_div_prepare(int d, unsigned* m, unsigned* shift) {
   *shift = 31u + (unsigned)L;
 }
 
+// (n, h, w) of a flat NHW pixel index / (pixel, channel-vector) of a flat element index.  The 64-bit `/` and `%` these
+// replace cost ~100 VALU instructions each (five per thread in the pooling / resize / im2col kernels); indices below 2^31
+// take the 32-bit route (three ~25-instruction unsigned divisions).
+__device__ __forceinline__ void split_pixel(long long pix, int W, int H, int& w, int& h, int& n) {
+  if (pix <= 0x7fffffffll) {
+    const unsigned p = (unsigned)pix, r = p / (unsigned)W, q = r / (unsigned)H;
+    w = (int)(p - r * (unsigned)W);
+    h = (int)(r - q * (unsigned)H);
+    n = (int)q;
+  } else {
+    const long long r = pix / W;
+    w = (int)(pix - r * W);
+    n = (int)(r / H);
+    h = (int)(r - (long long)n * H);
+  }
+}
+__device__ __forceinline__ void split_index(long long idx, int CV, int W, int H, int& cv, long long& pix, int& w, int& h,
+                                            int& n) {
+  if (idx <= 0x7fffffffll) {
+    const unsigned u = (unsigned)idx, p = u / (unsigned)CV;
+    cv = (int)(u - p * (unsigned)CV);
+    pix = (long long)p;
+  } else {
+    pix = idx / CV;
+    cv = (int)(idx - pix * CV);
+  }
+  split_pixel(pix, W, H, w, h, n);
+}
+
 // Bijective XCD-aware block remap (8 XCDs, block b is dispatched to XCD b % 8): gives each XCD a contiguous
 // range of logical tile ids so neighbouring tiles (which share an operand panel) hit the same private L2.
 __device__ __forceinline__ int xcd_remap(int bid, int nblk) {

@@ -63,11 +63,9 @@ __global__ __launch_bounds__(256) void conv3x3_smallcin_kernel(const float* __re
   const int G = Cout >> 4;
   const long long total = (long long)N * Ho * Wo * G;
   for (long long idx = blockIdx.x * 256ll + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
-    const int g = (int)(idx % G);
-    const long long pix = idx / G;
-    const int wo = (int)(pix % Wo);
-    const int ho = (int)((pix / Wo) % Ho);
-    const int n = (int)(pix / ((long long)Wo * Ho));
+    int g, wo, ho, n;
+    long long pix;
+    split_index(idx, G, Wo, Ho, g, pix, wo, ho, n);
     float acc[16];
 #pragma unroll
     for (int j = 0; j < 16; ++j) acc[j] = 0.f;
@@ -112,11 +110,9 @@ __global__ __launch_bounds__(256) void maxpool_kernel(const T* __restrict__ x, T
   const int CV = C / VE;
   const long long total = (long long)N * Ho * Wo * CV;
   for (long long idx = blockIdx.x * 256ll + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
-    const int cv = (int)(idx % CV);
-    const long long pix = idx / CV;
-    const int wo = (int)(pix % Wo);
-    const int ho = (int)((pix / Wo) % Ho);
-    const int n = (int)(pix / ((long long)Wo * Ho));
+    int cv, wo, ho, n;
+    long long pix;
+    split_index(idx, CV, Wo, Ho, cv, pix, wo, ho, n);
     float m[VE];
     int am[VE];   // window-relative position kh * k + kw of the FIRST maximum (strict >, scan order: as ATen)
     bool first = true;
@@ -201,11 +197,9 @@ __global__ __launch_bounds__(256) void bilinear_nhwc_kernel(const T* __restrict_
   const int CV = C / VE;
   const long long total = (long long)N * Ho * Wo * CV;
   for (long long idx = blockIdx.x * 256ll + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
-    const int cv = (int)(idx % CV);
-    const long long pix = idx / CV;
-    const int wo = (int)(pix % Wo);
-    const int ho = (int)((pix / Wo) % Ho);
-    const int n = (int)(pix / ((long long)Wo * Ho));
+    int cv, wo, ho, n;
+    long long pix;
+    split_index(idx, CV, Wo, Ho, cv, pix, wo, ho, n);
     int h0, h1, w0, w1;
     float lh, lw;
     src_index(ho, Hi, Ho, align, h0, h1, lh);
@@ -229,9 +223,8 @@ __global__ __launch_bounds__(256) void bilinear_to_nchw_kernel(const T* __restri
                                                                int align) {
   const long long total = (long long)N * Ho * Wo;
   for (long long pix = blockIdx.x * 256ll + threadIdx.x; pix < total; pix += (long long)gridDim.x * 256) {
-    const int wo = (int)(pix % Wo);
-    const int ho = (int)((pix / Wo) % Ho);
-    const int n = (int)(pix / ((long long)Wo * Ho));
+    int wo, ho, n;
+    split_pixel(pix, Wo, Ho, wo, ho, n);
     int h0, h1, w0, w1;
     float lh, lw;
     src_index(ho, Hi, Ho, align, h0, h1, lh);

@@ -576,11 +576,9 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const unsigned char* _
   const int CV = C / VE;
   const long long total = (long long)N * H * W * CV;
   for (long long idx = blockIdx.x * 256ll + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
-    const int cv = (int)(idx % CV);
-    const long long pix = idx / CV;
-    const int wi = (int)(pix % W);
-    const int hi = (int)((pix / W) % H);
-    const int n = (int)(pix / ((long long)W * H));
+    int cv, wi, hi, n;
+    long long pix;
+    split_index(idx, CV, W, H, cv, pix, wi, hi, n);
     float acc[VE];
 #pragma unroll
     for (int e = 0; e < VE; ++e) acc[e] = 0.f;
@@ -677,11 +675,9 @@ __global__ __launch_bounds__(256) void bilinear_bwd_nhwc_kernel(const T* __restr
   const int CV = C / VE;
   const long long total = (long long)N * Hi * Wi * CV;
   for (long long idx = blockIdx.x * 256ll + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
-    const int cv = (int)(idx % CV);
-    const long long pix = idx / CV;
-    const int wi = (int)(pix % Wi);
-    const int hi = (int)((pix / Wi) % Hi);
-    const int n = (int)(pix / ((long long)Wi * Hi));
+    int cv, wi, hi, n;
+    long long pix;
+    split_index(idx, CV, Wi, Hi, cv, pix, wi, hi, n);
     int hlo, hhi, wlo, whi;
     dst_range(hi, Hi, Ho, align, hlo, hhi);
     dst_range(wi, Wi, Wo, align, wlo, whi);
@@ -711,11 +707,9 @@ __global__ __launch_bounds__(256) void bilinear_bwd_from_nchw_kernel(const float
                                                                      int ld_dx, int Ho, int Wo, int align) {
   const long long total = (long long)N * Hi * Wi * C;
   for (long long idx = blockIdx.x * 256ll + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
-    const int c = (int)(idx % C);
-    const long long pix = idx / C;
-    const int wi = (int)(pix % Wi);
-    const int hi = (int)((pix / Wi) % Hi);
-    const int n = (int)(pix / ((long long)Wi * Hi));
+    int c, wi, hi, n;
+    long long pix;
+    split_index(idx, C, Wi, Hi, c, pix, wi, hi, n);
     float acc = 0.f;
     if (n < n_valid) {
       int hlo, hhi, wlo, whi;
@@ -961,9 +955,8 @@ __global__ __launch_bounds__(256) void smallcin_im2col_kernel(const float* __res
   constexpr int VE = VecT<T>::VE;
   const long long M = (long long)N * Ho * Wo;
   for (long long pix = blockIdx.x * 256ll + threadIdx.x; pix < M; pix += (long long)gridDim.x * 256) {
-    const int wo = (int)(pix % Wo);
-    const int ho = (int)((pix / Wo) % Ho);
-    const int n = (int)(pix / ((long long)Wo * Ho));
+    int wo, ho, n;
+    split_pixel(pix, Wo, Ho, wo, ho, n);
     float v[KP];
 #pragma unroll
     for (int j = 0; j < KP; ++j) {
