@@ -325,9 +325,13 @@ def main():
 
         def run_step():
             return model.train_step(image, audio, label)
+
+        def run_step_local():   # rank-local (no collectives): what rank 0 alone re-runs for the per-kernel timing
+            return model.train_step(image, audio, label, all_reduce=False)
     else:
         def run_step():
             return model(image, audio, eval_mode=True)
+        run_step_local = run_step
 
     with torch.no_grad():
         run_step()      # eager warm-up: packs weights, sizes the workspace
@@ -399,7 +403,7 @@ def main():
                        "launch": "eager" if a.no_graph else "hipGraph replay"},
         }
         if not a.no_roofline:
-            line["roofline"] = measure_roofline(model, run_step, image, a.dtype)
+            line["roofline"] = measure_roofline(model, run_step_local, image, a.dtype)
         if world == 1 and not a.no_cpu_baseline:
             if a.config == "c1p":
                 line["cpu_baseline"] = (cpu_baseline_train(sd, cfg, max(2, a.cpu_sample_batch // 2)) if train

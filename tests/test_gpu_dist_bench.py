@@ -27,7 +27,7 @@ def test_two_rank_bench_on_one_gpu(mode):
     env = dict(os.environ, CAVP_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
-           "--batch", "4", "--mode", mode, "--no-cpu-baseline", "--no-roofline"]
+           "--batch", "4", "--mode", mode]   # default flags, as the driver runs it: the roofline leg must stay rank-local
     r = subprocess.run(cmd, cwd=REPO, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
@@ -36,3 +36,4 @@ def test_two_rank_bench_on_one_gpu(mode):
     assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "weak" and d["value"] > 0
     assert d["config"]["global_batch"] == 8 and d["config"]["parallelism"] == "dp2"
     assert "capture failed" not in r.stderr
+    assert d["roofline"]["frac"] > 0 and "cpu_baseline" not in d   # per-kernel timing on rank 0 only; CPU baseline is an N=1 leg
