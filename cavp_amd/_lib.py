@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(HERE, "libcavp_hip.so")
 
 F32, BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_LEAKY, ACT_GELU = 0, 1, 2, 3
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 
 class CavpError(RuntimeError):
@@ -26,7 +26,7 @@ class ConvDesc(C.Structure):
     """struct cavp_conv_desc (include/cavp_hip.h)."""
     _fields_ = [(n, C.c_int32) for n in (
         "dtype", "N", "H", "W", "Cin", "ldx", "Cout", "ldy", "KH", "KW", "stride", "pad", "dil", "ldr", "act",
-        "splitk", "tile", "up", "Ho", "Wo", "stride_w", "dw_oihw")]
+        "splitk", "tile", "up", "Ho", "Wo", "stride_w", "dw_oihw", "dw_overwrite")]
 
 
 _vp, _i32, _i64, _f32, _sz = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_size_t

@@ -27,6 +27,9 @@ from ._lib import ACT_GELU, ACT_LEAKY, ACT_NONE, ACT_RELU, CavpError
 
 BN_EPS = 1e-5
 BN_MOMENTUM = 0.1
+# weights of at least this many elements take their first gradient of a step by overwrite (beta = 0) and are left out of the
+# arena memset; A/B knob CAVP_GRAD_OVERWRITE_MIN=0: every weight gradient accumulates onto a zeroed arena
+_GRAD_OVERWRITE_MIN = int(os.environ.get("CAVP_GRAD_OVERWRITE_MIN", str(1 << 19)))
 _FUSED_HEAD = os.environ.get("CAVP_FUSED_HEAD", "1") != "0"   # A/B knob: 0 = upsample, CE, and their backward as separate ops
 
 
@@ -631,7 +634,10 @@ class CAVP(nn.Module):
             raise CavpError("CAVP (MI355X path) needs inputs on a HIP device: there is no CPU fallback")
         arena = getattr(self, "_grad_arena", None)
         if arena is None or arena.flat.device != image.device:
-            arena = self._grad_arena = GradArena(list(self.parameters()), image.device, late_ids=self._late_grad_ids())
+            big = {id(m.weight) for m in self.modules() if isinstance(m, (nn.Linear, nn.Conv2d))
+                   and m.weight.numel() >= _GRAD_OVERWRITE_MIN} if _GRAD_OVERWRITE_MIN > 0 else set()
+            arena = self._grad_arena = GradArena(list(self.parameters()), image.device, late_ids=self._late_grad_ids(),
+                                                 no_zero_ids=big)
         arena.zero()
         tp = TrainPass(self, self.compute_dtype, arena=arena)
         B, C = image.shape[0], self.num_classes

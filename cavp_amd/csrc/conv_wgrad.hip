@@ -35,6 +35,7 @@ struct WgradParams {
   int rows_per_split;  // multiple of 64
   unsigned dv_co[2], dv_ci[2], dv_nt[2], dv_kw[2], dv_hw[2], dv_w[2], dv_cq[2];  // fast_div (multiplier, shift) of tiles_co, tiles_ci, ntaps, KW, Ho*Wo, Wo
   int x_bytes, dy_bytes;
+  int overwrite;       // 1: dw = gradient (beta = 0, dw is not read); 0: dw += gradient
   int oihw;            // dw layout: 0 = [Cout][taps][Cin] (OHWI), 1 = [Cout][Cin][taps] (torch .grad layout)
   int dbg;             // profiling only (env CAVP_WGRAD_DBG): 1 = loads out of range, 2 = no MFMAs, 4 = no DMA, 8 = no epilogue
   float* dbias;        // optional: dbias[co] += sum_pix dY[pix][co] (bias gradient), taken from the dY tiles streamed anyway
@@ -249,12 +250,17 @@ __global__ __launch_bounds__(256, (BK == 32 ? 4 : 2)) void wgrad_kernel(const Wg
       if (co < p.Cout && ci < p.Cin) {   // Cin % 4 == 0: a quad is in range as a whole
         if (p.ksplit == 1 && p.oihw) {   // straight into the torch-layout gradient: 4 strided read-modify-writes
           float* dst = out + ((size_t)co * p.Cin + ci) * p.ntaps_all + tap;
+          if (p.overwrite) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) dst[(size_t)e * p.ntaps_all] += acc[a][b][e];
+            for (int e = 0; e < 4; ++e) dst[(size_t)e * p.ntaps_all] = acc[a][b][e];
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) dst[(size_t)e * p.ntaps_all] += acc[a][b][e];
+          }
         } else {
           float4* dst = (float4*)(out + ((size_t)co * p.ntaps_all + tap) * p.Cin + ci);
           float4 v = make_float4(acc[a][b][0], acc[a][b][1], acc[a][b][2], acc[a][b][3]);
-          if (p.ksplit == 1) {
+          if (p.ksplit == 1 && !p.overwrite) {
             const float4 o = *dst;
             v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
           }
@@ -323,7 +329,13 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradParams p) 
     if (zg == 0 && i < total) {
       if (p.oihw) {   // off = (co * taps_all + tap) * Cin + ci  ->  (co * Cin + ci) * taps_all + tap
         float* d = p.dw + ((size_t)co * p.Cin + (size_t)c4 * 4) * p.ntaps_all + tap;
-        d[0] += s.x; d[p.ntaps_all] += s.y; d[2 * (size_t)p.ntaps_all] += s.z; d[3 * (size_t)p.ntaps_all] += s.w;
+        if (p.overwrite) {
+          d[0] = s.x; d[p.ntaps_all] = s.y; d[2 * (size_t)p.ntaps_all] = s.z; d[3 * (size_t)p.ntaps_all] = s.w;
+        } else {
+          d[0] += s.x; d[p.ntaps_all] += s.y; d[2 * (size_t)p.ntaps_all] += s.z; d[3 * (size_t)p.ntaps_all] += s.w;
+        }
+      } else if (p.overwrite) {
+        *(float4*)(p.dw + off) = s;
       } else {
         const float4 o = *(const float4*)(p.dw + off);
         *(float4*)(p.dw + off) = make_float4(o.x + s.x, o.y + s.y, o.z + s.z, o.w + s.w);
@@ -429,12 +441,21 @@ extern "C" int cavp_conv2d_wgrad_nhwc(const cavp_conv_desc* d, const void* x, co
   if (!d || !x || !dy || !dw) return CAVP_ERR_BAD_ARG;
   WgradPlan pl = make_wgrad_plan(d);
   if (pl.status != CAVP_OK) return pl.status;
-  if (pl.nblk == 0) return CAVP_OK;
+  const size_t dw_bytes = (size_t)d->Cout * d->KH * d->KW * d->Cin * sizeof(float);
+  if (pl.nblk == 0) {   // every tap is outside the image: the gradient is zero
+    if (d->dw_overwrite && hipMemsetAsync(dw, 0, dw_bytes, (hipStream_t)stream) != hipSuccess) return CAVP_ERR_LAUNCH;
+    return CAVP_OK;
+  }
   if (((uintptr_t)x & 15) || ((uintptr_t)dy & 15) || ((uintptr_t)dw & 15)) return CAVP_ERR_ALIGN;
   if (pl.ws_bytes > 0 && (!workspace || workspace_bytes < pl.ws_bytes || ((uintptr_t)workspace & 15))) return CAVP_ERR_WORKSPACE;
   WgradParams& p = pl.p;
   p.x = x; p.dy = dy; p.dw = dw; p.slabs = (float*)workspace; p.dbias = dbias;
   p.oihw = d->dw_oihw != 0 && p.ntaps_all > 1;   // (1x1: the two layouts coincide)
+  p.overwrite = d->dw_overwrite != 0;
+  if (p.overwrite && p.ntaps < p.ntaps_all) {   // dead taps of a dilated kernel are never visited: clear, then accumulate
+    if (hipMemsetAsync(dw, 0, dw_bytes, (hipStream_t)stream) != hipSuccess) return CAVP_ERR_LAUNCH;
+    p.overwrite = 0;
+  }
   p.bias_slabs = p.slabs ? p.slabs + (size_t)p.ksplit * d->Cout * p.ntaps_all * d->Cin : nullptr;
   {
     static const int dbg = getenv("CAVP_WGRAD_DBG") ? atoi(getenv("CAVP_WGRAD_DBG")) : 0;

@@ -71,7 +71,7 @@ class GradArena:
     """One flat f32 buffer holding every parameter gradient (views per parameter): a single memset per step and a
     single RCCL all-reduce over xGMI for data parallelism (C1 in SURVEY.md §2.3) instead of one per tensor/bucket."""
 
-    def __init__(self, params, device, late_ids=None):
+    def __init__(self, params, device, late_ids=None, no_zero_ids=None):
         """`late_ids`: ids of the parameters whose gradients become final LAST in the backward pass (backbone, ASPP,
         low-level reduce).  They are laid out first, so that `flat[split:]` - everything the backward finishes early
         (decoder head, cross attention, projector, the 73 M-parameter audio encoder = ~75 % of the bytes) - is one
@@ -82,16 +82,30 @@ class GradArena:
         total = sum((p.numel() + 3) // 4 * 4 for p in self.params)   # keep every view 16-byte aligned
         self.flat = torch.zeros(total, dtype=torch.float32, device=device)
         self.views: Dict[int, torch.Tensor] = {}
+        # `no_zero_ids`: large weights whose first gradient contribution of a step OVERWRITES the view (beta = 0 weight-
+        # gradient GEMM, TrainPass._wgrad): they are left out of the per-step memset (the 12288 x 4096 audio fc alone is a
+        # 201 MB clear + a 201 MB read-modify-write otherwise).  TrainPass clears such a view itself if its first touch comes
+        # from any other path.
+        self.no_zero = set(no_zero_ids or ())
         off = 0
         self.split = 0
+        ranges, start = [], 0   # [start, end) element ranges that zero() clears
         for p in self.params:
             if id(p) in late_ids:
                 self.split = off + (p.numel() + 3) // 4 * 4
             self.views[id(p)] = self.flat[off:off + p.numel()].view(p.shape)
+            if id(p) in self.no_zero:
+                if off > start:
+                    ranges.append((start, off))
+                start = off + (p.numel() + 3) // 4 * 4
             off += (p.numel() + 3) // 4 * 4
+        if off > start:
+            ranges.append((start, off))
+        self._zero_ranges = ranges
 
     def zero(self) -> None:
-        self.flat.zero_()
+        for a, b in self._zero_ranges:
+            self.flat[a:b].zero_()
 
 
 def dist_world() -> int:
@@ -229,13 +243,15 @@ class TrainPass:
             self.grads[k] = g.reshape(param.shape)
         self.touched.add(k)
 
-    def grad_buffer(self, param: torch.Tensor) -> torch.Tensor:
+    def grad_buffer(self, param: torch.Tensor, _overwrite: bool = False) -> torch.Tensor:
         """f32 zero-initialised gradient accumulator in the parameter's own layout (created on first use)."""
         k = id(param)
         self.touched.add(k)
         if k not in self.grads:
             if self.arena is not None and k in self.arena.views:
-                self.grads[k] = self.arena.views[k]       # zeroed once per step by GradArena.zero()
+                self.grads[k] = self.arena.views[k]       # zeroed once per step by GradArena.zero() ...
+                if k in self.arena.no_zero and not _overwrite:
+                    self.grads[k].zero_()                 # ... unless it is an overwrite-on-first-touch weight reached another way
             else:
                 self.grads[k] = torch.zeros(param.shape, dtype=torch.float32, device=self.dev)
         return self.grads[k]
@@ -339,12 +355,16 @@ class TrainPass:
 
     def wgrad(self, p: _P, x4: torch.Tensor, g4: torch.Tensor) -> None:
         db = self.grad_buffer(p.bias) if p.bias is not None else None
-        if p.kh * p.kw == 1:
-            dw = self.grad_buffer(p.weight)   # OHWI == OIHW for 1x1 / linear: accumulate in place
-            T.conv2d_wgrad(x4, g4, dw.view(p.cout, 1, 1, p.cin), kh=1, kw=1, stride=p.stride, pad=p.pad, dil=p.dil, dbias=db)
-        else:   # k x k: the kernel accumulates straight into the torch-layout gradient (no OHWI temporary + unpack pass)
-            T.conv2d_wgrad(x4, g4, self.grad_buffer(p.weight), kh=p.kh, kw=p.kw, stride=p.stride, pad=p.pad, dil=p.dil,
-                           dbias=db, dw_oihw=True)
+        k = id(p.weight)
+        # first contribution of the step to a weight the arena does not clear: beta = 0 (the view may hold last step's gradient)
+        ow = self.arena is not None and k in self.arena.no_zero and k not in self.grads and k not in self.touched
+        dw = self.grad_buffer(p.weight, _overwrite=ow)
+        if p.kh * p.kw == 1:   # OHWI == OIHW for 1x1 / linear: straight into the gradient
+            T.conv2d_wgrad(x4, g4, dw.view(p.cout, 1, 1, p.cin), kh=1, kw=1, stride=p.stride, pad=p.pad, dil=p.dil, dbias=db,
+                           overwrite=ow)
+        else:   # k x k: the kernel writes the torch-layout gradient directly (no OHWI temporary + unpack pass)
+            T.conv2d_wgrad(x4, g4, dw, kh=p.kh, kw=p.kw, stride=p.stride, pad=p.pad, dil=p.dil, dbias=db, dw_oihw=True,
+                           overwrite=ow)
 
     def conv_smallcin(self, x_nchw: torch.Tensor, key: str, stride: int, act: int) -> V:
         """First stem conv (raw, BN follows) / first VGG conv (bias + ReLU fused).  Input needs no gradient."""

@@ -77,9 +77,11 @@ def conv2d_dgrad(dy: torch.Tensor, w_t: torch.Tensor, dx: torch.Tensor, *, kh: i
 
 
 def conv2d_wgrad(x: torch.Tensor, dy: torch.Tensor, dw_ohwi: torch.Tensor, *, kh: int, kw: int, stride: int, pad: int,
-                 dil: int, splitk: int = 0, dbias: Optional[torch.Tensor] = None, dw_oihw: bool = False) -> torch.Tensor:
+                 dil: int, splitk: int = 0, dbias: Optional[torch.Tensor] = None, dw_oihw: bool = False,
+                 overwrite: bool = False) -> torch.Tensor:
     """dw_ohwi (f32 [Cout][kh][kw][Cin]) += wgrad(x, dy); dbias (optional f32 [Cout]) += column sums of dy.
-    dw_oihw=True: the destination is a torch-layout [Cout][Cin][kh][kw] gradient (no separate unpack pass)."""
+    dw_oihw=True: the destination is a torch-layout [Cout][Cin][kh][kw] gradient (no separate unpack pass).
+    overwrite=True: dw = wgrad(x, dy) (beta = 0: the destination is neither read nor assumed to be zero)."""
     _need_gpu(x, dy, dw_ohwi, dbias)
     n, h, w, cin, ldx = _nhwc(x)
     n2, ho, wo, cout, ldy = _nhwc(dy)
@@ -92,7 +94,7 @@ def conv2d_wgrad(x: torch.Tensor, dy: torch.Tensor, dw_ohwi: torch.Tensor, *, kh
         raise _lib.CavpError("conv2d_wgrad: dy extent does not match the forward conv")
     d = ConvDesc(dtype=dtype_code(x.dtype), N=n, H=h, W=w, Cin=cin, ldx=ldx, Cout=cout, ldy=ldy, KH=kh, KW=kw,
                  stride=stride, pad=pad, dil=dil, ldr=0, act=0, splitk=splitk, tile=0, up=0, Ho=0, Wo=0, stride_w=0,
-                 dw_oihw=int(dw_oihw))
+                 dw_oihw=int(dw_oihw), dw_overwrite=int(overwrite))
     lib = _lib.load()
     ws = ops.workspace(lib.cavp_conv2d_wgrad_workspace_bytes(C.byref(d)), x.device)
     if dbias is not None and (dbias.dtype != torch.float32 or dbias.numel() != cout or not dbias.is_contiguous()):

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define CAVP_ABI_VERSION 4
+#define CAVP_ABI_VERSION 5
 
 typedef enum { CAVP_F32 = 0, CAVP_BF16 = 1 } cavp_dtype_t;
 typedef enum { CAVP_ACT_NONE = 0, CAVP_ACT_RELU = 1, CAVP_ACT_LEAKY = 2, CAVP_ACT_GELU = 3 } cavp_act_t;
@@ -74,6 +74,8 @@ typedef struct cavp_conv_desc {
   int32_t stride_w;   /* 0 = same as `stride`; otherwise the horizontal stride (PVT spatial-reduction convs are run as
                          KH = sr, KW = 1 convs over the input viewed as [N][H][W/sr][sr*C] with stride (sr, 1)) */
   int32_t dw_oihw;    /* cavp_conv2d_wgrad_nhwc only: 1 = accumulate into a torch-layout [Cout][Cin][KH][KW] gradient (default 0: OHWI) */
+  int32_t dw_overwrite; /* cavp_conv2d_wgrad_nhwc only: 1 = dw = gradient (beta = 0: dw is neither read nor required to be zeroed;
+                           dead taps of a dilated kernel are written as zeros); default 0: dw += gradient */
 } cavp_conv_desc;
 
 size_t cavp_conv2d_workspace_bytes(const cavp_conv_desc* d);

@@ -45,6 +45,7 @@ CONV = [
     ("1x1_s2", 2, 16, 16, 128, 256, 1, 2, 0, 1),
     ("3x3_d2", 1, 14, 14, 128, 128, 3, 1, 2, 2),
     ("3x3_d12", 1, 14, 14, 128, 64, 3, 1, 12, 12),
+    ("3x3_d18_dead_taps", 1, 14, 14, 128, 64, 3, 1, 18, 18),   # ASPP rate 18 at 14x14: only the centre tap is live
     ("3x3_304", 1, 12, 12, 304, 256, 3, 1, 1, 1),
     ("1x1_304_48", 2, 9, 7, 256, 48, 1, 1, 0, 1),
 ]
@@ -82,6 +83,18 @@ def test_conv_dgrad_wgrad(case, dt):
         g2 = torch.full((cout, cin, k, k), 0.25, dtype=torch.float32, device=DEV)
         T.conv2d_wgrad(_nhwc(x.detach(), dt), dyv, g2, kh=k, kw=k, stride=s, pad=p, dil=d, dw_oihw=True, splitk=sk)
         _check(g2, wt.grad + 0.25, dt, name + f".wgrad.oihw.sk{sk}", f32_tol=5e-5, bf16_tol=2e-2)
+        # beta = 0: the destination holds garbage (last step's gradient) and is overwritten - bit-identical to
+        # accumulating onto zeros, both layouts, dead taps of a dilated kernel included (they become zeros)
+        for oihw in (True, False):
+            shape = (cout, cin, k, k) if oihw else (cout, k, k, cin)
+            ga = torch.zeros(shape, dtype=torch.float32, device=DEV)
+            gb = torch.full(shape, 7.5, dtype=torch.float32, device=DEV)
+            bb = torch.full((cout,), 0.5, dtype=torch.float32, device=DEV)
+            T.conv2d_wgrad(_nhwc(x.detach(), dt), dyv, ga, kh=k, kw=k, stride=s, pad=p, dil=d, dw_oihw=oihw, splitk=sk)
+            T.conv2d_wgrad(_nhwc(x.detach(), dt), dyv, gb, kh=k, kw=k, stride=s, pad=p, dil=d, dw_oihw=oihw, splitk=sk,
+                           overwrite=True, dbias=bb)
+            assert torch.equal(ga, gb), name + f".wgrad.overwrite.sk{sk}.oihw{oihw}"
+            _check(bb, dy.sum(dim=(0, 2, 3)) + 0.5, dt, name + ".dbias(overwrite keeps accumulating)", f32_tol=5e-5, bf16_tol=2e-2)
 
 
 @pytest.mark.parametrize("dt", DTYPES, ids=IDS)
