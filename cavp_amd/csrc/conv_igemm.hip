@@ -591,6 +591,8 @@ hipError_t launch_cfg(const IgemmParams& p, int nblk, hipStream_t s) {
   int bpc = (160 * 1024) / lds;   // resident workgroups per CU (LDS-limited; the 4-wave tiles use <= 128 VGPRs)
   if (bpc > 4) bpc = 4;
   if (bpc < 1) bpc = 1;
+  static const int bpc_cap = getenv("CAVP_IGEMM_BPC") ? atoi(getenv("CAVP_IGEMM_BPC")) : 0;   // A/B knob: resident workgroups per CU
+  if (bpc_cap > 0 && bpc > bpc_cap) bpc = bpc_cap;
   static const bool persistent = !(getenv("CAVP_IGEMM_PERSISTENT") && atoi(getenv("CAVP_IGEMM_PERSISTENT")) == 0);
   const int grid = (persistent && nblk > bpc * 256) ? bpc * 256 : nblk;
   static const int stagger = getenv("CAVP_IGEMM_STAGGER") ? atoi(getenv("CAVP_IGEMM_STAGGER")) : 0;
