@@ -21,6 +21,8 @@
 //   removed on the host; split-K writes f32 slabs that a small epilogue kernel reduces deterministically.
 #include <stdlib.h>
 
+#include <stdio.h>
+
 #include "common.h"
 
 struct IgemmParams {
@@ -570,11 +572,28 @@ struct TileCfg {
 const TileCfg kTiles[] = {
     // eff ~ operand bytes per flop relative to 128x128 (the K loop is bound by the LDS-DMA path, profiles/r01_notes.md),
     // softened for the small tiles whose launches are dominated by fixed costs; checked against tools/bench_conv.py sweeps
-    {1, 128, 128, 1.00f}, {2, 64, 128, 0.72f}, {3, 64, 64, 0.60f}, {4, 128, 64, 0.75f},
+    {1, 128, 128, 1.00f}, {2, 64, 128, 0.80f}, {3, 64, 64, 0.70f}, {4, 128, 64, 0.80f},   // (tools/eff_sweep.sh: end-to-end sweep)
     {5, 128, 32, 0.45f},  {6, 16, 128, 0.25f}, {7, 32, 128, 0.45f},
     {8, 256, 128, 1.00f}, {9, 128, 256, 1.00f},  // 8 waves, 3 stages (eff set to 1.0 until measured: kBigEff below)
 };
 inline int tile_stages(int id) { return id >= 8 ? 3 : 2; }
+// A/B knob: CAVP_IGEMM_EFF="e1,e2,...,e9" overrides the efficiency column of kTiles (time-model sweeps without a rebuild)
+inline double tile_eff(const TileCfg& t) {
+  static double ov[16];
+  static const bool have = [] {
+    const char* e = getenv("CAVP_IGEMM_EFF");
+    if (!e) return false;
+    int i = 1;
+    for (const char* q = e; *q && i < 16; ++i) {
+      ov[i] = atof(q);
+      while (*q && *q != ',') ++q;
+      if (*q == ',') ++q;
+    }
+    for (; i < 16; ++i) ov[i] = 0.0;
+    return true;
+  }();
+  return (have && t.id < 16 && ov[t.id] > 0.0) ? ov[t.id] : (double)t.eff;
+}
 constexpr int kNumTiles = sizeof(kTiles) / sizeof(kTiles[0]);
 
 template <typename T, int BC, int BP, int WC, int WP, bool UP, int NS = 2>
@@ -723,7 +742,7 @@ Plan make_plan(const cavp_conv_desc* d) {
       const double blocks = (double)nwg * use_sk;
       const double rounds = (double)((long long)((blocks + slots - 1) / slots));
       const double wg_flops = 2.0 * t.BC * t.BP * (double)BK * ((double)p.iters / use_sk);
-      double tt = rounds * wg_flops / (peak * t.eff / slots) + 2e-6;
+      double tt = rounds * wg_flops / (peak * tile_eff(t) / slots) + 2e-6;
       // HBM floor (input once, output once): on bandwidth-bound layers every tile ties on it and the smaller tile (more
       // workgroups in flight, cheaper prologue / epilogue each) wins the tie
       const double es_ = d->dtype == CAVP_F32 ? 4.0 : 2.0;
@@ -747,6 +766,10 @@ Plan make_plan(const cavp_conv_desc* d) {
   p.splitk = sk;
   pl.nblk = nwg * sk;
   pl.ws_bytes = sk > 1 ? (size_t)sk * p.M * p.Cout * sizeof(float) : 0;
+  static const bool trace = getenv("CAVP_IGEMM_TRACE") != nullptr;   // debugging: the plan of every make_plan call
+  if (trace)
+    fprintf(stderr, "[igemm plan] M=%d K=%d Cout=%d k%dx%d up=%d -> tile %d (%dx%d) splitk %d, %d workgroups, model %.1f us\n", p.M,
+            p.K, p.Cout, d->KH, d->KW, up, t.id, t.BC, t.BP, sk, pl.nblk, best_t * 1e6);
   return pl;
 }
 

@@ -62,6 +62,7 @@ def main():
     ap.add_argument("--variants", default="0")
     ap.add_argument("--shapes", default="")
     ap.add_argument("--reps", type=int, default=20)
+    ap.add_argument("--ldpad", type=int, default=0, help="round the channel stride of x / y / residual up to a multiple of this many elements")
     a = ap.parse_args()
     dt = torch.bfloat16 if a.dtype == "bf16" else torch.float32
     dev = "cuda:0"
@@ -71,10 +72,14 @@ def main():
     for name in names:
         n, h, w, cin, cout, k, s, p, d, res = SHAPES[name]
         ho, wo = (h + 2 * p - d * (k - 1) - 1) // s + 1, (w + 2 * p - d * (k - 1) - 1) // s + 1
-        x = torch.randn((n, h, w, cin), device=dev).to(dt)
+        def padded(shape):   # [..., C] view of a [..., ld] buffer
+            c = shape[-1]
+            ld = (c + a.ldpad - 1) // a.ldpad * a.ldpad if a.ldpad else c
+            return torch.randn(shape[:-1] + (ld,), device=dev).to(dt)[..., :c]
+        x = padded((n, h, w, cin))
         wt = (torch.randn((cout, k, k, cin), device=dev) * (cin * k * k) ** -0.5).to(dt)
-        y = torch.empty((n, ho, wo, cout), dtype=dt, device=dev)
-        r = torch.randn((n, ho, wo, cout), device=dev).to(dt) if res else None
+        y = padded((n, ho, wo, cout))
+        r = padded((n, ho, wo, cout)) if res else None
         sc, sh = torch.rand(cout, device=dev) + 0.5, torch.randn(cout, device=dev)
         flops = 2.0 * n * ho * wo * cout * cin * k * k
         nbytes = (x.numel() + wt.numel() + y.numel() * (2 if res else 1)) * x.element_size()
