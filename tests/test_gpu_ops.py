@@ -149,7 +149,7 @@ def test_linear(rows, cin, cout, dtype):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
-@pytest.mark.parametrize("cin,stride,hw", [(3, 2, (32, 40)), (1, 1, (96, 64)), (3, 2, (31, 45))])
+@pytest.mark.parametrize("cin,stride,hw", [(3, 2, (32, 40)), (1, 1, (96, 64)), (3, 2, (31, 45)), (3, 1, (6, 300)), (2, 2, (9, 515))])
 def test_conv3x3_smallcin(cin, stride, hw, dtype):
     ops = _ops()
     x, wt = _rand(2, cin, *hw, seed=18), _rand(64, cin, 3, 3, seed=19, scale=0.3)
