@@ -224,8 +224,9 @@ int launch_col_reduce(int dtype, ColArgs& a, hipStream_t s) {
   // workgroups per launch: every one ends with 2 x 128 device-scope f32 atomics, which are served memory-side (the L2s of
   // the 8 XCDs are not coherent): at 2048 workgroups the atomics were 40 % of the BN backward reduce (1.60 ms per step,
   // 0.95 without them); 512 keeps enough loads in flight and costs 1.27 ms (sweep: 2048 / 1024 / 512 / 256 -> 1.61 / 1.31 /
-  // 1.27 / 1.58 ms).  CAVP_REDUCE_BLOCKS overrides for A/B runs.
-  static const int target_blocks = getenv("CAVP_REDUCE_BLOCKS") ? atoi(getenv("CAVP_REDUCE_BLOCKS")) : 512;
+  // 1.27 / 1.58 ms; end-of-round whole-step sweep 256 / 384 / 512 / 768 / 1024 -> 19.20 / 18.91 / 18.80 / 18.75 / 18.80 ms).
+  // CAVP_REDUCE_BLOCKS overrides for A/B runs.
+  static const int target_blocks = getenv("CAVP_REDUCE_BLOCKS") ? atoi(getenv("CAVP_REDUCE_BLOCKS")) : 768;
   int gx = target_blocks / gy;
   if (gx < 1) gx = 1;
   int rpb = cdiv_h(a.rows, gx);
