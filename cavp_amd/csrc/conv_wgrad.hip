@@ -399,7 +399,7 @@ WgradPlan make_wgrad_plan(const cavp_conv_desc* d) {
   fast_div_prepare(p.Wo, &p.dv_w[0], &p.dv_w[1]);
   const int chunks = (p.M + 63) / 64;
   // Split count from a small time model fitted to tools/bench_wgrad.py on MI355X (profiles/r01_notes.md):
-  //   t(ks) = rounds * steps * 1.08 us  +  ks * |dW| * 8 B / 2.5 TB/s  (+ reduce launch)
+  //   t(ks) = rounds * steps * 1.08 us  +  ks * |dW| * 8 B / 5 TB/s (the slabs mostly live in the 256 MB MALL)  (+ reduce launch)
   // rounds = ceil(base * ks / 1024 resident workgroups: four 32 KiB workgroups per CU), steps = 32-row K tiles per
   // workgroup.  The first version aimed at "about 512 workgroups" with a ceil: 540 or 513 workgroups = a second, nearly
   // empty round (head conv 951 -> 600 us); 64-row stages (two workgroups per CU, 1.7 us per tile) -> 32-row stages:
@@ -410,12 +410,13 @@ WgradPlan make_wgrad_plan(const cavp_conv_desc* d) {
   } else {
     const double dw_bytes = (double)d->Cout * p.ntaps * d->Cin * 4.0;
     double best = 1e30;
+    static const double slab_bw = getenv("CAVP_WGRAD_SLAB_TBS") ? atof(getenv("CAVP_WGRAD_SLAB_TBS")) * 1e12 : 5e12;   // A/B knob; whole-step sweep 1.2 / 1.8 / 2.5 / 5 / 8 / 12 / 30 -> 18.85 / 18.65 / 18.55 / 18.47 / 18.50 / 18.58 / 18.69 ms
     const int ks_max = chunks / 2 > 1 ? chunks / 2 : 1;
     for (int k = 1; k <= ks_max && k <= 512; ++k) {
       const int steps = (chunks + k - 1) / k;
       const int kk = (chunks + steps - 1) / steps;   // effective split count for this step count
       const long long rounds = ((long long)base * kk + 1023) / 1024;
-      double t = (double)rounds * (2 * steps) * 1.08e-6 + (kk > 1 ? kk * dw_bytes * 2.0 / 2.5e12 + 6e-6 : 0.0);
+      double t = (double)rounds * (2 * steps) * 1.08e-6 + (kk > 1 ? kk * dw_bytes * 2.0 / slab_bw + 6e-6 : 0.0);
       if (t < best) { best = t; ks = kk; }
     }
   }
