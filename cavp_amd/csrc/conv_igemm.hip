@@ -724,6 +724,7 @@ Plan make_plan(const cavp_conv_desc* d) {
   p.dbg = (d->tile / 100) % 10 + ((d->tile / 10000) % 10) * 8 + ((d->tile / 100000) % 10) * 16;  // ten-thousands digit: issue no DMA at all  // d->tile = id + 1000 * (direct epilogue): testing / A-B knobs
   const int want_tile = d->tile % 100;
   const double peak = d->dtype == CAVP_F32 ? 100e12 : 600e12;
+  static const double slab_bw = getenv("CAVP_IGEMM_SLAB_TBS") ? atof(getenv("CAVP_IGEMM_SLAB_TBS")) * 1e12 : 3e12;   // A/B knob
   const int sk_opts[] = {1, 2, 3, 4, 6, 8, 12, 16, 24, 32};
   double best_t = 1e30;
   for (int i = 0; i < kNumTiles; ++i) {
@@ -749,7 +750,7 @@ Plan make_plan(const cavp_conv_desc* d) {
       const double t_mem = ((double)d->N * d->H * d->W * d->Cin + (double)p.M * p.Cout) * es_ / 3.5e12 + 2e-6;
       if (tt < t_mem) tt = t_mem;
       tt += 2e-7 * (double)(t.BC * t.BP) / 16384.0;
-      if (use_sk > 1) tt += (2.0 * use_sk + 1.0) * p.M * p.Cout * 4.0 / 3e12 + 4e-6;
+      if (use_sk > 1) tt += (2.0 * use_sk + 1.0) * p.M * p.Cout * 4.0 / slab_bw + 4e-6;
       if (tt < best_t) { best_t = tt; best = i; best_sk = use_sk; }
     }
   }
