@@ -341,6 +341,66 @@ __global__ __launch_bounds__(256) void bn_finalize_tiles_kernel(const float* __r
   }
 }
 
+// Same combine with one 256-thread workgroup per channel, for launches with >= 1024 tiles (the 112x112 and the 2B x 56x56
+// layers: 1568 / 3136 tiles): a lane of the one-wave version walks up to 49 scattered loads in 7 dependent batches.
+__global__ __launch_bounds__(256) void bn_finalize_tiles_wide_kernel(const float* __restrict__ ts, int tiles, int rows_per_tile,
+                                                                     long long M, const float* gamma, const float* beta,
+                                                                     float eps, float momentum, float* rmean, float* rvar,
+                                                                     float* scale, float* shift, float* mean_out,
+                                                                     float* rstd_out, int C) {
+  __shared__ float part[4][3];
+  const int c = blockIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  float n = 0.f, mean = 0.f, m2 = 0.f;
+  for (int t0 = threadIdx.x; t0 < tiles; t0 += 256 * 8) {
+    float2 q[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int t = t0 + 256 * u;
+      q[u] = t < tiles ? *(const float2*)(ts + ((size_t)t * C + c) * 2) : make_float2(0.f, 0.f);
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int t = t0 + 256 * u;
+      if (t < tiles) {
+        long long nb = M - (long long)t * rows_per_tile;
+        if (nb > rows_per_tile) nb = rows_per_tile;
+        chan_combine(n, mean, m2, (float)nb, q[u].x, q[u].y);
+      }
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float nb = __shfl_xor(n, o, 64), mb = __shfl_xor(mean, o, 64), m2b = __shfl_xor(m2, o, 64);
+    const float nt = n + nb;
+    if (nt > 0.f) {
+      const float dlt = mb - mean;
+      const float nm = mean + dlt * (nb / nt);
+      m2 = m2 + m2b + dlt * dlt * (n * nb / nt);
+      mean = nm;
+      n = nt;
+    }
+  }
+  if (lane == 0) { part[wv][0] = n; part[wv][1] = mean; part[wv][2] = m2; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    n = part[0][0]; mean = part[0][1]; m2 = part[0][2];
+    for (int w = 1; w < 4; ++w)
+      if (part[w][0] > 0.f) chan_combine(n, mean, m2, part[w][0], part[w][1], part[w][2]);
+    const float var = m2 / (float)M;
+    const float rstd = 1.f / sqrtf(var + eps);
+    const float sc = gamma[c] * rstd;
+    scale[c] = sc;
+    shift[c] = beta[c] - mean * sc;
+    mean_out[c] = mean;
+    rstd_out[c] = rstd;
+    if (rmean) {
+      const float unbias = M > 1 ? (float)((double)M / (double)(M - 1)) : 1.f;
+      rmean[c] = (1.f - momentum) * rmean[c] + momentum * mean;
+      rvar[c] = (1.f - momentum) * rvar[c] + momentum * var * unbias;
+    }
+  }
+}
+
 // y = act(x * scale + shift + residual)
 template <typename T>
 __global__ __launch_bounds__(256) void scale_shift_act_kernel(const T* __restrict__ x, const float* __restrict__ scale,
@@ -1175,9 +1235,14 @@ extern "C" int cavp_bn_finalize_tiles(const float* tile_stats, int32_t tiles, in
       C <= 0 || (long long)tiles * rows_per_tile < count)
     return CAVP_ERR_BAD_ARG;
   if ((running_mean == nullptr) != (running_var == nullptr)) return CAVP_ERR_BAD_ARG;
-  bn_finalize_tiles_kernel<<<(C + 3) / 4, 256, 0, (hipStream_t)stream>>>(tile_stats, tiles, rows_per_tile, count, gamma, beta,
-                                                                        eps, momentum, running_mean, running_var, scale,
-                                                                        shift, mean, rstd, C);
+  if (tiles >= 1024)
+    bn_finalize_tiles_wide_kernel<<<C, 256, 0, (hipStream_t)stream>>>(tile_stats, tiles, rows_per_tile, count, gamma, beta, eps,
+                                                                      momentum, running_mean, running_var, scale, shift, mean,
+                                                                      rstd, C);
+  else
+    bn_finalize_tiles_kernel<<<(C + 3) / 4, 256, 0, (hipStream_t)stream>>>(tile_stats, tiles, rows_per_tile, count, gamma, beta,
+                                                                          eps, momentum, running_mean, running_var, scale,
+                                                                          shift, mean, rstd, C);
   CHECK_LAUNCH();
 }
 
