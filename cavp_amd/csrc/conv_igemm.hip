@@ -24,53 +24,7 @@
 #include <stdio.h>
 
 #include "common.h"
-
-struct IgemmParams {
-  const void* x;
-  const void* w;
-  void* y;
-  const float* scale;
-  const float* shift;
-  const float* nbias;
-  const void* res;
-  float* partial;
-  int N, H, W, Cin, ldx, Cout, ldy, KW, stride, stride_w, pad, dil, ldr, act;
-  int Ho, Wo, M, K;
-  unsigned div_hw_m, div_hw_s, div_w_m, div_w_s, div_tc_m, div_tc_s, div_cq_m, div_cq_s;  // floor(n / (Ho*Wo)) and floor(n / Wo) as multiply + shift (fast_div)
-  int ntaps;
-  unsigned long long taps;  // 4 bits per live tap id (kh*KW + kw)
-  int cpt;                  // K tiles per tap
-  int iters;                // ntaps * cpt
-  int splitk;
-  int tiles_c, tiles_p;
-  int vec_io;               // epilogue may use vector loads/stores (Cout, ldy, ldr multiples of 4, pointers aligned)
-  int x_bytes, w_bytes;     // buffer-descriptor extents (< 2 GiB)
-  int up_shift, up_mask;    // transposed-conv input upsampling (log2, mask); 0, 0 for an ordinary conv
-  int tap_dh[9], tap_dw[9];  // per LIVE tap: kh*dil, kw*dil (input-space displacement)
-  int tap_xoff[9];          // per live tap: byte displacement (dh*W + dw)*ldx*sizeof(T) in x (ordinary conv only)
-  int tap_woff[9];          // per live tap: byte offset tap*Cin*sizeof(T) inside a weight row
-  float* tile_stats;        // optional [tiles_p][Cout][2] per-tile (mean, M2) of the raw outputs (BatchNorm statistics)
-  int nblk;                 // logical workgroups (tiles x split-K); the launch may use fewer, persistent, workgroups
-  int stagger;              // A/B knob: workgroups of the second residency slot start this many s_sleep(64) late
-  int dbg;                  // profiling only (tile knob, hundreds digit): 1 = skip the operand loads, 2 = skip the MFMAs
-  int coalesced;            // LDS-staged, fully coalesced 16-byte epilogue (needs Cout, ldy, ldr % VE == 0, 16-B aligned)
-};
-
-template <typename T> struct Mma;
-template <> struct Mma<float> {
-  __device__ static __forceinline__ void run(f32x4_t& acc, const u32x4_t& a, const u32x4_t& b) {
-    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a[0]), __uint_as_float(b[0]), acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a[1]), __uint_as_float(b[1]), acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a[2]), __uint_as_float(b[2]), acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a[3]), __uint_as_float(b[3]), acc, 0, 0, 0);
-  }
-};
-template <> struct Mma<bf16_t> {
-  __device__ static __forceinline__ void run(f32x4_t& acc, const u32x4_t& a, const u32x4_t& b) {
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), acc,
-                                                  0, 0, 0);
-  }
-};
+#include "igemm_params.h"
 
 // Shared epilogue math for one output element.
 __device__ __forceinline__ float epi_one(float v, int cc, int n_img, const IgemmParams& p) {
@@ -133,9 +87,6 @@ __device__ __forceinline__ void epilogue_store4(const IgemmParams& p, float v0, 
     }
   }
 }
-
-// s_waitcnt immediate that only waits for vmcnt <= n (gfx9 encoding: vmcnt[3:0] | expcnt[6:4] | lgkmcnt[11:8] | vmcnt[15:14])
-constexpr int vmcnt_imm(int n) { return (n & 15) | ((n >> 4) << 14) | (7 << 4) | (15 << 8); }
 
 template <typename T, int BC, int BP, int WC, int WP, bool UP, int NS>
 __global__ __launch_bounds__(64 * WC * WP, (WC * WP == 4 ? 2 : 1)) void igemm_kernel(const IgemmParams p) {
@@ -408,6 +359,48 @@ __global__ __launch_bounds__(64 * WC * WP, (WC * WP == 4 ? 2 : 1)) void igemm_ke
         }
       }
     }
+    float2* wstat = (float2*)(smem + NS * TILE_BYTES);   // [WP][BC] per-wave (mean, M2) partials (launch_cfg adds the bytes)
+    if (p.tile_stats) {
+      // BatchNorm batch statistics for free, straight from the f32 accumulators IN REGISTERS: a lane holds 4 channels x MP
+      // pixels per 16-row block; sums of (x - x0) and (x - x0)^2 about the wave's first row x0 (a sample of the same
+      // distribution, so the one-pass form does not cancel), reduced over the 16 row lanes with DPP adds.  The WP waves
+      // of a channel are combined after the staging barrier (Chan), the tiles in cavp_bn_finalize_tiles: no extra pass
+      // over the activation and no atomics.  (The first version walked the staged tile in LDS with one thread per
+      // channel: 2 x BP dependent LDS reads while the other threads idled, +20 % on the 3x3 head convs.)
+      const int nvw = p.M - (p_base + wp0);   // valid rows of this wave's slab (<= 0: none)
+#pragma unroll
+      for (int a = 0; a < MC; ++a) {
+        float s1[4], s2[4], x0[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          x0[i] = __shfl(acc[a][0][i], lane & 48, 64);
+          s1[i] = 0.f; s2[i] = 0.f;
+        }
+#pragma unroll
+        for (int b = 0; b < MP; ++b) {
+          const bool ok = b * 16 + lrow < nvw;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const float d = ok ? acc[a][b][i] - x0[i] : 0.f;
+            s1[i] += d;
+            s2[i] = fmaf(d, d, s2[i]);
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          s1[i] = row16_sum(s1[i]);
+          s2[i] = row16_sum(s2[i]);
+        }
+        if (lrow == 0) {
+          const float n = (float)(nvw < TP ? (nvw > 0 ? nvw : 1) : TP);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const float m = s1[i] / n;
+            wstat[(wave / WC) * BC + wc0 + a * 16 + lgrp * 4 + i] = make_float2(x0[i] + m, fmaxf(s2[i] - s1[i] * m, 0.f));
+          }
+        }
+      }
+    }
 #pragma unroll
     for (int a = 0; a < MC; ++a)
 #pragma unroll
@@ -418,18 +411,18 @@ __global__ __launch_bounds__(64 * WC * WP, (WC * WP == 4 ? 2 : 1)) void igemm_ke
       }
     __syncthreads();
     if (p.tile_stats && tid < BC && c_base + tid < p.Cout) {  // (BC <= NT for every tile)
-      // BatchNorm batch statistics for free: per-channel mean and centred second moment of this tile's rows, straight
-      // from the f32 accumulators in LDS (two passes over <= BP values; combined across tiles with Chan's formula in
-      // cavp_bn_finalize_tiles - no extra pass over the activation, no atomics, no E[x^2]-E[x]^2 cancellation)
-      const int nrows = (p.M - p_base) < BP ? (p.M - p_base) : BP;
-      const int slot = tid >> 2, sub = tid & 3;
-      float sum = 0.f;
-      for (int r = 0; r < nrows; ++r) sum += st[(size_t)r * BC + ((slot ^ (r & SWZ)) << 2) + sub];
-      const float mean = sum / (float)nrows;
-      float m2 = 0.f;
-      for (int r = 0; r < nrows; ++r) {
-        const float dlt = st[(size_t)r * BC + ((slot ^ (r & SWZ)) << 2) + sub] - mean;
-        m2 += dlt * dlt;
+      float n = 0.f, mean = 0.f, m2 = 0.f;
+#pragma unroll
+      for (int w = 0; w < WP; ++w) {
+        int nb = p.M - (p_base + w * TP);
+        nb = nb < TP ? nb : TP;
+        if (nb > 0) {
+          const float2 q = wstat[w * BC + tid];
+          const float fb = (float)nb, nt = n + fb, dlt = q.x - mean;
+          mean += dlt * (fb / nt);
+          m2 += q.y + dlt * dlt * (n * fb / nt);
+          n = nt;
+        }
       }
       float* o = p.tile_stats + ((size_t)tp * p.Cout + c_base + tid) * 2;
       o[0] = mean;
@@ -577,6 +570,7 @@ const TileCfg kTiles[] = {
     {8, 256, 128, 1.00f}, {9, 128, 256, 1.00f},  // 8 waves, 3 stages (eff set to 1.0 until measured: kBigEff below)
 };
 inline int tile_stages(int id) { return id >= 8 ? 3 : 2; }
+inline int tile_wp(int id) { return id == 5 ? 1 : (id == 6 || id == 7 || id == 9) ? 4 : 2; }   // waves along the pixel dimension (launch_tile)
 // A/B knob: CAVP_IGEMM_EFF="e1,e2,...,e9" overrides the efficiency column of kTiles (time-model sweeps without a rebuild)
 inline double tile_eff(const TileCfg& t) {
   static double ov[16];
@@ -598,8 +592,8 @@ constexpr int kNumTiles = sizeof(kTiles) / sizeof(kTiles[0]);
 
 template <typename T, int BC, int BP, int WC, int WP, bool UP, int NS = 2>
 hipError_t launch_cfg(const IgemmParams& p, int nblk, hipStream_t s) {
-  constexpr int lds = NS * (BC + BP) * 128;
-  static_assert(BP * BC * 4 <= lds, "epilogue staging must fit in the K-loop LDS");
+  constexpr int lds = NS * (BC + BP) * 128 + WP * BC * 8;   // + the per-wave BatchNorm-statistics partials
+  static_assert(BP * BC * 4 <= NS * (BC + BP) * 128, "epilogue staging must fit in the K-loop LDS");
   static_assert(BC <= 64 * WC * WP, "tile_stats: one thread per output channel of the tile");
   static bool attr_set = false;
   if (!attr_set) {
@@ -731,7 +725,7 @@ Plan make_plan(const cavp_conv_desc* d) {
     const TileCfg& t = kTiles[i];
     if (want_tile > 0 && t.id != want_tile) continue;
     const long long nwg = (long long)cdiv(p.Cout, t.BC) * cdiv(p.M, t.BP);
-    int bpc = (160 * 1024) / (tile_stages(t.id) * (t.BC + t.BP) * 128);
+    int bpc = (160 * 1024) / (tile_stages(t.id) * (t.BC + t.BP) * 128 + tile_wp(t.id) * t.BC * 8);
     if (bpc > 4) bpc = 4;
     if (t.id >= 8 && want_tile != t.id) continue;  // big tiles: explicit request only until the time model is refitted
     const double slots = 256.0 * bpc;

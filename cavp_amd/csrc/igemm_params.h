@@ -1,0 +1,68 @@
+// Kernel-argument block and MFMA wrappers shared by the implicit-GEMM kernels (conv_igemm.hip: the 2-stage 4-wave tiles,
+// conv_igemm_big.hip: the 256x256 ping-pong tile).
+#pragma once
+#include "common.h"
+
+struct IgemmParams {
+  const void* x;
+  const void* w;
+  void* y;
+  const float* scale;
+  const float* shift;
+  const float* nbias;
+  const void* res;
+  float* partial;
+  int N, H, W, Cin, ldx, Cout, ldy, KW, stride, stride_w, pad, dil, ldr, act;
+  int Ho, Wo, M, K;
+  unsigned div_hw_m, div_hw_s, div_w_m, div_w_s, div_tc_m, div_tc_s, div_cq_m, div_cq_s;  // floor(n / (Ho*Wo)) and floor(n / Wo) as multiply + shift (fast_div)
+  int ntaps;
+  unsigned long long taps;  // 4 bits per live tap id (kh*KW + kw)
+  int cpt;                  // K tiles per tap
+  int iters;                // ntaps * cpt
+  int splitk;
+  int tiles_c, tiles_p;
+  int vec_io;               // epilogue may use vector loads/stores (Cout, ldy, ldr multiples of 4, pointers aligned)
+  int x_bytes, w_bytes;     // buffer-descriptor extents (< 2 GiB)
+  int up_shift, up_mask;    // transposed-conv input upsampling (log2, mask); 0, 0 for an ordinary conv
+  int tap_dh[9], tap_dw[9];  // per LIVE tap: kh*dil, kw*dil (input-space displacement)
+  int tap_xoff[9];          // per live tap: byte displacement (dh*W + dw)*ldx*sizeof(T) in x (ordinary conv only)
+  int tap_woff[9];          // per live tap: byte offset tap*Cin*sizeof(T) inside a weight row
+  float* tile_stats;        // optional [tiles_p][Cout][2] per-tile (mean, M2) of the raw outputs (BatchNorm statistics)
+  int nblk;                 // logical workgroups (tiles x split-K); the launch may use fewer, persistent, workgroups
+  int stagger;              // A/B knob: workgroups of the second residency slot start this many s_sleep(64) late
+  int dbg;                  // profiling only (tile knob, hundreds digit): 1 = skip the operand loads, 2 = skip the MFMAs
+  int coalesced;            // LDS-staged, fully coalesced 16-byte epilogue (needs Cout, ldy, ldr % VE == 0, 16-B aligned)
+};
+
+template <typename T> struct Mma;
+template <> struct Mma<float> {
+  __device__ static __forceinline__ void run(f32x4_t& acc, const u32x4_t& a, const u32x4_t& b) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a[0]), __uint_as_float(b[0]), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a[1]), __uint_as_float(b[1]), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a[2]), __uint_as_float(b[2]), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a[3]), __uint_as_float(b[3]), acc, 0, 0, 0);
+  }
+};
+template <> struct Mma<bf16_t> {
+  __device__ static __forceinline__ void run(f32x4_t& acc, const u32x4_t& a, const u32x4_t& b) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), acc,
+                                                  0, 0, 0);
+  }
+};
+
+// sum over the 16 lanes of a DPP row (lanes 16k .. 16k+15): xor 1, xor 2 (quad_perm), then half-row and row mirrors, which
+// swap quads / half-rows and so act as xor 4 / xor 8 once the lower levels are uniform.  Every lane ends with the total.
+__device__ __forceinline__ float row16_sum(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true));   // quad_perm [1,0,3,2]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, true));   // quad_perm [2,3,0,1]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, true));  // row_half_mirror
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xf, 0xf, true));  // row_mirror
+  return v;
+}
+
+// s_waitcnt immediate that only waits for vmcnt <= n (gfx9 encoding: vmcnt[3:0] | expcnt[6:4] | lgkmcnt[11:8] | vmcnt[15:14])
+constexpr int vmcnt_imm(int n) { return (n & 15) | ((n >> 4) << 14) | (7 << 4) | (15 << 8); }
+
+
+// conv_igemm_big.hip
+hipError_t cavp_launch_igemm_big(const IgemmParams& p, int nblk, hipStream_t s);
