@@ -12,7 +12,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libcavp_hip.so")
-SOURCES = ["conv_igemm.hip", "pointwise.hip", "train_pointwise.hip", "conv_wgrad.hip", "contrast.hip", "pvt_ops.hip", "layernorm.hip", "attn_gate.hip", "mel_frontend.hip", "optimizer.hip"]
+SOURCES = ["conv_igemm.hip", "conv_igemm_big.hip", "pointwise.hip", "train_pointwise.hip", "conv_wgrad.hip", "contrast.hip", "pvt_ops.hip", "layernorm.hip", "attn_gate.hip", "mel_frontend.hip", "optimizer.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
          "-munsafe-fp-atomics", "-ffp-contract=on"]
 
@@ -32,16 +32,19 @@ def _stale() -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force: bool = False, verbose: bool = True) -> str:
+def build(force: bool = False, verbose: bool = True, profile: bool = False) -> str:
+    """profile=True adds -DCAVP_PROFILE: the kernels' compile-time anatomy variants (tools/bench_conv.py --variants);
+    the product library carries none of them."""
     if not force and not _stale():
         return LIB
     hipcc = _hipcc()
+    flags = FLAGS + (["-DCAVP_PROFILE"] if profile else [])
     objs = []
     os.makedirs(os.path.join(HERE, "build"), exist_ok=True)
     procs = []
     for src in SOURCES:
         obj = os.path.join(HERE, "build", src.replace(".hip", ".o"))
-        cmd = [hipcc, *FLAGS, "-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = [hipcc, *flags, "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         procs.append((cmd, subprocess.Popen(cmd)))
@@ -57,4 +60,4 @@ def build(force: bool = False, verbose: bool = True) -> str:
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv))
+    print(build(force="--force" in sys.argv or "--profile" in sys.argv, profile="--profile" in sys.argv))

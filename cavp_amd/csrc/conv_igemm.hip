@@ -568,8 +568,10 @@ const TileCfg kTiles[] = {
     {1, 128, 128, 1.00f}, {2, 64, 128, 0.80f}, {3, 64, 64, 0.70f}, {4, 128, 64, 0.80f},   // (tools/eff_sweep.sh: end-to-end sweep)
     {5, 128, 32, 0.45f},  {6, 16, 128, 0.25f}, {7, 32, 128, 0.45f},
     {8, 256, 128, 1.00f}, {9, 128, 256, 1.00f},  // 8 waves, 3 stages (eff set to 1.0 until measured: kBigEff below)
+    {10, 256, 256, 2.00f},                       // conv_igemm_big.hip: 8 waves in two ping-pong groups, one workgroup per CU
 };
-inline int tile_stages(int id) { return id >= 8 ? 3 : 2; }
+inline int tile_stages(int id) { return id == 10 ? 2 : id >= 8 ? 3 : 2; }
+inline bool tile_is_big(int id) { return id == 10; }
 inline int tile_wp(int id) { return id == 5 ? 1 : (id == 6 || id == 7 || id == 9) ? 4 : 2; }   // waves along the pixel dimension (launch_tile)
 // A/B knob: CAVP_IGEMM_EFF="e1,e2,...,e9" overrides the efficiency column of kTiles (time-model sweeps without a rebuild)
 inline double tile_eff(const TileCfg& t) {
@@ -628,6 +630,9 @@ hipError_t launch_tile(int id, const IgemmParams& p, int nblk, hipStream_t s) {
     case 7: return launch_cfg<T, 32, 128, 1, 4, UP>(p, nblk, s);
     case 8: return launch_cfg<T, 256, 128, 4, 2, UP, 3>(p, nblk, s);
     case 9: return launch_cfg<T, 128, 256, 2, 4, UP, 3>(p, nblk, s);
+    case 10:
+      if constexpr (sizeof(T) == 2 && !UP) return cavp_launch_igemm_big(p, nblk, s);
+      return hipErrorInvalidValue;
     default: return hipErrorInvalidValue;
   }
 }
@@ -643,7 +648,7 @@ struct Plan {
 
 inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
-Plan make_plan(const cavp_conv_desc* d) {
+Plan make_plan(const cavp_conv_desc* d, bool allow_big = true) {
   Plan pl{};
   pl.status = CAVP_OK;
   if (!d) { pl.status = CAVP_ERR_BAD_ARG; return pl; }
@@ -728,9 +733,14 @@ Plan make_plan(const cavp_conv_desc* d) {
     int bpc = (160 * 1024) / (tile_stages(t.id) * (t.BC + t.BP) * 128 + tile_wp(t.id) * t.BC * 8);
     if (bpc > 4) bpc = 4;
     if (t.id >= 8 && want_tile != t.id) continue;  // big tiles: explicit request only until the time model is refitted
+    if (tile_is_big(t.id) && (d->dtype != CAVP_BF16 || up > 1 || d->splitk > 1 || d->Cout % 8 || d->ldy % 8 ||
+                              (d->ldr && d->ldr % 8)))
+      continue;
+    if (tile_is_big(t.id)) bpc = 1;
     const double slots = 256.0 * bpc;
     for (int sk : sk_opts) {
       if (d->splitk > 0 && sk != 1) continue;
+      if (tile_is_big(t.id) && sk != 1) continue;
       int use_sk = d->splitk > 0 ? d->splitk : sk;
       if (use_sk > 1 && (use_sk > p.iters / 4)) continue;
       if (use_sk > p.iters) use_sk = p.iters > 0 ? p.iters : 1;
@@ -749,6 +759,20 @@ Plan make_plan(const cavp_conv_desc* d) {
     }
   }
   if (best < 0) { pl.status = CAVP_ERR_BAD_ARG; return pl; }
+  // The 256x256 ping-pong tile (conv_igemm_big.hip) by rule, not by the time model: measured on MI355X (bench_conv,
+  // profiles/r02_notes.md) it wins where its whole-tile quantisation is harmless - the output is (nearly) a multiple of 256
+  // channels wide, there are at least four K tiles to amortise its ~6 us epilogue, and the tiles fill whole rounds of 256
+  // workgroups to >= 75 % (3x3 304->256 at 2B x 56 x 56: -10 %, 304->1216 token linear: -24 %); it loses on 304- / 128- /
+  // 64-channel outputs.
+  if (allow_big && want_tile == 0 && d->dtype == CAVP_BF16 && up == 1 && d->splitk <= 1 && d->Cout % 8 == 0 && d->ldy % 8 == 0 &&
+      (d->ldr == 0 || d->ldr % 8 == 0) && (d->Cout % 256 == 0 || d->Cout % 256 >= 192) && p.iters >= 4) {
+    const long long nb = (long long)cdiv(p.Cout, 256) * cdiv(p.M, 256);
+    const long long rounds = (nb + 255) / 256;
+    if (nb >= 256 && (double)nb / (double)(rounds * 256) >= 0.75) {
+      for (int i = 0; i < kNumTiles; ++i)
+        if (tile_is_big(kTiles[i].id)) { best = i; best_sk = 1; }
+    }
+  }
   const TileCfg& t = kTiles[best];
   pl.tile_id = t.id;
   p.tiles_c = cdiv(p.Cout, t.BC);
@@ -782,6 +806,11 @@ extern "C" int cavp_conv2d_tile_stats_layout(const cavp_conv_desc* d, int32_t* t
   int BP = 0;
   for (int i = 0; i < kNumTiles; ++i)
     if (kTiles[i].id == pl.tile_id) BP = kTiles[i].BP;
+  if (tile_is_big(pl.tile_id)) {   // one statistics tile per 128-row wave slab
+    *tiles = (pl.p.M + 127) / 128;
+    *rows_per_tile = 128;
+    return 1;
+  }
   *tiles = pl.p.tiles_p;
   *rows_per_tile = BP;
   return 1;
@@ -800,6 +829,13 @@ extern "C" int cavp_conv2d_nhwc(const cavp_conv_desc* d, const void* x, const vo
   Plan pl = make_plan(d);
   if (pl.status != CAVP_OK) return pl.status;
   if (!aligned(x, 16) || !aligned(w, 16)) return CAVP_ERR_ALIGN;
+  if (tile_is_big(pl.tile_id) && d->tile % 100 == 0 &&
+      !(aligned(y, 16) && (!residual || aligned(residual, 16)) && (!scale || aligned(scale, 16)) && (!shift || aligned(shift, 16)) &&
+        (!nbias || aligned(nbias, 16)))) {
+    if (tile_stats) return CAVP_ERR_ALIGN;   // the statistics layout was sized for the 256x256 tile
+    pl = make_plan(d, false);                // automatically chosen big tile, but an operand is not 16-byte aligned
+    if (pl.status != CAVP_OK) return pl.status;
+  }
   if (residual && d->ldr < d->Cout) return CAVP_ERR_BAD_ARG;
   if (pl.ws_bytes > 0 && (!workspace || workspace_bytes < pl.ws_bytes || !aligned(workspace, 16)))
     return CAVP_ERR_WORKSPACE;
@@ -823,6 +859,7 @@ extern "C" int cavp_conv2d_nhwc(const cavp_conv_desc* d, const void* x, const vo
                 (!shift || aligned(shift, 16));
   p.tile_stats = tile_stats;
   if (tile_stats && !p.coalesced) return CAVP_ERR_UNSUPPORTED;   // see cavp_conv2d_tile_stats_layout
+  if (tile_is_big(pl.tile_id) && !p.coalesced) return CAVP_ERR_ALIGN;   // the 256x256 tile only has the 16-byte epilogue
   hipStream_t s = (hipStream_t)stream;
   const bool upm = p.up_mask != 0;
   hipError_t e = d->dtype == CAVP_F32

@@ -1,0 +1,442 @@
+// 256 x 256 implicit-GEMM tile for the large CAVP layers (bf16, gfx950): one 8-wave workgroup per CU, ping-pong wave groups.
+//
+// Why a second kernel: the 4-wave 128x128 tile of conv_igemm.hip moves 64 flop per operand byte through the LDS-DMA path
+// (~60 GB/s per CU), which caps it near 1 PF/s however its K loop is scheduled (profiles/r01_notes.md).  A 256x256 tile
+// needs half the operand bytes per flop; its 128 accumulator registers per lane leave room for only ONE workgroup per CU,
+// so the overlap that two co-resident workgroups gave for free has to be built into the schedule:
+//
+//  * 8 waves = 4 (channel) x 2 (pixel); wave tile 64 channels x 128 pixels = 4 x 8 MFMA 16x16x32 blocks.  The two pixel
+//    halves are two wave GROUPS (waves 0-3 / 4-7, one wave of each per SIMD) that run half a phase apart: while one group
+//    issues its 16 MFMAs the other issues its LDS fragment reads and the LDS-DMA of a future K tile (one extra s_barrier
+//    for group 1 before the loop, one for group 0 after it).
+//  * a K tile (64 channels of one tap) = 4 phases, one quadrant (32 channels x 64 pixels x K 64 = 16 MFMAs) each, two raw
+//    s_barrier per phase.  Per phase every thread issues the two 16-byte LDS-DMA pieces of ONE half tile (16 KiB):
+//    H0 = weights rows of the low channel halves, H1 = pixels of the low pixel halves, H2 / H3 = the high halves - the
+//    order in which the quadrants (c0,p0) (c1,p0) (c1,p1) (c0,p1) consume them.
+//  * the LDS ring holds 2 K tiles = 8 half-tile regions (128 KiB).  The half tile issued in phase g is the one consumed 6
+//    phases later: 4 half tiles (64 KiB per CU) are in flight behind a counted s_waitcnt vmcnt(8) per phase, a region is
+//    re-filled >= 2 phases after its last fragment read was issued (the stagger costs one of them), and data is read one
+//    phase after the wait + barrier that retires it.
+//  * the K-tile stream runs ACROSS the output tiles of the persistent workgroup: the loads of the next tile's first K
+//    tiles are in flight while the last quadrants of the current tile are multiplied and while its epilogue runs.
+//  * epilogue per WAVE, no workgroup barrier: 16-pixel x 64-channel f32 blocks go through a private 4 KiB LDS scratch (the
+//    last 32 KiB of the 160 KiB) and leave as 16-byte stores, 128 contiguous bytes per pixel; BatchNorm statistics come
+//    from the accumulators in registers (one 128-row statistics tile per wave slab).
+//
+// Same operand layout as conv_igemm.hip: weights = MFMA A (rows = output channels), gathered activations = MFMA B, 128-byte
+// LDS rows with the 16-byte slot index XOR-swizzled by (row >> 1) & 7 (applied to the SOURCE address of the DMA),
+// padding / K tails / M and Cout tails zero-filled by the buffer descriptor's bounds check.
+#include <type_traits>
+
+#include "igemm_params.h"
+
+// A loaded value is "used" in the block that loads it: hipcc's wait-count pass then retires the load there.  A load still
+// pending (from the compiler's point of view) on ANY path into the phase loop costs an s_waitcnt vmcnt(0) at the loop
+// header, i.e. drains the LDS-DMA ring in every K tile.
+#define CAVP_USE8(a) asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]))
+
+namespace {
+
+constexpr int BC = 256, BP = 256, NT = 512;
+constexpr int HALF_BYTES = 128 * 128;       // 128 rows x 128 B
+constexpr int BUF_BYTES = 4 * HALF_BYTES;   // one K tile: H0 H1 H2 H3
+constexpr int RING_BYTES = 2 * BUF_BYTES;
+constexpr int SCR_BYTES = 4096;             // per-wave epilogue scratch: 16 pixels x 64 channels f32
+constexpr int LDS_BYTES = RING_BYTES + 8 * SCR_BYTES;
+constexpr unsigned kOOB = 0x80000000u;
+static_assert(LDS_BYTES == 160 * 1024, "the whole LDS of a CU");
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+}  // namespace
+
+// DBG: compile-time profiling switches (instantiated only under -DCAVP_PROFILE; a RUN-time test of such a flag inside the
+// phase loop splits its basic blocks and made the product kernel 1.8x slower): 1 taps outermost, 2 no stagger, 4 no
+// s_setprio, 8 no DMA, 16 no MFMA, 32 no fragment reads, 64 no epilogue.
+template <int DBG>
+__global__ __launch_bounds__(512, 2) void igemm_big_kernel(const IgemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wc = wave & 3, wp = wave >> 2;   // wp = wave group
+  const int lrow = lane & 15, lgrp = lane >> 4;
+
+  const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.w_bytes, 0x00020000);
+
+  const int my_tiles = ((int)blockIdx.x < p.nblk) ? (p.nblk - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
+  if (my_tiles == 0) return;
+  const int HoWo = p.Ho * p.Wo;
+
+  // ---------------------------------------------------------------------------------------------------------------
+  // issue side: per-thread DMA descriptors of the tile whose K tiles are being fetched
+  // ---------------------------------------------------------------------------------------------------------------
+  // a wave DMA instruction writes 8 LDS rows (1 KiB) linearly; thread -> LDS row r0 (+64 for its second piece) of a half tile
+  const int r0 = 8 * wave + (lane >> 3);
+  const int kslot = ((lane & 7) ^ ((4 * wave + (lane >> 4)) & 7)) * 8;   // (r0 >> 1) & 7 == ((r0 + 64) >> 1) & 7
+  const int kbyte = kslot * 2;
+  unsigned w_off[4];   // [channel half * 2 + piece]
+  unsigned x_off[4];   // [pixel half * 2 + piece]
+  unsigned x_mask[4];
+  int iss_tile = 0;            // ordinal of the tile being fetched (my_tiles: past the end)
+  int iss_ti = 0, iss_cc = 0;  // tap index, channel tile
+  int iss_buf = 0;
+  // byte offsets of the current tap in a weight row / in x: re-loaded (scalar loads from the kernel arguments) when the tap
+  // advances, i.e. a whole phase before their next use - a scalar load waited for inside a phase would also drain the
+  // fragment reads issued before it (one lgkmcnt for both)
+  int iss_woff = p.tap_woff[0], iss_xoff = p.tap_xoff[0];
+
+  auto setup_tile = [&](int ord) {
+    const int vb = (int)blockIdx.x + ord * (int)gridDim.x;
+    const int sid = xcd_remap(vb, p.nblk);
+    const int tp = fast_div(sid, p.div_tc_m, p.div_tc_s), tc = sid - tp * p.tiles_c;
+    const int c_base = tc * BC, p_base = tp * BP;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      const int r = r0 + 64 * (m & 1), half = m >> 1;
+      const int c = c_base + (r >> 5) * 64 + half * 32 + (r & 31);
+      w_off[m] = c < p.Cout ? (unsigned)(((size_t)c * p.K + kslot) * 2) : kOOB;
+    }
+    int h0[4], w0[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      const int r = r0 + 64 * (m & 1), half = m >> 1;
+      const int pix = p_base + (r >> 6) * 128 + half * 64 + (r & 63);
+      const bool ok = pix < p.M;
+      const int pp = ok ? pix : 0;
+      const int n = fast_div(pp, p.div_hw_m, p.div_hw_s), rr = pp - n * HoWo;
+      const int ho = fast_div(rr, p.div_w_m, p.div_w_s), wo = rr - ho * p.Wo;
+      h0[m] = ok ? ho * p.stride - p.pad : -0x10000000;
+      w0[m] = wo * p.stride_w - p.pad;
+      x_mask[m] = 0;
+      x_off[m] = (unsigned)((n * p.H + h0[m]) * p.W + w0[m]) * (unsigned)(p.ldx * 2) + (unsigned)kbyte;
+    }
+    for (int t = 0; t < p.ntaps; ++t) {
+      const int dh = p.tap_dh[t], dw = p.tap_dw[t];
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+        x_mask[m] |= ((unsigned)(h0[m] + dh) < (unsigned)p.H && (unsigned)(w0[m] + dw) < (unsigned)p.W) ? (1u << t) : 0u;
+    }
+  };
+
+  // the two DMA pieces of half tile K (0 = H0 weights low, 1 = H1 pixels low, 2 = H2 weights high, 3 = H3 pixels high) of
+  // the current issue position; past the last tile the same instructions are issued with every lane out of range (zero
+  // fill into a region nobody reads any more), so the vmcnt arithmetic stays uniform
+  auto issue_half = [&](auto kc) {
+    constexpr int K = decltype(kc)::value;
+    const bool live = iss_tile < my_tiles;
+    const int ti = iss_ti, c0 = iss_cc * 64;
+    const unsigned oobm = (live && (c0 + kslot) < p.Cin) ? 0u : kOOB;
+    char* base = smem + iss_buf * BUF_BYTES + K * HALF_BYTES + wave * 1024;
+    if constexpr ((DBG & 8) != 0) {
+    } else if constexpr ((K & 1) == 0) {
+      const unsigned wk = (unsigned)(iss_woff + c0 * 2);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const unsigned off = (w_off[(K >> 1) * 2 + j] + wk) | oobm;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (lds_ptr_t)(base + j * 8192), 16, (int)off, 0, 0, 0);
+      }
+    } else {
+      const unsigned xk = (unsigned)(iss_xoff + c0 * 2);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int m = (K >> 1) * 2 + j;
+        const unsigned tapm = ((~(x_mask[m] >> ti)) & 1u) << 31;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (lds_ptr_t)(base + j * 8192), 16, (int)((x_off[m] + xk) | tapm | oobm), 0, 0,
+                                                 0);
+      }
+    }
+    if constexpr (K == 3) {   // next K tile of the stream
+      iss_buf ^= 1;
+      if (live) {
+        if constexpr ((DBG & 1) != 0) {   // A/B: taps outermost (the 2-stage kernel's order)
+          if (++iss_cc == p.cpt) {
+            iss_cc = 0;
+            if (++iss_ti == p.ntaps) {
+              iss_ti = 0;
+              if (++iss_tile < my_tiles) setup_tile(iss_tile);
+            }
+            iss_woff = p.tap_woff[iss_ti];
+            iss_xoff = p.tap_xoff[iss_ti];
+          }
+        } else {
+          // taps INNERMOST: the 9 shifted windows of one 64-channel slice are fetched back to back, so 8 of the 9 reads of
+          // an input line hit the XCD's L2 (with taps outermost a line is re-read after a whole pass over the channels,
+          // by which time the 32 tiles in flight on an XCD have pushed it out of the 4 MiB L2)
+          if (++iss_ti == p.ntaps) {
+            iss_ti = 0;
+            if (++iss_cc == p.cpt) {
+              iss_cc = 0;
+              if (++iss_tile < my_tiles) setup_tile(iss_tile);
+            }
+          }
+          iss_woff = p.tap_woff[iss_ti];
+          iss_xoff = p.tap_xoff[iss_ti];
+        }
+      }
+    }
+  };
+
+  // ---------------------------------------------------------------------------------------------------------------
+  // compute side
+  // ---------------------------------------------------------------------------------------------------------------
+  f32x4_t acc[4][8];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 8; ++b) acc[a][b] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  u32x4_t fa0[2][2], fa1[2][2], fb[4][2];   // [block][k sub-step]: weights low / high channel half, pixels of the current half
+
+  const int key = (lrow >> 1) & 7;
+  // byte offset of (row, slot) inside a half tile for k sub-step 0; sub-step 1 flips slot bit 2
+  const int a_off = (wc * 32 + lrow) * 128 + ((lgrp ^ key) << 4);
+  const int b_off = (wp * 64 + lrow) * 128 + ((lgrp ^ key) << 4);
+  int cmp_buf = 0, cmp_k = 0, cmp_tile = 0;
+
+  auto read_a = [&](u32x4_t (&f)[2][2], int half) {
+    const char* base = smem + cmp_buf * BUF_BYTES + (half ? 2 : 0) * HALF_BYTES + a_off;
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      f[a][0] = *(const u32x4_t*)(base + a * 2048);
+      f[a][1] = *(const u32x4_t*)(base + a * 2048 + ((((lgrp ^ key) ^ 4) - (lgrp ^ key)) << 4));
+    }
+  };
+  auto read_b = [&](int half) {
+    const char* base = smem + cmp_buf * BUF_BYTES + (half ? 3 : 1) * HALF_BYTES + b_off;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      fb[b][0] = *(const u32x4_t*)(base + b * 2048);
+      fb[b][1] = *(const u32x4_t*)(base + b * 2048 + ((((lgrp ^ key) ^ 4) - (lgrp ^ key)) << 4));
+    }
+  };
+  auto mma_quadrant = [&](const u32x4_t (&f)[2][2], auto hc, auto hq) {
+    constexpr int HC = decltype(hc)::value, HQ = decltype(hq)::value;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) Mma<bf16_t>::run(acc[HC * 2 + a][HQ * 4 + b], f[a][j], fb[b][j]);
+  };
+
+  // ---- epilogue of one wave: acc (64 channels x 128 pixels) -> y ----
+  auto epilogue = [&](int ord) {
+    const int vb = (int)blockIdx.x + ord * (int)gridDim.x;
+    const int sid = xcd_remap(vb, p.nblk);
+    const int tp = fast_div(sid, p.div_tc_m, p.div_tc_s), tc = sid - tp * p.tiles_c;
+    const int c_wave = tc * BC + wc * 64, p_wave = tp * BP + wp * 128;
+    const int nvw = p.M - p_wave;   // valid pixel rows of this wave's slab (<= 0: none)
+    if (p.tile_stats) {
+      // per-channel (mean, M2) of this wave's <= 128 rows: one statistics tile per wave slab (see conv_igemm.hip)
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        float s1[4], s2[4], x0[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          x0[i] = __shfl(acc[a][0][i], lane & 48, 64);
+          s1[i] = 0.f; s2[i] = 0.f;
+        }
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+          const bool ok = b * 16 + lrow < nvw;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const float d = ok ? acc[a][b][i] - x0[i] : 0.f;
+            s1[i] += d;
+            s2[i] = fmaf(d, d, s2[i]);
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          s1[i] = row16_sum(s1[i]);
+          s2[i] = row16_sum(s2[i]);
+        }
+        const int c = c_wave + a * 16 + lgrp * 4;
+        if (lrow == 0 && nvw > 0 && c < p.Cout) {
+          const float n = (float)(nvw < 128 ? nvw : 128);
+          float4 o;
+          float m = s1[0] / n; o.x = x0[0] + m; o.y = fmaxf(s2[0] - s1[0] * m, 0.f);
+          m = s1[1] / n; o.z = x0[1] + m; o.w = fmaxf(s2[1] - s1[1] * m, 0.f);
+          float4 o2;
+          m = s1[2] / n; o2.x = x0[2] + m; o2.y = fmaxf(s2[2] - s1[2] * m, 0.f);
+          m = s1[3] / n; o2.z = x0[3] + m; o2.w = fmaxf(s2[3] - s1[3] * m, 0.f);
+          float* dst = p.tile_stats + ((size_t)(tp * 2 + wp) * p.Cout + c) * 2;
+          *(float4*)dst = o;
+          *(float4*)(dst + 4) = o2;
+        }
+      }
+    }
+    // the lane finishes channels ec .. ec+7 of pixels (lane >> 3) and (lane >> 3) + 8 of every 16-pixel block
+    float* scr = (float*)(smem + RING_BYTES + wave * SCR_BYTES);
+    const int cg = lane & 7, ec = c_wave + cg * 8, pr = lane >> 3;
+    const bool ec_ok = ec < p.Cout;
+    float sc[8], sh[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { sc[e] = 1.f; sh[e] = 0.f; }
+    if (ec_ok) {
+      if (p.scale) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const float4 t = *(const float4*)(p.scale + ec + 4 * q);
+          sc[4 * q] = t.x; sc[4 * q + 1] = t.y; sc[4 * q + 2] = t.z; sc[4 * q + 3] = t.w;
+        }
+        CAVP_USE8(sc);
+      }
+      if (p.shift) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const float4 t = *(const float4*)(p.shift + ec + 4 * q);
+          sh[4 * q] = t.x; sh[4 * q + 1] = t.y; sh[4 * q + 2] = t.z; sh[4 * q + 3] = t.w;
+        }
+        CAVP_USE8(sh);
+      }
+    }
+    const bool has_ss = p.scale != nullptr || p.shift != nullptr;
+    bf16_t* yp = (bf16_t*)p.y + (size_t)(p_wave + pr) * p.ldy + ec;
+    const bf16_t* rp = p.res ? (const bf16_t*)p.res + (size_t)(p_wave + pr) * p.ldr + ec : nullptr;
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+      u32x4_t rr[2];
+      if (rp) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          rr[k] = (u32x4_t){0u, 0u, 0u, 0u};
+          if (ec_ok && b * 16 + pr + 8 * k < nvw) {
+            rr[k] = *(const u32x4_t*)(rp + (size_t)(b * 16 + 8 * k) * p.ldr);
+            asm volatile("" : "+v"(rr[k]));   // (see CAVP_USE8)
+          }
+        }
+      }
+      // scratch [16 pixels][16 slots of 4 channels], slot index XOR pixel: conflict-free 16-byte writes and reads
+#pragma unroll
+      for (int a = 0; a < 4; ++a) *(f32x4_t*)(scr + lrow * 64 + (((a * 4 + lgrp) ^ lrow) << 2)) = acc[a][b];
+      __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): the wave's own LDS writes are done before its reads
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const int px = pr + 8 * k;
+        float v[8];
+        {
+          const f32x4_t t0 = *(const f32x4_t*)(scr + px * 64 + (((2 * cg) ^ px) << 2));
+          const f32x4_t t1 = *(const f32x4_t*)(scr + px * 64 + (((2 * cg + 1) ^ px) << 2));
+          v[0] = t0[0]; v[1] = t0[1]; v[2] = t0[2]; v[3] = t0[3];
+          v[4] = t1[0]; v[5] = t1[1]; v[6] = t1[2]; v[7] = t1[3];
+        }
+        const int row = b * 16 + px;
+        if (!(ec_ok && row < nvw)) continue;
+        if (p.nbias) {
+          const float* nb = p.nbias + (size_t)fast_div(p_wave + row, p.div_hw_m, p.div_hw_s) * p.Cout + ec;
+          float nbv[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) nbv[e] = nb[e];
+          CAVP_USE8(nbv);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] += nbv[e];
+        }
+        if (has_ss) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = __fadd_rn(__fmul_rn(v[e], sc[e]), sh[e]);
+        }
+        if (rp) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            v[2 * e] += __uint_as_float(rr[k][e] << 16);
+            v[2 * e + 1] += __uint_as_float(rr[k][e] & 0xffff0000u);
+          }
+        }
+        apply_act_vec<8>(v, p.act);
+        u32x4_t o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = pack2bf(v[2 * e], v[2 * e + 1]);
+        *(u32x4_t*)(yp + (size_t)(b * 16 + 8 * k) * p.ldy) = o;
+      }
+      __builtin_amdgcn_s_waitcnt(0xc07f);   // reads of this block retired before the next block overwrites the scratch
+    }
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 8; ++b) acc[a][b] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  };
+
+  // ---------------------------------------------------------------------------------------------------------------
+  // the phase stream
+  // ---------------------------------------------------------------------------------------------------------------
+  setup_tile(0);
+  issue_half(std::integral_constant<int, 0>{});
+  issue_half(std::integral_constant<int, 1>{});
+  issue_half(std::integral_constant<int, 2>{});
+  issue_half(std::integral_constant<int, 3>{});
+  issue_half(std::integral_constant<int, 0>{});
+  issue_half(std::integral_constant<int, 1>{});
+  __builtin_amdgcn_s_waitcnt(vmcnt_imm(8));   // H0, H1 of K tile 0 landed (this thread's pieces)
+  __builtin_amdgcn_s_barrier();
+  constexpr bool stagger = !(DBG & 2);
+  if (stagger && wp == 1) __builtin_amdgcn_s_barrier();  // group 1 runs half a phase behind
+
+  const int total_k = my_tiles * p.iters;
+  // a phase: DMA of a later half tile, fragment reads, retire the half tile read next phase, rendezvous, multiply
+#define CAVP_BIG_PHASE(KISSUE, READS, FA, HC, HQ)                                      \
+  issue_half(std::integral_constant<int, KISSUE>{});                                  \
+  __builtin_amdgcn_sched_barrier(0);                                                  \
+  if constexpr (!(DBG & 32)) READS;                                                           \
+  __builtin_amdgcn_s_waitcnt(vmcnt_imm(8));                                           \
+  __builtin_amdgcn_s_barrier();                                                       \
+  __builtin_amdgcn_s_waitcnt(0xc07f);                                                 \
+  __builtin_amdgcn_sched_barrier(0);                                                  \
+  if constexpr (!(DBG & 4)) __builtin_amdgcn_s_setprio(1);                                    \
+  if constexpr (!(DBG & 16)) mma_quadrant(FA, std::integral_constant<int, HC>{}, std::integral_constant<int, HQ>{}); \
+  __builtin_amdgcn_s_setprio(0);                                                      \
+  __builtin_amdgcn_sched_barrier(0);                                                  \
+  __builtin_amdgcn_s_barrier();
+
+  for (int u = 0; u < total_k; ++u) {
+    CAVP_BIG_PHASE(2, { read_b(0); read_a(fa0, 0); }, fa0, 0, 0)   // quadrant (c0, p0): needs H0 and H1
+    CAVP_BIG_PHASE(3, { read_a(fa1, 1); }, fa1, 1, 0)              // (c1, p0): needs H2
+    CAVP_BIG_PHASE(0, { read_b(1); }, fa1, 1, 1)                   // (c1, p1): needs H3
+    CAVP_BIG_PHASE(1, {}, fa0, 0, 1)                               // (c0, p1): everything in registers
+    cmp_buf ^= 1;
+    if (++cmp_k == p.iters) {
+      cmp_k = 0;
+      // Both groups run their (latency-bound, ~5 us) epilogues AT THE SAME TIME: group 0 waits half a phase for group 1 to
+      // finish the tile, group 1 re-creates the stagger afterwards.  Left staggered, group 0 would sit in its next barrier
+      // for the whole of group 1's epilogue and vice versa (12.5 us per tile instead of ~6).
+      if (stagger && wp == 0) __builtin_amdgcn_s_barrier();
+      if constexpr (!(DBG & 64)) epilogue(cmp_tile);
+      if (stagger && wp == 1) __builtin_amdgcn_s_barrier();
+      ++cmp_tile;
+    }
+  }
+#undef CAVP_BIG_PHASE
+  if (stagger && wp == 0) __builtin_amdgcn_s_barrier();
+}
+
+template <int DBG>
+static hipError_t launch_big(const IgemmParams& p, int nblk, hipStream_t s) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)igemm_big_kernel<DBG>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    attr_set = true;
+  }
+  IgemmParams q = p;
+  q.nblk = nblk;
+  const int grid = nblk > 256 ? 256 : nblk;
+  igemm_big_kernel<DBG><<<dim3(grid), dim3(NT), LDS_BYTES, s>>>(q);
+  return hipGetLastError();
+}
+
+hipError_t cavp_launch_igemm_big(const IgemmParams& p, int nblk, hipStream_t s) {
+  switch (p.dbg) {
+    case 0: return launch_big<0>(p, nblk, s);
+#ifdef CAVP_PROFILE
+    case 1: return launch_big<1>(p, nblk, s);
+    case 2: return launch_big<2>(p, nblk, s);
+    case 4: return launch_big<4>(p, nblk, s);
+    case 8: return launch_big<8>(p, nblk, s);
+    case 16: return launch_big<16>(p, nblk, s);
+    case 32: return launch_big<32>(p, nblk, s);
+    case 64: return launch_big<64>(p, nblk, s);
+    case 72: return launch_big<72>(p, nblk, s);
+    case 120: return launch_big<120>(p, nblk, s);
+#endif
+    default: return hipErrorInvalidValue;
+  }
+}

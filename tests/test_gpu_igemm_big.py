@@ -1,0 +1,121 @@
+"""Parity of the 256x256 ping-pong implicit-GEMM tile (csrc/conv_igemm_big.hip, tile id 10) against a PyTorch fp32 CPU
+reference of the same conv on bf16-rounded operands, plus race screens (bit-identical repeats, a run against the 2-stage
+128x128 tile on the same inputs).  MI355X box only; through cavp_amd.ops -> ctypes -> libcavp_hip.so."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from tests.test_gpu_ops import DEV, _act, _check, _ops, _q, _rand, _to_nhwc_dev
+
+pytestmark = pytest.mark.gpu
+
+BF = torch.bfloat16
+BIG = 10
+
+CASES = [
+    # name, N, H, W, Cin, Cout, k, stride, pad, dil
+    ("1x1_one_ktile", 2, 16, 16, 64, 256, 1, 1, 0, 1),           # iters = 1: every phase of the stream is a tile boundary
+    ("1x1_304_304_ktail_ctail", 2, 24, 20, 304, 304, 1, 1, 0, 1),  # K tail (304 = 4.75 x 64) and a second, mostly empty, channel tile
+    ("3x3_304_256", 1, 40, 36, 304, 256, 3, 1, 1, 1),            # decoder head conv (encoder_decoder.py:62-75) at reduced size
+    ("3x3_s2", 2, 30, 30, 128, 128, 3, 2, 1, 1),
+    ("3x3_d12_deadtaps", 1, 14, 14, 256, 256, 3, 1, 12, 12),
+    ("ragged_13x7_cout40", 3, 13, 7, 48, 40, 3, 1, 1, 1),
+    ("1x1_many_tiles", 5, 132, 130, 64, 64, 1, 1, 0, 1),         # 336 pixel tiles on 256 workgroups: the stream crosses output tiles
+    ("3x3_many_tiles", 4, 136, 128, 64, 128, 3, 1, 1, 1),        # 272 tiles x 9 K tiles
+]
+
+
+def _run(case, **kw):
+    ops = _ops()
+    name, n, h, w, cin, cout, k, s, p, d = case
+    x = _rand(n, cin, h, w, seed=1)
+    wt = _rand(cout, cin, k, k, seed=2, scale=(cin * k * k) ** -0.5)
+    xv, _ = _to_nhwc_dev(x, BF)
+    wp = ops.pack_weight(wt.to(DEV), BF)
+    ref = F.conv2d(_q(x, BF), _q(wt, BF), None, s, p, d)
+    out = torch.empty((n, ref.shape[2], ref.shape[3], cout), dtype=BF, device=DEV)
+    ops.conv2d(xv, wp, out, kh=k, kw=k, stride=s, pad=p, dil=d, **kw)
+    return out, ref, (xv, wp)
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
+def test_big_tile_matches_reference(case):
+    out, ref, _ = _run(case, tile=BIG)
+    _check(out.permute(0, 3, 1, 2), ref, BF, case[0] + "/tile10")
+
+
+@pytest.mark.parametrize("case", [CASES[2], CASES[6], CASES[7]], ids=[CASES[2][0], CASES[6][0], CASES[7][0]])
+def test_big_tile_is_race_free(case):
+    """Same launch 6 times on the same buffers: bit-identical outputs (a fragment read that overtakes its DMA, or a DMA that
+    overtakes a read, shows up as run-to-run differences), and equal to the 128x128 tile up to summation order."""
+    ops = _ops()
+    name, n, h, w, cin, cout, k, s, p, d = case
+    out0, ref, (xv, wp) = _run(case, tile=BIG)
+    first = out0.clone()
+    for _ in range(5):
+        out = torch.empty_like(first)
+        ops.conv2d(xv, wp, out, kh=k, kw=k, stride=s, pad=p, dil=d, tile=BIG)
+        assert torch.equal(out, first), name + ": repeats differ"
+    small = torch.empty_like(first)
+    ops.conv2d(xv, wp, small, kh=k, kw=k, stride=s, pad=p, dil=d, tile=1)
+    err = float((small.float() - first.float()).abs().max())
+    assert err <= 2e-2 * max(1.0, float(ref.abs().max())), (name, err)
+
+
+@pytest.mark.parametrize("act", [0, 1, 2, 3])
+def test_big_tile_epilogue_fusions(act):
+    """scale/shift + per-image bias + residual + activation, reading and writing 16-byte-aligned channel slices."""
+    ops = _ops()
+    n, h, w, cin, cout = 3, 19, 21, 64, 48
+    x, wt = _rand(n, cin, h, w, seed=9), _rand(cout, cin, 1, 1, seed=10, scale=0.12)
+    sc, sh = torch.rand(cout, generator=torch.Generator().manual_seed(11)) + 0.5, _rand(cout, seed=12)
+    nb, res = _rand(n, cout, seed=13), _rand(n, cout, h, w, seed=14)
+    xv, _ = _to_nhwc_dev(x, BF, ld=96, c0=16)
+    rv, _ = _to_nhwc_dev(res, BF, ld=64, c0=8)
+    big = torch.full((n, h, w, 304), -3.0, dtype=BF, device=DEV)
+    out = big[..., 256:304]
+    ref = F.conv2d(_q(x, BF), _q(wt, BF)) + nb[:, :, None, None]
+    ref = _act(ref * sc[None, :, None, None] + sh[None, :, None, None] + _q(res, BF), act)
+    ops.conv2d(xv, ops.pack_weight(wt.to(DEV), BF), out, scale=sc.to(DEV), shift=sh.to(DEV), nbias=nb.to(DEV),
+               residual=rv, act=act, tile=BIG)
+    _check(out.permute(0, 3, 1, 2), ref, BF, f"tile10 epilogue act{act}")
+    assert float((big[..., :256].float() + 3.0).abs().max()) == 0.0, "wrote outside its channel slice"
+
+
+@pytest.mark.parametrize("case", [CASES[1], CASES[2], CASES[5], CASES[7]], ids=[CASES[1][0], CASES[2][0], CASES[5][0], CASES[7][0]])
+def test_big_tile_batchnorm_statistics(case):
+    """Per-slab (mean, M2) pairs from the accumulators -> Chan combine == mean / biased variance of the f32 conv output."""
+    ops = _ops()
+    name, n, h, w, cin, cout, k, s, p, d = case
+    x = _rand(n, cin, h, w, seed=21)
+    wt = _rand(cout, cin, k, k, seed=22, scale=(cin * k * k) ** -0.5)
+    xv, _ = _to_nhwc_dev(x, BF)
+    ref = F.conv2d(_q(x, BF), _q(wt, BF), None, s, p, d)
+    out = torch.empty((n, ref.shape[2], ref.shape[3], cout), dtype=BF, device=DEV)
+    _, stats = ops.conv2d(xv, ops.pack_weight(wt.to(DEV), BF), out, kh=k, kw=k, stride=s, pad=p, dil=d, tile=BIG,
+                          want_tile_stats=True)
+    assert stats is not None
+    ts, tiles, rpt = stats
+    rows = out.numel() // cout
+    assert rpt == 128 and tiles == (rows + 127) // 128
+    ts = ts.cpu().double()
+    cnt = torch.tensor([min(rpt, rows - t * rpt) for t in range(tiles)], dtype=torch.float64)
+    mean = (ts[:, :, 0] * cnt[:, None]).sum(0) / rows
+    m2 = (ts[:, :, 1] + cnt[:, None] * (ts[:, :, 0] - mean[None]) ** 2).sum(0)
+    flat = ref.permute(0, 2, 3, 1).reshape(rows, cout).double()
+    assert float((mean - flat.mean(0)).abs().max()) <= 1e-4 * max(1.0, float(flat.abs().max()))
+    var_ref = flat.var(0, unbiased=False)
+    assert float(((m2 / rows) - var_ref).abs().max()) <= 1e-4 * max(1.0, float(var_ref.max()))
+
+
+def test_big_tile_refuses_what_it_cannot_do():
+    ops = _ops()
+    from cavp_amd._lib import CavpError
+    x, _ = _to_nhwc_dev(_rand(1, 64, 8, 8, seed=1), torch.float32)
+    wt = ops.pack_weight(_rand(64, 64, 1, 1, seed=2).to(DEV), torch.float32)
+    with pytest.raises(CavpError):   # f32 has no 256x256 tile
+        ops.conv2d(x, wt, torch.empty((1, 8, 8, 64), dtype=torch.float32, device=DEV), tile=BIG)
+    xb, _ = _to_nhwc_dev(_rand(1, 64, 8, 8, seed=1), BF)
+    wb = ops.pack_weight(_rand(20, 64, 1, 1, seed=2).to(DEV), BF)
+    with pytest.raises(CavpError):   # Cout not a multiple of the 16-byte vector
+        ops.conv2d(xb, wb, torch.empty((1, 8, 8, 20), dtype=BF, device=DEV), tile=BIG)
