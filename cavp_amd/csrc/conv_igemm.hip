@@ -101,6 +101,7 @@ __global__ __launch_bounds__(64 * WC * WP, (WC * WP == 4 ? 2 : 1)) void igemm_ke
   constexpr int RSTEP = 8 * NW;  // LDS rows covered by one DMA instruction of the whole workgroup
   static_assert(NW == 4 || NW == 8, "4 or 8 waves per workgroup");
   static_assert(NS >= 2 && (NS - 2) * (LW + LX) < 64, "vmcnt is a 6-bit counter");
+  static_assert(NW == 4 || NS == 3, "the 8-wave tiles are written for three stages");
   static_assert(TC % 16 == 0 && TP % 16 == 0, "wave tile must be a multiple of the 16x16 MFMA block");
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -281,6 +282,29 @@ __global__ __launch_bounds__(64 * WC * WP, (WC * WP == 4 ? 2 : 1)) void igemm_ke
           }
         }
         buf ^= 1;
+      }
+    } else if constexpr (NW == 4) {
+      // NS >= 3 stages, 4 waves: a deep ring for the launches that cannot fill the chip (the 14x14 / 28x28 layers: <= 2
+      // workgroups per CU, nothing co-resident to hide a K tile's load latency behind).  NS-1 tiles are in flight; one
+      // barrier per K tile: it proves that everybody's tile `it` landed AND that everybody finished tile it-1, whose stage
+      // is refilled right after it.
+      constexpr int LD = LW + LX;
+      const int n = it_end - it_begin;
+#pragma unroll
+      for (int s = 0; s < NS - 1; ++s) gdma(s, s < n);
+      int buf = 0, fill = NS - 1;
+      for (int it = 0; it < n; ++it) {
+        __builtin_amdgcn_s_waitcnt(vmcnt_imm((NS - 2) * LD));
+        __builtin_amdgcn_s_barrier();
+        gdma(fill, it + NS - 1 < n);
+        u32x4_t af[MC], bfv[MP];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          read_frag(af, bfv, buf, j);
+          mma_block(af, bfv);
+        }
+        buf = buf + 1 == NS ? 0 : buf + 1;
+        fill = fill + 1 == NS ? 0 : fill + 1;
       }
     } else {
       // three stages, one 8-wave workgroup per CU, software-pipelined through two fragment register sets so that no
@@ -569,8 +593,9 @@ const TileCfg kTiles[] = {
     {5, 128, 32, 0.45f},  {6, 16, 128, 0.25f}, {7, 32, 128, 0.45f},
     {8, 256, 128, 1.00f}, {9, 128, 256, 1.00f},  // 8 waves, 3 stages (eff set to 1.0 until measured: kBigEff below)
     {10, 256, 256, 2.00f},                       // conv_igemm_big.hip: 8 waves in two ping-pong groups, one workgroup per CU
+    {11, 64, 64, 0.70f}, {12, 64, 64, 0.70f}, {13, 128, 64, 0.80f}, {14, 64, 128, 0.80f},   // deep rings (4 / 8 / 4 / 4 stages) for under-filled launches
 };
-inline int tile_stages(int id) { return id == 10 ? 2 : id >= 8 ? 3 : 2; }
+inline int tile_stages(int id) { return id == 12 ? 8 : id >= 11 ? 4 : id == 10 ? 2 : id >= 8 ? 3 : 2; }
 inline bool tile_is_big(int id) { return id == 10; }
 inline int tile_wp(int id) { return id == 5 ? 1 : (id == 6 || id == 7 || id == 9) ? 4 : 2; }   // waves along the pixel dimension (launch_tile)
 // A/B knob: CAVP_IGEMM_EFF="e1,e2,...,e9" overrides the efficiency column of kTiles (time-model sweeps without a rebuild)
@@ -633,6 +658,10 @@ hipError_t launch_tile(int id, const IgemmParams& p, int nblk, hipStream_t s) {
     case 10:
       if constexpr (sizeof(T) == 2 && !UP) return cavp_launch_igemm_big(p, nblk, s);
       return hipErrorInvalidValue;
+    case 11: return launch_cfg<T, 64, 64, 2, 2, UP, 4>(p, nblk, s);
+    case 12: return launch_cfg<T, 64, 64, 2, 2, UP, 8>(p, nblk, s);
+    case 13: return launch_cfg<T, 128, 64, 2, 2, UP, 4>(p, nblk, s);
+    case 14: return launch_cfg<T, 64, 128, 2, 2, UP, 4>(p, nblk, s);
     default: return hipErrorInvalidValue;
   }
 }
@@ -759,6 +788,14 @@ Plan make_plan(const cavp_conv_desc* d, bool allow_big = true) {
     }
   }
   if (best < 0) { pl.status = CAVP_ERR_BAD_ARG; return pl; }
+  // Under-filled launches (the 14x14 layers: <= 512 tiles of 64x64, i.e. at most two workgroups per CU whatever the
+  // split) with a long K loop: the 4-stage ring WITHOUT split-K (bench_conv on MI355X: 3x3 256->256 at 32x14x14 28.6 ->
+  // 18.5 us, 1x1 2048->256 23.9 -> 16.4 us; no slab pass, and the fused BatchNorm statistics stay available).  With more
+  // tiles than that the 2-stage tile at four workgroups per CU is faster.
+  if (want_tile == 0 && d->splitk <= 0 && p.iters >= 16 && (long long)cdiv(p.Cout, 64) * cdiv(p.M, 64) <= 512) {
+    for (int i = 0; i < kNumTiles; ++i)
+      if (kTiles[i].id == 11) { best = i; best_sk = 1; }
+  }
   // The 256x256 ping-pong tile (conv_igemm_big.hip) by rule, not by the time model: measured on MI355X (bench_conv,
   // profiles/r02_notes.md) it wins where its whole-tile quantisation is harmless - the output is (nearly) a multiple of 256
   // channels wide, there are at least four K tiles to amortise its ~6 us epilogue, and the tiles fill whole rounds of 256

@@ -72,11 +72,11 @@ CONV_CASES = [
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
 @pytest.mark.parametrize("case", CONV_CASES, ids=[c[0] for c in CONV_CASES])
-@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9])
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 11, 12, 13, 14])
 def test_conv_igemm_tiles(case, tile, dtype):
     ops = _ops()
     name, n, h, w, cin, cout, k, s, p, d = case
-    if tile in (5, 6, 7) and name not in ("1x1_64_64", "3x3_d12_deadtaps", "ragged_13x7"):
+    if tile in (5, 6, 7, 12, 13, 14) and name not in ("1x1_64_64", "3x3_d12_deadtaps", "ragged_13x7"):
         pytest.skip("small tiles swept on a subset")
     x = _rand(n, cin, h, w, seed=1)
     wt = _rand(cout, cin, k, k, seed=2, scale=(cin * k * k) ** -0.5)
