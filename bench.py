@@ -50,6 +50,7 @@ def parse():
                     help="force the two-graph replay of the data-parallel path (cut where the early gradients are final) on one GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-f32", action="store_true", help="skip the secondary f32 (parity path) training-step measurement")
     ap.add_argument("--cpu-sample-batch", type=int, default=8)
     return ap.parse_args()
 
@@ -71,6 +72,21 @@ def build_model(cfg, B, dtype, device):
     m.load_state_dict(sd, strict=True)
     m.eval().to(device).set_compute_dtype(dtype)
     return m, sd
+
+
+def live_taps(h_in, w_in, h_out, w_out, kh, kw, stride, pad, dil):
+    """Taps of a conv that touch the image for at least one output position: the kernels skip the others (ASPP d = 12 / 18 on
+    14x14), so they are not algorithmic work either."""
+    def axis(n_in, n_out, k):
+        return sum(1 for t in range(k) if any(0 <= o * stride - pad + t * dil < n_in for o in range(n_out)))
+    return axis(h_in, h_out, kh) * axis(w_in, w_out, kw)
+
+
+# Whole-step byte model (DESIGN.md section 6d): SURVEY.md section 8d's "perfectly fused" forward minimum (C1', bf16, B = 32:
+# 147.4 MB per frame) x the train-mode forward factor (57.8 / 39.41 GFLOP: the fusion block and the decoder head run on 2B)
+# x 3 (forward: every activation written once and read once; backward: every saved activation read once, every gradient
+# written once and read once; weights and their f32 gradients are < 3 % of that and are left out).
+FUSED_MIN_MB_PER_FRAME_BF16 = {"train": 147.4 * (57.8 / 39.41) * 3.0, "eval": 147.4}
 
 
 class KernelTimer:
@@ -125,12 +141,14 @@ class KernelTimer:
                 # dgrad(dy, w_t, dx): same MACs as the forward conv = M_dy * Cout_f * Cin_f * k * k (stride-1 form)
                 t0, t1, t2 = a[0], a[1], a[2]
                 es = t0.element_size()
-                kk = k.get("kh", 1) * k.get("kw", 1)
-                if name == "conv2d_dgrad":
+                kw_ = dict(kh=k.get("kh", 1), kw=k.get("kw", 1), stride=k.get("stride", 1), pad=k.get("pad", 0), dil=k.get("dil", 1))
+                if name == "conv2d_dgrad":   # (dy, w_t, dx): the MACs of the forward conv dx -> dy, live taps only
+                    kk = live_taps(t2.shape[1], t2.shape[2], t0.shape[1], t0.shape[2], **kw_)
                     m_dy = t0.shape[0] * t0.shape[1] * t0.shape[2]
                     flops = 2 * m_dy * t0.shape[3] * t2.shape[3] * kk
                     nbytes = (t0.numel() + t1.numel() + t2.numel()) * es
-                else:
+                else:                        # (x, dy, dw)
+                    kk = live_taps(t0.shape[1], t0.shape[2], t1.shape[1], t1.shape[2], **kw_)
                     m_dy = t1.shape[0] * t1.shape[1] * t1.shape[2]
                     flops = 2 * m_dy * t1.shape[3] * t0.shape[3] * kk
                     nbytes = (t0.numel() + t1.numel()) * es + t2.numel() * 4
@@ -138,7 +156,9 @@ class KernelTimer:
                 x, w, out = a[0], a[1], a[2]
                 es = x.element_size()
                 m = out.shape[0] * out.shape[1] * out.shape[2]
-                flops = 2 * m * out.shape[3] * (w.numel() // out.shape[3])
+                kk = live_taps(x.shape[1], x.shape[2], out.shape[1], out.shape[2], k.get("kh", 1), k.get("kw", 1),
+                               k.get("stride", 1), k.get("pad", 0), k.get("dil", 1))
+                flops = 2 * m * out.shape[3] * x.shape[3] * kk
                 nbytes = (x.shape[0] * x.shape[1] * x.shape[2] * x.shape[3] + w.numel() + m * out.shape[3]) * es
                 if k.get("residual") is not None:
                     nbytes += m * out.shape[3] * es
@@ -202,19 +222,25 @@ def measure_roofline(model, run_step, image, dtype_name, reps=3):
     gbs = nbytes / (ms * 1e-3) / 1e9
     frac_mfma = tflops / MFMA_PEAK_TFLOPS[dtype_name]
     frac_hbm = gbs / HBM_PEAK_GBS
-    if frac_mfma >= frac_hbm:
+    # which roof bounds the kernel follows from the roofline MODEL (arithmetic intensity of its launches vs the ridge point
+    # peak_flops / peak_bytes), not from whichever fraction happens to be larger
+    ridge = MFMA_PEAK_TFLOPS[dtype_name] * 1e12 / (HBM_PEAK_GBS * 1e9)
+    if flops / max(nbytes, 1) >= ridge:
         roof = {"bound": "mfma", "achieved": round(tflops, 2), "peak": MFMA_PEAK_TFLOPS[dtype_name], "unit": "TFLOP/s",
                 "frac": round(frac_mfma, 4)}
     else:
         roof = {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(frac_hbm, 4)}
+    roof["intensity_flop_per_byte"] = round(flops / max(nbytes, 1), 1)
+    roof["ridge_flop_per_byte"] = round(ridge, 1)
     traffic = None
-    tpath = os.path.join(REPO, "profiles", f"r01_traffic_{dtype_name}.json" if not getattr(model, "training", False)
-                         else f"r01_traffic_train_{dtype_name}.json")
-    if os.path.exists(tpath):  # PMC counters cannot be read from inside the process: measured with rocprofv3 --pmc
+    tname = f"traffic_{dtype_name}.json" if not getattr(model, "training", False) else f"traffic_train_{dtype_name}.json"
+    tpath = next((q for q in (os.path.join(REPO, "profiles", r + tname) for r in ("r02_", "r01_")) if os.path.exists(q)), "")
+    if tpath:  # PMC counters cannot be read from inside the process: measured with rocprofv3 --pmc
         with open(tpath) as f:
             tj = json.load(f)
         if tj.get("batch") == image.shape[0] and tj.get("dtype") == dtype_name:
             traffic = {"hbm_bytes_per_step": tj["hbm_bytes_per_step"], "hbm_bytes_per_launch": tj["hbm_bytes_per_launch"],
+                       "all_kernels_hbm_bytes_per_step": tj.get("all_kernels_hbm_bytes_per_step"),
                        "vs_algorithmic": round(tj["hbm_bytes_per_step"] / nbytes, 3), "source": "profiles/" + os.path.basename(tpath)}
     roof.update({
         "traffic": traffic,
@@ -229,66 +255,104 @@ def measure_roofline(model, run_step, image, dtype_name, reps=3):
         "share_of_step_kernel_time": round(ms / total_ms, 3),
         "other_kernels_ms": {k: round(v[1] / reps, 3) for k, v in agg.items() if k not in ("conv2d", "conv2d_dgrad")},
     })
+    step_flops = flops
     if "conv2d_wgrad" in agg:
         wl, wms, wf, wb = agg["conv2d_wgrad"]
         wms /= reps
+        step_flops += wf // reps
         roof["wgrad_kernel"] = {"launches_per_step": wl // reps, "ms_per_step": round(wms, 3),
                                 "achieved_tflops": round(wf / reps / (wms * 1e-3) / 1e12, 2),
                                 "frac_of_mfma_peak": round(wf / reps / (wms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS[dtype_name], 4)}
+    roof["_step_gflop"] = step_flops / 1e9   # consumed by main(): the whole-step object needs ms_per_step of the timed region
+    roof["_measured_step_bytes"] = traffic["all_kernels_hbm_bytes_per_step"] if traffic and "all_kernels_hbm_bytes_per_step" in traffic else None
     return roof
 
 
-def cpu_baseline_train(sd, cfg, sample_batch):
-    """Oracle forward_train + CE + autograd backward on the host cores (bounded sample)."""
-    from cavp_amd.synth import synth_inputs
-    from oracle import cavp_oracle as O
+def _host_cpu():
+    """(physical cores, model name, sockets) of the box."""
     cores = os.cpu_count() or 1
     try:
         import psutil
         cores = psutil.cpu_count(logical=False) or cores
     except Exception:
         pass
+    model, sockets = "unknown", set()
+    try:
+        with open("/proc/cpuinfo") as f:
+            for ln in f:
+                if ln.startswith("model name") and model == "unknown":
+                    model = ln.split(":", 1)[1].strip()
+                if ln.startswith("physical id"):
+                    sockets.add(ln.split(":", 1)[1].strip())
+    except OSError:
+        pass
+    return cores, model, max(1, len(sockets))
+
+
+def _timed_iters(fn, budget_s, min_iters, max_iters, warm=True):
+    """One untimed warm-up call, then >= min_iters timed calls (more while the budget lasts); (iterations, seconds, median s)."""
+    if warm:
+        fn()
+    ts = []
+    t_all = time.perf_counter()
+    while len(ts) < max_iters and (len(ts) < min_iters or time.perf_counter() - t_all < budget_s):
+        t0 = time.perf_counter()
+        fn()
+        ts.append(time.perf_counter() - t0)
+    ts.sort()
+    return len(ts), sum(ts), ts[len(ts) // 2]
+
+
+def cpu_baseline_train(sd, cfg, sample_batch):
+    """Oracle forward_train + CE + autograd backward on the host cores: bounded sample, one warm-up + >= 5 timed iterations on
+    all physical cores, plus a single-thread figure on a smaller batch."""
+    from cavp_amd.synth import synth_inputs
+    from oracle import cavp_oracle as O
+    cores, cpu_model, sockets = _host_cpu()
+
+    def make(batch):
+        image, audio, label = synth_inputs(batch, cfg["hw"], audio_batch=2 * batch, num_classes=cfg["C"], seed=0)
+        params = {k: v.clone().requires_grad_(True) for k, v in sd.items() if v.is_floating_point() and "running_" not in k}
+        sd2 = dict(sd)
+        sd2.update(params)
+
+        def step():
+            for q in params.values():
+                q.grad = None
+            out, _, _ = O.cavp_forward(sd2, image, audio, cfg["lds"], eval_mode=False)
+            O.ce_loss_train(out, label, batch).backward()
+        return step
+
     torch.set_num_threads(cores)
-    image, audio, label = synth_inputs(sample_batch, cfg["hw"], audio_batch=2 * sample_batch, num_classes=cfg["C"], seed=0)
-    params = {k: v.clone().requires_grad_(True) for k, v in sd.items() if v.is_floating_point() and "running_" not in k}
-    sd2 = dict(sd)
-    sd2.update(params)
-    t0, n = time.perf_counter(), 0
-    while True:
-        out, _, _ = O.cavp_forward(sd2, image, audio, cfg["lds"], eval_mode=False)
-        O.ce_loss_train(out, label, sample_batch).backward()
-        n += 1
-        dt = time.perf_counter() - t0
-        if dt > 15.0 or n >= 4:
-            break
-    return {"value": round(n * sample_batch / dt, 2), "unit": "frames/s", "cores": cores, "kind": "port",
-            "sample": f"{n} x (forward_train + CE + backward) of B={sample_batch} frames (audio {2 * sample_batch}), fp32, torch CPU "
-                      f"autograd over the oracle ({torch.get_num_threads()} threads), same C1' model and synthetic inputs"}
+    n, secs, med = _timed_iters(make(sample_batch), budget_s=18.0, min_iters=5, max_iters=12)
+    torch.set_num_threads(1)
+    # (B = 2 is the smallest batch the reference's training step accepts: the ASPP image-pooling BatchNorm sees B values per channel)
+    n1, secs1, med1 = _timed_iters(make(2), budget_s=8.0, min_iters=1, max_iters=2, warm=False)
+    torch.set_num_threads(cores)
+    return {"value": round(sample_batch / med, 2), "unit": "frames/s", "cores": cores, "kind": "port",
+            "cpu_model": cpu_model, "sockets": sockets, "iterations": n, "warmup_iterations": 1,
+            "single_thread": {"value": round(2.0 / med1, 3), "unit": "frames/s", "cores": 1, "iterations": n1,
+                              "sample": "B=2 frames (audio 4), same step, no warm-up"},
+            "sample": f"median of {n} x (forward_train + CE + backward) of B={sample_batch} frames (audio {2 * sample_batch}) after one "
+                      f"warm-up, fp32, torch CPU autograd over the oracle ({cores} threads), same C1' model and synthetic inputs"}
 
 
 def cpu_baseline(sd, cfg, sample_batch):
     """The oracle (kind 'port': our restatement of the reference, pinned by golden vectors) on the host cores."""
     from cavp_amd.synth import synth_inputs
     from oracle import cavp_oracle as O
-    cores = os.cpu_count() or 1
-    try:
-        import psutil
-        cores = psutil.cpu_count(logical=False) or cores
-    except Exception:
-        pass
-    torch.set_num_threads(cores)
+    cores, cpu_model, sockets = _host_cpu()
     image, audio, _ = synth_inputs(sample_batch, cfg["hw"], num_classes=cfg["C"], seed=0)
     with torch.no_grad():
-        O.cavp_forward(sd, image[:2], audio[:2], cfg["lds"], eval_mode=True)  # warm-up
-        t0, n = time.perf_counter(), 0
-        while True:
-            O.cavp_forward(sd, image, audio, cfg["lds"], eval_mode=True)
-            n += 1
-            dt = time.perf_counter() - t0
-            if dt > 12.0 or n >= 8:
-                break
-    return {"value": round(n * sample_batch / dt, 2), "unit": "frames/s", "cores": cores, "kind": "port",
-            "sample": f"{n} x eval forward of B={sample_batch} frames, fp32, torch CPU ({torch.get_num_threads()} threads), "
+        torch.set_num_threads(cores)
+        n, secs, med = _timed_iters(lambda: O.cavp_forward(sd, image, audio, cfg["lds"], eval_mode=True), 12.0, 5, 20)
+        torch.set_num_threads(1)
+        n1, secs1, med1 = _timed_iters(lambda: O.cavp_forward(sd, image[:1], audio[:1], cfg["lds"], eval_mode=True), 6.0, 1, 5)
+        torch.set_num_threads(cores)
+    return {"value": round(sample_batch / med, 2), "unit": "frames/s", "cores": cores, "kind": "port",
+            "cpu_model": cpu_model, "sockets": sockets, "iterations": n, "warmup_iterations": 1,
+            "single_thread": {"value": round(1.0 / med1, 3), "unit": "frames/s", "cores": 1, "iterations": n1, "sample": "B=1 frame"},
+            "sample": f"median of {n} x eval forward of B={sample_batch} frames after one warm-up, fp32, torch CPU ({cores} threads), "
                       f"same C1' model and synthetic inputs"}
 
 
@@ -385,7 +449,7 @@ def main():
     if rank == 0:
         value = world * B * a.steps / elapsed
         line = {
-            "metric": ("frames/sec end-to-end CAVP fwd+bwd, B=32 224x224" if train else
+            "metric": (f"frames/sec end-to-end CAVP fwd+bwd, B={B} {cfg['hw'][0]}x{cfg['hw'][1]}" if train else
                        f"frames/sec end-to-end CAVP forward (inference), B={B} {cfg['hw'][0]}x{cfg['hw'][1]}"),
             "value": round(value, 2), "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(elapsed / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
@@ -403,7 +467,41 @@ def main():
                        "launch": "eager" if a.no_graph else "hipGraph replay"},
         }
         if not a.no_roofline:
-            line["roofline"] = measure_roofline(model, run_step_local, image, a.dtype)
+            roof = measure_roofline(model, run_step_local, image, a.dtype)
+            step_gflop, meas_bytes = roof.pop("_step_gflop"), roof.pop("_measured_step_bytes")
+            ms_step = elapsed / a.steps * 1e3
+            if a.config == "c1p" and a.dtype == "bf16":
+                # the WHOLE step against both roofs (north_star: "fraction of the conv-bound HBM roofline"): algorithmic FLOPs of
+                # every conv / linear launch incl. weight gradients, and the perfectly-fused byte minimum
+                min_gb = FUSED_MIN_MB_PER_FRAME_BF16["train" if train else "eval"] * B / 1e3
+                roof["step"] = {
+                    "bound": "hbm", "ms_per_step": round(ms_step, 3),
+                    "algorithmic_gflop": round(step_gflop, 1), "fused_min_gb": round(min_gb, 2),
+                    "achieved_tflops": round(step_gflop / ms_step, 2), "frac_of_mfma_peak": round(step_gflop / ms_step / MFMA_PEAK_TFLOPS[a.dtype], 4),
+                    "achieved_gbs": round(min_gb / ms_step * 1e3, 1), "frac_of_hbm_peak": round(min_gb / ms_step * 1e3 / HBM_PEAK_GBS, 4),
+                    "measured_hbm_gb": round(meas_bytes / 1e9, 2) if meas_bytes else None,
+                    "measured_vs_fused_min": round(meas_bytes / 1e9 / min_gb, 2) if meas_bytes else None,
+                }
+            line["roofline"] = roof
+        if train and a.dtype == "bf16" and a.config == "c1p" and world == 1 and not a.no_f32:
+            # the same step on the f32 parity path (every kernel within 1e-3 of the reference, tests/): a throughput at the
+            # north-star tolerance next to the bf16 headline
+            del step
+            model32, _ = build_model(cfg, B, torch.float32, dev)
+            model32.train()
+            with torch.no_grad():
+                model32.train_step(image, audio, label)
+                st32 = model32.capture_train_step(image, audio, label)
+                for _ in range(2):
+                    st32()
+                torch.cuda.synchronize()
+                t32 = time.perf_counter()
+                for _ in range(5):
+                    st32()
+                torch.cuda.synchronize()
+                ms32 = (time.perf_counter() - t32) / 5 * 1e3
+            line["f32_parity_path"] = {"value": round(B / ms32 * 1e3, 2), "unit": "frames/s", "ms_per_step": round(ms32, 3), "steps": 5,
+                                       "dtype": "f32", "note": "same training step, exact-f32 MFMA kernels (logits within 1e-3 of the reference)"}
         if world == 1 and not a.no_cpu_baseline:
             if a.config == "c1p":
                 line["cpu_baseline"] = (cpu_baseline_train(sd, cfg, max(2, a.cpu_sample_batch // 2)) if train

@@ -295,12 +295,17 @@ class CAVP(nn.Module):
             self.latent_dim = 112
             self.backbone = pvt_v2_b5()
             ckpt_path = "../ckpts/pretrained/pvt_v2_b5.pth"   # the reference torch.load()s this path unconditionally
-            import os
             if os.path.exists(ckpt_path):
                 ckpt = torch.load(ckpt_path, map_location="cpu")
                 ckpt.pop("head.weight", None)
                 ckpt.pop("head.bias", None)
                 self.backbone.load_state_dict(ckpt)
+            elif not getattr(args, "allow_random_pvt", False):
+                # the reference fails here (cavp_model.py:109 torch.load of a missing file); a silently random backbone is
+                # worse than either, so say it loudly unless the caller opted in (args.allow_random_pvt = True)
+                import warnings
+                warnings.warn(f"PVTv2-B5 checkpoint {ckpt_path!r} not found: the visual backbone keeps its RANDOM "
+                              f"initialisation (set args.allow_random_pvt = True to silence this)", RuntimeWarning, stacklevel=2)
             self.segment = DeepLabV3Plus(num_classes=num_classes, aspp_in_plane=512, aspp_out_plane=64)
         elif seg_model in ("HRNet", "OCR"):
             raise NotImplementedError(f"seg_model={seg_model!r}: alternate backbones outside the north-star scope "
@@ -338,7 +343,15 @@ class CAVP(nn.Module):
     def _signature(self):
         ps = list(self.parameters()) + list(self.buffers())
         return (self.compute_dtype, ps[0].device, ps[0].data_ptr(), sum(p._version for p in ps),
+                getattr(self, "_param_epoch", 0),
                 any(m.training for m in self.modules() if isinstance(m, nn.modules.batchnorm._BatchNorm)))
+
+    def params_changed(self) -> None:
+        """Invalidate the eval-mode parameter pack (packed weights + folded BatchNorm).  Tensor `_version`s catch torch-side
+        updates; writes made by our own kernels through raw pointers - FusedSGDAdam.step, the running-statistics updates of
+        a training step, hipGraph replays of either - bump no version, so every such writer calls this."""
+        self._param_epoch = getattr(self, "_param_epoch", 0) + 1
+        self._packed = None
 
     # -- parameter packing --------------------------------------------------------------------------------------
     def _fold(self, bn, lo=None, hi=None):
@@ -417,9 +430,8 @@ class CAVP(nn.Module):
         sig = self._signature()
         if self._packed is None or sig != self._packed_sig:
             if sig[-1]:
-                raise NotImplementedError(
-                    "BatchNorm in training mode (batch statistics) is not built on the HIP path yet; call "
-                    ".eval() (parity target = eval-mode BN, SURVEY.md §7)")
+                raise CavpError("the eval-mode (folded BatchNorm) parameter pack was requested while a BatchNorm module is in "
+                                "training mode; batch-statistics BatchNorm runs through forward_train / train_step")
             self._packed, self._packed_sig = self._pack(), sig
         return self._packed
 
@@ -552,7 +564,7 @@ class CAVP(nn.Module):
             return t
         return ops.cast(t.contiguous(), torch.empty(t.shape, dtype=torch.float32, device=t.device))
 
-    def _forward_hip(self, image, audio, duplicate_visual: bool, taps: Optional[dict] = None):
+    def _forward_hip(self, image, audio, duplicate_visual: bool, taps: Optional[dict] = None, shuffle=None):
         if not image.is_cuda:
             raise CavpError("CAVP (MI355X path) needs inputs on a HIP device: there is no CPU fallback")
         if image.dtype != torch.float32 or audio.dtype != torch.float32:
@@ -569,10 +581,13 @@ class CAVP(nn.Module):
         fea_v, aspp = self._forward_feature_hip(feats, P)
         if duplicate_visual:  # forward_train: torch.cat((fea_v, fea_v.clone())) (cavp_model.py:181)
             fea_v = fea_v.repeat(2, 1, 1, 1)
-        if audio.shape[0] != fea_v.shape[0]:
-            raise CavpError(f"audio batch {audio.shape[0]} != visual batch {fea_v.shape[0]} "
-                            f"(train mode expects audio of 2B, cavp_model.py:181)")
         fea_a = self._audio_hip(audio, P)
+        if shuffle is not None:   # forward_audio (cavp_model.py:156-173): B clips -> features | shuffled features
+            idx = self._bank_and_shuffle(fea_a, shuffle[0], shuffle[1])
+            fea_a = torch.cat((fea_a, fea_a.index_select(0, idx)), dim=0)
+        if fea_a.shape[0] != fea_v.shape[0]:
+            raise CavpError(f"audio batch {fea_a.shape[0]} != visual batch {fea_v.shape[0]} "
+                            f"(train mode expects audio of 2B, cavp_model.py:181)")
         fusion, fea_v_proj, attn = self._fusion_hip(fea_v, fea_a, P)
         out_pred, lo = self._cls_hip(fusion, P, input_shape)
         if taps is not None:
@@ -587,17 +602,81 @@ class CAVP(nn.Module):
         return out_pred, out_fusion, pack
 
     # -- reference API ------------------------------------------------------------------------------------------
+    def _stage_guard(self, what):
+        if any(m.training for m in self.modules() if isinstance(m, nn.modules.batchnorm._BatchNorm)):
+            raise CavpError(f"{what} is a forward-only stage entry point (eval-mode BatchNorm); in training mode call the "
+                            f"model itself: forward_train runs all stages as one fused pass with a hand-written backward")
+
+    @staticmethod
+    def _nchw_to_nhwc(t, dtype):
+        """A caller's NCHW tensor as a dense NHWC tensor of the compute dtype (a channels_last tensor - what this model
+        returns - is re-viewed, anything else goes through one layout pass of the boundary)."""
+        v = t.permute(0, 2, 3, 1)
+        if not v.is_contiguous():
+            v = v.contiguous()
+        if v.dtype != dtype:
+            v = ops.cast(v, torch.empty(v.shape, dtype=dtype, device=v.device))
+        return v
+
+    def forward_cls(self, out, input_shape):
+        """cavp_model.py:138-141: decoder head (two 3x3 conv + BN + ReLU, 1x1 classifier) + bilinear x4 (align_corners=False).
+        `out`: fused features [B, 304, h, w] (NCHW-shaped, any memory layout) -> logits [B, C, *input_shape] f32."""
+        self._stage_guard("forward_cls")
+        with torch.no_grad():
+            x = self._nchw_to_nhwc(out, self.compute_dtype)
+            pred, _ = self._cls_hip(x, self.packed(), tuple(input_shape))
+        return pred
+
+    def forward_fusion(self, visual, fea_a):
+        """cavp_model.py:143-154: projector MLP + sigmoid cross-modal attention.  visual [B, 304, h, w], fea_a [B, 304] ->
+        (fea_v [B, 304, h, w], {"audio": [B, 304, 1, 1], "visual": projected features, "attn_v": [B, heads, h*w, 1]})."""
+        self._stage_guard("forward_fusion")
+        with torch.no_grad():
+            v = self._nchw_to_nhwc(visual, self.compute_dtype)
+            a = fea_a.reshape(fea_a.shape[0], -1).contiguous()
+            if a.dtype != self.compute_dtype:
+                a = ops.cast(a, torch.empty(a.shape, dtype=self.compute_dtype, device=a.device))
+            fusion, fea_v_proj, attn = self._fusion_hip(v, a, self.packed())
+        return (self._as_f32(fusion).permute(0, 3, 1, 2),
+                {"audio": self._as_f32(a)[:, :, None, None], "visual": self._as_f32(fea_v_proj).permute(0, 3, 1, 2),
+                 "attn_v": attn.unsqueeze(-1)})
+
+    def _bank_and_shuffle(self, fea_a, shuffle_info, ow_flag):
+        """Host half of forward_audio (cavp_model.py:160-173): SoundBank bookkeeping on the detached features and the shuffle
+        index the second half of the batch is gathered with."""
+        shuffle_idx = shuffle_info["shuffle_idx"]
+        if ow_flag:
+            f32 = self._as_f32(fea_a.detach())
+            # (the overwritten copy is discarded by the reference too: `shuffle_fea_a` is re-assigned from fea_a right after)
+            self.memory.overwrite_audio_feature(f32.clone()[shuffle_idx], f32, shuffle_info["mod_idx_map"])
+            self.memory.update_bank(f32, shuffle_info["image_label"])
+        return torch.as_tensor(shuffle_idx, device=fea_a.device).long()
+
+    def forward_audio(self, audio, shuffle_info=None, ow_flag=False):
+        """cavp_model.py:156-173: audio features of the B clips followed by the same features in shuffled order ([2B, 304]);
+        with ow_flag the SoundBank is updated from the image labels.  Forward-only here; inside forward_train(audio_func=True)
+        the gather is part of the training pass and carries gradients."""
+        self._stage_guard("forward_audio")
+        with torch.no_grad():
+            a = audio.contiguous()
+            fea_a = self._audio_hip(a, self.packed())
+            idx = self._bank_and_shuffle(fea_a, shuffle_info, ow_flag)
+            return self._as_f32(torch.cat((fea_a, fea_a.index_select(0, idx)), dim=0))
+
     def forward_inference(self, image, audio=None):
         return self._forward_hip(image, audio, duplicate_visual=False)
 
     def forward_train(self, image, audio=None, shuffle_info=None, ow_flag=False, audio_func=False):
-        if audio_func:
-            raise NotImplementedError("audio_func=True (forward_audio / SoundBank path) is dead under every reference "
-                                      "trainer (SURVEY.md §8a row a11) and not built on the HIP path")
+        """cavp_model.py:175-188.  audio_func=False (every reference trainer): `audio` holds 2B clips (matched | shuffled).
+        audio_func=True: `audio` holds B clips and `shuffle_info` = {"shuffle_idx", "mod_idx_map", "image_label"}; the
+        second half of the audio features is the first half gathered by shuffle_idx (forward_audio)."""
+        if audio_func and shuffle_info is None:
+            raise CavpError("audio_func=True needs shuffle_info (cavp_model.py:160-162 indexes it)")
+        shuffle = (shuffle_info, ow_flag) if audio_func else None
         bn_train = any(m.training for m in self.modules() if isinstance(m, nn.modules.batchnorm._BatchNorm))
         want_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
         if not bn_train and not want_grad:
-            return self._forward_hip(image, audio, duplicate_visual=True)   # frozen-BN, forward only
+            return self._forward_hip(image, audio, duplicate_visual=True, shuffle=shuffle)   # frozen-BN, forward only
         if self.seg_model != "DeepLabV3Plus":
             raise NotImplementedError("the training pass is built for the ResNet-50 path; PVTv2 runs forward-only so far")
         if not bn_train:
@@ -607,8 +686,14 @@ class CAVP(nn.Module):
             raise CavpError("CAVP (MI355X path) needs inputs on a HIP device: there is no CPU fallback")
         from .train import CAVPTrainFunction
         params = [p for p in self.parameters() if p.requires_grad] if want_grad else []
+        self._train_shuffle = shuffle
         out_pred, out_fusion, visual, audio_f, attn_v = CAVPTrainFunction.apply(self, image, audio, *params)
         return out_pred, out_fusion, {"audio": audio_f, "visual": visual, "attn_v": attn_v}
+
+    def params_without_grad(self):
+        """Parameters the forward never touches (present in checkpoints only): torch leaves their .grad None."""
+        ps = [self.cross_att.pos_embed_v, self.cross_att.pos_embed_a]
+        return ps + list(self.audio_backbone.cls_head.parameters())
 
     def _late_grad_ids(self):
         """Parameters whose gradients the backward finishes last (see GradArena): backbone, ASPP, low-level reduce."""
@@ -670,6 +755,7 @@ class CAVP(nn.Module):
             for p in arena.params:
                 p.grad = arena.views[id(p)] if id(p) in tp.touched else None   # untouched = None, as torch would leave it
         self._last_outputs = (out_pred, fusion, attn)
+        self.params_changed()   # running_mean / running_var were updated in place by the BatchNorm kernels
         return loss
 
     def capture_train_step(self, image, audio, label, ignore_index: int = 255, loss_scale: float = 1.0,
@@ -718,6 +804,7 @@ class CAVP(nn.Module):
         arena = self._grad_arena
 
         def replay():
+            self.params_changed()   # the graph updates the running statistics (and is usually followed by an optimiser step)
             graphs[0].replay()
             if len(graphs) == 2:
                 work = allreduce_arena_early(arena)
@@ -726,7 +813,9 @@ class CAVP(nn.Module):
             elif world > 1:
                 allreduce_arena_late(arena, None)
             return loss
-        self._train_graph = graphs   # keep alive
+        # keep alive: the graphs, and every scratch buffer whose address they baked in (ops.workspace never frees a buffer it
+        # has handed out, see there)
+        self._train_graph = graphs
         return replay
 
     def forward(self, image, audio=None, shuffle_info=None, ow_flag=False, eval_mode=False, audio_func=False):

@@ -822,6 +822,7 @@ __global__ __launch_bounds__(256) void ce_fwd_kernel(const float* __restrict__ l
   for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
     const long long lb = label[i];
     if (lb == ignore) continue;
+    if ((unsigned long long)lb >= (unsigned long long)C) { loss = NAN; continue; }   // torch device-asserts; here the loss is poisoned (no out-of-bounds read)
     const int n = (int)(i / HW);
     const float* p = logits + (size_t)n * C * HW + (i - (long long)n * HW);
     float m = -INFINITY;
@@ -852,7 +853,7 @@ __global__ __launch_bounds__(256) void ce_bwd_kernel(const float* __restrict__ l
     const long long off = (size_t)n * C * HW + (i - (long long)n * HW);
     float* d = dlogits + off;
     const long long lb = n < n_img ? label[i] : (long long)ignore;
-    if (lb == ignore) {
+    if (lb == ignore || (unsigned long long)lb >= (unsigned long long)C) {
       for (int c = 0; c < C; ++c) d[(size_t)c * HW] = 0.f;
       continue;
     }
@@ -881,7 +882,7 @@ __global__ __launch_bounds__(256) void ce_finish_kernel(float* acc, int nparts, 
     const float lt = (red[0] + red[1]) + (red[2] + red[3]), ct = (red[4] + red[5]) + (red[6] + red[7]);
     acc[0] = lt;
     acc[1] = ct;
-    loss[0] = ct > 0.f ? lt / ct : 0.f;
+    loss[0] = lt / ct;   // every label ignored: 0 / 0 = NaN, as torch's CrossEntropyLoss(reduction="mean")
   }
 }
 
@@ -911,6 +912,7 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const T* __restrict__ lo,
   for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
     const long long lb = label[i];
     if (lb == ignore) { lse[i] = 0.f; continue; }
+    if ((unsigned long long)lb >= (unsigned long long)C) { lse[i] = 0.f; loss = NAN; continue; }   // out-of-range label: poisoned loss
     const int wo = (int)(i % Wo);
     const int ho = (int)((i / Wo) % Ho);
     const int n = (int)(i / HW);
@@ -975,7 +977,8 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const T* __restrict__ lo,
     src_index_t(ho, Hi, Ho, align, h0, h1, lh);
     src_index_t(wo, Wi, Wo, align, w0, w1, lw);
     const float v = bilerp<T>(img, Wi, ld, c, h0, h1, w0, w1, lh, lw);
-    resid[(ho - rh0) * RW + (wo - rw0)] = lb == ignore ? 0.f : expf(v - l) - (c == lb ? 1.f : 0.f);
+    resid[(ho - rh0) * RW + (wo - rw0)] =
+        (lb == ignore || (unsigned long long)lb >= (unsigned long long)C) ? 0.f : expf(v - l) - (c == lb ? 1.f : 0.f);
   }
   __syncthreads();
   const int ly = threadIdx.x / tw, lx = threadIdx.x % tw;

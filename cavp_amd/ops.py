@@ -17,6 +17,7 @@ _TORCH_DTYPE = {F32: torch.float32, BF16: torch.bfloat16}
 _CODE = {torch.float32: F32, torch.bfloat16: BF16}
 
 _workspace = {}
+_retired = []   # outgrown workspaces: never freed, because a captured hipGraph may have baked their address in
 
 
 def torch_dtype(code: int) -> torch.dtype:
@@ -67,7 +68,10 @@ def _nhwc(t: torch.Tensor) -> Tuple[int, int, int, int, int]:
 
 
 def workspace(nbytes: int, device) -> Optional[torch.Tensor]:
-    """Grow-only scratch buffer per device (split-K slabs).  Must not grow while a graph is being captured."""
+    """Grow-only scratch buffer per device (split-K slabs).  Must not grow while a graph is being captured.  A buffer that
+    is outgrown later (say validation at another resolution after capture_train_step) is RETIRED, not freed: graphs captured
+    earlier keep replaying into the address they recorded, and the caching allocator must never hand that memory to anyone
+    else.  Sizes at least double, so the retired buffers sum to less than the live one."""
     if nbytes <= 0:
         return None
     key = torch.device(device).index or 0
@@ -75,7 +79,9 @@ def workspace(nbytes: int, device) -> Optional[torch.Tensor]:
     if ws is None or ws.numel() < nbytes:
         if torch.cuda.is_current_stream_capturing():
             raise _lib.CavpError("workspace would grow during hipGraph capture; run one eager warm-up pass first")
-        ws = torch.empty(max(nbytes, 64 << 20), dtype=torch.uint8, device=device)
+        if ws is not None:
+            _retired.append(ws)
+        ws = torch.empty(max(nbytes, 64 << 20, 2 * (ws.numel() if ws is not None else 0)), dtype=torch.uint8, device=device)
         _workspace[key] = ws
     return ws
 

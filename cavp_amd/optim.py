@@ -93,6 +93,8 @@ class FusedSGDAdam:
                  use_baseline: bool = False, betas=(0.9, 0.999), eps: float = 1e-8):
         self.base_lr, self.momentum, self.betas, self.eps = float(lr), float(momentum), betas, float(eps)
         self.steps = 0
+        import weakref
+        self._model = weakref.ref(model) if hasattr(model, "params_changed") else (lambda: None)
         dev = arena.flat.device
         specs = []   # (param, kind, lr_mult, wd)
         for g in set_group_lr(model, 1.0, use_baseline):
@@ -105,7 +107,10 @@ class FusedSGDAdam:
             if id(p) in seen:
                 raise _lib.CavpError("FusedSGDAdam: a parameter appears in two groups")
             seen.add(id(p))
-        specs = [s for s in specs if s[0].requires_grad and id(s[0]) in arena.views]
+        # torch.optim skips parameters whose .grad is None: cross_att.pos_embed_v / pos_embed_a and audio_backbone.cls_head never
+        # receive a gradient on this path (cavp_model.py / attn.py:235-238), so they get neither weight decay nor momentum
+        never = {id(p) for p in getattr(model, "params_without_grad", lambda: [])()}
+        specs = [s for s in specs if s[0].requires_grad and id(s[0]) in arena.views and id(s[0]) not in never]
         # state: one flat buffer for momentum / first moments, one for Adam's second moments
         offs, tot = [], 0
         for p, *_ in specs:
@@ -134,6 +139,8 @@ class FusedSGDAdam:
 
     def step(self, lr: float) -> None:
         self.steps += 1
+        if self._model() is not None:
+            self._model().params_changed()   # weights change through raw pointers: no tensor version is bumped
         b1, b2 = self.betas
         st = _lib.load().cavp_optimizer_step(_ptr(self.table), self.njobs, self.total_blocks, C.c_float(lr),
                                              C.c_float(self.base_lr), C.c_float(self.momentum), C.c_float(b1),

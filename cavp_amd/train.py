@@ -577,6 +577,23 @@ class TrainPass:
         self.tape.append(bwd)
         return y
 
+    def gather_cat(self, x: V, idx: torch.Tensor) -> V:
+        """torch.cat((x, x[idx])) over rows (forward_audio, cavp_model.py:171-173); backward: dx = g[:B] + scatter-add of
+        g[B:] by idx, accumulated row by row with the add kernel (B rows of 304 values, once per step)."""
+        n = x.t.shape[0]
+        y = V(torch.cat((x.t, x.t.index_select(0, idx)), dim=0))
+        rows = [int(i) for i in idx.tolist()]
+
+        def bwd():
+            if y.g is None:
+                return
+            g = y.g[:n].clone()
+            for j, i in enumerate(rows):
+                T.add(g[i], y.g[n + j].contiguous(), g[i])
+            self.acc_add(x, g)
+        self.tape.append(bwd)
+        return y
+
     def flatten(self, x: V) -> V:
         """[B, H, W, C] -> [B, H*W*C] view (VGG NHWC flatten)."""
         y = V(x.t.reshape(x.t.shape[0], -1))
@@ -616,7 +633,7 @@ class TrainPass:
 # ---------------------------------------------------------------------------------------------------------------
 # the model graph in training mode
 # ---------------------------------------------------------------------------------------------------------------
-def run_train_forward(model, image: torch.Tensor, audio: torch.Tensor, tp: TrainPass):
+def run_train_forward(model, image: torch.Tensor, audio: torch.Tensor, tp: TrainPass, shuffle=None):
     """Mirrors CAVP._forward_hip (eval) op by op with batch-statistics BN and a backward tape.  Returns the V's of
     (logits_lowres, fusion NHWC, fea_v_proj NHWC, fea_a, attn)."""
     from .cavp_model import VGG
@@ -702,8 +719,9 @@ def run_train_forward(model, image: torch.Tensor, audio: torch.Tensor, tp: Train
     tp.bn_act(tp.conv(f1, "reduce", stats=True), m.segment.reduce[1], ACT_RELU, out=fea_v.slice(co, co + tp.P["reduce"].cout))
     tp.mark_early_grads_final()   # backward: all parameter gradients of the ops below are final when this is reached
     # ---- audio on 2B (cavp_model.py:181-186; vgg.py:17-23) ----
-    if audio.shape[0] != 2 * B:
-        raise CavpError(f"train mode expects audio of 2B = {2 * B} (cavp_model.py:181), got {audio.shape[0]}")
+    if audio.shape[0] != (B if shuffle is not None else 2 * B):
+        raise CavpError(f"train mode expects audio of {'B' if shuffle is not None else '2B'} clips (cavp_model.py:181,160-173), "
+                        f"got {audio.shape[0]} for {B} images")
     a = tp.conv_smallcin(audio, "a.conv0", 1, ACT_RELU)
     ci = 1
     for v in VGG.CFG[1:]:
@@ -716,6 +734,8 @@ def run_train_forward(model, image: torch.Tensor, audio: torch.Tensor, tp: Train
     a = tp.conv(a, "a.fc0", act=ACT_RELU)
     a = tp.conv(a, "a.fc1", act=ACT_RELU)
     fea_a = tp.conv(a, "a.fc2", act=ACT_RELU)
+    if shuffle is not None:   # forward_audio (cavp_model.py:156-173): features | the same features gathered by shuffle_idx
+        fea_a = tp.gather_cat(fea_a, model._bank_and_shuffle(fea_a.t, shuffle[0], shuffle[1]))
     # ---- fusion (cavp_model.py:143-154; attn.py:232-244) ----
     # The reference duplicates the visual features to 2B first (`torch.cat((fea_v, fea_v.clone()))`, cavp_model.py:181)
     # and runs projector / patch_embed_v / norm1 / q on both identical halves.  Those four GEMMs + LN depend only on
@@ -765,7 +785,9 @@ class CAVPTrainFunction(torch.autograd.Function):
     def forward(ctx, model, image, audio, *params):
         tp = TrainPass(model, model.compute_dtype)
         with torch.no_grad():
-            lo, fusion, fea_v_proj, fea_a, attn = run_train_forward(model, image.contiguous(), audio.contiguous(), tp)
+            lo, fusion, fea_v_proj, fea_a, attn = run_train_forward(model, image.contiguous(), audio.contiguous(), tp,
+                                                                    shuffle=getattr(model, "_train_shuffle", None))
+            model._train_shuffle = None
             B2, C = lo.t.shape[0], model.num_classes
             out_pred = torch.empty((B2, C) + tuple(image.shape[-2:]), dtype=torch.float32, device=image.device)
             ops.bilinear_to_nchw(lo.t[..., :C], out_pred, align_corners=False)
@@ -799,5 +821,6 @@ class CAVPTrainFunction(torch.autograd.Function):
             g = tp.grads.get(id(p))
             grads.append(None if g is None else g.view(p.shape))
         ctx.model_ref._last_train_pass = tp if getattr(ctx.model_ref, '_keep_train_pass', False) else None
+        ctx.model_ref.params_changed()   # the forward updated running_mean / running_var through raw pointers
         ctx.tp = None
         return (None, None, None) + tuple(grads)

@@ -1,0 +1,135 @@
+"""The drop-in boundary exercised the way the reference's trainer / evaluation scripts use it, through
+the shipped `models.cavp_model` import path: the train-mode call `model(image, audio[2B], None, ow_flag)` followed by
+`out[:B] + out[B:] * 0` -> CrossEntropyLoss -> backward -> the two optimisers (trainer_cavp_vpo_mono.py:166-193), the eval
+call `model(image, audio, eval_mode=True)` (:272), the stage methods forward_fusion / forward_cls / forward_audio
+(cavp_model.py:138-173) and the `audio_func=True` variant of forward_train."""
+import types
+
+import pytest
+import torch
+
+from cavp_amd.synth import synth_inputs, synth_state_dict
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+CFG = dict(C=3, B=2, hw=(64, 64), lds=[False, False, False])
+
+
+def _model(train=False):
+    from models.cavp_model import CAVP   # the reference's import path
+    a = types.SimpleNamespace(seg_model="DeepLabV3Plus", last_three_dilation_stride=CFG["lds"], audio_backbone="vgg",
+                              num_classes=CFG["C"], batch_size=CFG["B"], local_rank=DEV)
+    m = CAVP(50, None, num_classes=CFG["C"], audio_backbone_pretrain_path=None, visual_backbone=50, args=a)
+    sd = synth_state_dict({k: tuple(v.shape) for k, v in m.state_dict().items()}, seed=1)
+    m.load_state_dict(sd, strict=True)
+    m.to(DEV)
+    m.train(train)
+    return m, sd
+
+
+def test_stage_methods_compose_to_the_forward():
+    """forward_cls(forward_fusion(fea_v, fea_a)) == forward(eval_mode=True); each stage vs the CPU oracle's stage."""
+    from oracle import cavp_oracle as O
+    m, sd = _model()
+    image, audio, _ = synth_inputs(CFG["B"], CFG["hw"], num_classes=CFG["C"], seed=5)
+    taps = {}
+    with torch.no_grad():
+        out, fus, pack = m._forward_hip(image.to(DEV), audio.to(DEV), duplicate_visual=False, taps=taps)
+        fus2, pack2 = m.forward_fusion(taps["fea_v"], taps["fea_a"])
+        out2 = m.forward_cls(fus2, image.shape[-2:])
+        # a plain contiguous NCHW tensor (what a foreign caller would hand over) takes the layout pass of the boundary
+        out3 = m.forward_cls(fus2.contiguous(), image.shape[-2:])
+    assert torch.equal(fus2, fus) and torch.equal(out2, out) and torch.equal(out3, out)
+    assert torch.equal(pack2["visual"], pack["visual"]) and torch.equal(pack2["attn_v"], pack["attn_v"])
+    feats = O.backbone_forward(image, sd, CFG["lds"])
+    fea_v = O.forward_feature(feats, sd)
+    fea_a = O.audio_forward(audio, sd)
+    rf, rp = O.forward_fusion(fea_v, fea_a, sd)
+    ro = O.forward_cls(rf, sd, image.shape[-2:])
+    assert float((fus2.cpu() - rf).abs().max()) <= 1e-3 and float((out2.cpu() - ro).abs().max()) <= 1e-3
+    assert pack2["audio"].shape == rp["audio"].shape == (CFG["B"], 304, 1, 1)
+
+
+def test_forward_audio_and_audio_func_path():
+    """forward_audio: [features | features[shuffle_idx]] + SoundBank update under ow_flag; forward_train(audio_func=True) on B
+    clips == forward_train on the explicitly concatenated 2B clips (forward and every parameter gradient)."""
+    m, sd = _model()
+    B = CFG["B"]
+    image, audio, label = synth_inputs(B, CFG["hw"], audio_batch=B, num_classes=CFG["C"], seed=6)
+    image, audio, label = image.to(DEV), audio.to(DEV), label.to(DEV)
+    idx = torch.tensor([1, 0], device=DEV)
+    img_label = torch.tensor([[1, 1, 0], [1, 0, 1]], device=DEV)   # column 0 = background (zeroed by update_bank)
+    info = {"shuffle_idx": idx, "mod_idx_map": {0: 2}, "image_label": img_label}
+    bank0 = m.memory.bank_vault.clone()
+    with torch.no_grad():
+        fa = m.forward_audio(audio, info, ow_flag=True)
+    assert fa.shape == (2 * B, 304) and torch.equal(fa[B:], fa[:B][idx])
+    assert not torch.equal(m.memory.bank_vault, bank0), "ow_flag=True must queue the single-class clips into the SoundBank"
+    assert torch.equal(m.memory.bank_vault[1][-1], fa[0]) and torch.equal(m.memory.bank_vault[2][-1], fa[1])
+
+    m.train()
+    crit = torch.nn.CrossEntropyLoss(ignore_index=255)
+
+    def step(**kw):
+        m.zero_grad(set_to_none=True)
+        for mod in m.modules():   # same running statistics for both calls
+            if isinstance(mod, torch.nn.modules.batchnorm._BatchNorm):
+                mod.load_state_dict({k[len(mod._pfx):]: v.to(DEV) for k, v in sd.items() if k.startswith(mod._pfx)}, strict=False)
+        out, fus, pack = m(image, **kw)
+        loss = crit(out[:B] + out[B:] * 0.0, label)
+        loss.backward()
+        return out.detach().clone(), {k: p.grad.detach().clone() for k, p in m.named_parameters() if p.grad is not None}
+    for name, mod in m.named_modules():
+        mod._pfx = name + "."
+    o1, g1 = step(audio=audio, shuffle_info=info, ow_flag=False, audio_func=True)
+    o2, g2 = step(audio=torch.cat((audio, audio[idx])), shuffle_info=None, ow_flag=False)
+    assert o1.shape == (2 * B, CFG["C"]) + CFG["hw"]
+    # (B = 2 batch-statistics BatchNorm amplifies the different summation order of the audio encoder's GEMMs: M = B vs 2B rows)
+    assert float((o1 - o2).abs().max()) <= 5e-3 * max(1.0, float(o2.abs().max()))
+    assert g1.keys() == g2.keys()
+    for k in g1:
+        a, b = g1[k].double().flatten(), g2[k].double().flatten()
+        if float(b.norm()) == 0.0:
+            continue
+        # the audio encoder sees every clip once (B) instead of twice (2B): same gradient, different summation order
+        # Two runs of the SAME step already differ by a few % of the gradient norm at the far end of the backward (f32 atomics in
+        # the reductions, amplified through 50 batch-statistics BatchNorm layers at B = 2: DESIGN.md 6c), so the backbone gets a
+        # direction check and everything the audio path feeds directly (audio encoder, attention, head) a tight one
+        rel, cos = float((a - b).norm() / b.norm()), float((a @ b) / (a.norm() * b.norm()))
+        if k.startswith("backbone.") or k.startswith("segment.aspp") or k.startswith("segment.reduce"):
+            assert rel <= 0.25 and cos >= 0.97, (k, rel, cos)
+        else:
+            assert rel <= 6e-2 and cos >= 0.998, (k, rel, cos)
+
+
+def test_trainer_call_sequence():
+    """trainer_cavp_vpo_mono.py:166-193 with the reference's own optimiser grouping (main_vpo_mono.py:45-65,118-125), then the
+    validation call (:272) - twice, so that a stale packed-weight cache would show."""
+    from cavp_amd.optim import set_group_lr
+    m, _ = _model(train=True)
+    B = CFG["B"]
+    image, audio, label = synth_inputs(B, CFG["hw"], audio_batch=2 * B, num_classes=CFG["C"], seed=7)
+    image, audio, label = image.to(DEV), audio.to(DEV), label.to(DEV)
+    opt_v = torch.optim.SGD(set_group_lr(m, 1e-3), lr=1e-3, momentum=0.9, weight_decay=1e-4)
+    opt_a = torch.optim.Adam(m.audio_backbone.parameters(), lr=1e-4)
+    crit = torch.nn.CrossEntropyLoss(ignore_index=255)
+    losses = []
+    for it in range(2):
+        opt_v.zero_grad()
+        opt_a.zero_grad()
+        output_cat, ctr_feature_cat, pack_ = m(image, audio, None, False)
+        output = output_cat[:B] + output_cat[B:] * 0.0
+        assert ctr_feature_cat[:B].shape[0] == ctr_feature_cat[B:].shape[0]
+        loss = crit(output, label)
+        loss.backward()
+        opt_v.step()
+        opt_a.step()
+        losses.append(float(loss))
+        m.eval()
+        with torch.no_grad():
+            ev, _, _ = m(image, audio[:B], eval_mode=True)
+        m.train()
+        if it == 0:
+            ev0 = ev.clone()
+    assert all(torch.isfinite(torch.tensor(losses)))
+    assert not torch.equal(ev, ev0), "the second validation pass must see the updated weights / running statistics"

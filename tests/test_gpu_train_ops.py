@@ -307,9 +307,21 @@ def test_fused_upsample_ce_head(C, ld, hw, HW, dt):
     # loss only
     l2, none = T.upsample_ce_head(x, label.to(DEV), B, C, 255, want_grad=False)
     assert none is None and float(l2.item()) == float(l.item())
-    # everything ignored: loss 0, zero gradient (the three-op path's convention; torch returns nan)
+    # everything ignored: loss nan (0 / 0, torch's CrossEntropyLoss(reduction="mean") convention), zero gradient
     l0, d0 = T.upsample_ce_head(x, torch.full_like(label, 255).to(DEV), B, C, 255)
-    assert float(l0.item()) == 0.0 and float(d0.abs().max()) == 0.0
+    assert torch.isnan(l0).all() and float(d0.abs().max()) == 0.0
+    l0b, d0b = T.ce_loss(outp, torch.full_like(label, 255).to(DEV), B, 255)
+    assert torch.isnan(l0b).all() and float(d0b.abs().max()) == 0.0
+    # a label outside [0, C) that is not the ignore value (torch device-asserts): no out-of-bounds read, the loss is poisoned
+    # with nan and the offending pixels get no gradient
+    bad = label.clone()
+    bad[0, 0, :3] = C + 5
+    bad[0, 1, 0] = -7
+    lb1, db1 = T.upsample_ce_head(x, bad.to(DEV), B, C, 255)
+    lb2, db2 = T.ce_loss(outp, bad.to(DEV), B, 255)
+    assert torch.isnan(lb1).all() and torch.isnan(lb2).all()
+    assert torch.isfinite(db1.float()).all() and torch.isfinite(db2).all()
+    assert float(db2[0, :, 0, :3].abs().max()) == 0.0 and float(db2[0, :, 1, 0].abs().max()) == 0.0
 
 
 @pytest.mark.parametrize("dt", DTYPES, ids=IDS)

@@ -123,3 +123,34 @@ def test_load_reference_checkpoint_strips_module_prefix(tmp_path):
         assert torch.equal(got[k], sd[k])
     res2 = load_reference_checkpoint(m, {"module.module." + k: v for k, v in sd.items()}, strict=True)   # DDP over DataParallel
     assert not res2.missing_keys and not res2.unexpected_keys
+
+
+def test_reference_import_paths_and_signatures():
+    """the trainers do `from models.cavp_model import CAVP` (main_vpo_mono.py:98) and import SoundBank
+    (trainer_cavp_vpo_mono.py:29), the AVS trainers `from loss.contrastive_aud import ContrastLoss`.  The shipped shim packages
+    must resolve to the MI355X classes, and the method signatures must be the reference's (cavp_model.py:70-79,138,143,156,
+    175,190,199-201; contrastive_aud.py:9,144)."""
+    import inspect
+
+    import loss.contrastive_aud as LC
+    import models.cavp_model as MC
+    from cavp_amd import cavp_model as impl
+    from cavp_amd.contrast import ContrastLoss
+    assert MC.CAVP is impl.CAVP and MC.SoundBank is impl.SoundBank and LC.ContrastLoss is ContrastLoss
+
+    def params(fn):
+        return [(p.name, p.default) for p in list(inspect.signature(fn).parameters.values())[1:]]
+    E = inspect.Parameter.empty
+    assert params(MC.CAVP.__init__) == [("backbone", E), ("pretrain_path", E), ("num_classes", 2), ("ignore_index", 255),
+                                        ("audio_backbone_pretrain_path", None), ("visual_backbone", 50), ("args", None),
+                                        ("in_plane", 1)]
+    assert params(MC.CAVP.forward) == [("image", E), ("audio", None), ("shuffle_info", None), ("ow_flag", False),
+                                       ("eval_mode", False), ("audio_func", False)]
+    assert params(MC.CAVP.forward_train) == [("image", E), ("audio", None), ("shuffle_info", None), ("ow_flag", False),
+                                             ("audio_func", False)]
+    assert params(MC.CAVP.forward_inference) == [("image", E), ("audio", None)]
+    assert params(MC.CAVP.forward_cls) == [("out", E), ("input_shape", E)]
+    assert params(MC.CAVP.forward_fusion) == [("visual", E), ("fea_a", E)]
+    assert params(MC.CAVP.forward_audio) == [("audio", E), ("shuffle_info", None), ("ow_flag", False)]
+    assert [n for n, _ in params(LC.ContrastLoss.forward)] == ["embeds_match", "gt_match", "embeds_shuffle", "gt_shuffle"]
+    assert [n for n, _ in params(LC.ContrastLoss.__init__)][:3] == ["temperature", "ignore_idx", "max_views"]

@@ -6,8 +6,8 @@ cd $GRAFT_REPO_ROOT
 for r in 1 2 3; do
   for v in A B; do
     cp cavp_amd/lib_$v.so.bin cavp_amd/libcavp_hip.so
-    t=$(python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-roofline "$@" 2>/dev/null | python -c "import json,sys; print(json.loads(sys.stdin.read())['ms_per_step'])")
-    e=$(python bench.py --mode eval --steps 20 --warmup 5 --no-cpu-baseline --no-roofline "$@" 2>/dev/null | python -c "import json,sys; print(json.loads(sys.stdin.read())['ms_per_step'])")
+    t=$(python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-roofline --no-f32 "$@" 2>/dev/null | python -c "import json,sys; print(json.loads(sys.stdin.read())['ms_per_step'])")
+    e=$(python bench.py --mode eval --steps 20 --warmup 5 --no-cpu-baseline --no-roofline --no-f32 "$@" 2>/dev/null | python -c "import json,sys; print(json.loads(sys.stdin.read())['ms_per_step'])")
     echo "$v train $t eval $e"
   done
 done

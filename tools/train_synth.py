@@ -78,7 +78,9 @@ def main():
         loss = model.train_step(image, audio, label)
         if opt is None:
             opt = FusedSGDAdam(model, model._grad_arena, a.lr, momentum=a.momentum, weight_decay=a.weight_decay)
-        opt.step(sched(it))
+        # the reference sets the learning rate AFTER the optimiser step (trainer_cavp_vpo_mono.py:193-203): step `it` runs with
+        # the rate computed at the end of step it - 1 (the configured start rate for the first one)
+        opt.step(sched(it - 1) if it > 0 else a.lr)
         if it == 1:                                             # skip the first two (allocation / warm-up) steps
             torch.cuda.synchronize()
             t0 = time.time()
