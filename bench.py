@@ -65,7 +65,7 @@ def model_cfg(name="c1p"):
 def build_model(cfg, B, dtype, device):
     from cavp_amd.cavp_model import CAVP
     from cavp_amd.synth import synth_state_dict
-    args = types.SimpleNamespace(seg_model=cfg.get("seg_model", "DeepLabV3Plus"), last_three_dilation_stride=cfg["lds"], audio_backbone="vgg",
+    args = types.SimpleNamespace(seg_model=cfg.get("seg_model", "DeepLabV3Plus"), last_three_dilation_stride=cfg["lds"], audio_backbone="vgg", allow_random_pvt=True,
                                  num_classes=cfg["C"], batch_size=B, local_rank="cpu")
     m = CAVP(50, None, num_classes=cfg["C"], audio_backbone_pretrain_path=None, visual_backbone=50, args=args)
     sd = synth_state_dict({k: tuple(v.shape) for k, v in m.state_dict().items()}, seed=1)

@@ -28,9 +28,10 @@ from ._lib import ACT_GELU, ACT_LEAKY, ACT_NONE, ACT_RELU, CavpError
 BN_EPS = 1e-5
 BN_MOMENTUM = 0.1
 # weights of at least this many elements take their first gradient of a step by overwrite (beta = 0) and are left out of the
-# arena memset; A/B knob CAVP_GRAD_OVERWRITE_MIN=0: every weight gradient accumulates onto a zeroed arena
-_GRAD_OVERWRITE_MIN = int(os.environ.get("CAVP_GRAD_OVERWRITE_MIN", str(1 << 19)))
-_FUSED_HEAD = os.environ.get("CAVP_FUSED_HEAD", "1") != "0"   # A/B knob: 0 = upsample, CE, and their backward as separate ops
+# arena memset (0: every weight gradient accumulates onto a zeroed arena).  Module constants, not environment variables: the
+# product path reads no environment; tests / A-B scripts set them on the module.
+_GRAD_OVERWRITE_MIN = 1 << 19
+_FUSED_HEAD = True   # False: upsample, CE, and their backward as separate ops
 
 
 class _Container(nn.Module):

@@ -13,6 +13,22 @@ typedef unsigned short bf16_t;  // raw bfloat16 bits
 
 #define CAVP_WAVE 64
 
+// A/B and profiling knobs exist only in -DCAVP_PROFILE builds (python -m cavp_amd.build --profile; tools/bench_conv.py,
+// tools/ab_bench.sh).  The product library reads no environment variable and carries no profiling branch in a kernel:
+// cavp_knob_* fold to their defaults and CAVP_DBG(p, bit) to `false`.
+#ifdef CAVP_PROFILE
+#include <stdlib.h>
+inline int cavp_knob_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
+inline double cavp_knob_double(const char* name, double dflt) { const char* e = getenv(name); return e ? atof(e) : dflt; }
+inline const char* cavp_knob_str(const char* name) { return getenv(name); }
+#define CAVP_DBG(p, bit) (((p).dbg & (bit)) != 0)
+#else
+inline int cavp_knob_int(const char*, int dflt) { return dflt; }
+inline double cavp_knob_double(const char*, double dflt) { return dflt; }
+inline const char* cavp_knob_str(const char*) { return nullptr; }
+#define CAVP_DBG(p, bit) false
+#endif
+
 __device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float(((unsigned)h) << 16); }
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_hw_t;
 typedef __attribute__((ext_vector_type(2))) float f32x2_hw_t;

@@ -109,8 +109,6 @@ __global__ __launch_bounds__(64 * WC * WP, (WC * WP == 4 ? 2 : 1)) void igemm_ke
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   // persistent workgroups: gridDim.x (a multiple of 8, so a workgroup keeps its XCD) physical workgroups walk the
   // p.nblk logical ones: launch, kernel-argument load and teardown are paid once per physical workgroup
-  if (p.stagger > 0 ? ((blockIdx.x >> 8) & 1) : p.stagger < 0 ? ((blockIdx.x >> 3) & 1) : 0)
-    for (int i = 0; i < (p.stagger < 0 ? -p.stagger : p.stagger); ++i) __builtin_amdgcn_s_sleep(64);
   for (int vb = blockIdx.x; vb < p.nblk; vb += gridDim.x) {
   if (vb != (int)blockIdx.x) __syncthreads();   // the previous tile's epilogue is done with the LDS
   const int sid = xcd_remap(vb, p.nblk);
@@ -272,8 +270,8 @@ __global__ __launch_bounds__(64 * WC * WP, (WC * WP == 4 ? 2 : 1)) void igemm_ke
       for (int it = it_begin; it < it_end; ++it) {
         __builtin_amdgcn_s_waitcnt(vmcnt_imm(0));
         __builtin_amdgcn_s_barrier();
-        if (!(p.dbg & 8)) gdma(buf ^ 1, it + 1 < it_end && !(p.dbg & 1));
-        if (!(p.dbg & 2)) {
+        if (!CAVP_DBG(p, 8)) gdma(buf ^ 1, it + 1 < it_end && !CAVP_DBG(p, 1));
+        if (!CAVP_DBG(p, 2)) {
           u32x4_t af[MC], bfv[MP];
 #pragma unroll
           for (int j = 0; j < 2; ++j) {
@@ -327,16 +325,16 @@ __global__ __launch_bounds__(64 * WC * WP, (WC * WP == 4 ? 2 : 1)) void igemm_ke
       int buf = 0;
       for (int it = 0; it < n; ++it) {
         const int nb = buf == 2 ? 0 : buf + 1;
-        if (!(p.dbg & 4)) read_frag(a1, b1, buf, 1);
+        if (!CAVP_DBG(p, 4)) read_frag(a1, b1, buf, 1);
         __builtin_amdgcn_sched_barrier(0);
-        if (!(p.dbg & 2)) mma_block(a0, b0);
+        if (!CAVP_DBG(p, 2)) mma_block(a0, b0);
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_waitcnt((LD & 15) | ((LD >> 4) << 14) | (7 << 4) | (0 << 8));  // vmcnt(LD) & lgkmcnt(0)
         __builtin_amdgcn_s_barrier();
-        if (!(p.dbg & 8)) gdma(buf, it + 3 < n && !(p.dbg & 1));
-        if (!(p.dbg & 4)) read_frag(a0, b0, nb, 0);
+        if (!CAVP_DBG(p, 8)) gdma(buf, it + 3 < n && !CAVP_DBG(p, 1));
+        if (!CAVP_DBG(p, 4)) read_frag(a0, b0, nb, 0);
         __builtin_amdgcn_sched_barrier(0);
-        if (!(p.dbg & 2)) mma_block(a1, b1);
+        if (!CAVP_DBG(p, 2)) mma_block(a1, b1);
         __builtin_amdgcn_sched_barrier(0);
         buf = nb;
       }
@@ -345,7 +343,7 @@ __global__ __launch_bounds__(64 * WC * WP, (WC * WP == 4 ? 2 : 1)) void igemm_ke
   }
 
   // ---- epilogue ----
-  if (p.dbg & 16) continue;
+  if (CAVP_DBG(p, 16)) continue;
   if (p.coalesced) {
     // Stage the f32 accumulators in LDS as [pixel][cout] (16-byte slots XOR-swizzled by pixel & 7), then let each
     // thread finish VE consecutive channels of one pixel: scale/shift/bias/residual are 16-byte vector loads and the
@@ -431,7 +429,7 @@ __global__ __launch_bounds__(64 * WC * WP, (WC * WP == 4 ? 2 : 1)) void igemm_ke
       for (int b = 0; b < MP; ++b) {
         const int prow = wp0 + b * 16 + lrow;
         const int slot = (wc0 + a * 16) / 4 + lgrp;
-        if (!(p.dbg & 64)) *(f32x4_t*)(st + (size_t)prow * BC + ((slot ^ (prow & SWZ)) << 2)) = acc[a][b];
+        if (!CAVP_DBG(p, 64)) *(f32x4_t*)(st + (size_t)prow * BC + ((slot ^ (prow & SWZ)) << 2)) = acc[a][b];
       }
     __syncthreads();
     if (p.tile_stats && tid < BC && c_base + tid < p.Cout) {  // (BC <= NT for every tile)
@@ -518,7 +516,7 @@ __global__ __launch_bounds__(64 * WC * WP, (WC * WP == 4 ? 2 : 1)) void igemm_ke
 #pragma unroll
           for (int e = 0; e < 4; ++e) o[e] = pack2bf(v[2 * e], v[2 * e + 1]);
         }
-        if (!(p.dbg & 32) || o[0] == 0x12345678u) *(u32x4_t*)(yp + (size_t)k * ystep) = o;
+        if (!CAVP_DBG(p, 32) || o[0] == 0x12345678u) *(u32x4_t*)(yp + (size_t)k * ystep) = o;
       }
     }
     continue;
@@ -602,7 +600,7 @@ inline int tile_wp(int id) { return id == 5 ? 1 : (id == 6 || id == 7 || id == 9
 inline double tile_eff(const TileCfg& t) {
   static double ov[16];
   static const bool have = [] {
-    const char* e = getenv("CAVP_IGEMM_EFF");
+    const char* e = cavp_knob_str("CAVP_IGEMM_EFF");
     if (!e) return false;
     int i = 1;
     for (const char* q = e; *q && i < 16; ++i) {
@@ -631,14 +629,12 @@ hipError_t launch_cfg(const IgemmParams& p, int nblk, hipStream_t s) {
   int bpc = (160 * 1024) / lds;   // resident workgroups per CU (LDS-limited; the 4-wave tiles use <= 128 VGPRs)
   if (bpc > 4) bpc = 4;
   if (bpc < 1) bpc = 1;
-  static const int bpc_cap = getenv("CAVP_IGEMM_BPC") ? atoi(getenv("CAVP_IGEMM_BPC")) : 0;   // A/B knob: resident workgroups per CU
+  static const int bpc_cap = cavp_knob_int("CAVP_IGEMM_BPC", 0);   // A/B knob: resident workgroups per CU
   if (bpc_cap > 0 && bpc > bpc_cap) bpc = bpc_cap;
-  static const bool persistent = !(getenv("CAVP_IGEMM_PERSISTENT") && atoi(getenv("CAVP_IGEMM_PERSISTENT")) == 0);
+  static const bool persistent = cavp_knob_int("CAVP_IGEMM_PERSISTENT", 1) != 0;
   const int grid = (persistent && nblk > bpc * 256) ? bpc * 256 : nblk;
-  static const int stagger = getenv("CAVP_IGEMM_STAGGER") ? atoi(getenv("CAVP_IGEMM_STAGGER")) : 0;
   IgemmParams q = p;
   q.nblk = nblk;
-  q.stagger = grid > 256 ? stagger : 0;
   igemm_kernel<T, BC, BP, WC, WP, UP, NS><<<dim3(grid), dim3(64 * WC * WP), lds, s>>>(q);
   return hipGetLastError();
 }
@@ -749,10 +745,12 @@ Plan make_plan(const cavp_conv_desc* d, bool allow_big = true) {
   // more operand bytes per flop (eff below).  Resident workgroups per CU follow from the tile's LDS footprint.
   int best = -1, best_sk = 1;
   pl.direct_epi = (d->tile / 1000) % 10;
-  p.dbg = (d->tile / 100) % 10 + ((d->tile / 10000) % 10) * 8 + ((d->tile / 100000) % 10) * 16;  // ten-thousands digit: issue no DMA at all  // d->tile = id + 1000 * (direct epilogue): testing / A-B knobs
+  // d->tile = id + 1000 * (direct epilogue: testing) + profiling digits (hundreds, ten- and hundred-thousands: pieces of the
+  // kernel switched off for the K-loop anatomy; honoured by -DCAVP_PROFILE builds only, the product kernels ignore p.dbg)
+  p.dbg = (d->tile / 100) % 10 + ((d->tile / 10000) % 10) * 8 + ((d->tile / 100000) % 10) * 16;
   const int want_tile = d->tile % 100;
   const double peak = d->dtype == CAVP_F32 ? 100e12 : 600e12;
-  static const double slab_bw = getenv("CAVP_IGEMM_SLAB_TBS") ? atof(getenv("CAVP_IGEMM_SLAB_TBS")) * 1e12 : 3e12;   // A/B knob
+  static const double slab_bw = cavp_knob_double("CAVP_IGEMM_SLAB_TBS", 3.0) * 1e12;   // A/B knob
   const int sk_opts[] = {1, 2, 3, 4, 6, 8, 12, 16, 24, 32};
   double best_t = 1e30;
   for (int i = 0; i < kNumTiles; ++i) {
@@ -822,7 +820,7 @@ Plan make_plan(const cavp_conv_desc* d, bool allow_big = true) {
   p.splitk = sk;
   pl.nblk = nwg * sk;
   pl.ws_bytes = sk > 1 ? (size_t)sk * p.M * p.Cout * sizeof(float) : 0;
-  static const bool trace = getenv("CAVP_IGEMM_TRACE") != nullptr;   // debugging: the plan of every make_plan call
+  static const bool trace = cavp_knob_str("CAVP_IGEMM_TRACE") != nullptr;   // debugging: the plan of every make_plan call
   if (trace)
     fprintf(stderr, "[igemm plan] M=%d K=%d Cout=%d k%dx%d up=%d -> tile %d (%dx%d) splitk %d, %d workgroups, model %.1f us\n", p.M,
             p.K, p.Cout, d->KH, d->KW, up, t.id, t.BC, t.BP, sk, pl.nblk, best_t * 1e6);

@@ -37,7 +37,7 @@ struct WgradParams {
   int x_bytes, dy_bytes;
   int overwrite;       // 1: dw = gradient (beta = 0, dw is not read); 0: dw += gradient
   int oihw;            // dw layout: 0 = [Cout][taps][Cin] (OHWI), 1 = [Cout][Cin][taps] (torch .grad layout)
-  int dbg;             // profiling only (env CAVP_WGRAD_DBG): 1 = loads out of range, 2 = no MFMAs, 4 = no DMA, 8 = no epilogue
+  int dbg;             // -DCAVP_PROFILE builds only (CAVP_WGRAD_DBG): 1 = loads out of range, 2 = no MFMAs, 4 = no DMA, 8 = no epilogue
   float* dbias;        // optional: dbias[co] += sum_pix dY[pix][co] (bias gradient), taken from the dY tiles streamed anyway
   float* bias_slabs;   // ksplit > 1: [ksplit][Cout] partial column sums
   float* slabs;        // ksplit > 1: per-split partial gradients [ksplit][Cout][taps][Cin] (plain stores, then reduced)
@@ -101,7 +101,7 @@ __global__ __launch_bounds__(256, (BK == 32 ? 4 : 2)) void wgrad_kernel(const Wg
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
       const int pix = pixr[i];
-      const bool pok = pix < r_end && !(p.dbg & 1);
+      const bool pok = pix < r_end && !CAVP_DBG(p, 1);
       unsigned xoff;
       bool xok = pok && ci_ok;
       if (pointwise) {
@@ -218,8 +218,8 @@ __global__ __launch_bounds__(256, (BK == 32 ? 4 : 2)) void wgrad_kernel(const Wg
     __syncthreads();
     int buf = 0;
     for (int r0 = r_begin; r0 < r_end; r0 += BK) {
-      if (r0 + BK < r_end && !(p.dbg & 4)) gdma(buf ^ 1);
-      if (!(p.dbg & 2)) compute(buf);
+      if (r0 + BK < r_end && !CAVP_DBG(p, 4)) gdma(buf ^ 1);
+      if (!CAVP_DBG(p, 2)) compute(buf);
       __syncthreads();
       buf ^= 1;
     }
@@ -228,7 +228,7 @@ __global__ __launch_bounds__(256, (BK == 32 ? 4 : 2)) void wgrad_kernel(const Wg
   // D[i = ci][j = co]: lane holds ci = 4*lgrp + {0..3} (rows) of co = lrow (col) in each 16x16 block = 16 contiguous
   // bytes of dW.  ksplit == 1: this workgroup owns the tile -> plain read-modify-write; otherwise plain stores into
   // this split's slab (reduced afterwards, deterministic, no atomics).
-  if (p.dbg & 8) return;
+  if (CAVP_DBG(p, 8)) return;
   if (BIAS && do_bias) {   // lanes (lrow, lgrp) hold 4 disjoint pixel subsets of column co = wco0 + 16 b + lrow
     float* bo = p.ksplit > 1 ? p.bias_slabs + (size_t)z * p.Cout : p.dbias;
 #pragma unroll
@@ -410,7 +410,7 @@ WgradPlan make_wgrad_plan(const cavp_conv_desc* d) {
   } else {
     const double dw_bytes = (double)d->Cout * p.ntaps * d->Cin * 4.0;
     double best = 1e30;
-    static const double slab_bw = getenv("CAVP_WGRAD_SLAB_TBS") ? atof(getenv("CAVP_WGRAD_SLAB_TBS")) * 1e12 : 5e12;   // A/B knob; whole-step sweep 1.2 / 1.8 / 2.5 / 5 / 8 / 12 / 30 -> 18.85 / 18.65 / 18.55 / 18.47 / 18.50 / 18.58 / 18.69 ms
+    static const double slab_bw = cavp_knob_double("CAVP_WGRAD_SLAB_TBS", 5.0) * 1e12;   // A/B knob; whole-step sweep 1.2 / 1.8 / 2.5 / 5 / 8 / 12 / 30 -> 18.85 / 18.65 / 18.55 / 18.47 / 18.50 / 18.58 / 18.69 ms
     const int ks_max = chunks / 2 > 1 ? chunks / 2 : 1;
     for (int k = 1; k <= ks_max && k <= 512; ++k) {
       const int steps = (chunks + k - 1) / k;
@@ -459,10 +459,10 @@ extern "C" int cavp_conv2d_wgrad_nhwc(const cavp_conv_desc* d, const void* x, co
   }
   p.bias_slabs = p.slabs ? p.slabs + (size_t)p.ksplit * d->Cout * p.ntaps_all * d->Cin : nullptr;
   {
-    static const int dbg = getenv("CAVP_WGRAD_DBG") ? atoi(getenv("CAVP_WGRAD_DBG")) : 0;
+    static const int dbg = cavp_knob_int("CAVP_WGRAD_DBG", 0);
     p.dbg = dbg;
   }
-  static const int bk = getenv("CAVP_WGRAD_BK") ? atoi(getenv("CAVP_WGRAD_BK")) : 32;   // A/B knob (profiling)
+  static const int bk = cavp_knob_int("CAVP_WGRAD_BK", 32);   // A/B knob (profiling)
   const int lds = 2 * 2 * bk * 256;
   hipStream_t s = (hipStream_t)stream;
   static bool attr = false;

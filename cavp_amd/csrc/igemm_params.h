@@ -29,8 +29,7 @@ struct IgemmParams {
   int tap_woff[9];          // per live tap: byte offset tap*Cin*sizeof(T) inside a weight row
   float* tile_stats;        // optional [tiles_p][Cout][2] per-tile (mean, M2) of the raw outputs (BatchNorm statistics)
   int nblk;                 // logical workgroups (tiles x split-K); the launch may use fewer, persistent, workgroups
-  int stagger;              // A/B knob: workgroups of the second residency slot start this many s_sleep(64) late
-  int dbg;                  // profiling only (tile knob, hundreds digit): 1 = skip the operand loads, 2 = skip the MFMAs
+  int dbg;                  // -DCAVP_PROFILE builds only (tile knob digits): pieces of the kernel switched off for the K-loop anatomy
   int coalesced;            // LDS-staged, fully coalesced 16-byte epilogue (needs Cout, ldy, ldr % VE == 0, 16-B aligned)
 };
 

@@ -209,7 +209,7 @@ int launch_col_reduce(int dtype, ColArgs& a, hipStream_t s) {
   const int VE = dtype == CAVP_F32 ? 4 : 8;
   // (measured: the contiguous geometry helps the read + write kernels, 1.69 -> 1.23 ms per step for scale_shift_act,
   // but not the reductions - 1.59 -> 1.85 ms for the BN backward reduce - so it stays behind CAVP_FLAT_REDUCE=1)
-  static const bool flat_reduce = getenv("CAVP_FLAT_REDUCE") != nullptr;
+  static const bool flat_reduce = cavp_knob_str("CAVP_FLAT_REDUCE") != nullptr;
   if (flat_reduce && (MODE != 1 || a.b != nullptr) && flat_ok(a.C, VE, a.mean, a.rstd)) {
     const int CV = a.C / VE;
     a.rows_per_block = flat_rows_per_block(a.rows, a.C, 16 / VE, CV, 32 << 10, 4096);   // <= 4096 atomics per channel
@@ -226,7 +226,7 @@ int launch_col_reduce(int dtype, ColArgs& a, hipStream_t s) {
   // 0.95 without them); 512 keeps enough loads in flight and costs 1.27 ms (sweep: 2048 / 1024 / 512 / 256 -> 1.61 / 1.31 /
   // 1.27 / 1.58 ms; end-of-round whole-step sweep 256 / 384 / 512 / 768 / 1024 -> 19.20 / 18.91 / 18.80 / 18.75 / 18.80 ms).
   // CAVP_REDUCE_BLOCKS overrides for A/B runs.
-  static const int target_blocks = getenv("CAVP_REDUCE_BLOCKS") ? atoi(getenv("CAVP_REDUCE_BLOCKS")) : 768;
+  static const int target_blocks = cavp_knob_int("CAVP_REDUCE_BLOCKS", 768);
   int gx = target_blocks / gy;
   if (gx < 1) gx = 1;
   int rpb = cdiv_h(a.rows, gx);

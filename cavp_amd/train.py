@@ -152,7 +152,7 @@ def allreduce_bn_stats(bn, buf: torch.Tensor, count: int) -> int:
     return count
 
 
-_BN_BWD_READ_Y = bool(int(os.environ.get("CAVP_BN_BWD_READ_Y", "0")))   # A/B knob: always read y in the BN backward
+_BN_BWD_READ_Y = False   # True (tests / A-B only): the BatchNorm backward always re-reads y instead of re-deriving the mask from z
 
 
 class TrainPass:

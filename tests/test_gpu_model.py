@@ -117,6 +117,7 @@ def test_pvt_forward_matches_reference_golden(dtype, tol):
     z, cfg = load_case("pvt_eval")
     a = _args(cfg)
     a.seg_model = "PVT"
+    a.allow_random_pvt = True   # synthetic weights are loaded right after
     m = CAVP(50, None, num_classes=cfg["C"], args=a)
     sd = synth_state_dict({k: tuple(v.shape) for k, v in m.state_dict().items()}, seed=1)
     m.load_state_dict(sd, strict=True)

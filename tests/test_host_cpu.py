@@ -94,6 +94,7 @@ def test_pvt_state_dict_key_tree_matches_reference():
     from tests.shapes import cavp_state_shapes
     a = _args(71)
     a.seg_model = "PVT"
+    a.allow_random_pvt = True   # synthetic weights are loaded right after
     m = CAVP(50, None, num_classes=71, args=a)
     mine = {k: tuple(v.shape) for k, v in m.state_dict().items()}
     ref = cavp_state_shapes(71, "PVT")
