@@ -715,7 +715,8 @@ class CAVP(nn.Module):
         additionally materialises the full-resolution prediction into `self._last_outputs[0]` (otherwise None).
         Returns the (local) loss as a 1-element device tensor."""
         from . import train_ops as T
-        from .train import GradArena, TrainPass, allreduce_arena_early, allreduce_arena_late, dist_world, run_train_forward
+        from .train import (GradArena, TrainPass, allreduce_arena_early, allreduce_arena_late, collectives_on, dist_world,
+                            run_train_forward)
         if not image.is_cuda:
             raise CavpError("CAVP (MI355X path) needs inputs on a HIP device: there is no CPU fallback")
         arena = getattr(self, "_grad_arena", None)
@@ -747,11 +748,11 @@ class CAVP(nn.Module):
             early = []
             if _split_hook is not None:
                 tp.on_early_final = _split_hook
-            elif world > 1:
+            elif all_reduce and collectives_on():
                 tp.on_early_final = lambda: early.append(allreduce_arena_early(arena))
             tp.backward()
             tp.finish_padded()
-            if world > 1:
+            if all_reduce and collectives_on():
                 allreduce_arena_late(arena, early[0] if early else None)   # + joins the early collective
             for p in arena.params:
                 p.grad = arena.views[id(p)] if id(p) in tp.touched else None   # untouched = None, as torch would leave it
@@ -767,10 +768,10 @@ class CAVP(nn.Module):
         Single process: ONE graph.  Data parallel (or `split=True`): TWO graphs cut where the early gradient range is
         final; replay() = graph 1 -> asynchronous RCCL all-reduce of that range -> graph 2 (rest of the backward, runs
         concurrently with the collective) -> all-reduce of the late range -> join."""
-        from .train import allreduce_arena_early, allreduce_arena_late, dist_world
+        from .train import allreduce_arena_early, allreduce_arena_late, collectives_on, dist_world
         world = dist_world()
         if split is None:
-            split = world > 1
+            split = collectives_on()
         with torch.no_grad():
             self.train_step(image, audio, label, ignore_index, loss_scale, all_reduce=False)   # warm-up: workspace, arena
             torch.cuda.synchronize()
@@ -811,7 +812,7 @@ class CAVP(nn.Module):
                 work = allreduce_arena_early(arena)
                 graphs[1].replay()
                 allreduce_arena_late(arena, work)
-            elif world > 1:
+            elif collectives_on():
                 allreduce_arena_late(arena, None)
             return loss
         # keep alive: the graphs, and every scratch buffer whose address they baked in (ops.workspace never frees a buffer it

@@ -114,6 +114,22 @@ __device__ __forceinline__ void apply_act_vec(float* v, int act) {
   }
 }
 
+// Zero-fill of an f32 buffer as a KERNEL.  hipMemsetAsync nodes captured into a hipGraph were observed (ROCm 7.2, MI355X) to
+// be mis-ordered against their neighbours from the second replay on: the four weight gradients that were cleared by a
+// captured memset came out as inf / 1e25 on every replay but the first (found by the RCCL single-rank test, round 2).  A
+// kernel node has ordinary stream-order dependencies.
+static __global__ __launch_bounds__(256) void cavp_zero_f32_kernel(float* __restrict__ p, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) p[i] = 0.f;
+}
+static inline hipError_t cavp_zero_f32_async(void* ptr, size_t bytes, hipStream_t s) {
+  const size_t n = bytes / 4;
+  if (n == 0) return hipSuccess;
+  size_t nb = (n + 255) / 256;
+  if (nb > 2048) nb = 2048;
+  cavp_zero_f32_kernel<<<dim3((unsigned)nb), dim3(256), 0, s>>>((float*)ptr, n);
+  return hipGetLastError();
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

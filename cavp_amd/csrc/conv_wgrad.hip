@@ -444,7 +444,7 @@ extern "C" int cavp_conv2d_wgrad_nhwc(const cavp_conv_desc* d, const void* x, co
   if (pl.status != CAVP_OK) return pl.status;
   const size_t dw_bytes = (size_t)d->Cout * d->KH * d->KW * d->Cin * sizeof(float);
   if (pl.nblk == 0) {   // every tap is outside the image: the gradient is zero
-    if (d->dw_overwrite && hipMemsetAsync(dw, 0, dw_bytes, (hipStream_t)stream) != hipSuccess) return CAVP_ERR_LAUNCH;
+    if (d->dw_overwrite && cavp_zero_f32_async(dw, dw_bytes, (hipStream_t)stream) != hipSuccess) return CAVP_ERR_LAUNCH;
     return CAVP_OK;
   }
   if (((uintptr_t)x & 15) || ((uintptr_t)dy & 15) || ((uintptr_t)dw & 15)) return CAVP_ERR_ALIGN;
@@ -454,7 +454,7 @@ extern "C" int cavp_conv2d_wgrad_nhwc(const cavp_conv_desc* d, const void* x, co
   p.oihw = d->dw_oihw != 0 && p.ntaps_all > 1;   // (1x1: the two layouts coincide)
   p.overwrite = d->dw_overwrite != 0;
   if (p.overwrite && p.ntaps < p.ntaps_all) {   // dead taps of a dilated kernel are never visited: clear, then accumulate
-    if (hipMemsetAsync(dw, 0, dw_bytes, (hipStream_t)stream) != hipSuccess) return CAVP_ERR_LAUNCH;
+    if (cavp_zero_f32_async(dw, dw_bytes, (hipStream_t)stream) != hipSuccess) return CAVP_ERR_LAUNCH;
     p.overwrite = 0;
   }
   p.bias_slabs = p.slabs ? p.slabs + (size_t)p.ksplit * d->Cout * p.ntaps_all * d->Cin : nullptr;

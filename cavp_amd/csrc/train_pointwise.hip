@@ -1576,7 +1576,7 @@ extern "C" int cavp_conv3x3_smallcin_wgrad(int32_t dtype, const float* x_nchw, c
   else
     smallcin_im2col_kernel<bf16_t, 32><<<(int)nb, 256, 0, s>>>(x_nchw, (bf16_t*)col, N, Cin, H, W, stride, pl.Ho, pl.Wo);
   if (hipGetLastError() != hipSuccess) return CAVP_ERR_LAUNCH;
-  if (hipMemsetAsync(tmp, 0, (size_t)Cout * pl.KP * 4, s) != hipSuccess) return CAVP_ERR_LAUNCH;
+  if (cavp_zero_f32_async(tmp, (size_t)Cout * pl.KP * 4, s) != hipSuccess) return CAVP_ERR_LAUNCH;
   const int st = cavp_conv2d_wgrad_nhwc(&pl.d, col, dy_nhwc, tmp, nullptr, ws, pl.ws_bytes, stream);
   if (st != CAVP_OK) return st;
   const int K = Cin * 9;

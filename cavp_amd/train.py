@@ -113,11 +113,21 @@ def dist_world() -> int:
     return dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
 
 
+# True (tests only): issue the gradient collectives even in a process group of ONE rank, so that the real RCCL backend, its
+# streams and its interplay with the hipGraph replays are exercised on a single-GPU box (tests/test_gpu_nccl_world1.py).
+FORCE_COLLECTIVES = False
+
+
+def collectives_on() -> bool:
+    import torch.distributed as dist
+    return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or FORCE_COLLECTIVES)
+
+
 def allreduce_arena(arena: GradArena) -> None:
     """The single gradient collective of a data-parallel step: SUM over ranks of the flat arena (RCCL over xGMI on
     MI355X; gloo in the CPU tests).  The loss gradient is pre-scaled by 1/world in train_step, so SUM == DDP's mean."""
     import torch.distributed as dist
-    if dist_world() > 1:
+    if collectives_on():
         dist.all_reduce(arena.flat)
 
 
@@ -125,7 +135,7 @@ def allreduce_arena_early(arena: GradArena):
     """Start the all-reduce of the early-final range `flat[split:]` without blocking the launching stream (the collective
     runs on RCCL's own stream behind everything queued so far); returns the work handle (None for a single process)."""
     import torch.distributed as dist
-    if dist_world() > 1 and arena.split < arena.flat.numel():
+    if collectives_on() and arena.split < arena.flat.numel():
         return dist.all_reduce(arena.flat[arena.split:], async_op=True)
     return None
 
@@ -133,7 +143,7 @@ def allreduce_arena_early(arena: GradArena):
 def allreduce_arena_late(arena: GradArena, early_work) -> None:
     """All-reduce the late range `flat[:split]` and join the early collective: afterwards the whole arena is reduced."""
     import torch.distributed as dist
-    if dist_world() > 1:
+    if collectives_on():
         if early_work is None:
             dist.all_reduce(arena.flat)
             return

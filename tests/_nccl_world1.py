@@ -1,0 +1,71 @@
+"""Child process of tests/test_gpu_nccl_world1.py: the data-parallel training path on the REAL RCCL backend with a process
+group of one rank (a 1-GPU box cannot host two), collectives forced on (cavp_amd.train.FORCE_COLLECTIVES).  Exercises what
+gloo runs cannot: ncclCommInit, all-reduce of the flat f32 gradient arena (early range asynchronously on RCCL's stream, late
+range, join), and both interleaved with hipGraph replays of the two-graph training step."""
+import os
+import sys
+import types
+
+import torch
+import torch.distributed as dist
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+
+
+def main():
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    from cavp_amd import train as TR
+    from cavp_amd.cavp_model import CAVP
+    from cavp_amd.synth import synth_inputs, synth_state_dict
+    C, B, hw = 3, 4, (64, 64)
+    args = types.SimpleNamespace(seg_model="DeepLabV3Plus", last_three_dilation_stride=[False, False, False], audio_backbone="vgg",
+                                 num_classes=C, batch_size=B, local_rank="cpu")
+    m = CAVP(50, None, num_classes=C, args=args)
+    sd = synth_state_dict({k: tuple(v.shape) for k, v in m.state_dict().items()}, seed=1)
+    m.load_state_dict(sd, strict=True)
+    m.train().to(dev)
+    image, audio, label = [t.to(dev) for t in synth_inputs(B, hw, audio_batch=2 * B, num_classes=C, seed=2)]
+
+    def reset_bn():
+        m.load_state_dict({k: v for k, v in sd.items() if "running_" in k or "num_batches" in k}, strict=False)
+
+    # reference: no collective at all
+    reset_bn()
+    l0 = float(m.train_step(image, audio, label, all_reduce=False).item())
+    ref = m._grad_arena.flat.clone()
+    assert not TR.collectives_on()
+    TR.FORCE_COLLECTIVES = True
+    assert TR.collectives_on()
+    # eager step with the early (async) + late all-reduce: SUM over one rank = identity
+    reset_bn()
+    l1 = float(m.train_step(image, audio, label).item())
+    torch.cuda.synchronize()
+    e1 = float((m._grad_arena.flat - ref).abs().max() / ref.abs().max())
+    # two-graph replay around the collectives (what bench.py --gpus N times)
+    reset_bn()
+    step = m.capture_train_step(image, audio, label)
+    assert len(m._train_graph) == 2, "a live process group must give the two-graph (split) capture"
+    errs = []
+    for _ in range(3):
+        reset_bn()
+        l2 = float(step().item())
+        torch.cuda.synchronize()
+        errs.append(float((m._grad_arena.flat - ref).abs().max() / ref.abs().max()))
+    # a plain all-reduce of a known buffer really goes through RCCL
+    t = torch.arange(1 << 20, dtype=torch.float32, device=dev)
+    dist.all_reduce(t)
+    torch.cuda.synchronize()
+    assert float(t[12345]) == 12345.0
+    print(f"NCCL_WORLD1_OK backend={dist.get_backend()} loss {l0:.6f} {l1:.6f} {l2:.6f} eager_err {e1:.2e} replay_err {max(errs):.2e}")
+    # f32 atomics in the BatchNorm reductions: run-to-run differences of a few 1e-2 of the largest gradient are the documented
+    # noise floor; a missing / misordered collective would leave garbage or zeros
+    assert abs(l1 - l0) <= 1e-4 * max(1.0, abs(l0)) and abs(l2 - l0) <= 1e-4 * max(1.0, abs(l0))
+    assert e1 <= 0.1 and max(errs) <= 0.1
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
