@@ -50,6 +50,7 @@ def parse():
                     help="force the two-graph replay of the data-parallel path (cut where the early gradients are final) on one GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-token-fusion", action="store_true", help="A/B: GELU as a separate pass, duplicated token tensors copied")
     ap.add_argument("--no-f32", action="store_true", help="skip the secondary f32 (parity path) training-step measurement")
     ap.add_argument("--cpu-sample-batch", type=int, default=8)
     return ap.parse_args()
@@ -358,6 +359,9 @@ def cpu_baseline(sd, cfg, sample_batch):
 
 def main():
     a = parse()
+    if a.no_token_fusion:
+        import cavp_amd.train as _tr
+        _tr._FUSE_TOKEN_PATH = False
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

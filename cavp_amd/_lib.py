@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(HERE, "libcavp_hip.so")
 
 F32, BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_LEAKY, ACT_GELU = 0, 1, 2, 3
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 
 class CavpError(RuntimeError):
@@ -26,7 +26,7 @@ class ConvDesc(C.Structure):
     """struct cavp_conv_desc (include/cavp_hip.h)."""
     _fields_ = [(n, C.c_int32) for n in (
         "dtype", "N", "H", "W", "Cin", "ldx", "Cout", "ldy", "KH", "KW", "stride", "pad", "dil", "ldr", "act",
-        "splitk", "tile", "up", "Ho", "Wo", "stride_w", "dw_oihw", "dw_overwrite")]
+        "splitk", "tile", "up", "Ho", "Wo", "stride_w", "dw_oihw", "dw_overwrite", "res_rows", "aux_mode", "ld_aux")]
 
 
 _vp, _i32, _i64, _f32, _sz = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_size_t
@@ -37,6 +37,7 @@ PROTOTYPES = {
     "cavp_error_string": (C.c_char_p, [_i32]),
     "cavp_conv2d_workspace_bytes": (_sz, [C.POINTER(ConvDesc)]),
     "cavp_conv2d_nhwc": (_i32, [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _vp]),
+    "cavp_conv2d_nhwc_aux": (_i32, [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _vp]),
     "cavp_conv2d_tile_stats_layout": (_i32, [C.POINTER(ConvDesc), C.POINTER(_i32), C.POINTER(_i32)]),
     "cavp_bn_finalize_tiles": (_i32, [_vp, _i32, _i32, _i64, _vp, _vp, _f32, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp]),
     "cavp_conv3x3_smallcin_nchw": (_i32, [_i32, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
@@ -45,7 +46,7 @@ PROTOTYPES = {
     "cavp_bilinear_nhwc": (_i32, [_i32, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "cavp_bilinear_nhwc_to_nchw": (_i32, [_i32, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "cavp_layernorm": (_i32, [_i32, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _vp]),
-    "cavp_attn_gate": (_i32, [_i32, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _vp]),
+    "cavp_attn_gate": (_i32, [_i32, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _i32, _vp]),
     "cavp_bn_fold": (_i32, [_vp, _vp, _vp, _vp, _f32, _vp, _vp, _i32, _vp]),
     "cavp_pack_weight_ohwi": (_i32, [_i32, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "cavp_cast": (_i32, [_i32, _vp, _i32, _vp, _i64, _vp]),
@@ -73,7 +74,7 @@ PROTOTYPES = {
     "cavp_add": (_i32, [_i32, _vp, _vp, _vp, _i64, _vp]),
     "cavp_colsum": (_i32, [_i32, _vp, _i64, _i32, _i32, _vp, _vp]),
     "cavp_layernorm_bwd": (_i32, [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _vp]),
-    "cavp_attn_gate_bwd": (_i32, [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _vp]),
+    "cavp_attn_gate_bwd": (_i32, [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _i32, _vp]),
     "cavp_maxpool_bwd_nhwc": (_i32, [_i32, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "cavp_bilinear_bwd_nhwc": (_i32, [_i32, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "cavp_bilinear_bwd_nchw_to_nhwc": (_i32, [_i32, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),

@@ -39,7 +39,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void attn_gate_kernel(const T* __restrict__ q, const T* __restrict__ k,
                                                         const T* __restrict__ v, T* __restrict__ o,
                                                         float* __restrict__ attn, int B, int Tn, int heads, int hd,
-                                                        float scale) {
+                                                        float scale, long long q_rows) {
   const int lane = threadIdx.x & 63;
   const int C = heads * hd, NQ = C >> 2, qh = hd >> 2;  // quads per row / per head
   const bool ok0 = lane < NQ, ok1 = lane + 64 < NQ;
@@ -47,7 +47,7 @@ __global__ __launch_bounds__(256) void attn_gate_kernel(const T* __restrict__ q,
   const long long rows = (long long)B * Tn;
   for (long long row = blockIdx.x * 4ll + (threadIdx.x >> 6); row < rows; row += (long long)gridDim.x * 4) {
     const int b = (int)(row / Tn), t = (int)(row - (long long)b * Tn);
-    const T* qp = q + (size_t)row * C;
+    const T* qp = q + (size_t)(row >= q_rows ? row % q_rows : row) * C;   // q_batch < B: the query rows repeat
     const T* kp = k + (size_t)b * C;
     const T* vp = v + (size_t)b * C;
     float q0[4] = {0.f, 0.f, 0.f, 0.f}, q1[4] = {0.f, 0.f, 0.f, 0.f}, k0[4] = {0.f, 0.f, 0.f, 0.f}, k1[4] = {0.f, 0.f, 0.f, 0.f};
@@ -85,7 +85,8 @@ __global__ __launch_bounds__(256) void attn_gate_bwd_kernel(const T* __restrict_
                                                             const float* __restrict__ attn,
                                                             const float* __restrict__ dattn, T* __restrict__ dq,
                                                             float* __restrict__ dk, float* __restrict__ dv, int Tn,
-                                                            int heads, int hd, float scale, int tok_per_block) {
+                                                            int heads, int hd, float scale, int tok_per_block,
+                                                            int q_batch) {
   __shared__ float part[2][4][512];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, b = blockIdx.y;
   const int C = heads * hd, NQ = C >> 2, qh = hd >> 2;
@@ -100,9 +101,10 @@ __global__ __launch_bounds__(256) void attn_gate_bwd_kernel(const T* __restrict_
   if (t_end > Tn) t_end = Tn;
   for (int t = t_begin + wv; t < t_end; t += 4) {
     const size_t row = ((size_t)b * Tn + t) * C;
+    const size_t qrow = ((size_t)(b % q_batch) * Tn + t) * C;   // q_batch < B: the query rows repeat
     float d0[4] = {0.f, 0.f, 0.f, 0.f}, d1[4] = {0.f, 0.f, 0.f, 0.f}, q0[4] = {0.f, 0.f, 0.f, 0.f}, q1[4] = {0.f, 0.f, 0.f, 0.f};
-    if (ok0) { Quad<T>::load(dout + row + 4 * lane, d0); Quad<T>::load(q + row + 4 * lane, q0); }
-    if (ok1) { Quad<T>::load(dout + row + 4 * (lane + 64), d1); Quad<T>::load(q + row + 4 * (lane + 64), q1); }
+    if (ok0) { Quad<T>::load(dout + row + 4 * lane, d0); Quad<T>::load(q + qrow + 4 * lane, q0); }
+    if (ok1) { Quad<T>::load(dout + row + 4 * (lane + 64), d1); Quad<T>::load(q + qrow + 4 * (lane + 64), q1); }
     const float p0 = d0[0] * v0[0] + d0[1] * v0[1] + d0[2] * v0[2] + d0[3] * v0[3];
     const float p1 = d1[0] * v1[0] + d1[1] * v1[1] + d1[2] * v1[2] + d1[3] * v1[3];
     float da0 = 0.f, da1 = 0.f, g0 = 0.f, g1 = 0.f;
@@ -153,23 +155,25 @@ inline bool shape_ok(int dtype, int heads, int hd, const void* a, const void* b,
 }  // namespace
 
 extern "C" int cavp_attn_gate(int32_t dtype, const void* q, const void* k, const void* v, void* o, float* attn,
-                              int32_t B, int32_t T, int32_t heads, int32_t hd, float scale, void* stream) {
-  if (!q || !k || !v || !o || !attn || B <= 0 || T <= 0 || heads <= 0 || hd <= 0) return CAVP_ERR_BAD_ARG;
+                              int32_t B, int32_t T, int32_t heads, int32_t hd, float scale, int32_t q_batch, void* stream) {
+  if (!q || !k || !v || !o || !attn || B <= 0 || T <= 0 || heads <= 0 || hd <= 0 || q_batch <= 0 || B % q_batch) return CAVP_ERR_BAD_ARG;
+  const long long q_rows = (long long)q_batch * T;
   if (!dt_ok(dtype) || !shape_ok(dtype, heads, hd, q, k, v, o)) return CAVP_ERR_UNSUPPORTED;
   long long nbl = ((long long)B * T + 3) / 4;
   if (nbl > 16384) nbl = 16384;
   hipStream_t s = (hipStream_t)stream;
   if (dtype == CAVP_F32)
-    attn_gate_kernel<float><<<(int)nbl, 256, 0, s>>>((const float*)q, (const float*)k, (const float*)v, (float*)o, attn, B, T, heads, hd, scale);
+    attn_gate_kernel<float><<<(int)nbl, 256, 0, s>>>((const float*)q, (const float*)k, (const float*)v, (float*)o, attn, B, T, heads, hd, scale, q_rows);
   else
-    attn_gate_kernel<bf16_t><<<(int)nbl, 256, 0, s>>>((const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)o, attn, B, T, heads, hd, scale);
+    attn_gate_kernel<bf16_t><<<(int)nbl, 256, 0, s>>>((const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)o, attn, B, T, heads, hd, scale, q_rows);
   return hipGetLastError() == hipSuccess ? CAVP_OK : CAVP_ERR_LAUNCH;
 }
 
 extern "C" int cavp_attn_gate_bwd(int32_t dtype, const void* dout, const void* q, const void* k, const void* v,
                                   const float* attn, const float* dattn, void* dq, float* dk, float* dv, int32_t B,
-                                  int32_t T, int32_t heads, int32_t hd, float scale, void* stream) {
-  if (!dout || !q || !k || !v || !attn || !dq || !dk || !dv || B <= 0 || T <= 0 || heads <= 0 || hd <= 0)
+                                  int32_t T, int32_t heads, int32_t hd, float scale, int32_t q_batch, void* stream) {
+  if (!dout || !q || !k || !v || !attn || !dq || !dk || !dv || B <= 0 || T <= 0 || heads <= 0 || hd <= 0 || q_batch <= 0 ||
+      B % q_batch)
     return CAVP_ERR_BAD_ARG;
   if (!dt_ok(dtype) || !shape_ok(dtype, heads, hd, q, k, v, dq) || !shape_ok(dtype, heads, hd, dout, dout, dout, dout))
     return CAVP_ERR_UNSUPPORTED;
@@ -181,8 +185,8 @@ extern "C" int cavp_attn_gate_bwd(int32_t dtype, const void* dout, const void* q
   gx = (T + tpb - 1) / tpb;
   hipStream_t s = (hipStream_t)stream;
   if (dtype == CAVP_F32)
-    attn_gate_bwd_kernel<float><<<dim3(gx, B), 256, 0, s>>>((const float*)dout, (const float*)q, (const float*)k, (const float*)v, attn, dattn, (float*)dq, dk, dv, T, heads, hd, scale, tpb);
+    attn_gate_bwd_kernel<float><<<dim3(gx, B), 256, 0, s>>>((const float*)dout, (const float*)q, (const float*)k, (const float*)v, attn, dattn, (float*)dq, dk, dv, T, heads, hd, scale, tpb, q_batch);
   else
-    attn_gate_bwd_kernel<bf16_t><<<dim3(gx, B), 256, 0, s>>>((const bf16_t*)dout, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, attn, dattn, (bf16_t*)dq, dk, dv, T, heads, hd, scale, tpb);
+    attn_gate_bwd_kernel<bf16_t><<<dim3(gx, B), 256, 0, s>>>((const bf16_t*)dout, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, attn, dattn, (bf16_t*)dq, dk, dv, T, heads, hd, scale, tpb, q_batch);
   return hipGetLastError() == hipSuccess ? CAVP_OK : CAVP_ERR_LAUNCH;
 }

@@ -94,6 +94,30 @@ __device__ __forceinline__ float apply_act(float v, int act) {
   }
 }
 
+__device__ __forceinline__ float gelu_grad(float x) {  // d/dx [0.5 x (1 + erf(x / sqrt 2))]
+  const float cdf = 0.5f * (1.f + erff(x * 0.70710678118654752f));
+  const float pdf = 0.3989422804014327f * expf(-0.5f * x * x);
+  return cdf + x * pdf;
+}
+
+// gelu(x) and gelu'(x) together, for the fused fc1 + GELU epilogue (cavp_conv_desc.aux_mode 1), where this math is NOT hidden
+// behind memory traffic: two erff + one expf per element (~70 VALU) made the fused epilogue cost what the two elementwise
+// passes it replaces had cost.  One exp(-x^2/2) serves the density AND the Abramowitz-Stegun 7.1.26 form of erf
+// (|error| <= 1.5e-7, below bf16 and f32-accumulation noise): ~18 VALU per element.
+__device__ __forceinline__ void gelu_and_grad(float x, float& g, float& dg) {
+  const float ax = fabsf(x);
+  const float e = __expf(-0.5f * x * x);                       // exp(-z^2), z = |x| / sqrt 2
+  const float t = __frcp_rn(fmaf(0.3275911f * 0.70710678118654752f, ax, 1.f));
+  float poly = fmaf(1.061405429f, t, -1.453152027f);
+  poly = fmaf(poly, t, 1.421413741f);
+  poly = fmaf(poly, t, -0.284496736f);
+  poly = fmaf(poly, t, 0.254829592f);
+  const float h = 0.5f * poly * t * e;                         // 0.5 * erfc(z)
+  const float cdf = x >= 0.f ? 1.f - h : h;
+  g = x * cdf;
+  dg = fmaf(x * e, 0.3989422804014327f, cdf);
+}
+
 // activation of N values with ONE (wave-uniform) dispatch on the activation code
 template <int N>
 __device__ __forceinline__ void apply_act_vec(float* v, int act) {

@@ -460,7 +460,10 @@ __global__ __launch_bounds__(64 * WC * WP, (WC * WP == 4 ? 2 : 1)) void igemm_ke
     const float* lds0 = st + (size_t)eprow0 * BC + (((ecc / 4) ^ key) << 2);                       // first f32x4 of chunk 0
     const float* lds1 = VE == 8 ? st + (size_t)eprow0 * BC + (((ecc / 4 + 1) ^ key) << 2) : lds0;  // second (bf16 only)
     T* yp = (T*)p.y + (size_t)(p_base + eprow0) * p.ldy + ec;
-    const T* rp = p.res ? (const T*)p.res + (size_t)(p_base + eprow0) * p.ldr + ec : nullptr;
+    // (res_rows: a multiple of every tile height, so a tile never straddles the wrap)
+    const T* rp = p.res ? (const T*)p.res + (size_t)((p.res_rows ? p_base % p.res_rows : p_base) + eprow0) * p.ldr + ec : nullptr;
+    T* xp = p.aux_mode ? (T*)p.aux + (size_t)(p_base + eprow0) * p.ld_aux + ec : nullptr;
+    const size_t xstep = (size_t)RSTR * p.ld_aux;
     const size_t ystep = (size_t)RSTR * p.ldy, rstep = (size_t)RSTR * p.ldr;
     const bool has_ss = p.scale != nullptr || p.shift != nullptr;
     const int rows_left = p.M - (p_base + eprow0);   // chunk k is in range iff k * RSTR < rows_left
@@ -495,6 +498,12 @@ __global__ __launch_bounds__(64 * WC * WP, (WC * WP == 4 ? 2 : 1)) void igemm_ke
 #pragma unroll
           for (int e = 0; e < VE; ++e) v[e] = __fadd_rn(__fmul_rn(v[e], sc[e]), sh[e]);  // two roundings, as every other epilogue path
         }
+        if (p.aux_mode == 2) {   // d(pre) = d(hidden) * gelu'(pre): the multiplier tensor of the forward (aux_mode 1)
+          float m[VE];
+          VecT<T>::load(xp + (size_t)k * xstep, m);
+#pragma unroll
+          for (int e = 0; e < VE; ++e) v[e] *= m[e];
+        }
         if (rp) {
           if constexpr (sizeof(T) == 4) {
 #pragma unroll
@@ -507,7 +516,14 @@ __global__ __launch_bounds__(64 * WC * WP, (WC * WP == 4 ? 2 : 1)) void igemm_ke
             }
           }
         }
-        apply_act_vec<VE>(v, p.act);
+        if (p.aux_mode == 1) {   // GELU forward: the derivative goes to aux, the pre-activation is never stored
+          float m[VE];
+#pragma unroll
+          for (int e = 0; e < VE; ++e) gelu_and_grad(v[e], v[e], m[e]);
+          VecT<T>::store(xp + (size_t)k * xstep, m);
+        } else {
+          apply_act_vec<VE>(v, p.act);
+        }
         u32x4_t o;
         if constexpr (sizeof(T) == 4) {
 #pragma unroll
@@ -673,7 +689,11 @@ struct Plan {
 
 inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
-Plan make_plan(const cavp_conv_desc* d, bool allow_big = true) {
+Plan make_plan(const cavp_conv_desc* d_in, bool allow_big = true) {
+  cavp_conv_desc dd{};
+  if (d_in) dd = *d_in;
+  if (dd.aux_mode != 0 || dd.res_rows > 0) dd.splitk = 1;   // the fused token-path epilogues live in the 16-byte epilogue only
+  const cavp_conv_desc* d = d_in ? &dd : nullptr;
   Plan pl{};
   pl.status = CAVP_OK;
   if (!d) { pl.status = CAVP_ERR_BAD_ARG; return pl; }
@@ -790,7 +810,9 @@ Plan make_plan(const cavp_conv_desc* d, bool allow_big = true) {
   // split) with a long K loop: the 4-stage ring WITHOUT split-K (bench_conv on MI355X: 3x3 256->256 at 32x14x14 28.6 ->
   // 18.5 us, 1x1 2048->256 23.9 -> 16.4 us; no slab pass, and the fused BatchNorm statistics stay available).  With more
   // tiles than that the 2-stage tile at four workgroups per CU is faster.
-  if (want_tile == 0 && d->splitk <= 0 && p.iters >= 16 && (long long)cdiv(p.Cout, 64) * cdiv(p.M, 64) <= 512) {
+  // (not for very long K loops: the ASPP 3x3 2048 -> 256 convs, 288 K tiles, are faster split over K on 128x128 tiles:
+  // 76 vs 100 us)
+  if (want_tile == 0 && d->splitk <= 0 && p.iters >= 16 && p.iters <= 96 && (long long)cdiv(p.Cout, 64) * cdiv(p.M, 64) <= 512) {
     for (int i = 0; i < kNumTiles; ++i)
       if (kTiles[i].id == 11) { best = i; best_sk = 1; }
   }
@@ -859,7 +881,19 @@ extern "C" size_t cavp_conv2d_workspace_bytes(const cavp_conv_desc* d) {
 extern "C" int cavp_conv2d_nhwc(const cavp_conv_desc* d, const void* x, const void* w, const float* scale,
                                 const float* shift, const float* nbias, const void* residual, void* y, void* workspace,
                                 size_t workspace_bytes, float* tile_stats, void* stream) {
+  if (d && (d->aux_mode != 0)) return CAVP_ERR_BAD_ARG;   // the auxiliary tensor travels through cavp_conv2d_nhwc_aux
+  return cavp_conv2d_nhwc_aux(d, x, w, scale, shift, nbias, residual, y, nullptr, workspace, workspace_bytes, tile_stats, stream);
+}
+
+extern "C" int cavp_conv2d_nhwc_aux(const cavp_conv_desc* d, const void* x, const void* w, const float* scale,
+                                    const float* shift, const float* nbias, const void* residual, void* y, void* aux,
+                                    void* workspace, size_t workspace_bytes, float* tile_stats, void* stream) {
   if (!d || !x || !w || !y) return CAVP_ERR_BAD_ARG;
+  const bool fused = d->aux_mode != 0 || (residual && d->res_rows > 0);
+  if (d->aux_mode < 0 || d->aux_mode > 2 || (d->aux_mode != 0) != (aux != nullptr) || (d->aux_mode == 1 && d->act != CAVP_ACT_GELU) ||
+      (d->aux_mode && d->ld_aux < d->Cout) || d->res_rows < 0 || (d->res_rows % 256) != 0)
+    return CAVP_ERR_BAD_ARG;
+  if (fused && (tile_stats || d->splitk > 1)) return CAVP_ERR_UNSUPPORTED;
   if (tile_stats && (scale || shift || nbias || residual || d->act != CAVP_ACT_NONE)) return CAVP_ERR_BAD_ARG;
   Plan pl = make_plan(d);
   if (pl.status != CAVP_OK) return pl.status;
@@ -893,6 +927,9 @@ extern "C" int cavp_conv2d_nhwc(const cavp_conv_desc* d, const void* x, const vo
                 (!residual || (d->ldr % VE == 0 && aligned(residual, 16))) && (!scale || aligned(scale, 16)) &&
                 (!shift || aligned(shift, 16));
   p.tile_stats = tile_stats;
+  p.aux = aux; p.aux_mode = d->aux_mode; p.ld_aux = d->ld_aux; p.res_rows = residual ? d->res_rows : 0;
+  if (fused && !(p.coalesced && (!aux || (d->ld_aux % VE == 0 && aligned(aux, 16))))) return CAVP_ERR_UNSUPPORTED;
+  if (p.res_rows > 0 && (long long)p.res_rows > p.M) return CAVP_ERR_BAD_ARG;
   if (tile_stats && !p.coalesced) return CAVP_ERR_UNSUPPORTED;   // see cavp_conv2d_tile_stats_layout
   if (tile_is_big(pl.tile_id) && !p.coalesced) return CAVP_ERR_ALIGN;   // the 256x256 tile only has the 16-byte epilogue
   hipStream_t s = (hipStream_t)stream;

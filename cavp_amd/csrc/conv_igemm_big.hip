@@ -293,10 +293,22 @@ __global__ __launch_bounds__(512, 2) void igemm_big_kernel(const IgemmParams p) 
     }
     const bool has_ss = p.scale != nullptr || p.shift != nullptr;
     bf16_t* yp = (bf16_t*)p.y + (size_t)(p_wave + pr) * p.ldy + ec;
-    const bf16_t* rp = p.res ? (const bf16_t*)p.res + (size_t)(p_wave + pr) * p.ldr + ec : nullptr;
+    // (res_rows is a multiple of 256: a wave slab never straddles the wrap)
+    const bf16_t* rp = p.res ? (const bf16_t*)p.res + (size_t)((p.res_rows ? p_wave % p.res_rows : p_wave) + pr) * p.ldr + ec : nullptr;
+    bf16_t* xp = p.aux_mode ? (bf16_t*)p.aux + (size_t)(p_wave + pr) * p.ld_aux + ec : nullptr;
 #pragma unroll
     for (int b = 0; b < 8; ++b) {
-      u32x4_t rr[2];
+      u32x4_t rr[2], mm[2];
+      if (p.aux_mode == 2) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          mm[k] = (u32x4_t){0u, 0u, 0u, 0u};
+          if (ec_ok && b * 16 + pr + 8 * k < nvw) {
+            mm[k] = *(const u32x4_t*)(xp + (size_t)(b * 16 + 8 * k) * p.ld_aux);
+            asm volatile("" : "+v"(mm[k]));   // (see CAVP_USE8)
+          }
+        }
+      }
       if (rp) {
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
@@ -336,6 +348,13 @@ __global__ __launch_bounds__(512, 2) void igemm_big_kernel(const IgemmParams p) 
 #pragma unroll
           for (int e = 0; e < 8; ++e) v[e] = __fadd_rn(__fmul_rn(v[e], sc[e]), sh[e]);
         }
+        if (p.aux_mode == 2) {   // d(pre) = d(hidden) * gelu'(pre)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            v[2 * e] *= __uint_as_float(mm[k][e] << 16);
+            v[2 * e + 1] *= __uint_as_float(mm[k][e] & 0xffff0000u);
+          }
+        }
         if (rp) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
@@ -343,7 +362,17 @@ __global__ __launch_bounds__(512, 2) void igemm_big_kernel(const IgemmParams p) 
             v[2 * e + 1] += __uint_as_float(rr[k][e] & 0xffff0000u);
           }
         }
-        apply_act_vec<8>(v, p.act);
+        if (p.aux_mode == 1) {   // GELU forward: gelu'(t) goes to aux, the pre-activation is never stored
+          float dgv[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) gelu_and_grad(v[e], v[e], dgv[e]);
+          u32x4_t d;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) d[e] = pack2bf(dgv[2 * e], dgv[2 * e + 1]);
+          *(u32x4_t*)(xp + (size_t)(b * 16 + 8 * k) * p.ld_aux) = d;
+        } else {
+          apply_act_vec<8>(v, p.act);
+        }
         u32x4_t o;
 #pragma unroll
         for (int e = 0; e < 4; ++e) o[e] = pack2bf(v[2 * e], v[2 * e + 1]);

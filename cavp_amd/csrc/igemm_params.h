@@ -31,6 +31,10 @@ struct IgemmParams {
   int nblk;                 // logical workgroups (tiles x split-K); the launch may use fewer, persistent, workgroups
   int dbg;                  // -DCAVP_PROFILE builds only (tile knob digits): pieces of the kernel switched off for the K-loop anatomy
   int coalesced;            // LDS-staged, fully coalesced 16-byte epilogue (needs Cout, ldy, ldr % VE == 0, 16-B aligned)
+  // token-path epilogue fusions (16-byte epilogue only): see cavp_conv_desc.res_rows / aux_mode
+  void* aux;                // aux_mode 1: gelu'(t) is stored here; 2: the result is multiplied by it
+  int aux_mode, ld_aux;
+  int res_rows;             // 0, or: output pixel p adds residual row p % res_rows (a multiple of 256)
 };
 
 template <typename T> struct Mma;

@@ -19,11 +19,6 @@ __device__ __forceinline__ float act_grad_from_out(float y, int act) {  // d act
     default: return 1.f;
   }
 }
-__device__ __forceinline__ float gelu_grad(float x) {  // d/dx [0.5 x (1 + erf(x / sqrt 2))]
-  const float cdf = 0.5f * (1.f + erff(x * 0.70710678118654752f));
-  const float pdf = 0.3989422804014327f * expf(-0.5f * x * x);
-  return cdf + x * pdf;
-}
 
 inline int cdiv_h(long long a, long long b) { return (int)((a + b - 1) / b); }
 inline bool dt_ok(int dt) { return dt == CAVP_F32 || dt == CAVP_BF16; }

@@ -89,8 +89,12 @@ def workspace(nbytes: int, device) -> Optional[torch.Tensor]:
 def conv2d(x: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, kh: int = 1, kw: int = 1, stride: int = 1,
            pad: int = 0, dil: int = 1, scale: Optional[torch.Tensor] = None, shift: Optional[torch.Tensor] = None,
            nbias: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None, act: int = ACT_NONE,
-           splitk: int = 0, tile: int = 0, want_tile_stats: bool = False, stride_w: int = 0):
+           splitk: int = 0, tile: int = 0, want_tile_stats: bool = False, stride_w: int = 0,
+           res_rows: int = 0, aux: Optional[torch.Tensor] = None, aux_mode: int = 0):
     """out = act((conv(x, w) + nbias[n]) * scale + shift + residual); x/out/residual NHWC views, w OHWI packed.
+    res_rows > 0: `residual` has res_rows pixel rows and output pixel p adds row p % res_rows (a batch-periodic residual).
+    aux / aux_mode: 1 = act is GELU and gelu'(pre-activation) is stored into `aux` (out's shape); 2 = the result is multiplied
+    by `aux` before the residual is added (include/cavp_hip.h, cavp_conv_desc.aux_mode).
     want_tile_stats=True (plain convs only) returns (out, stats) where stats is None when this launch cannot produce the
     fused BatchNorm statistics, else (tile_stats f32 [tiles][Cout][2], tiles, rows_per_tile)."""
     _need_gpu(x, w, out, scale, shift, nbias, residual)
@@ -109,15 +113,24 @@ def conv2d(x: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, kh: int = 1, 
     ldr = 0
     if residual is not None:
         rn, rh, rw, rc, ldr = _nhwc(residual)
-        if (rn, rh, rw, rc) != (n, eho, ewo, cout) or residual.dtype != x.dtype:
+        if res_rows:
+            if rn * rh * rw != res_rows or rc != cout or residual.dtype != x.dtype or (n * eho * ewo) % res_rows:
+                raise _lib.CavpError("conv2d: a periodic residual must have res_rows rows dividing the output's")
+        elif (rn, rh, rw, rc) != (n, eho, ewo, cout) or residual.dtype != x.dtype:
             raise _lib.CavpError("conv2d: residual must match the output view")
+    ld_aux = 0
+    if aux_mode:
+        an, ah, aw, ac, ld_aux = _nhwc(aux)
+        if (an, ah, aw, ac) != (n, eho, ewo, cout) or aux.dtype != x.dtype:
+            raise _lib.CavpError("conv2d: aux must match the output view")
     for name, v in (("scale", scale), ("shift", shift)):
         if v is not None and (v.dtype != torch.float32 or v.numel() != cout or not v.is_contiguous()):
             raise _lib.CavpError(f"conv2d: {name} must be a contiguous f32 [{cout}]")
     if nbias is not None and (nbias.dtype != torch.float32 or nbias.numel() != n * cout or not nbias.is_contiguous()):
         raise _lib.CavpError(f"conv2d: nbias must be a contiguous f32 [{n},{cout}]")
     d = ConvDesc(dtype=dt, N=n, H=h, W=wd, Cin=cin, ldx=ldx, Cout=cout, ldy=ldy, KH=kh, KW=kw, stride=stride, pad=pad,
-                 dil=dil, ldr=ldr, act=act, splitk=splitk, tile=tile, up=0, Ho=0, Wo=0, stride_w=stride_w)
+                 dil=dil, ldr=ldr, act=act, splitk=splitk, tile=tile, up=0, Ho=0, Wo=0, stride_w=stride_w,
+                 res_rows=res_rows if residual is not None else 0, aux_mode=aux_mode, ld_aux=ld_aux)
     nbytes = lib.cavp_conv2d_workspace_bytes(C.byref(d))
     ws = workspace(nbytes, x.device)
     stats = None
@@ -125,9 +138,10 @@ def conv2d(x: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, kh: int = 1, 
         tiles, rpt = C.c_int32(0), C.c_int32(0)
         if lib.cavp_conv2d_tile_stats_layout(C.byref(d), C.byref(tiles), C.byref(rpt)) and out.data_ptr() % 16 == 0:
             stats = (torch.empty((tiles.value, cout, 2), dtype=torch.float32, device=x.device), tiles.value, rpt.value)
-    st = lib.cavp_conv2d_nhwc(C.byref(d), _ptr(x), _ptr(w), _ptr(scale), _ptr(shift), _ptr(nbias), _ptr(residual),
-                              _ptr(out), _ptr(ws), C.c_size_t(ws.numel() if ws is not None else 0),
-                              _ptr(stats[0]) if stats is not None else None, C.c_void_p(_stream()))
+    st = lib.cavp_conv2d_nhwc_aux(C.byref(d), _ptr(x), _ptr(w), _ptr(scale), _ptr(shift), _ptr(nbias), _ptr(residual),
+                                  _ptr(out), _ptr(aux) if aux_mode else None, _ptr(ws),
+                                  C.c_size_t(ws.numel() if ws is not None else 0),
+                                  _ptr(stats[0]) if stats is not None else None, C.c_void_p(_stream()))
     _lib.check(st, f"cavp_conv2d_nhwc N{n} H{h} W{wd} Cin{cin} Cout{cout} k{kh}x{kw} s{stride} p{pad} d{dil}")
     if want_tile_stats:
         return out, stats
@@ -242,17 +256,21 @@ def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, out: tor
 
 def attn_gate(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Tensor, attn: torch.Tensor, heads: int,
               scale: float) -> torch.Tensor:
+    """q may hold fewer batch items than out / k / v (a divisor): batch item b then reads q[b % q_batch]."""
     _need_gpu(q, k, v, out, attn)
-    b, t, c = q.shape
+    qb = q.shape[0]
+    b, t, c = out.shape
+    if q.shape[1:] != out.shape[1:] or b % qb:
+        raise _lib.CavpError("attn_gate: q must be [q_batch, T, C] with q_batch dividing the batch")
     for name, ten in (("q", q), ("k", k), ("v", v), ("out", out), ("attn", attn)):
         if not ten.is_contiguous():
             raise _lib.CavpError(f"attn_gate: {name} must be contiguous")
-    if k.numel() != b * c or v.numel() != b * c or out.shape != q.shape or attn.numel() != b * heads * t:
+    if k.numel() != b * c or v.numel() != b * c or attn.numel() != b * heads * t:
         raise _lib.CavpError("attn_gate: shape mismatch")
     if attn.dtype != torch.float32 or len({q.dtype, k.dtype, v.dtype, out.dtype}) != 1:
         raise _lib.CavpError("attn_gate: dtype mismatch")
     st = _lib.load().cavp_attn_gate(dtype_code(q.dtype), _ptr(q), _ptr(k), _ptr(v), _ptr(out), _ptr(attn), b, t, heads,
-                                    c // heads, C.c_float(scale), C.c_void_p(_stream()))
+                                    c // heads, C.c_float(scale), qb, C.c_void_p(_stream()))
     _lib.check(st, "cavp_attn_gate")
     return out
 

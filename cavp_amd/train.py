@@ -29,11 +29,14 @@ from ._lib import ACT_GELU, ACT_LEAKY, ACT_NONE, ACT_RELU, CavpError
 class V:
     """An activation (NHWC / token / vector tensor) and its gradient.  A channel slice of a wider buffer is a child
     whose gradient is the matching slice of the parent's gradient (free concat in both directions)."""
-    __slots__ = ("t", "_g", "parent", "lo", "hi", "needs_grad", "tile_stats")
+    __slots__ = ("t", "_g", "parent", "lo", "hi", "needs_grad", "tile_stats", "grad_mul", "g_premul")
 
     def __init__(self, t: torch.Tensor, parent: Optional["V"] = None, lo: int = 0, hi: int = 0, needs_grad: bool = True):
         self.t, self._g, self.parent, self.lo, self.hi, self.needs_grad = t, None, parent, lo, hi, needs_grad
         self.tile_stats = None   # (buf, tiles, rows_per_tile) when the producing conv computed BN statistics
+        # fused fc1 + GELU (TrainPass.conv(act=ACT_GELU)): the gelu' tensor the producer of this activation's gradient multiplies
+        # into its epilogue, and whether .g already carries that factor
+        self.grad_mul, self.g_premul = None, False
 
     @property
     def g(self) -> Optional[torch.Tensor]:
@@ -162,6 +165,8 @@ def allreduce_bn_stats(bn, buf: torch.Tensor, count: int) -> int:
     return count
 
 
+# False (tests / A-B only): GELU as a separate pass with the pre-activation stored, and the duplicated token tensors copied
+_FUSE_TOKEN_PATH = True
 _BN_BWD_READ_Y = False   # True (tests / A-B only): the BatchNorm backward always re-reads y instead of re-deriving the mask from z
 
 
@@ -291,6 +296,15 @@ class TrainPass:
             return
         if x.parent is not None:
             raise CavpError("accumulating into a slice is not supported")
+        if x.grad_mul is not None:
+            # the single consumer of a fused-GELU hidden activation: d(pre) = d(hidden) * gelu'(pre) inside its epilogue
+            if x.g is not None:
+                raise CavpError("a fused-GELU activation takes its gradient from exactly one producer")
+            g = self.empty(x.t.shape, x.t.dtype)
+            compute(g, None, x.grad_mul)
+            x.set_g(g)
+            x.g_premul = True
+            return
         if x.g is None:
             g = self.empty(x.t.shape, x.t.dtype)
             compute(g, None)
@@ -316,9 +330,13 @@ class TrainPass:
 
     # ---- ops -------------------------------------------------------------------------------------------------
     def conv(self, x: V, key: str, *, act: int = ACT_NONE, residual: Optional[V] = None, nbias: Optional[V] = None,
-             out: Optional[V] = None, stats: bool = False) -> V:
+             out: Optional[V] = None, stats: bool = False, residual_periodic: bool = False) -> V:
         """y = act(conv(x) + nbias[n] + bias + residual); fused epilogue forward, tape entry for backward.
-        stats=True: a plain conv feeding a BatchNorm - ask the epilogue for the per-tile batch statistics."""
+        stats=True: a plain conv feeding a BatchNorm - ask the epilogue for the per-tile batch statistics.
+        act=ACT_GELU (timm Mlp's fc1, attn.py:136-150): y = gelu(t) and gelu'(t) are both written by the epilogue; the
+        pre-activation never reaches HBM and the backward multiplier is applied inside the GEMM that produces dy.
+        residual_periodic: `residual` holds the first 1/k of the batch and is added to every k-th part (the un-duplicated half
+        of forward_train's torch.cat((x, x.clone())), cavp_model.py:181); its gradient is the sum over the parts."""
         p = self.P[key]
         x4 = _as4(x.t)
         n, h, w, _ = x4.shape
@@ -326,16 +344,23 @@ class TrainPass:
         wo = (w + 2 * p.pad - p.dil * (p.kw - 1) - 1) // p.stride + 1
         if out is None:
             out = V(self.empty(x.t.shape[:-1] + (p.cout,)) if x.t.dim() != 4 else self.empty((n, ho, wo, p.cout)))
-        if act == ACT_GELU:
-            raise CavpError("GELU is applied by a separate op in the training pass (its backward needs the pre-activation)")
         bias = p.bias.detach() if p.bias is not None else None
         fuse = stats and bias is None and nbias is None and residual is None and act == ACT_NONE and out.parent is None
+        deriv = self.empty(out.t.shape, out.t.dtype) if act == ACT_GELU else None
+        res_rows = 0
+        if residual_periodic:
+            res_rows = residual.t.numel() // residual.t.shape[-1]
+            if (out.t.numel() // out.t.shape[-1]) % res_rows or res_rows % 256:
+                raise CavpError("periodic residual: its rows must divide the output's and be a multiple of 256")
         r = ops.conv2d(x4, p.w, _as4(out.t), kh=p.kh, kw=p.kw, stride=p.stride, pad=p.pad, dil=p.dil, shift=bias,
                        nbias=nbias.t if nbias is not None else None,
-                       residual=_as4(residual.t) if residual is not None else None, act=act, want_tile_stats=fuse)
+                       residual=_as4(residual.t) if residual is not None else None, act=act, want_tile_stats=fuse,
+                       res_rows=res_rows, aux=_as4(deriv) if deriv is not None else None, aux_mode=1 if deriv is not None else 0)
         if fuse:
             out.tile_stats = r[1]
         y = out
+        if deriv is not None:
+            y.grad_mul = deriv
 
         def bwd():
             dy = y.g
@@ -344,10 +369,24 @@ class TrainPass:
             if act in (ACT_RELU, ACT_LEAKY):
                 g = self.empty(y.t.shape, y.t.dtype)
                 T.act_bwd(dy, y.t, g, act)
+            elif act == ACT_GELU:
+                if not y.g_premul:
+                    raise CavpError("fused GELU: the gradient must come from a data-gradient GEMM (TrainPass.acc)")
+                g = dy   # already d(hidden) * gelu'(pre)
             else:
                 g = dy
             if residual is not None:
-                self.acc_add(residual, g)
+                if residual_periodic:   # gradient of the shared residual = sum over the batch parts
+                    rr = residual.t.numel() // residual.t.shape[-1]
+                    g2 = g.reshape(-1, g.shape[-1])
+                    parts = [g2[i:i + rr] for i in range(0, g2.shape[0], rr)]
+                    acc_g = self.empty(residual.t.shape, residual.t.dtype)
+                    T.add(parts[0], parts[1], acc_g.view(rr, -1))
+                    for extra in parts[2:]:
+                        T.add(acc_g.view(rr, -1), extra, acc_g.view(rr, -1))
+                    self.acc_add(residual, acc_g)
+                else:
+                    self.acc_add(residual, g)
             if nbias is not None:
                 nb = self.zeros_f32(*nbias.t.shape)
                 g4 = _as4(g)
@@ -356,9 +395,9 @@ class TrainPass:
                 self.acc_add(nbias, nb)
             self.wgrad(p, x4, _as4(g))      # (+ the bias gradient: column sums of g taken inside the same kernel)
             if x.needs_grad:
-                def dg(o, r):
+                def dg(o, r, mul=None):
                     T.conv2d_dgrad(_as4(g), p.wT, _as4(o), kh=p.kh, kw=p.kw, stride=p.stride, pad=p.pad, dil=p.dil,
-                                   residual=_as4(r) if r is not None else None)
+                                   residual=_as4(r) if r is not None else None, mul=_as4(mul) if mul is not None else None)
                 self.acc(x, dg)
         self.tape.append(bwd)
         return y
@@ -553,18 +592,28 @@ class TrainPass:
         return y
 
     def attn_gate(self, q: V, k: V, v: V, heads: int, scale: float):
-        b, t, c = q.t.shape
+        """q may hold only the first 1/k of the batch (the query projection of the un-duplicated images): batch item b reads
+        q[b % q_batch]; dq is then the sum over the k parts."""
+        qb, t, c = q.t.shape
+        b = k.t.shape[0]
         attn = V(self.empty((b, heads, t), torch.float32))
-        o = V(self.empty(q.t.shape, q.t.dtype))
+        o = V(self.empty((b, t, c), q.t.dtype))
         ops.attn_gate(q.t, k.t, v.t, o.t, attn.t, heads, scale)
 
         def bwd():
             if o.g is None and attn.g is None:
                 return
             do = o.g if o.g is not None else torch.zeros_like(o.t)
-            dq = self.empty(q.t.shape, q.t.dtype)
+            dq = self.empty(o.t.shape, q.t.dtype)
             dk, dv = self.zeros_f32(b, c), self.zeros_f32(b, c)
             T.attn_gate_bwd(do, q.t, k.t, v.t, attn.t, attn.g, dq, dk, dv, heads, scale)
+            if qb != b:
+                parts = [dq[i:i + qb] for i in range(0, b, qb)]
+                dqs = self.empty(q.t.shape, q.t.dtype)
+                T.add(parts[0], parts[1], dqs)
+                for extra in parts[2:]:
+                    T.add(dqs, extra, dqs)
+                dq = dqs
             self.acc_add(q, dq)
             self.acc_add(k, dk if k.t.dtype == torch.float32 else ops.cast(dk, self.empty(dk.shape, k.t.dtype)))
             self.acc_add(v, dv if v.t.dtype == torch.float32 else ops.cast(dv, self.empty(dv.shape, v.t.dtype)))
@@ -754,22 +803,25 @@ def run_train_forward(model, image: torch.Tensor, audio: torch.Tensor, tp: Train
     Bv, hh, ww, Cc = fea_v.t.shape
     B2 = 2 * Bv
     tokB = tp.reshape(fea_v, (Bv, hh * ww, Cc))
-    hidp = tp.gelu(tp.conv(tokB, "proj.fc1"))
+    hidp = tp.conv(tokB, "proj.fc1", act=ACT_GELU) if _FUSE_TOKEN_PATH else tp.gelu(tp.conv(tokB, "proj.fc1"))
     fea_v_projB = tp.conv(hidp, "proj.fc2")
     v0B = tp.conv(fea_v_projB, "ca.pe_v")
     a0 = tp.conv(fea_a, "ca.pe_a")
     vnB = tp.layernorm(v0B, blk.norm1)
     an = tp.layernorm(a0, blk.norm1)
     qB = tp.conv(vnB, "ca.q")
-    vn, q = tp.dup2(vnB), tp.dup2(qB)
-    fea_v_proj = tp.dup2(fea_v_projB)   # pack["visual"] (output only)
+    # the 2B rows of `vn` / `q` / pack["visual"] are never materialised: the gate reads q[b % B], ca.proj adds the residual row
+    # p % (B * T), and the output-only duplicate of fea_v_proj is made by whoever returns it (three 2 x 61 MB copies per step)
+    periodic = (Bv * hh * ww) % 256 == 0 and _FUSE_TOKEN_PATH
+    vn, q = (vnB, qB) if periodic else (tp.dup2(vnB), tp.dup2(qB))
+    fea_v_proj = fea_v_projB
     fea_v2 = fea_v
     k = tp.conv(an, "ca.k")
     vv = tp.conv(an, "ca.v")
     o, attn = tp.attn_gate(q, k, vv, blk.attn.num_heads, blk.attn.scale)
-    r1 = tp.conv(o, "ca.proj", residual=vn)
+    r1 = tp.conv(o, "ca.proj", residual=vn, residual_periodic=periodic)
     l2 = tp.layernorm(r1, blk.norm2)
-    hh2 = tp.gelu(tp.conv(l2, "ca.fc1"))
+    hh2 = tp.conv(l2, "ca.fc1", act=ACT_GELU) if _FUSE_TOKEN_PATH else tp.gelu(tp.conv(l2, "ca.fc1"))
     r2 = tp.conv(hh2, "ca.fc2", residual=r1)
     fus_tok = tp.layernorm(r2, ca.norm)
     fusion = tp.reshape(fus_tok, (B2, hh, ww, Cc))
@@ -803,7 +855,8 @@ class CAVPTrainFunction(torch.autograd.Function):
             ops.bilinear_to_nchw(lo.t[..., :C], out_pred, align_corners=False)
             f32 = model._as_f32
             out_fusion = f32(fusion.t).permute(0, 3, 1, 2)
-            visual = f32(fea_v_proj.t).view(fusion.t.shape).permute(0, 3, 1, 2)
+            vis = f32(fea_v_proj.t).view((-1,) + tuple(fusion.t.shape[1:]))
+            visual = torch.cat((vis, vis), dim=0).permute(0, 3, 1, 2)   # cavp_model.py:181: the two halves are identical
             audio_f = f32(fea_a.t)[:, :, None, None]
             attn_v = attn.t.unsqueeze(-1)
         ctx.tp, ctx.lo, ctx.fusion, ctx.params, ctx.hw = tp, lo, fusion, params, tuple(image.shape[-2:])

@@ -45,8 +45,10 @@ def _s():
 
 
 def conv2d_dgrad(dy: torch.Tensor, w_t: torch.Tensor, dx: torch.Tensor, *, kh: int, kw: int, stride: int, pad: int,
-                 dil: int, residual: Optional[torch.Tensor] = None, scale=None, shift=None, act: int = 0) -> torch.Tensor:
-    """Data gradient of a forward conv (kh x kw, stride, pad, dil): dx = conv_transpose(dy, w) (+ residual).
+                 dil: int, residual: Optional[torch.Tensor] = None, scale=None, shift=None, act: int = 0,
+                 mul: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Data gradient of a forward conv (kh x kw, stride, pad, dil): dx = conv_transpose(dy, w) [* mul] (+ residual).
+    mul (dx's shape): element-wise multiplier applied in the epilogue - the gelu' tensor of a fused fc1 + GELU forward.
     dy: [N,Ho,Wo,Cout_f] view, w_t: cavp_pack_weight_dgrad weights [Cin_f][kh][kw][Cout_f], dx: [N,H,W,Cin_f] view."""
     _need_gpu(dy, w_t, dx, residual)
     lib = _lib.load()
@@ -62,16 +64,22 @@ def conv2d_dgrad(dy: torch.Tensor, w_t: torch.Tensor, dx: torch.Tensor, *, kh: i
     padt = dil * (kh - 1) - pad
     if padt < 0:
         raise _lib.CavpError("conv2d_dgrad: pad > dil*(k-1) is not supported")
+    ld_aux = 0
+    if mul is not None:
+        mn, mh, mw, mc, ld_aux = _nhwc(mul)
+        if (mn, mh, mw, mc) != (n, h, w, cif) or mul.dtype != dy.dtype:
+            raise _lib.CavpError("conv2d_dgrad: mul must match dx")
     d = ConvDesc(dtype=dtype_code(dy.dtype), N=n, H=ho, W=wo, Cin=cof, ldx=ldx, Cout=cif, ldy=ldy, KH=kh, KW=kw,
-                 stride=1, pad=padt, dil=dil, ldr=ldr, act=act, splitk=0, tile=0, up=stride, Ho=h, Wo=w, stride_w=0)
+                 stride=1, pad=padt, dil=dil, ldr=ldr, act=act, splitk=0, tile=0, up=stride, Ho=h, Wo=w, stride_w=0,
+                 aux_mode=2 if mul is not None else 0, ld_aux=ld_aux)
     if stride == 1:
         eh, ew = ho + 2 * padt - dil * (kh - 1), wo + 2 * padt - dil * (kw - 1)
         if (eh, ew) != (h, w):
             raise _lib.CavpError(f"conv2d_dgrad: dx extent {(h, w)} != {(eh, ew)}")
     nbytes = lib.cavp_conv2d_workspace_bytes(C.byref(d))
     ws = ops.workspace(nbytes, dy.device)
-    st = lib.cavp_conv2d_nhwc(C.byref(d), _ptr(dy), _ptr(w_t), _ptr(scale), _ptr(shift), None, _ptr(residual), _ptr(dx),
-                              _ptr(ws), C.c_size_t(ws.numel() if ws is not None else 0), None, _s())
+    st = lib.cavp_conv2d_nhwc_aux(C.byref(d), _ptr(dy), _ptr(w_t), _ptr(scale), _ptr(shift), None, _ptr(residual), _ptr(dx),
+                                  _ptr(mul), _ptr(ws), C.c_size_t(ws.numel() if ws is not None else 0), None, _s())
     _check(st, "cavp_conv2d_nhwc(dgrad)")
     return dx
 
@@ -296,10 +304,14 @@ def layernorm_bwd(dy, x, gamma, dx, dgamma, dbeta, eps: float) -> torch.Tensor:
 
 
 def attn_gate_bwd(dout, q, k, v, attn, dattn, dq, dk, dv, heads: int, scale: float) -> None:
+    """q: [q_batch, T, C] (q_batch divides the batch of dout / dq), as in ops.attn_gate."""
     _need_gpu(dout, q, k, v, attn, dq, dk, dv)
-    b, t, c = q.shape
+    b, t, c = dout.shape
+    qb = q.shape[0]
+    if b % qb or dq.shape != dout.shape:
+        raise _lib.CavpError("attn_gate_bwd: shape mismatch")
     _check(_lib.load().cavp_attn_gate_bwd(dtype_code(q.dtype), _ptr(dout), _ptr(q), _ptr(k), _ptr(v), _ptr(attn), _ptr(dattn),
-                                          _ptr(dq), _ptr(dk), _ptr(dv), b, t, heads, c // heads, C.c_float(scale), _s()),
+                                          _ptr(dq), _ptr(dk), _ptr(dv), b, t, heads, c // heads, C.c_float(scale), qb, _s()),
            "cavp_attn_gate_bwd")
 
 

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define CAVP_ABI_VERSION 5
+#define CAVP_ABI_VERSION 6
 
 typedef enum { CAVP_F32 = 0, CAVP_BF16 = 1 } cavp_dtype_t;
 typedef enum { CAVP_ACT_NONE = 0, CAVP_ACT_RELU = 1, CAVP_ACT_LEAKY = 2, CAVP_ACT_GELU = 3 } cavp_act_t;
@@ -76,6 +76,16 @@ typedef struct cavp_conv_desc {
   int32_t dw_oihw;    /* cavp_conv2d_wgrad_nhwc only: 1 = accumulate into a torch-layout [Cout][Cin][KH][KW] gradient (default 0: OHWI) */
   int32_t dw_overwrite; /* cavp_conv2d_wgrad_nhwc only: 1 = dw = gradient (beta = 0: dw is neither read nor required to be zeroed;
                            dead taps of a dilated kernel are written as zeros); default 0: dw += gradient */
+  /* ---- ABI 6: epilogue fusions of the token path (cavp_conv2d_nhwc_aux) ---- */
+  int32_t res_rows;   /* 0 = the residual has one row per output pixel; > 0: it has res_rows pixel rows and output pixel p
+                         adds row p mod res_rows - the un-duplicated half of forward_train's `torch.cat((x, x.clone()))`
+                         (cavp_model.py:181) read twice instead of copied (must be a multiple of 256 rows) */
+  int32_t aux_mode;   /* 0 = none.  1 (act must be CAVP_ACT_GELU): besides y = gelu(t) the epilogue stores gelu'(t) into
+                         `aux` (y's shape, stride ld_aux) - what the backward of timm's Mlp needs (attn.py:136-150,
+                         cavp_model.py:123-128), so the pre-activation is never written.  2: the result is multiplied
+                         element-wise by `aux` before the residual is added: d(pre) = d(hidden) * gelu'(pre) fused into
+                         the data-gradient GEMM that produces d(hidden) */
+  int32_t ld_aux;     /* pixel stride of aux (elements) */
 } cavp_conv_desc;
 
 size_t cavp_conv2d_workspace_bytes(const cavp_conv_desc* d);
@@ -87,6 +97,12 @@ int cavp_conv2d_tile_stats_layout(const cavp_conv_desc* d, int32_t* tiles, int32
 int cavp_conv2d_nhwc(const cavp_conv_desc* d, const void* x, const void* w, const float* scale, const float* shift,
                      const float* nbias, const void* residual, void* y, void* workspace, size_t workspace_bytes,
                      float* tile_stats, void* stream);
+/* The same with the auxiliary epilogue tensor of d->aux_mode (dtype of y; written for mode 1, read for mode 2).  Launches
+ * that use res_rows / aux_mode need the 16-byte epilogue (Cout, ldy, ldr, ld_aux multiples of 8 bf16 / 4 f32 elements,
+ * 16-byte aligned pointers) and are never split over K: CAVP_ERR_UNSUPPORTED otherwise. */
+int cavp_conv2d_nhwc_aux(const cavp_conv_desc* d, const void* x, const void* w, const float* scale, const float* shift,
+                         const float* nbias, const void* residual, void* y, void* aux, void* workspace,
+                         size_t workspace_bytes, float* tile_stats, void* stream);
 
 /* Direct 3x3 conv for Cin in {1,2,3} reading an NCHW f32 tensor and writing NHWC (dtype) with scale/shift + act:
  * the ResNet deep-stem first conv (resnet.py:108-110, stride 2) and the first VGGish conv (vgg.py:26-36). */
@@ -118,9 +134,11 @@ int cavp_layernorm(int32_t dtype, const void* x, const float* gamma, const float
 
 /* Sigmoid-gated single-key attention (attn.py:73-106 with N_kv == 1):
  *   s[b,h,t] = sigmoid(scale * <q[b,t,h,:], k[b,h,:]>);  o[b,t,h,:] = s[b,h,t] * v[b,h,:];  attn[b,h,t] = s.
- * q,o: [B][T][heads*hd] (dtype); k,v: [B][heads*hd] (dtype); attn: f32 [B][heads][T]. */
+ * q: [q_batch][T][heads*hd], o: [B][T][heads*hd] (dtype); k,v: [B][heads*hd] (dtype); attn: f32 [B][heads][T].
+ * q_batch = B, or a divisor of B: batch item b reads q[b mod q_batch] (forward_train runs the query projection once on the B
+ * images and gates it with the 2B audio clips, cavp_model.py:181). */
 int cavp_attn_gate(int32_t dtype, const void* q, const void* k, const void* v, void* o, float* attn, int32_t B,
-                   int32_t T, int32_t heads, int32_t hd, float scale, void* stream);
+                   int32_t T, int32_t heads, int32_t hd, float scale, int32_t q_batch, void* stream);
 
 /* BatchNorm (eval) folding: scale = gamma * rsqrt(var + eps), shift = beta - mean * scale (f32, C entries). */
 int cavp_bn_fold(const float* gamma, const float* beta, const float* mean, const float* var, float eps, float* scale,
@@ -217,10 +235,11 @@ int cavp_colsum(int32_t dtype, const void* x, int64_t rows, int32_t C, int32_t l
 int cavp_layernorm_bwd(int32_t dtype, const void* dy, const void* x, const float* gamma, void* dx, float* dgamma,
                        float* dbeta, int32_t rows, int32_t C, int32_t ld_dy, int32_t ld_x, int32_t ld_dx, float eps,
                        void* stream);
-/* backward of cavp_attn_gate; dk, dv: f32 [B][heads*hd] accumulated with atomics (caller zeroes); dattn optional. */
+/* backward of cavp_attn_gate; dk, dv: f32 [B][heads*hd] accumulated with atomics (caller zeroes); dattn optional.
+ * q: [q_batch][T][heads*hd] as in the forward; dq: [B][T][heads*hd] (the caller sums the q_batch-periodic parts). */
 int cavp_attn_gate_bwd(int32_t dtype, const void* dout, const void* q, const void* k, const void* v, const float* attn,
                        const float* dattn, void* dq, float* dk, float* dv, int32_t B, int32_t T, int32_t heads,
-                       int32_t hd, float scale, void* stream);
+                       int32_t hd, float scale, int32_t q_batch, void* stream);
 /* dx [N][H][W][C] = gradient routed to the recorded arg-max of every window (argmax from cavp_maxpool_nhwc) */
 int cavp_maxpool_bwd_nhwc(int32_t dtype, const uint8_t* argmax, const void* dy, void* dx, int32_t N, int32_t H, int32_t W,
                           int32_t C, int32_t k, int32_t stride, int32_t pad, void* stream);

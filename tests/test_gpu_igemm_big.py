@@ -119,3 +119,38 @@ def test_big_tile_refuses_what_it_cannot_do():
     wb = ops.pack_weight(_rand(20, 64, 1, 1, seed=2).to(DEV), BF)
     with pytest.raises(CavpError):   # Cout not a multiple of the 16-byte vector
         ops.conv2d(xb, wb, torch.empty((1, 8, 8, 20), dtype=BF, device=DEV), tile=BIG)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, BF], ids=["f32", "bf16"])
+@pytest.mark.parametrize("tile", [0, 1, BIG])
+def test_token_path_epilogue_fusions(tile, dtype):
+    """ABI 6 (cavp_conv2d_nhwc_aux): fc1 + GELU with the derivative as a second output (aux_mode 1), a data-gradient GEMM
+    whose result is multiplied by that derivative (aux_mode 2), and a batch-periodic residual (res_rows) - timm Mlp /
+    forward_train's duplicated features (attn.py:136-150, cavp_model.py:181) - against plain PyTorch."""
+    ops = _ops()
+    if tile == BIG and dtype != BF:
+        pytest.skip("the 256x256 tile is bf16 only")
+    n, t, cin, cout = 4, 512, 96, 256           # 2048 token rows; residual period = 1024 rows
+    x = _rand(n, cin, 1, t, seed=31)
+    wt = _rand(cout, cin, 1, 1, seed=32, scale=cin ** -0.5)
+    bias = _rand(cout, seed=33)
+    xv, _ = _to_nhwc_dev(x, dtype)
+    wp = ops.pack_weight(wt.to(DEV), dtype)
+    pre = F.conv2d(_q(x, dtype), _q(wt, dtype), bias)
+    # aux_mode 1
+    y = torch.empty((n, 1, t, cout), dtype=dtype, device=DEV)
+    d = torch.empty_like(y)
+    ops.conv2d(xv, wp, y, shift=bias.to(DEV), act=ops.ACT_GELU, aux=d, aux_mode=1, tile=tile)
+    p64 = pre.double()
+    dref = (0.5 * (1 + torch.erf(p64 / 2 ** 0.5)) + p64 * torch.exp(-0.5 * p64 * p64) / (2 * torch.pi) ** 0.5).float()
+    _check(y.permute(0, 3, 1, 2), F.gelu(pre), dtype, f"gelu out tile{tile}")
+    _check(d.permute(0, 3, 1, 2), dref, dtype, f"gelu' out tile{tile}")
+    # aux_mode 2 + periodic residual: out = conv * mul + res[p % rows]
+    mul = _rand(n, cout, 1, t, seed=34)
+    res = _rand(n // 2, cout, 1, t, seed=35)
+    mv, _ = _to_nhwc_dev(mul, dtype)
+    rv, _ = _to_nhwc_dev(res, dtype)
+    out = torch.empty((n, 1, t, cout), dtype=dtype, device=DEV)
+    ops.conv2d(xv, wp, out, shift=bias.to(DEV), residual=rv, res_rows=(n // 2) * t, aux=mv, aux_mode=2, tile=tile)
+    ref = pre * _q(mul, dtype) + torch.cat((_q(res, dtype), _q(res, dtype)), 0)
+    _check(out.permute(0, 3, 1, 2), ref, dtype, f"mul + periodic residual tile{tile}")

@@ -43,9 +43,12 @@ def _step(m, cfg, use_hip_ce):
     return out, fus, pack, loss
 
 
+@pytest.mark.parametrize("case", ["c1p_train", "c1_train"])
 @pytest.mark.parametrize("use_hip_ce", [False, True], ids=["torch_ce", "hip_ce"])
-def test_train_step_matches_reference_f32(use_hip_ce):
-    z, cfg = load_case("c1p_train")
+def test_train_step_matches_reference_f32(use_hip_ce, case):
+    """c1p_train: the native 224 / OS16 / 2-class model; c1_train: config #1's model (OS8: layer3 / layer4 at 28 x 28 with
+    dilation, 22 classes) - forward, CE loss and every parameter gradient against the reference's own autograd."""
+    z, cfg = load_case(case)
     m, _ = _build(cfg)
     out, fus, pack, loss = _step(m, cfg, use_hip_ce)
     assert abs(loss - float(z["loss"][0])) <= 2e-5 * max(1.0, abs(float(z["loss"][0]))), (loss, float(z["loss"][0]))
@@ -338,3 +341,49 @@ def test_graph_replays_stay_correct(split):
             # (DESIGN.md 6c); a gradient that was not cleared / was cleared late is inf or >> 1
             e, s = float((v - r).norm()), float(r.norm())
             assert torch.isfinite(v).all() and e <= 0.5 * s + 1e-6, (it, names[id(p)], e, s)
+
+
+def test_clip_shaped_ce_plus_contrast_matches_reference_golden():
+    """Config #5 (AVSBench-MS): one clip = 5 frames batched as B = 5 (the reference loops the frames at B = 1,
+    trainer_cavp_avs_obj.py:317-330), loss = CE on `out[:B] + out[B:]*0` + ContrastLoss on the fusion halves
+    (trainer_cavp_vpo_mono.py:171-189).  Golden: the REFERENCE's own model + ContrastLoss + autograd on these inputs
+    (tools/make_golden.py, case c5_clip_train): both loss terms and every parameter gradient."""
+    from cavp_amd.contrast import ContrastLoss
+    z, cfg = load_case("c5_clip_train")
+    B = cfg["B"]
+    assert B == 5
+    m, _ = _build(cfg)
+    image, audio, _ = synth_inputs(B, cfg["hw"], audio_batch=2 * B, num_classes=cfg["C"], seed=0)
+    label = torch.from_numpy(z["label"].astype(np.int64)).to(DEV)
+    label_shuf = torch.from_numpy(z["label_shuffle"].astype(np.int64)).to(DEV)
+    out, fus, _ = m(image.to(DEV), audio.to(DEV), None, False)
+    crit = ContrastLoss(temperature=0.1, ignore_idx=255, max_views=512)
+    torch.manual_seed(4321)                         # the generator seeds its anchor sampling the same way
+    l_ctr = crit(fus[:B], label, fus[B:], label_shuf)
+    l_ce = F.cross_entropy(out[:B] + out[B:] * 0.0, label, ignore_index=255)
+    (l_ce + l_ctr).backward()
+    torch.cuda.synchronize()
+    r_ce, r_ctr = float(z["loss_ce"][0]), float(z["loss_ctr"][0])
+    print(f"clip: CE {float(l_ce):.6f} (reference {r_ce:.6f}), contrast {float(l_ctr):.6f} (reference {r_ctr:.6f})")
+    assert abs(float(l_ce) - r_ce) <= 1e-4 * max(1.0, abs(r_ce))
+    # the anchors are pixels of the fusion map picked by label only (same randperm stream): the loss differs by rounding
+    assert abs(float(l_ctr) - r_ctr) <= 2e-3 * max(1.0, abs(r_ctr))
+    params = dict(m.named_parameters())
+    keys, vals = list(z["grad_norm_keys"]), z["grad_norm_vals"]
+    rels = []
+    for k, v in zip(keys, vals):
+        g = params[k].grad
+        assert g is not None, f"no gradient for {k}"
+        rels.append(abs(float(g.double().norm()) - v) / max(v, 1e-9))
+    rels = np.array(rels)
+    print(f"clip: gradient-norm rel. error median {np.median(rels):.2e} max {rels.max():.2e} ({keys[int(rels.argmax())]})")
+    # same noise floor as the B = 2 fixtures (batch-statistics BatchNorm on 5 samples in the ASPP pooling branch)
+    assert np.median(rels) <= 5e-3 and rels.max() <= 5e-2
+    for s_ in [s_ for s_ in z.files if s_.startswith("grad_sample/")]:
+        k = s_[len("grad_sample/"):]
+        g = params[k].grad.detach().float().cpu().contiguous().flatten()
+        ref = z[s_]
+        smp = g[:: max(1, g.numel() // 4096)][:4096].numpy()
+        a, b = smp.astype(np.float64), ref.astype(np.float64)
+        cos = float(a @ b / (np.linalg.norm(a) * np.linalg.norm(b) + 1e-30))
+        assert cos >= 0.99, (k, cos)

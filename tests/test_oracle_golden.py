@@ -29,8 +29,10 @@ def test_oracle_eval_matches_reference(case):
         assert np.abs(out.numpy() - z["full/out_pred"]).max() <= ATOL * 10
 
 
-def test_oracle_train_matches_reference():
-    z, cfg = load_case("c1p_train")
+@pytest.mark.parametrize("case", ["c1p_train", "c1_train"])
+def test_oracle_train_matches_reference(case):
+    """c1_train = config #1's model (OS8, 22 classes) in training mode."""
+    z, cfg = load_case(case)
     B = cfg["B"]
     sd = synth_state_dict(cavp_state_shapes(cfg["C"]), seed=1)
     image, audio, label = synth_inputs(B, cfg["hw"], audio_batch=2 * B, num_classes=cfg["C"], seed=0)
@@ -63,7 +65,10 @@ def test_oracle_train_matches_reference():
         ref = z["grad_sample/" + k]
         n = g.numel()
         s = g.flatten()[:: max(1, n // 4096)][:4096].numpy()
-        assert np.abs(s - ref).max() <= 1e-5 * max(1.0, np.abs(ref).max()), k
+        # (c1_train: OS8 keeps 13 more batch-statistics BatchNorm layers at 28 x 28, and the f32 summation order of the conv
+        # backward differs with the thread count the fixture was generated with: 1.6e-4 of max|grad| measured on the stem)
+        tol = 1e-5 if case == "c1p_train" else 1e-3
+        assert np.abs(s - ref).max() <= tol * max(1.0, np.abs(ref).max()), k
 
 
 def test_oracle_pvt_matches_reference():
@@ -79,3 +84,29 @@ def test_oracle_pvt_matches_reference():
     for k in sorted(taps):
         scale = max(1.0, float(np.abs(z["sample/" + k]).max()))
         check_tap(z, k, taps[k], 2 * ATOL * scale, what="pvt:")
+
+
+def test_oracle_clip_ce_plus_contrast_matches_reference():
+    """config #5: a 5-frame clip batched as B = 5, CE + ContrastLoss on the fusion halves (golden c5_clip_train from the
+    reference's own model, loss and autograd): pins oracle.cavp_oracle + oracle.contrast_oracle together on that shape."""
+    import torch
+    from oracle.contrast_oracle import contrast_loss
+    z, cfg = load_case("c5_clip_train")
+    B = cfg["B"]
+    sd = synth_state_dict(cavp_state_shapes(cfg["C"]), seed=1)
+    image, audio, _ = synth_inputs(B, cfg["hw"], audio_batch=2 * B, num_classes=cfg["C"], seed=0)
+    label = torch.from_numpy(z["label"].astype(np.int64))
+    label_shuf = torch.from_numpy(z["label_shuffle"].astype(np.int64))
+    params = {k: v.clone().requires_grad_(True) for k, v in sd.items() if v.is_floating_point() and "running_" not in k}
+    sd2 = dict(sd)
+    sd2.update(params)
+    out, fus, _ = O.cavp_forward(sd2, image, audio, cfg["lds"], eval_mode=False)
+    torch.manual_seed(4321)
+    l_ctr = contrast_loss(fus[:B], label, fus[B:], label_shuf, 0.1, 255, 512)
+    l_ce = O.ce_loss_train(out, label, B)
+    assert abs(l_ce.item() - float(z["loss_ce"][0])) <= 1e-5
+    assert abs(l_ctr.item() - float(z["loss_ctr"][0])) <= 1e-4
+    (l_ce + l_ctr).backward()
+    for k, v in zip(list(z["grad_norm_keys"]), z["grad_norm_vals"]):
+        n = params[k].grad.double().norm().item()
+        assert abs(n - v) <= 2e-4 * max(v, 1e-3), (k, n, v)

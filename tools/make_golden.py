@@ -42,7 +42,28 @@ CASES = {
     "c1_eval": dict(lds=[False, True, True], C=22, B=2, hw=(224, 224), mode="eval"),        # config_vpo_ss.py plumbing @224
     "ragged_eval": dict(lds=[False, False, False], C=24, B=3, hw=(96, 160), mode="eval"),   # odd batch, H != W
     "c1p_train": dict(lds=[False, False, False], C=2, B=2, hw=(224, 224), mode="train"),   # BN batch stats, audio 2B, CE grads
+    # config #1's model (config_vpo_ss.py plumbing: OS8, 22 classes) in training mode
+    "c1_train": dict(lds=[False, True, True], C=22, B=2, hw=(224, 224), mode="train"),
+    # config #5 (AVSBench-MS: a clip = 5 frames batched as B = 5, reference loops the frames at B = 1,
+    # trainer_cavp_avs_obj.py:317-330): CE + ContrastLoss on the fusion halves, trainer_cavp_vpo_mono.py:171-189
+    "c5_clip_train": dict(lds=[False, False, False], C=2, B=5, hw=(224, 224), mode="train", contrast=True),
 }
+
+
+def clip_labels(B, hw, num_classes, seed):
+    """Blocky label maps for the clip fixture (ContrastLoss needs classes with many pixels): one rectangle of class 1 per frame
+    that drifts over the clip, a few rows of ignore_index; the shuffled-audio labels are the matched ones where the shuffled
+    clip index equals the original and background elsewhere (trainer_cavp_vpo_mono.py:173-179)."""
+    g = torch.Generator().manual_seed(seed)
+    gt = torch.zeros((B,) + tuple(hw), dtype=torch.long)
+    for b in range(B):
+        h0 = 20 + 12 * b
+        w0 = int(torch.randint(10, hw[1] - 130, (1,), generator=g))
+        gt[b, h0:h0 + 90, w0:w0 + 120] = 1 if num_classes == 2 else 1 + b % (num_classes - 1)
+        gt[b, :4, :] = 255
+    gs = gt.clone()
+    gs[1:] = 0
+    return gt, gs
 
 SENTINELS = [
     "backbone.backbone.conv1.0.weight", "backbone.backbone.layer1.0.conv1.weight",
@@ -105,7 +126,20 @@ def run_case(name, cfg, out_dir):
         m.train()
         out, fus, pack = m(image, audio, None, False)
         output = out[:B] + out[B:] * 0.0                       # trainer_cavp_vpo_mono.py:171
-        loss = F.cross_entropy(output, label, ignore_index=255)  # loss/losser.py:60-62
+        if cfg.get("contrast"):
+            from loss.contrastive_aud import ContrastLoss
+            label, label_shuf = clip_labels(B, cfg["hw"], cfg["C"], seed=21)
+            store["label"] = label.numpy().astype(np.int16)
+            store["label_shuffle"] = label_shuf.numpy().astype(np.int16)
+            crit = ContrastLoss(temperature=0.1, ignore_idx=255, max_views=512)
+            torch.manual_seed(4321)                               # ContrastLoss samples anchors with torch.randperm
+            l_ctr = crit(fus[:B], label, fus[B:], label_shuf)       # :178-181
+            l_ce = F.cross_entropy(output, label, ignore_index=255)
+            loss = l_ce + l_ctr                                   # :189
+            store["loss_ce"] = np.array([l_ce.item()], dtype=np.float64)
+            store["loss_ctr"] = np.array([l_ctr.item()], dtype=np.float64)
+        else:
+            loss = F.cross_entropy(output, label, ignore_index=255)  # loss/losser.py:60-62
         loss.backward()
         store["loss"] = np.array([loss.item()], dtype=np.float64)
         gn = {}
