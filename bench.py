@@ -50,6 +50,7 @@ def parse():
                     help="force the two-graph replay of the data-parallel path (cut where the early gradients are final) on one GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--deterministic", action="store_true", help="opt-in bit-reproducible reductions (cavp_set_deterministic)")
     ap.add_argument("--no-token-fusion", action="store_true", help="A/B: GELU as a separate pass, duplicated token tensors copied")
     ap.add_argument("--no-f32", action="store_true", help="skip the secondary f32 (parity path) training-step measurement")
     ap.add_argument("--cpu-sample-batch", type=int, default=8)
@@ -378,6 +379,9 @@ def main():
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=dev)
+    if a.deterministic:
+        from cavp_amd import _lib as _cl
+        _cl.set_deterministic(True, dev)
     dtype = torch.bfloat16 if a.dtype == "bf16" else torch.float32
     cfg = model_cfg(a.config)
     if a.config == "c4":
@@ -468,7 +472,7 @@ def main():
                                      f"C1' (config_avss_binary shape): CAVP ResNet-50 OS16 + VGGish, eval forward, "
                                      f"B={B}/GPU, 224x224 RGB + 96x64 mel, num_classes=2, random-init (synthetic) weights")),
                        "global_batch": world * B, "per_gpu_batch": B, "parallelism": f"dp{world}",
-                       "launch": "eager" if a.no_graph else "hipGraph replay"},
+                       "launch": "eager" if a.no_graph else "hipGraph replay", "deterministic": bool(a.deterministic)},
         }
         if not a.no_roofline:
             roof = measure_roofline(model, run_step_local, image, a.dtype)

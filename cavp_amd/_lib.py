@@ -34,6 +34,8 @@ _vp, _i32, _i64, _f32, _sz = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_si
 # name -> (restype, argtypes): every symbol include/cavp_hip.h declares
 PROTOTYPES = {
     "cavp_abi_version": (_i32, []),
+    "cavp_set_deterministic": (_i32, [_vp, _sz]),
+    "cavp_get_deterministic": (_i32, []),
     "cavp_error_string": (C.c_char_p, [_i32]),
     "cavp_conv2d_workspace_bytes": (_sz, [C.POINTER(ConvDesc)]),
     "cavp_conv2d_nhwc": (_i32, [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _vp]),
@@ -127,3 +129,26 @@ def check(status: int, what: str = "") -> None:
     if status != 0:
         msg = load().cavp_error_string(status).decode()
         raise CavpError(f"{what}: libcavp_hip status {status} ({msg})")
+
+
+_det_scratch = None
+
+
+def set_deterministic(on: bool, device=None, scratch_bytes: int = 8 << 20) -> None:
+    """Opt-in bit-reproducible training (the reference runs with cudnn.deterministic = True, main_vpo_mono.py:39-41): the
+    reductions that otherwise end in f32 atomics add their per-workgroup partials in a fixed order (cavp_set_deterministic,
+    include/cavp_hip.h).  Call it BEFORE capturing a training step into a hipGraph: the scratch buffer's address is baked into
+    the captured launches.  Costs ~0.3 ms per C1' step (a few dozen extra small launches)."""
+    global _det_scratch
+    import torch
+    lib = load()
+    if on:
+        _det_scratch = torch.empty(scratch_bytes, dtype=torch.uint8, device=device if device is not None else torch.device("cuda", torch.cuda.current_device()))
+        check(lib.cavp_set_deterministic(C.c_void_p(_det_scratch.data_ptr()), C.c_size_t(scratch_bytes)), "cavp_set_deterministic")
+    else:
+        check(lib.cavp_set_deterministic(None, C.c_size_t(0)), "cavp_set_deterministic")
+        _det_scratch = None   # (graphs captured while it was on must not be replayed any more)
+
+
+def is_deterministic() -> bool:
+    return bool(load().cavp_get_deterministic())

@@ -86,7 +86,7 @@ __global__ __launch_bounds__(256) void attn_gate_bwd_kernel(const T* __restrict_
                                                             const float* __restrict__ dattn, T* __restrict__ dq,
                                                             float* __restrict__ dk, float* __restrict__ dv, int Tn,
                                                             int heads, int hd, float scale, int tok_per_block,
-                                                            int q_batch) {
+                                                            int q_batch, float* __restrict__ det_part) {
   __shared__ float part[2][4][512];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, b = blockIdx.y;
   const int C = heads * hd, NQ = C >> 2, qh = hd >> 2;
@@ -141,7 +141,10 @@ __global__ __launch_bounds__(256) void attn_gate_bwd_kernel(const T* __restrict_
   for (int i = threadIdx.x; i < 2 * C; i += 256) {
     const int st = i / C, c = i - st * C;
     const float s = (part[st][0][c] + part[st][1][c]) + (part[st][2][c] + part[st][3][c]);
-    atomicAdd((st == 0 ? dk : dv) + (size_t)b * C + c, s);
+    if (det_part)   // deterministic mode: [2][gridDim.x][B * C] partials, added in token-chunk order afterwards
+      det_part[((size_t)st * gridDim.x + blockIdx.x) * ((size_t)gridDim.y * C) + (size_t)b * C + c] = s;
+    else
+      atomicAdd((st == 0 ? dk : dv) + (size_t)b * C + c, s);
   }
 }
 
@@ -184,9 +187,14 @@ extern "C" int cavp_attn_gate_bwd(int32_t dtype, const void* dout, const void* q
   tpb = (tpb + 3) / 4 * 4;
   gx = (T + tpb - 1) / tpb;
   hipStream_t s = (hipStream_t)stream;
+  bool det_err;
+  float* det = cavp_det_scratch(gx, B * heads * hd, &det_err);
+  if (det_err) return CAVP_ERR_WORKSPACE;
   if (dtype == CAVP_F32)
-    attn_gate_bwd_kernel<float><<<dim3(gx, B), 256, 0, s>>>((const float*)dout, (const float*)q, (const float*)k, (const float*)v, attn, dattn, (float*)dq, dk, dv, T, heads, hd, scale, tpb, q_batch);
+    attn_gate_bwd_kernel<float><<<dim3(gx, B), 256, 0, s>>>((const float*)dout, (const float*)q, (const float*)k, (const float*)v, attn, dattn, (float*)dq, dk, dv, T, heads, hd, scale, tpb, q_batch, det);
   else
-    attn_gate_bwd_kernel<bf16_t><<<dim3(gx, B), 256, 0, s>>>((const bf16_t*)dout, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, attn, dattn, (bf16_t*)dq, dk, dv, T, heads, hd, scale, tpb, q_batch);
-  return hipGetLastError() == hipSuccess ? CAVP_OK : CAVP_ERR_LAUNCH;
+    attn_gate_bwd_kernel<bf16_t><<<dim3(gx, B), 256, 0, s>>>((const bf16_t*)dout, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, attn, dattn, (bf16_t*)dq, dk, dv, T, heads, hd, scale, tpb, q_batch, det);
+  if (hipGetLastError() != hipSuccess) return CAVP_ERR_LAUNCH;
+  if (det && cavp_det_finish(det, gx, B * heads * hd, dk, dv, s) != hipSuccess) return CAVP_ERR_LAUNCH;
+  return CAVP_OK;
 }

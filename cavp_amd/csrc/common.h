@@ -154,6 +154,40 @@ static inline hipError_t cavp_zero_f32_async(void* ptr, size_t bytes, hipStream_
   return hipGetLastError();
 }
 
+// Deterministic mode (cavp_set_deterministic, include/cavp_hip.h): the four reductions that normally end in one f32 atomic per
+// (workgroup, channel) - BatchNorm / bias column sums, LayerNorm and attention-gate parameter gradients - store their
+// per-workgroup partials into a caller-provided scratch buffer instead and a second kernel adds them in workgroup order.
+// Process-wide state (one process per GPU); defined in pointwise.hip.
+struct CavpDetState {
+  float* scratch;
+  size_t floats;
+};
+extern CavpDetState g_cavp_det;
+// out0[i] += sum_p part[p][i], out1[i] += sum_p part[nparts + p][i]  (p ascending: fixed summation order)
+static __global__ __launch_bounds__(256) void cavp_det_finish_kernel(const float* __restrict__ part, int nparts, int n,
+                                                                    float* __restrict__ out0, float* __restrict__ out1) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  float s0 = 0.f, s1 = 0.f;
+  for (int q = 0; q < nparts; ++q) s0 += part[(size_t)q * n + i];
+  out0[i] += s0;
+  if (out1) {
+    for (int q = 0; q < nparts; ++q) s1 += part[(size_t)(nparts + q) * n + i];
+    out1[i] += s1;
+  }
+}
+// scratch for 2 x nparts x n floats, or nullptr when the mode is off; *err is set when it is on but the buffer is too small
+static inline float* cavp_det_scratch(int nparts, int n, bool* err) {
+  *err = false;
+  if (!g_cavp_det.scratch) return nullptr;
+  if ((size_t)2 * nparts * n > g_cavp_det.floats) { *err = true; return nullptr; }
+  return g_cavp_det.scratch;
+}
+static inline hipError_t cavp_det_finish(const float* part, int nparts, int n, float* out0, float* out1, hipStream_t s) {
+  cavp_det_finish_kernel<<<dim3((n + 255) / 256), dim3(256), 0, s>>>(part, nparts, n, out0, out1);
+  return hipGetLastError();
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

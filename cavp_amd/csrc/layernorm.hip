@@ -86,7 +86,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_vec_kernel(const T* __restr
                                                                 const float* __restrict__ gamma, T* __restrict__ dx,
                                                                 float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                                 int rows, int C, int ld_dy, int ld_x, int ld_dx, float eps,
-                                                                int rows_per_block) {
+                                                                int rows_per_block, float* __restrict__ det_part) {
   constexpr int VE = VecT<T>::VE, RW = 64 / G, CW = G * PLV * VE;  // channels covered by a row group
   __shared__ float part[2][4][CW];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -181,7 +181,10 @@ __global__ __launch_bounds__(256) void layernorm_bwd_vec_kernel(const T* __restr
   for (int i = threadIdx.x; i < 2 * C; i += 256) {
     const int st = i / C, c = i - st * C;
     const float s = (part[st][0][c] + part[st][1][c]) + (part[st][2][c] + part[st][3][c]);
-    atomicAdd((st == 0 ? dgamma : dbeta) + c, s);
+    if (det_part)   // deterministic mode: [2][gridDim.x][C] partials, added in workgroup order by cavp_det_finish_kernel
+      det_part[((size_t)st * gridDim.x + blockIdx.x) * C + c] = s;
+    else
+      atomicAdd((st == 0 ? dgamma : dbeta) + c, s);
   }
 }
 
@@ -270,14 +273,19 @@ extern "C" int cavp_layernorm_bwd(int32_t dtype, const void* dy, const void* x, 
   rpb = (rpb + rpi - 1) / rpi * rpi;
   gx = (rows + rpb - 1) / rpb;
   hipStream_t s = (hipStream_t)stream;
+  bool det_err;
+  float* det = cavp_det_scratch(gx, C, &det_err);
+  if (det_err) return CAVP_ERR_WORKSPACE;
   if (dtype == CAVP_F32) {
-#define CALL(g, p) layernorm_bwd_vec_kernel<float, g, p><<<gx, 256, 0, s>>>((const float*)dy, (const float*)x, gamma, (float*)dx, dgamma, dbeta, rows, C, ld_dy, ld_x, ld_dx, eps, rpb)
+#define CALL(g, p) layernorm_bwd_vec_kernel<float, g, p><<<gx, 256, 0, s>>>((const float*)dy, (const float*)x, gamma, (float*)dx, dgamma, dbeta, rows, C, ld_dy, ld_x, ld_dx, eps, rpb, det)
     LN_DISPATCH(CALL)
 #undef CALL
   } else {
-#define CALL(g, p) layernorm_bwd_vec_kernel<bf16_t, g, p><<<gx, 256, 0, s>>>((const bf16_t*)dy, (const bf16_t*)x, gamma, (bf16_t*)dx, dgamma, dbeta, rows, C, ld_dy, ld_x, ld_dx, eps, rpb)
+#define CALL(g, p) layernorm_bwd_vec_kernel<bf16_t, g, p><<<gx, 256, 0, s>>>((const bf16_t*)dy, (const bf16_t*)x, gamma, (bf16_t*)dx, dgamma, dbeta, rows, C, ld_dy, ld_x, ld_dx, eps, rpb, det)
     LN_DISPATCH_BF16(CALL)
 #undef CALL
   }
-  return hipGetLastError() == hipSuccess ? CAVP_OK : CAVP_ERR_LAUNCH;
+  if (hipGetLastError() != hipSuccess) return CAVP_ERR_LAUNCH;
+  if (det && cavp_det_finish(det, gx, C, dgamma, dbeta, s) != hipSuccess) return CAVP_ERR_LAUNCH;
+  return CAVP_OK;
 }

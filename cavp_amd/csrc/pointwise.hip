@@ -327,6 +327,15 @@ inline bool dtype_ok(int dt) { return dt == CAVP_F32 || dt == CAVP_BF16; }
 
 extern "C" int cavp_abi_version(void) { return CAVP_ABI_VERSION; }
 
+CavpDetState g_cavp_det = {nullptr, 0};
+extern "C" int cavp_set_deterministic(void* scratch, size_t bytes) {
+  if (scratch && (((uintptr_t)scratch & 15) || bytes < (1u << 20))) return CAVP_ERR_BAD_ARG;
+  g_cavp_det.scratch = (float*)scratch;
+  g_cavp_det.floats = scratch ? bytes / sizeof(float) : 0;
+  return CAVP_OK;
+}
+extern "C" int cavp_get_deterministic(void) { return g_cavp_det.scratch != nullptr; }
+
 extern "C" const char* cavp_error_string(int s) {
   switch (s) {
     case CAVP_OK: return "ok";

@@ -40,6 +40,7 @@ struct ColArgs {
   float* out0;
   float* out1;
   int rows, C, lda, ldb, ldc, act, rows_per_block;
+  float* part;   // deterministic mode: [2][gridDim.x][C] per-workgroup partials instead of atomics
 };
 
 // MODE 0: out0 += sum a, out1 += sum a^2       (BN forward statistics)
@@ -120,7 +121,10 @@ __global__ __launch_bounds__(256) void col_reduce_kernel(const ColArgs p) {
     float s = 0.f;
 #pragma unroll
     for (int k = 0; k < 16; ++k) s += red[st][k][ch];
-    atomicAdd((st == 0 ? p.out0 : p.out1) + c, s);
+    if (p.part)
+      p.part[((size_t)st * gridDim.x + blockIdx.x) * p.C + c] = s;
+    else
+      atomicAdd((st == 0 ? p.out0 : p.out1) + c, s);
   }
 }
 
@@ -205,7 +209,8 @@ int launch_col_reduce(int dtype, ColArgs& a, hipStream_t s) {
   // (measured: the contiguous geometry helps the read + write kernels, 1.69 -> 1.23 ms per step for scale_shift_act,
   // but not the reductions - 1.59 -> 1.85 ms for the BN backward reduce - so it stays behind CAVP_FLAT_REDUCE=1)
   static const bool flat_reduce = cavp_knob_str("CAVP_FLAT_REDUCE") != nullptr;
-  if (flat_reduce && (MODE != 1 || a.b != nullptr) && flat_ok(a.C, VE, a.mean, a.rstd)) {
+  a.part = nullptr;
+  if (flat_reduce && !g_cavp_det.scratch && (MODE != 1 || a.b != nullptr) && flat_ok(a.C, VE, a.mean, a.rstd)) {
     const int CV = a.C / VE;
     a.rows_per_block = flat_rows_per_block(a.rows, a.C, 16 / VE, CV, 32 << 10, 4096);   // <= 4096 atomics per channel
     const int gx = (int)((a.rows + a.rows_per_block - 1) / a.rows_per_block);
@@ -229,10 +234,17 @@ int launch_col_reduce(int dtype, ColArgs& a, hipStream_t s) {
   rpb = (rpb + 15) / 16 * 16;
   gx = cdiv_h(a.rows, rpb);
   a.rows_per_block = rpb;
+  bool det_err;
+  a.part = cavp_det_scratch(gx, a.C, &det_err);
+  if (det_err) return CAVP_ERR_WORKSPACE;
   if (dtype == CAVP_F32)
     col_reduce_kernel<float, MODE><<<dim3(gx, gy), 256, 0, s>>>(a);
   else
     col_reduce_kernel<bf16_t, MODE><<<dim3(gx, gy), 256, 0, s>>>(a);
+  if (a.part) {
+    if (hipGetLastError() != hipSuccess) return CAVP_ERR_LAUNCH;
+    return cavp_det_finish(a.part, gx, a.C, a.out0, MODE == 2 ? nullptr : a.out1, s) == hipSuccess ? CAVP_OK : CAVP_ERR_LAUNCH;
+  }
   CHECK_LAUNCH();
 }
 

@@ -41,6 +41,15 @@ typedef enum {
 } cavp_status_t;
 
 int cavp_abi_version(void);
+
+/* Opt-in deterministic training (the reference runs with cudnn.deterministic = True, main_vpo_mono.py:39-41).  With a scratch
+ * buffer registered (>= 1 MiB, 16-byte aligned device memory that stays alive; 8 MiB covers every CAVP shape) the reductions
+ * that otherwise finish with f32 atomics - cavp_colsum / cavp_colstats / cavp_bn_act_bwd_reduce, the dgamma / dbeta of
+ * cavp_layernorm_bwd and the dk / dv of cavp_attn_gate_bwd - write per-workgroup partials and add them in a fixed order:
+ * a training step is then bit-reproducible run to run.  scratch = NULL switches the mode off.  Process-wide (one process per
+ * GPU); launches that need more scratch than registered return CAVP_ERR_WORKSPACE. */
+int cavp_set_deterministic(void* scratch, size_t bytes);
+int cavp_get_deterministic(void);
 const char* cavp_error_string(int status);
 
 /* ---------------------------------------------------------------------------------------------------------

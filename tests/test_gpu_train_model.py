@@ -387,3 +387,43 @@ def test_clip_shaped_ce_plus_contrast_matches_reference_golden():
         a, b = smp.astype(np.float64), ref.astype(np.float64)
         cos = float(a @ b / (np.linalg.norm(a) * np.linalg.norm(b) + 1e-30))
         assert cos >= 0.99, (k, cos)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+def test_deterministic_mode_is_bit_reproducible(dtype):
+    """Opt-in deterministic training (the reference sets cudnn.deterministic = True, main_vpo_mono.py:39-41): with the mode on,
+    two runs of the same step - eager and as hipGraph replays - give bit-identical losses and gradients; with it off the f32
+    atomics make them differ.  The deterministic result agrees with the default one up to that summation-order noise."""
+    from cavp_amd import _lib
+    cfg = dict(C=3, B=4, hw=(64, 64), lds=[False, False, False])
+    B = cfg["B"]
+    image, audio, label = [t.to(DEV) for t in synth_inputs(B, cfg["hw"], audio_batch=2 * B, num_classes=cfg["C"], seed=2)]
+
+    def run(m, sd, step=None):
+        m.load_state_dict({k: v for k, v in sd.items() if "running_" in k or "num_batches" in k}, strict=False)
+        loss = (step() if step is not None else m.train_step(image, audio, label, all_reduce=False)).clone()
+        torch.cuda.synchronize()
+        return loss, m._grad_arena.flat.clone()
+
+    m, sd = _build(cfg, dtype)
+    l_a, g_a = run(m, sd)
+    l_b, g_b = run(m, sd)
+    assert not torch.equal(g_a, g_b), "the default mode is expected to be order-dependent (f32 atomics)"
+    _lib.set_deterministic(True)
+    try:
+        assert _lib.is_deterministic()
+        m2, sd2 = _build(cfg, dtype)
+        l1, g1 = run(m2, sd2)
+        l2, g2 = run(m2, sd2)
+        assert torch.equal(l1, l2) and torch.equal(g1, g2), "eager steps differ in deterministic mode"
+        step = m2.capture_train_step(image, audio, label)
+        for _ in range(3):
+            l3, g3 = run(m2, sd2, step)
+            assert torch.equal(l3, l1) and torch.equal(g3, g1), "graph replay differs from the eager step in deterministic mode"
+        if dtype == torch.float32:   # same math, other summation order
+            assert abs(float(l1) - float(l_a)) <= 1e-4 * max(1.0, abs(float(l_a)))
+            cos = float((g1.double() @ g_a.double()) / (g1.double().norm() * g_a.double().norm()))
+            assert cos >= 0.999, cos
+    finally:
+        _lib.set_deterministic(False)
+    assert not _lib.is_deterministic()
