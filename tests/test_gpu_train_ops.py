@@ -398,3 +398,63 @@ def test_pack_weights_multi_matches_single(dtype):
             assert torch.equal(o, ops.pack_weight(w, dtype))
         if d is not None:
             assert torch.equal(d, T.pack_weight_dgrad(w, dtype))
+
+
+def test_training_entry_points_fail_loudly():
+    """Error paths of the training-side C-ABI (round-1 review: only the forward ones were covered): too-small workspace,
+    misaligned operands, unsupported strides, bad batch periods, misuse of the auxiliary epilogue tensor, and a deterministic
+    -mode scratch that is too small - each a CAVP_ERR_* status surfaced as CavpError, never a silent wrong answer."""
+    import ctypes as C
+    from cavp_amd import _lib
+    from cavp_amd._lib import CavpError, ConvDesc
+    ops, T = _mods()
+    lib = _lib.load()
+    dt = torch.bfloat16
+    x = torch.zeros((2, 16, 16, 64), dtype=dt, device=DEV)
+    dy = torch.zeros((2, 16, 16, 128), dtype=dt, device=DEV)
+    dw = torch.zeros((128, 3, 3, 64), dtype=torch.float32, device=DEV)
+    d = ConvDesc(dtype=ops.dtype_code(dt), N=2, H=16, W=16, Cin=64, ldx=64, Cout=128, ldy=128, KH=3, KW=3, stride=1, pad=1, dil=1,
+                 ldr=0, act=0, splitk=4, tile=0, up=0, Ho=0, Wo=0, stride_w=0)
+    need = lib.cavp_conv2d_wgrad_workspace_bytes(C.byref(d))
+    assert need > 0, "the split weight-gradient plan of this shape is expected to need slabs"
+    ws = torch.empty(need, dtype=torch.uint8, device=DEV)
+    p = lambda t: C.c_void_p(t.data_ptr())
+    s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    assert lib.cavp_conv2d_wgrad_nhwc(C.byref(d), p(x), p(dy), p(dw), None, p(ws), C.c_size_t(need), s) == 0
+    st = lib.cavp_conv2d_wgrad_nhwc(C.byref(d), p(x), p(dy), p(dw), None, p(ws), C.c_size_t(need // 2), s)      # workspace too small
+    assert st != 0 and b"workspace" in lib.cavp_error_string(st).lower()
+    st = lib.cavp_conv2d_wgrad_nhwc(C.byref(d), C.c_void_p(x.data_ptr() + 2), p(dy), p(dw), None, p(ws), C.c_size_t(need), s)  # x not 16-byte aligned
+    assert st != 0 and b"align" in lib.cavp_error_string(st).lower()
+    assert lib.cavp_conv2d_wgrad_nhwc(C.byref(d), None, p(dy), p(dw), None, p(ws), C.c_size_t(need), s) != 0    # null operand
+    with pytest.raises(CavpError):   # dy extent does not match the forward conv
+        T.conv2d_wgrad(x, dy[:, :8], dw, kh=3, kw=3, stride=1, pad=1, dil=1)
+    with pytest.raises(CavpError):   # dgrad: transposed padding would be negative
+        T.conv2d_dgrad(dy, torch.zeros((64, 3, 3, 128), dtype=dt, device=DEV), x, kh=3, kw=3, stride=1, pad=5, dil=1)
+    # LayerNorm backward: channel stride not a multiple of the 16-byte vector
+    xs = torch.zeros((32, 300), dtype=dt, device=DEV)
+    with pytest.raises(CavpError):
+        T.layernorm_bwd(xs, xs, torch.ones(300, device=DEV), torch.empty_like(xs), torch.zeros(300, device=DEV),
+                        torch.zeros(300, device=DEV), 1e-5)
+    # attention gate: the query batch must divide the batch
+    q = torch.zeros((3, 8, 304), dtype=dt, device=DEV)
+    kv = torch.zeros((4, 304), dtype=dt, device=DEV)
+    with pytest.raises(CavpError):
+        ops.attn_gate(q, kv, kv, torch.empty((4, 8, 304), dtype=dt, device=DEV), torch.empty((4, 4, 8), device=DEV), 4, 0.1)
+    # auxiliary epilogue tensor: derivative output without GELU, and a periodic residual that is not a multiple of 256 rows
+    w = torch.zeros((128, 1, 1, 64), dtype=dt, device=DEV)
+    y = torch.empty((2, 16, 16, 128), dtype=dt, device=DEV)
+    with pytest.raises(CavpError):
+        ops.conv2d(x, w, y, aux=torch.empty_like(y), aux_mode=1, act=ops.ACT_RELU)
+    with pytest.raises(CavpError):
+        ops.conv2d(x, w, y, residual=y[:1, :10].contiguous(), res_rows=160)
+    # deterministic mode with a scratch buffer smaller than one launch's partials
+    small = torch.empty(1 << 20, dtype=torch.uint8, device=DEV)
+    assert lib.cavp_set_deterministic(p(small), C.c_size_t(small.numel())) == 0
+    try:
+        big = torch.zeros((200704, 304), dtype=dt, device=DEV)
+        with pytest.raises(CavpError):
+            T.layernorm_bwd(big, big, torch.ones(304, device=DEV), torch.empty_like(big), torch.zeros(304, device=DEV),
+                            torch.zeros(304, device=DEV), 1e-5)
+    finally:
+        assert lib.cavp_set_deterministic(None, C.c_size_t(0)) == 0
+    assert lib.cavp_set_deterministic(C.c_void_p(small.data_ptr() + 4), C.c_size_t(1 << 20)) != 0   # misaligned scratch

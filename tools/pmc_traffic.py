@@ -20,7 +20,7 @@ def one_pass(counter, mode, steps, warmup):
     subprocess.run(["rm", "-rf", d])
     cmd = ["timeout", "400", "rocprofv3", "--pmc", counter, "--output-format", "csv", "-d", d, "-o", "p", "--",
            sys.executable, os.path.join(REPO, "bench.py"), "--mode", mode, "--steps", str(steps), "--warmup", str(warmup),
-           "--no-graph", "--no-cpu-baseline", "--no-roofline"]
+           "--no-graph", "--no-cpu-baseline", "--no-roofline", "--no-f32"]
     env = dict(os.environ, TMPDIR="/tmp")
     r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if r.returncode != 0:
@@ -51,7 +51,7 @@ def main():
 
     def total(agg, pred):
         return sum(v[1] for k, v in agg.items() if pred(k)), sum(v[0] for k, v in agg.items() if pred(k))
-    is_igemm = lambda k: "igemm_kernel" in k
+    is_igemm = lambda k: "igemm_kernel" in k or "igemm_big_kernel" in k
     is_wgrad = lambda k: "wgrad_kernel" in k
     everything = lambda k: True
     out = {"source": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, kernel trace only), bench.py --mode {a.mode} "
