@@ -448,10 +448,10 @@ class CAVP(nn.Module):
                           shift=p.shift, nbias=nbias, residual=residual, act=act)
 
     @staticmethod
-    def _lin(x, p: _ConvP, act=ACT_NONE, residual=None, out=None):
+    def _lin(x, p: _ConvP, act=ACT_NONE, residual=None, out=None, res_rows=0):
         if out is None:
             out = torch.empty(x.shape[:-1] + (p.cout,), dtype=x.dtype, device=x.device)
-        return ops.linear(x, p.w, out, bias=p.shift, scale=p.scale, residual=residual, act=act)
+        return ops.linear(x, p.w, out, bias=p.shift, scale=p.scale, residual=residual, act=act, res_rows=res_rows)
 
     def _backbone_hip(self, image, P):
         dt, dev = self.compute_dtype, image.device
@@ -526,11 +526,16 @@ class CAVP(nn.Module):
     def _fusion_hip(self, fea_v, fea_a, P):
         """forward_fusion (cavp_model.py:143-154) + CROSS_ATTENTION.forward (attn.py:232-244), dead audio-query
         branch (attn.py:161, dropped at cavp_model.py:151) elided."""
-        B, h, w, Cc = fea_v.shape
+        Bv, h, w, Cc = fea_v.shape
+        B = fea_a.shape[0]
+        if B % Bv:
+            raise CavpError(f"audio batch {B} is not a multiple of the visual batch {Bv}")
+        # B > Bv (forward_train: audio of 2B, cavp_model.py:181): everything that depends on the images only runs once on Bv
+        # rows; the gate reads q[b % Bv] and ca.proj adds residual row p % (Bv * T) instead of 2B copies of both
         T = h * w
         dt, dev = fea_v.dtype, fea_v.device
         blk = self.cross_att.blocks[0]
-        tok = fea_v.view(B, T, Cc)
+        tok = fea_v.view(Bv, T, Cc)
         hid = self._lin(tok, P["proj.fc1"], act=ACT_GELU)
         fea_v_proj = self._lin(hid, P["proj.fc2"])
         v0 = self._lin(fea_v_proj, P["ca.pe_v"])
@@ -543,13 +548,20 @@ class CAVP(nn.Module):
         vv = self._lin(an, P["ca.v"])
         heads = blk.attn.num_heads
         attn = torch.empty((B, heads, T), dtype=torch.float32, device=dev)
-        o = ops.attn_gate(q, k, vv, torch.empty_like(q), attn, heads, blk.attn.scale)
-        r1 = self._lin(o, P["ca.proj"], residual=vn)
+        o = ops.attn_gate(q, k, vv, torch.empty((B, T, Cc), dtype=dt, device=dev), attn, heads, blk.attn.scale)
+        if B == Bv:
+            r1 = self._lin(o, P["ca.proj"], residual=vn)
+        elif (Bv * T) % 256 == 0:
+            r1 = self._lin(o, P["ca.proj"], residual=vn, res_rows=Bv * T)
+        else:   # the periodic-residual epilogue wants a multiple of 256 rows: tiny inputs take the copy
+            r1 = self._lin(o, P["ca.proj"], residual=vn.repeat(B // Bv, 1, 1))
         l2 = ops.layernorm(r1, blk.norm2.weight.detach(), blk.norm2.bias.detach(), torch.empty_like(r1), blk.norm2.eps)
         hh = self._lin(l2, P["ca.fc1"], act=ACT_GELU)
         r2 = self._lin(hh, P["ca.fc2"], residual=r1)
         fn = self.cross_att.norm
         fus = ops.layernorm(r2, fn.weight.detach(), fn.bias.detach(), torch.empty_like(r2), fn.eps)
+        if B != Bv:   # pack["visual"]: the reference returns the duplicated projection
+            fea_v_proj = fea_v_proj.repeat(B // Bv, 1, 1)
         return fus.view(B, h, w, Cc), fea_v_proj.view(B, h, w, Cc), attn
 
     def _cls_hip(self, fusion, P, input_shape):
@@ -580,15 +592,15 @@ class CAVP(nn.Module):
         else:
             feats = self._backbone_hip(image, P)
         fea_v, aspp = self._forward_feature_hip(feats, P)
-        if duplicate_visual:  # forward_train: torch.cat((fea_v, fea_v.clone())) (cavp_model.py:181)
-            fea_v = fea_v.repeat(2, 1, 1, 1)
         fea_a = self._audio_hip(audio, P)
         if shuffle is not None:   # forward_audio (cavp_model.py:156-173): B clips -> features | shuffled features
             idx = self._bank_and_shuffle(fea_a, shuffle[0], shuffle[1])
             fea_a = torch.cat((fea_a, fea_a.index_select(0, idx)), dim=0)
-        if fea_a.shape[0] != fea_v.shape[0]:
-            raise CavpError(f"audio batch {fea_a.shape[0]} != visual batch {fea_v.shape[0]} "
-                            f"(train mode expects audio of 2B, cavp_model.py:181)")
+        # forward_train duplicates the visual features to 2B (`torch.cat((fea_v, fea_v.clone()))`, cavp_model.py:181); here the
+        # fusion stage reads the B rows periodically instead (see _fusion_hip)
+        if fea_a.shape[0] != (2 if duplicate_visual else 1) * fea_v.shape[0]:
+            raise CavpError(f"audio batch {fea_a.shape[0]} vs visual batch {fea_v.shape[0]}: train mode expects audio of 2B "
+                            f"(cavp_model.py:181), inference one clip per image")
         fusion, fea_v_proj, attn = self._fusion_hip(fea_v, fea_a, P)
         out_pred, lo = self._cls_hip(fusion, P, input_shape)
         if taps is not None:

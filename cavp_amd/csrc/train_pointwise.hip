@@ -296,7 +296,7 @@ __global__ __launch_bounds__(256) void bn_finalize_tiles_kernel(const float* __r
                                                                 long long M, const float* gamma, const float* beta,
                                                                 float eps, float momentum, float* rmean, float* rvar,
                                                                 float* scale, float* shift, float* mean_out,
-                                                                float* rstd_out, int C) {
+                                                                float* rstd_out, int C, float* moments) {
   const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (c >= C) return;
   float n = 0.f, mean = 0.f, m2 = 0.f;
@@ -332,7 +332,10 @@ __global__ __launch_bounds__(256) void bn_finalize_tiles_kernel(const float* __r
       n = nt;
     }
   }
-  if (lane == 0) {
+  if (lane == 0 && moments) {   // SyncBatchNorm: this rank's (mean, M2), combined across ranks by a second call
+    moments[2 * c] = mean;
+    moments[2 * c + 1] = m2;
+  } else if (lane == 0) {
     const float var = m2 / (float)M;
     const float rstd = 1.f / sqrtf(var + eps);
     const float sc = gamma[c] * rstd;
@@ -354,7 +357,7 @@ __global__ __launch_bounds__(256) void bn_finalize_tiles_wide_kernel(const float
                                                                      long long M, const float* gamma, const float* beta,
                                                                      float eps, float momentum, float* rmean, float* rvar,
                                                                      float* scale, float* shift, float* mean_out,
-                                                                     float* rstd_out, int C) {
+                                                                     float* rstd_out, int C, float* moments) {
   __shared__ float part[4][3];
   const int c = blockIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   float n = 0.f, mean = 0.f, m2 = 0.f;
@@ -393,6 +396,11 @@ __global__ __launch_bounds__(256) void bn_finalize_tiles_wide_kernel(const float
     n = part[0][0]; mean = part[0][1]; m2 = part[0][2];
     for (int w = 1; w < 4; ++w)
       if (part[w][0] > 0.f) chan_combine(n, mean, m2, part[w][0], part[w][1], part[w][2]);
+    if (moments) {
+      moments[2 * c] = mean;
+      moments[2 * c + 1] = m2;
+      return;
+    }
     const float var = m2 / (float)M;
     const float rstd = 1.f / sqrtf(var + eps);
     const float sc = gamma[c] * rstd;
@@ -489,20 +497,31 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_flat_kernel(const T* __restr
   constexpr int VE = VecT<T>::VE;
   const int cv = threadIdx.x % CV, rsub = threadIdx.x / CV, RPB = 256 / CV;
   const int c = cv * VE;
+  // per-channel coefficients with 16-byte loads (C % VE == 0 and 16-byte aligned vectors: flat_ok): the first version issued
+  // 7 x VE scalar loads per thread in front of a row loop of only four trips
   float ca[VE], cb[VE], cc[VE];
+  {
+    float rs[VE], gm[VE], sg[VE], sgz[VE], mu[VE];
 #pragma unroll
-  for (int e = 0; e < VE; ++e) {
-    const float rs = rstd[c + e], a = gamma[c + e] * rs;
-    ca[e] = a;
-    cb[e] = -a * rs * sum_gz[c + e] * inv_m;
-    cc[e] = -a * sum_g[c + e] * inv_m - cb[e] * mean[c + e];
+    for (int q = 0; q < VE; q += 4) {
+      VecT<float>::load(rstd + c + q, rs + q); VecT<float>::load(gamma + c + q, gm + q); VecT<float>::load(sum_g + c + q, sg + q);
+      VecT<float>::load(sum_gz + c + q, sgz + q); VecT<float>::load(mean + c + q, mu + q);
+    }
+#pragma unroll
+    for (int e = 0; e < VE; ++e) {
+      const float a = gm[e] * rs[e];
+      ca[e] = a;
+      cb[e] = -a * rs[e] * sgz[e] * inv_m;
+      cc[e] = -a * sg[e] * inv_m - cb[e] * mu[e];
+    }
   }
   const bool from_z = y == nullptr;   // activation mask re-derived from z (layers without a residual): y is not read
   float fs[VE], fh[VE];
 #pragma unroll
-  for (int e = 0; e < VE; ++e) {
-    fs[e] = (from_z && act != CAVP_ACT_NONE) ? fscale[c + e] : 1.f;
-    fh[e] = (from_z && act != CAVP_ACT_NONE) ? fshift[c + e] : 0.f;
+  for (int e = 0; e < VE; ++e) { fs[e] = 1.f; fh[e] = 0.f; }
+  if (from_z && act != CAVP_ACT_NONE) {
+#pragma unroll
+    for (int q = 0; q < VE; q += 4) { VecT<float>::load(fscale + c + q, fs + q); VecT<float>::load(fshift + c + q, fh + q); }
   }
   const long long r0 = (long long)blockIdx.x * rows_per_block;
   long long r1 = r0 + rows_per_block;
@@ -1248,11 +1267,26 @@ extern "C" int cavp_bn_finalize_tiles(const float* tile_stats, int32_t tiles, in
   if (tiles >= 1024)
     bn_finalize_tiles_wide_kernel<<<C, 256, 0, (hipStream_t)stream>>>(tile_stats, tiles, rows_per_tile, count, gamma, beta, eps,
                                                                       momentum, running_mean, running_var, scale, shift, mean,
-                                                                      rstd, C);
+                                                                      rstd, C, nullptr);
   else
     bn_finalize_tiles_kernel<<<(C + 3) / 4, 256, 0, (hipStream_t)stream>>>(tile_stats, tiles, rows_per_tile, count, gamma, beta,
                                                                           eps, momentum, running_mean, running_var, scale,
-                                                                          shift, mean, rstd, C);
+                                                                          shift, mean, rstd, C, nullptr);
+  CHECK_LAUNCH();
+}
+
+extern "C" int cavp_bn_tiles_to_moments(const float* tile_stats, int32_t tiles, int32_t rows_per_tile, int64_t count,
+                                        float* moments, int32_t C, void* stream) {
+  if (!tile_stats || !moments || tiles <= 0 || rows_per_tile <= 0 || count <= 0 || C <= 0 || (long long)tiles * rows_per_tile < count)
+    return CAVP_ERR_BAD_ARG;
+  if (tiles >= 1024)
+    bn_finalize_tiles_wide_kernel<<<C, 256, 0, (hipStream_t)stream>>>(tile_stats, tiles, rows_per_tile, count, nullptr, nullptr, 0.f,
+                                                                      0.f, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, C,
+                                                                      moments);
+  else
+    bn_finalize_tiles_kernel<<<(C + 3) / 4, 256, 0, (hipStream_t)stream>>>(tile_stats, tiles, rows_per_tile, count, nullptr, nullptr,
+                                                                          0.f, 0.f, nullptr, nullptr, nullptr, nullptr, nullptr,
+                                                                          nullptr, C, moments);
   CHECK_LAUNCH();
 }
 
@@ -1276,7 +1310,8 @@ extern "C" int cavp_scale_shift_act(int32_t dtype, const void* x, const float* s
   }
   if (flat_ok(C, VE, scale, shift)) {
     const int CV = C / VE;
-    const int rpb = flat_rows_per_block(rows, C, 16 / VE, CV, 16 << 10, 1 << 20);
+    static const int flat_kb = cavp_knob_int("CAVP_FLAT_SSA_KB", 16);
+    const int rpb = flat_rows_per_block(rows, C, 16 / VE, CV, (long long)flat_kb << 10, 1 << 20);
     const int gx = (int)((rows + rpb - 1) / rpb);
     if (dtype == CAVP_F32)
       scale_shift_act_flat_kernel<float><<<gx, 256, 0, s>>>((const float*)x, scale, shift, (const float*)residual, (float*)y, rows, rpb, CV, ldx, ldr, ldy, act);
@@ -1324,9 +1359,10 @@ extern "C" int cavp_bn_act_bwd_apply(int32_t dtype, const void* dy, const void* 
   if (!al16(dy) || (y && !al16(y)) || !al16(z) || !al16(dz) || (g_out && !al16(g_out))) return CAVP_ERR_ALIGN;
   const float inv_m = (float)(1.0 / (double)rows);
   hipStream_t s = (hipStream_t)stream;
-  if (flat_ok(C, VE, nullptr, nullptr)) {
+  if (flat_ok(C, VE, mean, rstd) && al16(gamma) && al16(sum_g) && al16(sum_gz) && (!fwd_scale || (al16(fwd_scale) && al16(fwd_shift)))) {
     const int CV = C / VE;
-    const int rpb = flat_rows_per_block(rows, C, 16 / VE, CV, 16 << 10, 1 << 20);
+    static const int flat_kb = cavp_knob_int("CAVP_FLAT_APPLY_KB", 16);
+    const int rpb = flat_rows_per_block(rows, C, 16 / VE, CV, (long long)flat_kb << 10, 1 << 20);
     const int gx = (int)((rows + rpb - 1) / rpb);
     if (dtype == CAVP_F32)
       bn_bwd_apply_flat_kernel<float><<<gx, 256, 0, s>>>((const float*)dy, (const float*)y, (const float*)z, mean, rstd, gamma, sum_g, sum_gz, inv_m, (float*)dz, (float*)g_out, rows, rpb, CV, ld_dy, ld_y, ld_z, ld_dz, ld_g, act, fwd_scale, fwd_shift);

@@ -149,7 +149,7 @@ def conv2d(x: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, kh: int = 1, 
 
 
 def linear(x: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, bias=None, scale=None, residual=None,
-           nbias=None, act: int = ACT_NONE, splitk: int = 0, tile: int = 0) -> torch.Tensor:
+           nbias=None, act: int = ACT_NONE, splitk: int = 0, tile: int = 0, res_rows: int = 0) -> torch.Tensor:
     """x: [B, T, Cin] (or [B, Cin]) view, out: [B, T, Cout].  Linear = 1x1 conv over N=B, H=1, W=T."""
     def as4(t):
         if t is None:
@@ -160,7 +160,7 @@ def linear(x: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, bias=None, sc
             return t.unsqueeze(1)
         return t
     conv2d(as4(x), w, as4(out), scale=scale, shift=bias, nbias=nbias, residual=as4(residual), act=act,
-           splitk=splitk, tile=tile)
+           splitk=splitk, tile=tile, res_rows=res_rows)
     return out
 
 

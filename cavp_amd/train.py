@@ -165,6 +165,22 @@ def allreduce_bn_stats(bn, buf: torch.Tensor, count: int) -> int:
     return count
 
 
+def gather_bn_moments(local: torch.Tensor) -> torch.Tensor:
+    """SyncBatchNorm forward exchange: every rank's per-channel (mean, M2) [C, 2] -> [world, C, 2] on every rank, ONE
+    collective per layer.  RCCL: all-gather.  Other backends (gloo in the tests, which has no device all-gather): the same
+    result as an all-reduce of a buffer that is zero outside this rank's slot."""
+    import torch.distributed as dist
+    world = dist.get_world_size()
+    if dist.get_backend() == "nccl":
+        out = torch.empty((world,) + tuple(local.shape), dtype=local.dtype, device=local.device)
+        dist.all_gather_into_tensor(out, local.contiguous())
+        return out
+    out = torch.zeros((world,) + tuple(local.shape), dtype=local.dtype, device=local.device)
+    out[dist.get_rank()].copy_(local)
+    dist.all_reduce(out)
+    return out
+
+
 # False (tests / A-B only): GELU as a separate pass with the pre-activation stored, and the duplicated token tensors copied
 _FUSE_TOKEN_PATH = True
 _BN_BWD_READ_Y = False   # True (tests / A-B only): the BatchNorm backward always re-reads y instead of re-deriving the mask from z
@@ -455,15 +471,34 @@ class TrainPass:
             T.bn_finalize_tiles(ts, tiles, rpt, rows, bn.weight.detach(), bn.bias.detach(), bn.eps, mom,
                                 bn.running_mean if track else None, bn.running_var if track else None, scale, shift,
                                 mean, rstd)
+        elif sync:
+            # SyncBatchNorm (main_vpo_mono.py:130): this rank's (mean, M2) -> ONE all-gather -> Chan combine over the ranks (the
+            # same kernel that combines tiles; every rank holds `rows` samples).  Round 1 issued three all-reduces per layer.
+            world = dist_world()
+            if z.tile_stats is not None:
+                ts, tiles, rpt = z.tile_stats
+                local = self.empty((c, 2), torch.float32)
+                T.bn_tiles_to_moments(ts, tiles, rpt, rows, local)
+            else:
+                s1 = self.zeros_f32(c)
+                T.colsum(z.t, s1)
+                m0 = T.scale_f32(s1, 1.0 / rows, self.empty((c,), torch.float32))
+                st = self.zeros_f32(2, c)
+                T.colstats(z.t, st[0], st[1], shift=m0)
+                local = torch.stack((m0, st[1]), dim=-1).contiguous()   # (mean, sum (x - mean)^2): data movement only
+            gathered = gather_bn_moments(local)
+            count = rows * world
+            T.bn_finalize_tiles(gathered, world, rows, count, bn.weight.detach(), bn.bias.detach(), bn.eps, mom,
+                                bn.running_mean if track else None, bn.running_var if track else None, scale, shift,
+                                mean, rstd)
         else:
-            # two-pass statistics: sum -> mean (all-reduced for SyncBN), then centred second moment (cancellation-free)
+            # two-pass statistics: sum -> mean, then centred second moment (cancellation-free)
             s1 = self.zeros_f32(c)
             T.colsum(z.t, s1)
-            count = self._allreduce_stats(bn, s1, rows)
+            count = rows
             m0 = T.scale_f32(s1, 1.0 / count, self.empty((c,), torch.float32))
             stats = self.zeros_f32(2, c)
             T.colstats(z.t, stats[0], stats[1], shift=m0)
-            self._allreduce_stats(bn, stats, rows)
             T.bn_finalize(stats[0], stats[1], count, bn.weight.detach(), bn.bias.detach(), bn.eps, mom,
                           bn.running_mean if track else None, bn.running_var if track else None, scale, shift, mean,
                           rstd, stat_shift=m0)

@@ -217,6 +217,13 @@ def bn_finalize(sums, sumsq, count: int, gamma, beta, eps: float, momentum: floa
                                         _ptr(mean), _ptr(rstd), gamma.numel(), _s()), "cavp_bn_finalize")
 
 
+def bn_tiles_to_moments(tile_stats, tiles: int, rows_per_tile: int, count: int, moments) -> None:
+    """this rank's per-channel (mean, M2) [C, 2] from its tile statistics (SyncBatchNorm: gathered, then bn_finalize_tiles)."""
+    _need_gpu(tile_stats, moments)
+    _check(_lib.load().cavp_bn_tiles_to_moments(_ptr(tile_stats), tiles, rows_per_tile, count, _ptr(moments), moments.shape[0], _s()),
+           "cavp_bn_tiles_to_moments")
+
+
 def bn_finalize_tiles(tile_stats, tiles: int, rows_per_tile: int, count: int, gamma, beta, eps: float, momentum: float,
                       running_mean, running_var, scale, shift, mean, rstd) -> None:
     _need_gpu(tile_stats, gamma, beta, scale, shift, mean, rstd)

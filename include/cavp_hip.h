@@ -221,6 +221,11 @@ int cavp_bn_finalize_tiles(const float* tile_stats, int32_t tiles, int32_t rows_
                            const float* gamma, const float* beta, float eps, float momentum, float* running_mean,
                            float* running_var, float* scale, float* shift, float* mean, float* rstd, int32_t C,
                            void* stream);
+/* SyncBatchNorm (main_vpo_mono.py:130): this rank's per-channel (mean, M2) from its tile statistics, f32 [C][2].  The ranks'
+ * moments are all-gathered into [world][C][2] and combined by cavp_bn_finalize_tiles(tiles = world, rows_per_tile = the
+ * per-rank row count): ONE collective per BatchNorm layer in the forward. */
+int cavp_bn_tiles_to_moments(const float* tile_stats, int32_t tiles, int32_t rows_per_tile, int64_t count, float* moments,
+                             int32_t C, void* stream);
 int cavp_scale_shift_act(int32_t dtype, const void* x, const float* scale, const float* shift, const void* residual,
                          void* y, int64_t rows, int32_t C, int32_t ldx, int32_t ldr, int32_t ldy, int32_t act,
                          void* stream);

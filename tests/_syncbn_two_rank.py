@@ -1,0 +1,100 @@
+"""Child of tests/test_gpu_syncbn.py (launched twice by torch.distributed.run; both ranks share cuda:0 and talk over gloo):
+nn.SyncBatchNorm.convert_sync_batchnorm(model) (main_vpo_mono.py:130) + the data-parallel training step on HALF the batch per
+rank must reproduce the single-process step on the FULL batch with plain BatchNorm: loss, every BatchNorm running statistic,
+and - after the gradient all-reduce - every parameter gradient.  Negative control: without the conversion the running
+statistics of the two half batches differ from the full-batch ones by far more than the tolerance."""
+import os
+import sys
+import types
+
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+
+
+def main():
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from cavp_amd import _lib
+    from cavp_amd.cavp_model import CAVP
+    from cavp_amd.synth import synth_inputs, synth_state_dict
+    _lib.set_deterministic(True, device=dev)   # ordered reductions: what is left is the 2 x 4 vs 1 x 8 summation order
+    C, Bl, hw = 3, 4, (64, 64)
+    B = Bl * world
+    args = types.SimpleNamespace(seg_model="DeepLabV3Plus", last_three_dilation_stride=[False, False, False], audio_backbone="vgg",
+                                 num_classes=C, batch_size=B, local_rank="cpu")
+
+    def build(sync):
+        m = CAVP(50, None, num_classes=C, args=args)
+        sd = synth_state_dict({k: tuple(v.shape) for k, v in m.state_dict().items()}, seed=1)
+        m.load_state_dict(sd, strict=True)
+        if sync:
+            m = nn.SyncBatchNorm.convert_sync_batchnorm(m)
+        return m.train().to(dev)
+
+    image, audio, label = synth_inputs(B, hw, audio_batch=2 * B, num_classes=C, seed=5)
+    label[label == 255] = 0                     # equal valid-pixel counts per rank: mean of the rank losses == full-batch loss
+    image, audio, label = image.to(dev), audio.to(dev), label.to(dev)
+    sl = slice(rank * Bl, (rank + 1) * Bl)
+    # forward_train pairs audio row i with image i % B (cavp_model.py:175-188): this rank's clips of both halves
+    my_audio = torch.cat((audio[sl], audio[B + rank * Bl:B + (rank + 1) * Bl]), 0).contiguous()
+
+    def running(m):
+        return {k: v.detach().double().cpu() for k, v in m.state_dict().items() if "running_" in k}
+
+    def grads(m):
+        return {k: p.grad.detach().double().flatten().cpu() for k, p in m.named_parameters() if p.grad is not None}
+
+    # (a) single process, full batch, plain BatchNorm, no collective
+    ref = build(False)
+    l_ref = float(ref.train_step(image, audio, label, all_reduce=False).item())
+    torch.cuda.synchronize()
+    r_ref, g_ref = running(ref), grads(ref)
+    del ref
+
+    def two_rank(sync):
+        m = build(sync)
+        n_sync = sum(isinstance(x, nn.SyncBatchNorm) for x in m.modules())
+        loss = m.train_step(image[sl].contiguous(), my_audio, label[sl].contiguous())
+        torch.cuda.synchronize()
+        lt = loss.detach().double().cpu().reshape(1)
+        dist.all_reduce(lt)
+        return float(lt) / world, running(m), grads(m), n_sync
+
+    def rel(a, b):
+        return float((a - b).abs().max() / (b.abs().max() + 1e-12))
+
+    l_s, r_s, g_s, n_sync = two_rank(True)
+    assert n_sync >= 50, n_sync
+    e_run = max(rel(r_s[k], r_ref[k]) for k in r_ref)
+    # per-tensor L2 error relative to the tensor's norm, floored at 1e-3 of the largest gradient norm of the model (conv biases
+    # in front of a BatchNorm have an exactly-zero true gradient: what is there is rounding noise).  Single elements of the
+    # layer4 weights (BatchNorm over 32 samples per channel at this input size) move by up to 25 % of the tensor's maximum
+    # between the 2 x 4 and 1 x 8 summation orders; the direction of every gradient does not.
+    gmax = max(float(v.norm()) for v in g_ref.values())
+    e_grad = {k: float((g_s[k] - g_ref[k]).norm() / max(float(g_ref[k].norm()), 1e-3 * gmax)) for k in g_ref}
+    cos = {k: float((g_s[k] @ g_ref[k]) / (g_s[k].norm() * g_ref[k].norm() + 1e-300)) for k in g_ref
+           if float(g_ref[k].norm()) > 1e-4 * gmax}
+    l_n, r_n, _, n0 = two_rank(False)
+    assert n0 == 0
+    e_ctl = max(rel(r_n[k], r_ref[k]) for k in r_ref)
+    if rank == 0:
+        print(f"SYNCBN_OK layers {n_sync} loss {l_s:.6f} vs {l_ref:.6f}; running-stat err {e_run:.2e} (no sync: {e_ctl:.2e}); "
+              f"grad err max {max(e_grad.values()):.2e} ({max(e_grad, key=e_grad.get)}); grad cosine min {min(cos.values()):.5f} "
+              f"({min(cos, key=cos.get)})")
+    assert g_s.keys() == g_ref.keys()
+    assert abs(l_s - l_ref) <= 1e-4 * max(1.0, abs(l_ref)), (l_s, l_ref)
+    assert e_run <= 2e-3, e_run
+    assert e_ctl >= 10 * max(e_run, 1e-3), (e_ctl, e_run)
+    assert max(e_grad.values()) <= 0.05 and min(cos.values()) >= 0.99, (max(e_grad.values()), min(cos.values()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

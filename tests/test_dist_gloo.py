@@ -65,6 +65,17 @@ def _worker(rank, world, port, q):
                                                    [3.0 * world, sum(4.0 * (r + 1) for r in range(world))]]))
         local = torch.tensor([[5.0 + rank, 1.0]])
         assert allreduce_bn_stats(nn.BatchNorm2d(2), local, 10) == 10 and float(local[0, 0]) == 5.0 + rank
+        # 2b) SyncBatchNorm forward: ONE exchange of (mean, M2) per layer; Chan combine over ranks == full-batch moments
+        from cavp_amd.train import gather_bn_moments
+        g = torch.Generator().manual_seed(7)
+        full = torch.randn(world * 6, 3, generator=g) * 2 + 5
+        mine = full[rank * 6:(rank + 1) * 6]
+        loc = torch.stack((mine.mean(0), ((mine - mine.mean(0)) ** 2).sum(0)), -1)
+        allm = gather_bn_moments(loc)
+        assert allm.shape == (world, 3, 2) and torch.equal(allm[rank], loc)
+        mean = allm[:, :, 0].mean(0)
+        m2 = (allm[:, :, 1] + 6 * (allm[:, :, 0] - mean) ** 2).sum(0)
+        assert torch.allclose(mean, full.mean(0), atol=1e-5) and torch.allclose(m2 / full.shape[0], full.var(0, unbiased=False), atol=1e-4)
         # 3) bench.py timing reduction: MAX over ranks
         t = torch.tensor([1.0 + rank], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -110,11 +110,13 @@ def test_cpu_tensors_fail_loudly():
         m(image, audio, eval_mode=True)
 
 
+@pytest.mark.parametrize("case", ["pvt_eval", "pvt_eval_512"])
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-3), (torch.bfloat16, None)], ids=["f32", "bf16"])
-def test_pvt_forward_matches_reference_golden(dtype, tol):
-    """config #4: PVTv2-B5 backbone (MFMA softmax attention, SR convs, depth-wise MLP) + 112-d fusion + decoder."""
+def test_pvt_forward_matches_reference_golden(dtype, tol, case):
+    """config #4: PVTv2-B5 backbone (MFMA softmax attention, SR convs, depth-wise MLP) + 112-d fusion + decoder, at 256 x 256
+    and at the config's own 512 x 512 (config_avss.py:12-13; 16384 fusion tokens, 71 classes)."""
     from cavp_amd.cavp_model import CAVP
-    z, cfg = load_case("pvt_eval")
+    z, cfg = load_case(case)
     a = _args(cfg)
     a.seg_model = "PVT"
     a.allow_random_pvt = True   # synthetic weights are loaded right after

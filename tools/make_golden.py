@@ -176,7 +176,7 @@ def run_case(name, cfg, out_dir):
           + " ".join(f"{k}:{taps[k].std().item():.2f}" for k in ("layer1", "layer2", "layer3", "layer4", "aspp")))
 
 
-def run_pvt(out_dir, hw=(256, 256), C=71, B=1):
+def run_pvt(out_dir, hw=(256, 256), C=71, B=1, name="pvt_eval"):
     """config #4 (seg_model="PVT", config_avss.py shape family): reference forward with the hard-coded
     `torch.load("../ckpts/pretrained/pvt_v2_b5.pth")` (cavp_model.py:109) patched to a fresh random state."""
     import models.cavp_model as CM
@@ -199,7 +199,7 @@ def run_pvt(out_dir, hw=(256, 256), C=71, B=1):
     sd = synth_state_dict({k: tuple(v.shape) for k, v in m.state_dict().items()}, seed=1)
     m.load_state_dict(sd, strict=True)
     import json
-    with open(os.path.join(out_dir, "state_dict_shapes_pvt.json"), "w") as f:
+    with open(os.path.join(out_dir, "state_dict_shapes_pvt.json" if name == "pvt_eval" else os.devnull), "w") as f:
         json.dump({k: ["C" if (k.startswith("segment.upsample.classifier") and i == 0) else int(d) for i, d in enumerate(v.shape)]
                    for k, v in m.state_dict().items()}, f, indent=0)
     image, audio, _ = synth_inputs(B, hw, num_classes=C, seed=0)
@@ -224,9 +224,9 @@ def run_pvt(out_dir, hw=(256, 256), C=71, B=1):
     store["cfg/CBHW"] = np.array([C, B, hw[0], hw[1]], dtype=np.int64)
     store["cfg/lds"] = np.array([0, 0, 0], dtype=np.int64)
     store["cfg/train"] = np.array([0], dtype=np.int64)
-    path = os.path.join(out_dir, "pvt_eval.npz")
+    path = os.path.join(out_dir, name + ".npz")
     np.savez_compressed(path, **store)
-    print(f"pvt_eval: wrote {path}; |out|max={out.abs().max().item():.3f} " +
+    print(f"{name}: wrote {path}; |out|max={out.abs().max().item():.3f} " +
           " ".join(f"{k}:{taps[k].std().item():.2f}" for k in ("stage1", "stage2", "stage3", "stage4")))
 
 
@@ -347,5 +347,7 @@ if __name__ == "__main__":
         run_contrast(a.out)
     if not a.only or a.only == "pvt":
         run_pvt(a.out)
+    if not a.only or a.only == "pvt512":   # config #4 at its own resolution (config_avss.py:12-13): samples + checksums only
+        run_pvt(a.out, hw=(512, 512), name="pvt_eval_512")
     if not a.only or a.only == "optstep":
         run_optstep(a.out)
