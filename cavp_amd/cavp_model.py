@@ -692,9 +692,6 @@ class CAVP(nn.Module):
             return self._forward_hip(image, audio, duplicate_visual=True, shuffle=shuffle)   # frozen-BN, forward only
         if self.seg_model != "DeepLabV3Plus":
             raise NotImplementedError("the training pass is built for the ResNet-50 path; PVTv2 runs forward-only so far")
-        if not bn_train:
-            raise NotImplementedError("backward with BatchNorm in eval mode (frozen statistics) is not built; the "
-                                      "reference trains with model.train() (trainer_cavp_vpo_mono.py:120)")
         if not image.is_cuda:
             raise CavpError("CAVP (MI355X path) needs inputs on a HIP device: there is no CPU fallback")
         from .train import CAVPTrainFunction

@@ -464,7 +464,17 @@ class TrainPass:
         track = bn.track_running_stats and bn.running_mean is not None
         mom = bn.momentum if bn.momentum is not None else 0.1
         sync = isinstance(bn, nn.SyncBatchNorm) and dist_world() > 1
-        if z.tile_stats is not None and not sync:
+        frozen = (not bn.training) and bn.running_mean is not None   # torch: eval-mode BatchNorm normalises with the running statistics
+        if frozen:
+            # fine-tuning with frozen statistics: y = gamma (z - running_mean) rstd + beta, no update of the running buffers;
+            # backward dz = gamma rstd g, dgamma = sum g zhat, dbeta = sum g (no batch-mean terms)
+            from . import ops as O
+            track, count = False, rows
+            O.bn_fold(bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var, bn.eps, scale, shift)
+            one, zero = self.empty((c,), torch.float32).fill_(1.0), self.zeros_f32(c)
+            O.bn_fold(one, zero, bn.running_mean, bn.running_var, bn.eps, rstd, zero.clone())
+            mean = bn.running_mean
+        elif z.tile_stats is not None and not sync:
             # statistics came out of the producing conv's epilogue (per-tile mean / M2): just combine them
             ts, tiles, rpt = z.tile_stats
             count = rows
@@ -528,6 +538,8 @@ class TrainPass:
                 local = sums.clone()
                 self._allreduce_stats(bn, sums, rows)
                 sums = sums * (float(rows) / float(count))
+            if frozen:
+                sums = self.zeros_f32(2, c)     # the batch-mean terms of dz vanish; `local` keeps the affine gradients
             dz = self.empty(z.t.shape, z.t.dtype)
             g_out = self.empty(z.t.shape, z.t.dtype) if (residual is not None and residual.needs_grad) else None
             T.bn_act_bwd_apply(dy, yb, z.t, mean, rstd, bn.weight.detach(), sums[0], sums[1], act, dz, g_out=g_out,
