@@ -690,8 +690,6 @@ class CAVP(nn.Module):
         want_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
         if not bn_train and not want_grad:
             return self._forward_hip(image, audio, duplicate_visual=True, shuffle=shuffle)   # frozen-BN, forward only
-        if self.seg_model != "DeepLabV3Plus":
-            raise NotImplementedError("the training pass is built for the ResNet-50 path; PVTv2 runs forward-only so far")
         if not image.is_cuda:
             raise CavpError("CAVP (MI355X path) needs inputs on a HIP device: there is no CPU fallback")
         from .train import CAVPTrainFunction

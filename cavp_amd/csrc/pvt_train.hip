@@ -1,0 +1,509 @@
+// Backward kernels of the PVTv2-B5 backbone (models/visual/backbones/pvt/pvt.py) for gfx950: spatial-reduction attention
+// (dq | dk, dv), depth-wise 3x3 conv weight gradient, weight gradient of the 7x7 / stride-4 patch embedding, the sr x sr
+// space-to-depth rearrangement that turns the spatial-reduction conv (kernel = stride) into a token GEMM, and the
+// stochastic-depth residual add.  All matrix products run on the f32 matrix pipe (v_mfma_f32_16x16x4f32) whatever the
+// storage type: the attention backward is ~10 % of the backbone's FLOPs and its K / V / Q tiles are converted once when
+// they are staged into LDS.
+#include "common.h"
+
+namespace {
+
+template <typename T> __device__ __forceinline__ float4 ld4(const T* p);
+template <> __device__ __forceinline__ float4 ld4<float>(const float* p) { return *(const float4*)p; }
+template <> __device__ __forceinline__ float4 ld4<bf16_t>(const bf16_t* p) {
+  const uint2 t = *(const uint2*)p;
+  return make_float4(__uint_as_float(t.x << 16), __uint_as_float(t.x & 0xffff0000u), __uint_as_float(t.y << 16),
+                     __uint_as_float(t.y & 0xffff0000u));
+}
+template <typename T> __device__ __forceinline__ void st4(T* p, float a, float b, float c, float d);
+template <> __device__ __forceinline__ void st4<float>(float* p, float a, float b, float c, float d) {
+  *(float4*)p = make_float4(a, b, c, d);
+}
+template <> __device__ __forceinline__ void st4<bf16_t>(bf16_t* p, float a, float b, float c, float d) {
+  *(uint2*)p = make_uint2(pack2bf(a, b), pack2bf(c, d));
+}
+
+// LDS tile of f32 rows of 64 channels (256 bytes); the 16-byte slot index is XORed with (row & 7) so that 16 lanes reading
+// the same slot of 16 consecutive rows spread over the banks.
+__device__ __forceinline__ int tile_off(int row, int d) { return row * 256 + ((((d >> 2) ^ (row & 7))) << 4) + ((d & 3) << 2); }
+__device__ __forceinline__ float4 tile_ld4(const char* base, int row, int slot) {
+  return *(const float4*)(base + row * 256 + ((slot ^ (row & 7)) << 4));
+}
+__device__ __forceinline__ float tile_ld1(const char* base, int row, int d) { return *(const float*)(base + tile_off(row, d)); }
+
+// stage `rows` rows (row r of the source = src + r * ld, 64 channels of T) into a swizzled f32 tile of `cap` rows (zero fill)
+template <typename T>
+__device__ __forceinline__ void stage_tile(char* dst, const T* src, size_t ld, int rows, int cap, int tid) {
+  for (int i = tid; i < cap * 16; i += 256) {
+    const int r = i >> 4, sl = i & 15;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (r < rows) v = ld4<T>(src + (size_t)r * ld + sl * 4);
+    *(float4*)(dst + r * 256 + ((sl ^ (r & 7)) << 4)) = v;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// Attention backward, part 1 (pvt.py:120-126): one (batch, head) and 64 queries per workgroup, K and V of the head in LDS.
+//   S^T[key][query] = K Q^T, P = softmax(scale S), dP^T = V dO^T, delta = sum_key P dP, dS = scale P (dP - delta),
+//   dQ^T[d][query] = sum_key K[key][d] dS^T[key][query].  Also writes the row statistics (log-sum-exp, delta) that part 2
+//   needs.  Same lane <-> (key, query) mapping as the forward kernel (pvt_ops.hip): a lane owns one query column.
+// ------------------------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void sra_bwd_q_kernel(const T* __restrict__ q, const T* __restrict__ kv,
+                                                        const T* __restrict__ dout, T* __restrict__ dq,
+                                                        float* __restrict__ stats, int Nq, int Nk, int heads, float scale) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* ks = smem;
+  char* vs = smem + 256 * 256;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int bh = blockIdx.y, b = bh / heads, h = bh - b * heads;
+  const int C = heads * 64;
+  const T* kvb = kv + (size_t)b * Nk * 2 * C + h * 64;
+  stage_tile<T>(ks, kvb, (size_t)2 * C, Nk, 256, tid);
+  stage_tile<T>(vs, kvb + C, (size_t)2 * C, Nk, 256, tid);
+  __syncthreads();
+  const int lrow = lane & 15, lgrp = lane >> 4;
+  const int qi = blockIdx.x * 64 + wave * 16 + lrow;
+  const bool qok = qi < Nq;
+  const size_t qoff = ((size_t)b * Nq + (qok ? qi : 0)) * C + h * 64;
+  f32x4_t s[16], dp[16];
+#pragma unroll
+  for (int kb = 0; kb < 16; ++kb) { s[kb] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; dp[kb] = s[kb]; }
+  // MFMA k index of instruction (j, c) in lane group g <-> channel d = 16 j + 4 g + c, for both operands
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    float4 qv = make_float4(0.f, 0.f, 0.f, 0.f), gv = qv;
+    if (qok) { qv = ld4<T>(q + qoff + j * 16 + lgrp * 4); gv = ld4<T>(dout + qoff + j * 16 + lgrp * 4); }
+    const float qa[4] = {qv.x, qv.y, qv.z, qv.w}, ga[4] = {gv.x, gv.y, gv.z, gv.w};
+#pragma unroll
+    for (int kb = 0; kb < 16; ++kb) {
+      const int key = kb * 16 + lrow;
+      const float4 kf = tile_ld4(ks, key, j * 4 + lgrp), vf = tile_ld4(vs, key, j * 4 + lgrp);
+      const float ka[4] = {kf.x, kf.y, kf.z, kf.w}, va[4] = {vf.x, vf.y, vf.z, vf.w};
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        s[kb] = __builtin_amdgcn_mfma_f32_16x16x4f32(ka[c], qa[c], s[kb], 0, 0, 0);
+        dp[kb] = __builtin_amdgcn_mfma_f32_16x16x4f32(va[c], ga[c], dp[kb], 0, 0, 0);
+      }
+    }
+  }
+  // softmax over the keys of this lane's query: key = 16 kb + 4 lgrp + r
+  float m = -INFINITY;
+#pragma unroll
+  for (int kb = 0; kb < 16; ++kb)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int key = kb * 16 + lgrp * 4 + r;
+      const float v = key < Nk ? s[kb][r] * scale : -INFINITY;
+      s[kb][r] = v;
+      m = fmaxf(m, v);
+    }
+  m = fmaxf(m, __shfl_xor(m, 16, 64));
+  m = fmaxf(m, __shfl_xor(m, 32, 64));
+  float sum = 0.f;
+#pragma unroll
+  for (int kb = 0; kb < 16; ++kb)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float e = expf(s[kb][r] - m);
+      s[kb][r] = e;
+      sum += e;
+    }
+  sum += __shfl_xor(sum, 16, 64);
+  sum += __shfl_xor(sum, 32, 64);
+  const float inv = 1.f / sum;
+  float delta = 0.f;
+#pragma unroll
+  for (int kb = 0; kb < 16; ++kb)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      s[kb][r] *= inv;
+      delta += s[kb][r] * dp[kb][r];   // padded keys: p = 0
+    }
+  delta += __shfl_xor(delta, 16, 64);
+  delta += __shfl_xor(delta, 32, 64);
+#pragma unroll
+  for (int kb = 0; kb < 16; ++kb)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) s[kb][r] = s[kb][r] * (dp[kb][r] - delta) * scale;   // dS^T
+  // dQ^T[d][query] = sum_key K[key][d] dS^T[key][query]: MFMA (kb, r) has k index lgrp <-> key 16 kb + 4 lgrp + r
+  f32x4_t acc[4];
+#pragma unroll
+  for (int db = 0; db < 4; ++db) acc[db] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int kb = 0; kb < 16; ++kb)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int key = kb * 16 + lgrp * 4 + r;
+#pragma unroll
+      for (int db = 0; db < 4; ++db)
+        acc[db] = __builtin_amdgcn_mfma_f32_16x16x4f32(tile_ld1(ks, key, db * 16 + lrow), s[kb][r], acc[db], 0, 0, 0);
+    }
+  if (qok) {
+#pragma unroll
+    for (int db = 0; db < 4; ++db) st4<T>(dq + qoff + db * 16 + lgrp * 4, acc[db][0], acc[db][1], acc[db][2], acc[db][3]);
+    if (lgrp == 0) {
+      stats[(size_t)bh * Nq + qi] = m + logf(sum);
+      stats[(size_t)gridDim.y * Nq + (size_t)bh * Nq + qi] = delta;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// Attention backward, part 2: dK, dV.  Workgroup = (query split, batch x head, block of 64 keys); wave w owns 16 keys whose
+// K / V rows stay in registers; chunks of 64 queries (Q, dO as f32 tiles in LDS) stream past them:
+//   S[query][key] = Q K^T, P = exp(scale S - lse), dP = dO V^T, dS = scale P (dP - delta),
+//   dV^T[d][key] += sum_query dO^T[d][query] P[query][key],  dK^T[d][key] += sum_query Q^T[d][query] dS[query][key].
+// The per-split partial sums are added into the f32 gradient with atomics (one split: plain adds, deterministic).
+// ------------------------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void sra_bwd_kv_kernel(const T* __restrict__ q, const T* __restrict__ kv,
+                                                         const T* __restrict__ dout, const float* __restrict__ stats,
+                                                         float* __restrict__ dkv, int Nq, int Nk, int heads, float scale) {
+  __shared__ __attribute__((aligned(16))) char qs[64 * 256];
+  __shared__ __attribute__((aligned(16))) char gs[64 * 256];
+  __shared__ float lse_s[64], del_s[64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lrow = lane & 15, lgrp = lane >> 4;
+  const int bh = blockIdx.y, b = bh / heads, h = bh - b * heads;
+  const int C = heads * 64;
+  const int key = blockIdx.z * 64 + wave * 16 + lrow;
+  const bool kok = key < Nk;
+  float4 kr[4], vr[4];
+  {
+    const T* kp = kv + ((size_t)b * Nk + (kok ? key : 0)) * 2 * C + h * 64;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      kr[j] = kok ? ld4<T>(kp + j * 16 + lgrp * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+      vr[j] = kok ? ld4<T>(kp + C + j * 16 + lgrp * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+  f32x4_t dk[4], dv[4];
+#pragma unroll
+  for (int db = 0; db < 4; ++db) { dk[db] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; dv[db] = dk[db]; }
+  const int chunks = (Nq + 63) / 64;
+  for (int ch = blockIdx.x; ch < chunks; ch += gridDim.x) {
+    const int q0 = ch * 64, rows = min(64, Nq - q0);
+    __syncthreads();   // the previous chunk's tiles are no longer read
+    stage_tile<T>(qs, q + ((size_t)b * Nq + q0) * C + h * 64, (size_t)C, rows, 64, tid);
+    stage_tile<T>(gs, dout + ((size_t)b * Nq + q0) * C + h * 64, (size_t)C, rows, 64, tid);
+    if (tid < 64) {
+      const bool ok = tid < rows;
+      lse_s[tid] = ok ? stats[(size_t)bh * Nq + q0 + tid] : 0.f;
+      del_s[tid] = ok ? stats[(size_t)gridDim.y * Nq + (size_t)bh * Nq + q0 + tid] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int qb = 0; qb < 4; ++qb) {
+      f32x4_t sa = (f32x4_t){0.f, 0.f, 0.f, 0.f}, da = sa;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float4 qf = tile_ld4(qs, qb * 16 + lrow, j * 4 + lgrp), gf = tile_ld4(gs, qb * 16 + lrow, j * 4 + lgrp);
+        const float qa[4] = {qf.x, qf.y, qf.z, qf.w}, ga[4] = {gf.x, gf.y, gf.z, gf.w};
+        const float ka[4] = {kr[j].x, kr[j].y, kr[j].z, kr[j].w}, va[4] = {vr[j].x, vr[j].y, vr[j].z, vr[j].w};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          sa = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[c], ka[c], sa, 0, 0, 0);
+          da = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[c], va[c], da, 0, 0, 0);
+        }
+      }
+      // sa[r] = S[query = 16 qb + 4 lgrp + r][key = this lane's]
+      float p[4], ds[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int ql = qb * 16 + lgrp * 4 + r;
+        const bool ok = kok && ql < rows;
+        p[r] = ok ? expf(sa[r] * scale - lse_s[ql]) : 0.f;
+        ds[r] = p[r] * (da[r] - del_s[ql]) * scale;
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int ql = qb * 16 + lgrp * 4 + r;   // MFMA k index lgrp <-> query ql
+#pragma unroll
+        for (int db = 0; db < 4; ++db) {
+          dv[db] = __builtin_amdgcn_mfma_f32_16x16x4f32(tile_ld1(gs, ql, db * 16 + lrow), p[r], dv[db], 0, 0, 0);
+          dk[db] = __builtin_amdgcn_mfma_f32_16x16x4f32(tile_ld1(qs, ql, db * 16 + lrow), ds[r], dk[db], 0, 0, 0);
+        }
+      }
+    }
+  }
+  if (kok) {
+    float* op = dkv + ((size_t)b * Nk + key) * 2 * C + h * 64;
+#pragma unroll
+    for (int db = 0; db < 4; ++db)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        atomicAdd(op + db * 16 + lgrp * 4 + r, dk[db][r]);
+        atomicAdd(op + C + db * 16 + lgrp * 4 + r, dv[db][r]);
+      }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// Depth-wise 3x3 (pad 1) weight + bias gradient: dw[c][t] += sum_p x[p + off_t][c] g[p][c], db[c] += sum_p g[p][c].
+// thread = 4 channels x one of 4 pixel lanes; workgroup = 64 channel quads x `ppb` pixels; LDS reduce over the pixel lanes,
+// then one atomic per (channel, tap) and workgroup.
+// ------------------------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void dwconv3x3_wgrad_kernel(const T* __restrict__ x, const T* __restrict__ g,
+                                                              float* __restrict__ dw, float* __restrict__ db, int N, int H,
+                                                              int W, int C, int ppb) {
+  __shared__ float red[3][64][41];
+  const int cl = threadIdx.x & 63, pl = threadIdx.x >> 6;
+  const int cv = blockIdx.x * 64 + cl;
+  const bool cok = cv * 4 < C;
+  const long long total = (long long)N * H * W;
+  const long long p0 = (long long)blockIdx.y * ppb, p1 = min(total, p0 + ppb);
+  float acc[40];
+#pragma unroll
+  for (int i = 0; i < 40; ++i) acc[i] = 0.f;
+  if (cok)
+    for (long long p = p0 + pl; p < p1; p += 4) {
+      const int wi = (int)(p % W), hi = (int)((p / W) % H);
+      const float4 gv = ld4<T>(g + (size_t)p * C + cv * 4);
+      const float ga[4] = {gv.x, gv.y, gv.z, gv.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[36 + e] += ga[e];
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh) {
+        const int h2 = hi - 1 + kh;
+        if ((unsigned)h2 >= (unsigned)H) continue;
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+          const int w2 = wi - 1 + kw;
+          if ((unsigned)w2 >= (unsigned)W) continue;
+          const float4 xv = ld4<T>(x + ((size_t)p + (long long)(kh - 1) * W + (kw - 1)) * C + cv * 4);
+          const float xa[4] = {xv.x, xv.y, xv.z, xv.w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[(kh * 3 + kw) * 4 + e] += xa[e] * ga[e];
+        }
+      }
+    }
+  if (pl > 0)
+#pragma unroll
+    for (int i = 0; i < 40; ++i) red[pl - 1][cl][i] = acc[i];
+  __syncthreads();
+  if (pl == 0 && cok) {
+#pragma unroll
+    for (int i = 0; i < 40; ++i) acc[i] += red[0][cl][i] + red[1][cl][i] + red[2][cl][i];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int c = cv * 4 + e;
+#pragma unroll
+      for (int t = 0; t < 9; ++t) atomicAdd(dw + c * 9 + t, acc[t * 4 + e]);
+      if (db) atomicAdd(db + c, acc[36 + e]);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// Weight gradient of the KS x KS / Cin <= 3 patch embedding (NCHW f32 input, NHWC gradient):
+//   dw[o][tap] += sum_pixels g[pixel][o] x[pixel, tap].  thread = (output channel, tap group); the x value of a tap is the
+//   same for the 64 lanes of a wave (one scalar-like load), g is read coalesced over o.
+// ------------------------------------------------------------------------------------------------------------------------
+constexpr int PE_MAXT = 40;
+template <typename T>
+__global__ __launch_bounds__(256) void smallcin_kxk_wgrad_kernel(const float* __restrict__ x, const T* __restrict__ g,
+                                                                 float* __restrict__ dw, int N, int Cin, int H, int W,
+                                                                 int Cout, int KS, int stride, int pad, int Ho, int Wo, int ppb) {
+  const int o = threadIdx.x % Cout, tg = threadIdx.x / Cout, TG = 256 / Cout;
+  const int K = Cin * KS * KS;
+  int tap_code[PE_MAXT];
+  float acc[PE_MAXT];
+#pragma unroll
+  for (int t = 0; t < PE_MAXT; ++t) {
+    const int tap = tg + t * TG;
+    acc[t] = 0.f;
+    if (tap < K) {
+      const int ci = tap / (KS * KS), rem = tap - ci * KS * KS, kh = rem / KS, kw = rem - kh * KS;
+      tap_code[t] = (ci << 16) | (kh << 8) | kw;
+    } else {
+      tap_code[t] = -1;
+    }
+  }
+  const long long total = (long long)N * Ho * Wo;
+  const long long p0 = (long long)blockIdx.x * ppb, p1 = min(total, p0 + ppb);
+  for (long long p = p0; p < p1; ++p) {
+    const int wo = (int)(p % Wo), ho = (int)((p / Wo) % Ho), n = (int)(p / ((long long)Wo * Ho));
+    const float gv = Elem<T>::ld(g + (size_t)p * Cout + o);
+    const float* xn = x + (size_t)n * Cin * H * W;
+#pragma unroll
+    for (int t = 0; t < PE_MAXT; ++t) {
+      const int code = tap_code[t];
+      if (code < 0) continue;
+      const int ci = code >> 16, kh = (code >> 8) & 255, kw = code & 255;
+      const int hi = ho * stride - pad + kh, wi = wo * stride - pad + kw;
+      if ((unsigned)hi < (unsigned)H && (unsigned)wi < (unsigned)W) acc[t] = fmaf(gv, xn[((size_t)ci * H + hi) * W + wi], acc[t]);
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < PE_MAXT; ++t) {
+    const int tap = tg + t * TG;
+    if (tap < K) atomicAdd(dw + (size_t)o * K + tap, acc[t]);
+  }
+}
+
+// [B][H][W][C] <-> [B][H/s][W/s][s*s*C] (patch element order (row, column, channel) = OHWI weight order); 16-byte vectors
+template <typename T>
+__global__ __launch_bounds__(256) void space_to_depth_kernel(const T* __restrict__ src, T* __restrict__ dst, int B, int H,
+                                                             int W, int C, int s, int inverse) {
+  constexpr int VE = 16 / (int)sizeof(T);
+  const int CV = C / VE, Ho = H / s, Wo = W / s;
+  const long long total = (long long)B * H * W * CV;
+  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    // i enumerates the patch-major tensor: (b, yo, xo, r, c2, cv)
+    long long t = i;
+    const int cv = (int)(t % CV); t /= CV;
+    const int c2 = (int)(t % s); t /= s;
+    const int r = (int)(t % s); t /= s;
+    const int xo = (int)(t % Wo); t /= Wo;
+    const int yo = (int)(t % Ho);
+    const int b = (int)(t / Ho);
+    const size_t img = (((size_t)b * H + yo * s + r) * W + xo * s + c2) * C + (size_t)cv * VE;
+    if (inverse) *(uint4*)(dst + img) = *(const uint4*)(src + i * VE);
+    else *(uint4*)(dst + i * VE) = *(const uint4*)(src + img);
+  }
+}
+
+// stochastic depth (timm DropPath, pvt.py:167-168): out = x + s[sample] * branch  (x == nullptr: out = s[sample] * branch)
+template <typename T>
+__global__ __launch_bounds__(256) void row_scale_add_kernel(const T* __restrict__ x, const T* __restrict__ br,
+                                                            const float* __restrict__ s, T* __restrict__ out,
+                                                            long long per_sample_vec, long long total_vec) {
+  constexpr int VE = VecT<T>::VE;
+  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total_vec; i += (long long)gridDim.x * 256) {
+    const float sc = s[i / per_sample_vec];
+    float a[VE], v[VE];
+    VecT<T>::load(br + i * VE, v);
+    if (x) {
+      VecT<T>::load(x + i * VE, a);
+#pragma unroll
+      for (int e = 0; e < VE; ++e) v[e] = a[e] + sc * v[e];
+    } else {
+#pragma unroll
+      for (int e = 0; e < VE; ++e) v[e] *= sc;
+    }
+    VecT<T>::store(out + i * VE, v);
+  }
+}
+
+inline bool dt_ok(int dt) { return dt == CAVP_F32 || dt == CAVP_BF16; }
+}  // namespace
+#define CHECK_LAUNCH() return hipGetLastError() == hipSuccess ? CAVP_OK : CAVP_ERR_LAUNCH
+
+extern "C" size_t cavp_sra_attention_bwd_workspace_bytes(int32_t B, int32_t Nq, int32_t heads) {
+  return (size_t)2 * B * heads * Nq * sizeof(float);
+}
+
+extern "C" int cavp_sra_attention_bwd(int32_t dtype, const void* q, const void* kv, const void* dout, void* dq, float* dkv,
+                                      int32_t B, int32_t Nq, int32_t Nk, int32_t heads, int32_t head_dim, float scale,
+                                      void* workspace, size_t workspace_bytes, void* stream) {
+  if (!q || !kv || !dout || !dq || !dkv || !workspace || B <= 0 || Nq <= 0 || Nk <= 0 || heads <= 0) return CAVP_ERR_BAD_ARG;
+  if (!dt_ok(dtype) || head_dim != 64 || Nk > 256) return CAVP_ERR_UNSUPPORTED;
+  if (workspace_bytes < cavp_sra_attention_bwd_workspace_bytes(B, Nq, heads)) return CAVP_ERR_WORKSPACE;
+  if (((uintptr_t)q & 15) || ((uintptr_t)kv & 15) || ((uintptr_t)dout & 15) || ((uintptr_t)dq & 15) || ((uintptr_t)dkv & 15) ||
+      ((uintptr_t)workspace & 15))
+    return CAVP_ERR_ALIGN;
+  hipStream_t s = (hipStream_t)stream;
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)sra_bwd_q_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 256 * 256);
+    (void)hipFuncSetAttribute((const void*)sra_bwd_q_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 256 * 256);
+    attr = true;
+  }
+  float* stats = (float*)workspace;
+  const int C = heads * 64;
+  if (cavp_zero_f32_async(dkv, (size_t)B * Nk * 2 * C * sizeof(float), s) != hipSuccess) return CAVP_ERR_LAUNCH;
+  const dim3 ga((Nq + 63) / 64, B * heads);
+  const int chunks = (Nq + 63) / 64, kblocks = (Nk + 63) / 64;
+  int splits = 1;
+  if (!g_cavp_det.scratch) {   // deterministic mode: one split = one contribution per element, in a fixed order
+    splits = 1024 / (B * heads * kblocks);
+    splits = splits < 1 ? 1 : (splits > chunks ? chunks : splits);
+  }
+  const dim3 gb(splits, B * heads, kblocks);
+  if (dtype == CAVP_F32) {
+    sra_bwd_q_kernel<float><<<ga, 256, 2 * 256 * 256, s>>>((const float*)q, (const float*)kv, (const float*)dout, (float*)dq, stats,
+                                                          Nq, Nk, heads, scale);
+    sra_bwd_kv_kernel<float><<<gb, 256, 0, s>>>((const float*)q, (const float*)kv, (const float*)dout, stats, dkv, Nq, Nk, heads,
+                                                scale);
+  } else {
+    sra_bwd_q_kernel<bf16_t><<<ga, 256, 2 * 256 * 256, s>>>((const bf16_t*)q, (const bf16_t*)kv, (const bf16_t*)dout, (bf16_t*)dq,
+                                                           stats, Nq, Nk, heads, scale);
+    sra_bwd_kv_kernel<bf16_t><<<gb, 256, 0, s>>>((const bf16_t*)q, (const bf16_t*)kv, (const bf16_t*)dout, stats, dkv, Nq, Nk,
+                                                 heads, scale);
+  }
+  CHECK_LAUNCH();
+}
+
+extern "C" int cavp_dwconv3x3_wgrad(int32_t dtype, const void* x, const void* dy, float* dw_c133, float* dbias, int32_t N,
+                                    int32_t H, int32_t W, int32_t C, void* stream) {
+  if (!x || !dy || !dw_c133 || N <= 0 || H <= 0 || W <= 0 || C <= 0) return CAVP_ERR_BAD_ARG;
+  if (!dt_ok(dtype) || C % 8) return CAVP_ERR_UNSUPPORTED;
+  const long long total = (long long)N * H * W;
+  const int gx = (C / 4 + 63) / 64;
+  int ppb = 256;
+  while ((total + ppb - 1) / ppb * gx > 4096) ppb *= 2;
+  const dim3 grid(gx, (unsigned)((total + ppb - 1) / ppb));
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == CAVP_F32)
+    dwconv3x3_wgrad_kernel<float><<<grid, 256, 0, s>>>((const float*)x, (const float*)dy, dw_c133, dbias, N, H, W, C, ppb);
+  else
+    dwconv3x3_wgrad_kernel<bf16_t><<<grid, 256, 0, s>>>((const bf16_t*)x, (const bf16_t*)dy, dw_c133, dbias, N, H, W, C, ppb);
+  CHECK_LAUNCH();
+}
+
+extern "C" int cavp_conv_smallcin_kxk_wgrad(int32_t dtype, const float* x_nchw, const void* dy_nhwc, float* dw_oihw, int32_t N,
+                                            int32_t Cin, int32_t H, int32_t W, int32_t Cout, int32_t KS, int32_t stride,
+                                            int32_t pad, void* stream) {
+  if (!x_nchw || !dy_nhwc || !dw_oihw || N <= 0 || H <= 0 || W <= 0 || stride <= 0 || KS <= 0 || pad < 0) return CAVP_ERR_BAD_ARG;
+  if (!dt_ok(dtype) || Cin < 1 || Cin > 3 || Cout < 16 || Cout > 256 || 256 % Cout || KS > 15) return CAVP_ERR_UNSUPPORTED;
+  if ((Cin * KS * KS + 256 / Cout - 1) / (256 / Cout) > PE_MAXT) return CAVP_ERR_UNSUPPORTED;
+  const int Ho = (H + 2 * pad - KS) / stride + 1, Wo = (W + 2 * pad - KS) / stride + 1;
+  const long long total = (long long)N * Ho * Wo;
+  int ppb = 64;
+  while ((total + ppb - 1) / ppb > 2048) ppb *= 2;
+  const int nb = (int)((total + ppb - 1) / ppb);
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == CAVP_F32)
+    smallcin_kxk_wgrad_kernel<float><<<nb, 256, 0, s>>>(x_nchw, (const float*)dy_nhwc, dw_oihw, N, Cin, H, W, Cout, KS, stride, pad,
+                                                        Ho, Wo, ppb);
+  else
+    smallcin_kxk_wgrad_kernel<bf16_t><<<nb, 256, 0, s>>>(x_nchw, (const bf16_t*)dy_nhwc, dw_oihw, N, Cin, H, W, Cout, KS, stride,
+                                                         pad, Ho, Wo, ppb);
+  CHECK_LAUNCH();
+}
+
+extern "C" int cavp_space_to_depth(int32_t dtype, const void* src, void* dst, int32_t B, int32_t H, int32_t W, int32_t C,
+                                   int32_t s, int32_t inverse, void* stream) {
+  if (!src || !dst || B <= 0 || H <= 0 || W <= 0 || C <= 0 || s <= 0) return CAVP_ERR_BAD_ARG;
+  if (!dt_ok(dtype) || H % s || W % s || C % (dtype == CAVP_F32 ? 4 : 8)) return CAVP_ERR_UNSUPPORTED;
+  if (((uintptr_t)src & 15) || ((uintptr_t)dst & 15)) return CAVP_ERR_ALIGN;
+  const long long total = (long long)B * H * W * (C / (dtype == CAVP_F32 ? 4 : 8));
+  long long nb = (total + 255) / 256;
+  if (nb > 16384) nb = 16384;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == CAVP_F32)
+    space_to_depth_kernel<float><<<(int)nb, 256, 0, st>>>((const float*)src, (float*)dst, B, H, W, C, s, inverse);
+  else
+    space_to_depth_kernel<bf16_t><<<(int)nb, 256, 0, st>>>((const bf16_t*)src, (bf16_t*)dst, B, H, W, C, s, inverse);
+  CHECK_LAUNCH();
+}
+
+extern "C" int cavp_row_scale_add(int32_t dtype, const void* x, const void* branch, const float* sample_scale, void* out,
+                                  int32_t B, int64_t per_sample, void* stream) {
+  if (!branch || !sample_scale || !out || B <= 0 || per_sample <= 0) return CAVP_ERR_BAD_ARG;
+  const int VE = dtype == CAVP_F32 ? 4 : 8;
+  if (!dt_ok(dtype) || per_sample % VE) return CAVP_ERR_UNSUPPORTED;
+  if (((uintptr_t)branch & 15) || ((uintptr_t)out & 15) || ((uintptr_t)x & 15)) return CAVP_ERR_ALIGN;
+  const long long psv = per_sample / VE, total = psv * B;
+  long long nb = (total + 255) / 256;
+  if (nb > 16384) nb = 16384;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == CAVP_F32)
+    row_scale_add_kernel<float><<<(int)nb, 256, 0, st>>>((const float*)x, (const float*)branch, sample_scale, (float*)out, psv, total);
+  else
+    row_scale_add_kernel<bf16_t><<<(int)nb, 256, 0, st>>>((const bf16_t*)x, (const bf16_t*)branch, sample_scale, (bf16_t*)out, psv,
+                                                          total);
+  CHECK_LAUNCH();
+}

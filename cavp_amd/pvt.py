@@ -55,8 +55,9 @@ class PvtAttention(_Container):
 
 
 class PvtBlock(_Container):
-    def __init__(self, dim, num_heads, mlp_ratio, sr_ratio, norm_layer):
+    def __init__(self, dim, num_heads, mlp_ratio, sr_ratio, norm_layer, drop_path: float = 0.0):
         super().__init__()
+        self.drop_prob = float(drop_path)         # timm DropPath probability (pvt.py:144); training pass only
         self.norm1 = norm_layer(dim)
         self.attn = PvtAttention(dim, num_heads, sr_ratio)
         self.drop_path = nn.Identity()
@@ -73,20 +74,23 @@ class OverlapPatchEmbed(_Container):
 
 class PyramidVisionTransformerV2(_Container):
     def __init__(self, embed_dims=(64, 128, 320, 512), num_heads=(1, 2, 5, 8), mlp_ratios=(4, 4, 4, 4),
-                 depths=(3, 6, 40, 3), sr_ratios=(8, 4, 2, 1)):
+                 depths=(3, 6, 40, 3), sr_ratios=(8, 4, 2, 1), drop_path_rate: float = 0.1):
         super().__init__()
         norm_layer = partial(nn.LayerNorm, eps=1e-6)
         self.depths, self.embed_dims, self.num_stages = tuple(depths), tuple(embed_dims), 4
+        dpr = [x.item() for x in torch.linspace(0, drop_path_rate, sum(depths))]   # stochastic depth decay rule (pvt.py:229)
+        cur = 0
         for i in range(4):
             setattr(self, f"patch_embed{i + 1}", OverlapPatchEmbed(7 if i == 0 else 3, 4 if i == 0 else 2,
                                                                   3 if i == 0 else embed_dims[i - 1], embed_dims[i]))
             setattr(self, f"block{i + 1}", nn.ModuleList([PvtBlock(embed_dims[i], num_heads[i], mlp_ratios[i], sr_ratios[i],
-                                                                   norm_layer) for _ in range(depths[i])]))
+                                                                   norm_layer, dpr[cur + j]) for j in range(depths[i])]))
             setattr(self, f"norm{i + 1}", norm_layer(embed_dims[i]))
+            cur += depths[i]
 
 
 def pvt_v2_b5():
-    """pvt.py:413-421."""
+    """pvt.py:413-421 (drop_path_rate = 0.1)."""
     return PyramidVisionTransformerV2()
 
 

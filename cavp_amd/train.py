@@ -744,20 +744,22 @@ def run_train_forward(model, image: torch.Tensor, audio: torch.Tensor, tp: Train
     (logits_lowres, fusion NHWC, fea_v_proj NHWC, fea_a, attn)."""
     from .cavp_model import VGG
     m = model
-    rn = m.backbone.backbone
+    pvt = m.seg_model == "PVT"
+    rn = None if pvt else m.backbone.backbone
     B = image.shape[0]
     # ---- pack ----
-    tp.pack("stem0", rn.conv1[0], raw=True)
-    tp.pack("stem1", rn.conv1[3])
-    tp.pack("stem2", rn.conv1[6])
-    for si in range(4):
-        for bi, blk in enumerate(getattr(rn, f"layer{si + 1}")):
-            key = f"l{si + 1}.{bi}"
-            tp.pack(key + ".c1", blk.conv1)
-            tp.pack(key + ".c2", blk.conv2)
-            tp.pack(key + ".c3", blk.conv3)
-            if blk.downsample is not None:
-                tp.pack(key + ".ds", blk.downsample[0])
+    if not pvt:
+        tp.pack("stem0", rn.conv1[0], raw=True)
+        tp.pack("stem1", rn.conv1[3])
+        tp.pack("stem2", rn.conv1[6])
+        for si in range(4):
+            for bi, blk in enumerate(getattr(rn, f"layer{si + 1}")):
+                key = f"l{si + 1}.{bi}"
+                tp.pack(key + ".c1", blk.conv1)
+                tp.pack(key + ".c2", blk.conv2)
+                tp.pack(key + ".c3", blk.conv3)
+                if blk.downsample is not None:
+                    tp.pack(key + ".ds", blk.downsample[0])
     aspp = m.segment.aspp
     for i, cv in enumerate(aspp.map_convs):
         tp.pack(f"aspp.map{i}", cv)
@@ -788,23 +790,30 @@ def run_train_forward(model, image: torch.Tensor, audio: torch.Tensor, tp: Train
     tp.flush_packs()
 
     dt = tp.dt
-    # ---- backbone (resnet.py:186-201) ----
-    z = tp.conv_smallcin(image, "stem0", 2, ACT_NONE)
-    x = tp.bn_act(z, rn.conv1[1], ACT_RELU)
-    x = tp.bn_act(tp.conv(x, "stem1", stats=True), rn.conv1[4], ACT_RELU)
-    x = tp.bn_act(tp.conv(x, "stem2", stats=True), rn.bn1, ACT_RELU)
-    x = tp.maxpool(x, 3, 2, 1)
-    feats = []
-    for si, stage in enumerate(rn.block_table):
-        for bi, (_, _, _, has_ds) in enumerate(stage):
-            blkm = getattr(rn, f"layer{si + 1}")[bi]
-            key = f"l{si + 1}.{bi}"
-            o = tp.bn_act(tp.conv(x, key + ".c1", stats=True), blkm.bn1, ACT_RELU)
-            o = tp.bn_act(tp.conv(o, key + ".c2", stats=True), blkm.bn2, ACT_RELU)
-            res = tp.bn_act(tp.conv(x, key + ".ds", stats=True), blkm.downsample[1], ACT_NONE) if has_ds else x
-            x = tp.bn_act(tp.conv(o, key + ".c3", stats=True), blkm.bn3, ACT_RELU, residual=res)
-            tp.named[key] = x
-        feats.append(x)
+    if pvt:
+        # ---- PVTv2-B5 backbone (pvt.py:291-306; cavp_amd/pvt_train.py) ----
+        from .pvt_train import pvt_train_forward
+        feats = pvt_train_forward(tp, m.backbone, image, drop_scales=getattr(m, "_pvt_drop_scales", None))
+    else:
+        # ---- backbone (resnet.py:186-201) ----
+        z = tp.conv_smallcin(image, "stem0", 2, ACT_NONE)
+        x = tp.bn_act(z, rn.conv1[1], ACT_RELU)
+        x = tp.bn_act(tp.conv(x, "stem1", stats=True), rn.conv1[4], ACT_RELU)
+        x = tp.bn_act(tp.conv(x, "stem2", stats=True), rn.bn1, ACT_RELU)
+        x = tp.maxpool(x, 3, 2, 1)
+        feats = []
+        for si, stage in enumerate(rn.block_table):
+            for bi, (_, _, _, has_ds) in enumerate(stage):
+                blkm = getattr(rn, f"layer{si + 1}")[bi]
+                key = f"l{si + 1}.{bi}"
+                o = tp.bn_act(tp.conv(x, key + ".c1", stats=True), blkm.bn1, ACT_RELU)
+                o = tp.bn_act(tp.conv(o, key + ".c2", stats=True), blkm.bn2, ACT_RELU)
+                res = tp.bn_act(tp.conv(x, key + ".ds", stats=True), blkm.downsample[1], ACT_NONE) if has_ds else x
+                x = tp.bn_act(tp.conv(o, key + ".c3", stats=True), blkm.bn3, ACT_RELU, residual=res)
+                tp.named[key] = x
+            feats.append(x)
+    for i, f in enumerate(feats):
+        tp.named[f"stage{i + 1}"] = f
     f1, f4 = feats[0], feats[-1]
     # ---- ASPP + skip (encoder_decoder.py:97-105,137-156) ----
     n, h, w, _ = f4.t.shape

@@ -394,3 +394,60 @@ def upsample_ce_head(lo, labels, n_img: int, n_classes: int, ignore_index: int =
                                              int(align_corners), ignore_index, C.c_float(grad_scale), _ptr(loss),
                                              _ptr(dlo), _ptr(lse), _ptr(scratch), _s()), "cavp_upsample_ce_head")
     return loss, dlo
+
+
+# ---- PVTv2-B5 training pass (csrc/pvt_train.hip) ------------------------------------------------------------------------
+def sra_attention_bwd(q, kv, dout, dq, dkv, heads: int, scale: float) -> None:
+    """dq (q's dtype) and dkv (f32 [B, Nk, 2C], overwritten) of ops.sra_attention (pvt.py:120-126)."""
+    _need_gpu(q, kv, dout, dq, dkv)
+    b, nq, c = q.shape
+    nk = kv.shape[1]
+    if not all(t.is_contiguous() for t in (q, kv, dout, dq, dkv)) or dkv.dtype != torch.float32 or dkv.shape != kv.shape \
+            or dout.shape != q.shape or dq.shape != q.shape or dout.dtype != q.dtype or kv.dtype != q.dtype:
+        raise _lib.CavpError("sra_attention_bwd: contiguous [B,Nq,C] / [B,Nk,2C] tensors of one dtype + f32 dkv required")
+    lib = _lib.load()
+    nbytes = lib.cavp_sra_attention_bwd_workspace_bytes(b, nq, heads)
+    ws = ops.workspace(nbytes, q.device)
+    _check(lib.cavp_sra_attention_bwd(dtype_code(q.dtype), _ptr(q), _ptr(kv), _ptr(dout), _ptr(dq), _ptr(dkv), b, nq, nk, heads,
+                                      c // heads, C.c_float(scale), _ptr(ws), C.c_size_t(ws.numel()), _s()),
+           f"cavp_sra_attention_bwd B{b} Nq{nq} Nk{nk} heads{heads}")
+
+
+def dwconv3x3_wgrad(x, dy, dw, dbias) -> None:
+    """dw f32 [C,1,3,3] +=, dbias f32 [C] += of ops.dwconv3x3 (pvt.py:320-326)."""
+    _need_gpu(x, dy, dw, dbias)
+    n, h, w, c = x.shape
+    if not (x.is_contiguous() and dy.is_contiguous() and dw.is_contiguous()) or dy.shape != x.shape or dw.numel() != 9 * c:
+        raise _lib.CavpError("dwconv3x3_wgrad: dense NHWC x / dy and a [C,1,3,3] f32 gradient required")
+    _check(_lib.load().cavp_dwconv3x3_wgrad(dtype_code(x.dtype), _ptr(x), _ptr(dy), _ptr(dw), _ptr(dbias), n, h, w, c, _s()),
+           "cavp_dwconv3x3_wgrad")
+
+
+def conv_smallcin_kxk_wgrad(x_nchw, dy, dw_oihw, ks: int, stride: int, pad: int) -> None:
+    _need_gpu(x_nchw, dy, dw_oihw)
+    n, cin, h, w = x_nchw.shape
+    if not (x_nchw.is_contiguous() and dy.is_contiguous() and dw_oihw.is_contiguous()) or x_nchw.dtype != torch.float32:
+        raise _lib.CavpError("conv_smallcin_kxk_wgrad: contiguous f32 NCHW input, NHWC dy, OIHW f32 gradient required")
+    _check(_lib.load().cavp_conv_smallcin_kxk_wgrad(dtype_code(dy.dtype), _ptr(x_nchw), _ptr(dy), _ptr(dw_oihw), n, cin, h, w,
+                                                    dy.shape[-1], ks, stride, pad, _s()), "cavp_conv_smallcin_kxk_wgrad")
+
+
+def space_to_depth(src, dst, b: int, h: int, w: int, c: int, s: int, inverse: bool = False):
+    """[B,H,W,C] -> [B,H/s,W/s,s*s*C] (inverse: back).  Both tensors dense."""
+    _need_gpu(src, dst)
+    if not (src.is_contiguous() and dst.is_contiguous()) or src.numel() != dst.numel() or src.numel() != b * h * w * c:
+        raise _lib.CavpError("space_to_depth: dense tensors of B*H*W*C elements required")
+    _check(_lib.load().cavp_space_to_depth(dtype_code(src.dtype), _ptr(src), _ptr(dst), b, h, w, c, s, 1 if inverse else 0, _s()),
+           "cavp_space_to_depth")
+    return dst
+
+
+def row_scale_add(x, branch, sample_scale, out):
+    """out = x + sample_scale[b] * branch (x None: sample_scale[b] * branch); sample_scale f32 [B]."""
+    _need_gpu(x, branch, sample_scale, out)
+    b = branch.shape[0]
+    if not (branch.is_contiguous() and out.is_contiguous() and (x is None or x.is_contiguous())) or sample_scale.numel() != b:
+        raise _lib.CavpError("row_scale_add: dense tensors and one scale per batch item required")
+    _check(_lib.load().cavp_row_scale_add(dtype_code(branch.dtype), _ptr(x), _ptr(branch), _ptr(sample_scale), _ptr(out), b,
+                                          branch.numel() // b, _s()), "cavp_row_scale_add")
+    return out

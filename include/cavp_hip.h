@@ -348,6 +348,30 @@ int cavp_conv_smallcin_kxk_nchw(int32_t dtype, const float* x_nchw, const float*
                                 int32_t N, int32_t Cin, int32_t H, int32_t W, int32_t Cout, int32_t KS, int32_t stride,
                                 int32_t pad, void* stream);
 
+/* ---- PVTv2-B5 training pass (backward of the kernels above; pvt.py:102-130,46-55,187-188,167-168) ---- */
+/* Attention backward: dq [B][Nq][heads*64] (dtype), dkv f32 [B][Nk][2*heads*64] (dk | dv; overwritten) from q, kv, dout.
+ * The softmax is recomputed from q and kv (nothing is saved by the forward).  workspace: row statistics,
+ * cavp_sra_attention_bwd_workspace_bytes(B, Nq, heads) bytes, 16-byte aligned. */
+size_t cavp_sra_attention_bwd_workspace_bytes(int32_t B, int32_t Nq, int32_t heads);
+int cavp_sra_attention_bwd(int32_t dtype, const void* q, const void* kv, const void* dout, void* dq, float* dkv, int32_t B,
+                           int32_t Nq, int32_t Nk, int32_t heads, int32_t head_dim, float scale, void* workspace,
+                           size_t workspace_bytes, void* stream);
+/* DWConv weight / bias gradient: dw_c133 f32 [C][1][3][3] += , dbias f32 [C] += (may be NULL).  The data gradient is
+ * cavp_dwconv3x3_nhwc with the taps reversed. */
+int cavp_dwconv3x3_wgrad(int32_t dtype, const void* x, const void* dy, float* dw_c133, float* dbias, int32_t N, int32_t H,
+                         int32_t W, int32_t C, void* stream);
+/* Weight gradient of cavp_conv_smallcin_kxk_nchw: dw_oihw f32 += . */
+int cavp_conv_smallcin_kxk_wgrad(int32_t dtype, const float* x_nchw, const void* dy_nhwc, float* dw_oihw, int32_t N, int32_t Cin,
+                                 int32_t H, int32_t W, int32_t Cout, int32_t KS, int32_t stride, int32_t pad, void* stream);
+/* [B][H][W][C] -> [B][H/s][W/s][s*s*C] (inverse != 0: back): the spatial-reduction conv (kernel = stride = s,
+ * pvt.py:76-79) becomes a token GEMM over the rearranged rows, forward and backward. */
+int cavp_space_to_depth(int32_t dtype, const void* src, void* dst, int32_t B, int32_t H, int32_t W, int32_t C, int32_t s,
+                        int32_t inverse, void* stream);
+/* timm DropPath around a residual branch (pvt.py:167-168): out = x + sample_scale[b] * branch; x == NULL: the branch's
+ * gradient sample_scale[b] * g.  per_sample = elements per batch item. */
+int cavp_row_scale_add(int32_t dtype, const void* x, const void* branch, const float* sample_scale, void* out, int32_t B,
+                       int64_t per_sample, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -126,10 +126,17 @@ def _lne(x, sd, p, eps):
     return F.layer_norm(x, (x.shape[-1],), sd[p + ".weight"], sd[p + ".bias"], eps)
 
 
-def pvt_forward(image, sd, p="backbone"):
+def pvt_forward(image, sd, p="backbone", drop_scales=None):
     """PyramidVisionTransformerV2.forward_features (pvt.py:291-306); Block :166-170; Attention :102-130 (softmax);
     Mlp :46-55 with DWConv :320-326; OverlapPatchEmbed :209-215.  Block / stage norms use eps 1e-6, the patch-embed
-    norm and the attention's sr norm the LayerNorm default 1e-5."""
+    norm and the attention's sr norm the LayerNorm default 1e-5.
+    drop_scales (training, pvt.py:144,167-168): timm DropPath as one per-sample factor mask / keep_prob [B] (or None) per
+    residual branch in forward order - x + drop_path(f(x)) == x + factor[:, None, None] * f(x)."""
+    def dp(t):
+        s_ = None if drop_scales is None else drop_scales[dp.i]
+        dp.i += 1
+        return t if s_ is None else t * s_.to(t.dtype).view(-1, 1, 1)
+    dp.i = 0
     x = image
     feats = []
     B = image.shape[0]
@@ -153,13 +160,13 @@ def pvt_forward(image, sd, p="backbone"):
             kv = _linear(x_, sd, b + ".attn.kv").reshape(B, -1, 2, nh, C // nh).permute(2, 0, 3, 1, 4)
             attn = ((q @ kv[0].transpose(-2, -1)) * (C // nh) ** -0.5).softmax(dim=-1)
             o = (attn @ kv[1]).transpose(1, 2).reshape(B, N, C)
-            x = x + _linear(o, sd, b + ".attn.proj")
+            x = x + dp(_linear(o, sd, b + ".attn.proj"))
             n2 = _lne(x, sd, b + ".norm2", 1e-6)
             h = _linear(n2, sd, b + ".mlp.fc1")
             hc = h.shape[-1]
             h = F.conv2d(h.transpose(1, 2).reshape(B, hc, H, W), sd[b + ".mlp.dwconv.dwconv.weight"],
                          sd[b + ".mlp.dwconv.dwconv.bias"], 1, 1, 1, hc).flatten(2).transpose(1, 2)
-            x = x + _linear(F.gelu(h), sd, b + ".mlp.fc2")
+            x = x + dp(_linear(F.gelu(h), sd, b + ".mlp.fc2"))
         x = _lne(x, sd, f"{p}.norm{i + 1}", 1e-6)
         x = x.reshape(B, H, W, -1).permute(0, 3, 1, 2).contiguous()
         feats.append(x)
@@ -286,7 +293,7 @@ def forward_cls(x, sd, input_shape, train=False, taps=None):
 # --------------------------------------------------------------------------------------------------------------
 def cavp_forward(sd: Dict[str, torch.Tensor], image, audio, last_three_dilation_stride=(False, False, False),
                  eval_mode: bool = True, bn_train: Optional[bool] = None, taps: Optional[dict] = None,
-                 seg_model: str = "DeepLabV3Plus"):
+                 seg_model: str = "DeepLabV3Plus", drop_scales=None):
     """Returns (out_pred, out_fusion, {"audio","visual","attn_v"}).
 
     eval_mode=True  -> forward_inference: image [B], audio [B].
@@ -296,7 +303,7 @@ def cavp_forward(sd: Dict[str, torch.Tensor], image, audio, last_three_dilation_
         bn_train = not eval_mode
     input_shape = tuple(image.shape[-2:])
     if seg_model == "PVT":   # cavp_model.py:106-115
-        feats = pvt_forward(image, sd)
+        feats = pvt_forward(image, sd, drop_scales=drop_scales)
     else:
         feats = backbone_forward(image, sd, last_three_dilation_stride, bn_train)
     if taps is not None:

@@ -1,0 +1,183 @@
+"""Backward kernels of the PVTv2-B5 training pass (csrc/pvt_train.hip) against PyTorch's autograd on the CPU, op by op, and
+the whole PVT training step (cavp_amd/pvt_train.py) against the CPU oracle's autograd and the reference's golden fixture."""
+import types
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from cavp_amd.synth import synth_inputs, synth_state_dict
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+BF = torch.bfloat16
+
+
+def _r(*shape, seed, scale=1.0):
+    return torch.randn(shape, generator=torch.Generator().manual_seed(seed)) * scale
+
+
+def _q(t, dtype):
+    return t.to(dtype).float()
+
+
+def _rel(a, b):
+    return float((a.double() - b.double()).norm() / (b.double().norm() + 1e-30))
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (BF, 2e-2)], ids=["f32", "bf16"])
+@pytest.mark.parametrize("shape", [(2, 100, 49, 2), (1, 256, 256, 1), (3, 1024, 64, 5), (2, 70, 4, 8)],
+                         ids=["ragged", "full256", "stage3", "tiny_kv"])
+def test_sra_attention_backward(shape, dtype, tol):
+    from cavp_amd import ops, train_ops as T
+    B, Nq, Nk, heads = shape
+    C = heads * 64
+    q, kv, do = _r(B, Nq, C, seed=1), _r(B, Nk, 2 * C, seed=2), _r(B, Nq, C, seed=3)
+    scale = 64 ** -0.5
+    qr, kvr = _q(q, dtype).requires_grad_(True), _q(kv, dtype).requires_grad_(True)
+    qh = qr.view(B, Nq, heads, 64).permute(0, 2, 1, 3)
+    k, v = kvr.view(B, Nk, 2, heads, 64).permute(2, 0, 3, 1, 4)
+    o = ((qh @ k.transpose(-2, -1) * scale).softmax(-1) @ v).transpose(1, 2).reshape(B, Nq, C)
+    o.backward(_q(do, dtype))
+    qd, kvd, dod = q.to(DEV, dtype), kv.to(DEV, dtype), do.to(DEV, dtype)
+    out = ops.sra_attention(qd, kvd, torch.empty_like(qd), heads, scale)
+    assert _rel(out.float().cpu(), o.detach()) <= (1e-5 if dtype == torch.float32 else 1e-2)
+    dq, dkv = torch.empty_like(qd), torch.empty(kvd.shape, dtype=torch.float32, device=DEV)
+    T.sra_attention_bwd(qd, kvd, dod, dq, dkv, heads, scale)
+    torch.cuda.synchronize()
+    assert _rel(dq.float().cpu(), qr.grad) <= tol, ("dq", _rel(dq.float().cpu(), qr.grad))
+    assert _rel(dkv.cpu(), kvr.grad) <= tol, ("dkv", _rel(dkv.cpu(), kvr.grad))
+    # deterministic mode: single split, bit-identical repeats
+    from cavp_amd import _lib
+    _lib.set_deterministic(True, device=torch.device(DEV))
+    try:
+        a, b = torch.empty_like(dkv), torch.empty_like(dkv)
+        T.sra_attention_bwd(qd, kvd, dod, dq, a, heads, scale)
+        T.sra_attention_bwd(qd, kvd, dod, dq, b, heads, scale)
+        assert torch.equal(a, b) and _rel(a.cpu(), kvr.grad) <= tol
+    finally:
+        _lib.set_deterministic(False)
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-5), (BF, 1e-2)], ids=["f32", "bf16"])
+@pytest.mark.parametrize("shape", [(2, 16, 16, 256), (1, 7, 9, 64), (3, 32, 32, 1280)], ids=["s1", "ragged", "wide"])
+def test_dwconv_backward(shape, dtype, tol):
+    from cavp_amd import ops, train_ops as T
+    B, H, W, C = shape
+    x, g = _r(B, C, H, W, seed=4), _r(B, C, H, W, seed=5)
+    w, b = _r(C, 1, 3, 3, seed=6, scale=0.3), _r(C, seed=7)
+    xr, wr, br = _q(x, dtype).requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    y = F.conv2d(xr, wr, br, 1, 1, 1, C)
+    y.backward(_q(g, dtype))
+    xd = x.permute(0, 2, 3, 1).contiguous().to(DEV, dtype)
+    gd = g.permute(0, 2, 3, 1).contiguous().to(DEV, dtype)
+    w9c = ops.pack_dwconv_weight(w.to(DEV))
+    dx = ops.dwconv3x3(gd, w9c.flip(0).contiguous(), None, torch.empty_like(gd))
+    dw, db = torch.zeros((C, 1, 3, 3), device=DEV), torch.zeros(C, device=DEV)
+    T.dwconv3x3_wgrad(xd, gd, dw, db)
+    T.dwconv3x3_wgrad(xd, gd, dw, db)     # accumulates
+    torch.cuda.synchronize()
+    assert _rel(dx.float().cpu().permute(0, 3, 1, 2), xr.grad) <= tol
+    assert _rel(dw.cpu() / 2, wr.grad) <= max(tol, 2e-5) and _rel(db.cpu() / 2, br.grad) <= max(tol, 2e-5)
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (BF, 1e-2)], ids=["f32", "bf16"])
+def test_patch_embed_weight_gradient(dtype, tol):
+    from cavp_amd import train_ops as T
+    B, H, W, Cout = 2, 50, 70, 64
+    x, w = _r(B, 3, H, W, seed=8), _r(Cout, 3, 7, 7, seed=9, scale=0.1)
+    wr = w.clone().requires_grad_(True)
+    y = F.conv2d(x, wr, None, 4, 3)
+    g = _r(*y.shape, seed=10)
+    y.backward(_q(g, dtype))
+    gd = g.permute(0, 2, 3, 1).contiguous().to(DEV, dtype)
+    dw = torch.zeros_like(w, device=DEV)
+    T.conv_smallcin_kxk_wgrad(x.to(DEV), gd, dw, 7, 4, 3)
+    torch.cuda.synchronize()
+    assert _rel(dw.cpu(), wr.grad) <= tol
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, BF], ids=["f32", "bf16"])
+def test_space_to_depth_and_row_scale(dtype):
+    from cavp_amd import train_ops as T
+    B, H, W, C, s = 2, 16, 24, 64, 4
+    x = _r(B, H, W, C, seed=11).to(dtype)
+    ref = x.view(B, H // s, s, W // s, s, C).permute(0, 1, 3, 2, 4, 5).reshape(B, (H // s) * (W // s), s * s * C)
+    xd = x.to(DEV)
+    y = T.space_to_depth(xd, torch.empty((B, (H // s) * (W // s), s * s * C), dtype=dtype, device=DEV), B, H, W, C, s)
+    assert torch.equal(y.cpu(), ref)
+    back = T.space_to_depth(y, torch.empty_like(xd), B, H, W, C, s, inverse=True)
+    assert torch.equal(back.cpu(), x)
+    # the rearranged rows times the OHWI-flattened weight == the sr x sr / stride-sr conv (pvt.py:76-79,113-116)
+    w = _r(32, C, s, s, seed=12, scale=0.05)
+    conv = F.conv2d(x.float().permute(0, 3, 1, 2), w, None, s).flatten(2).transpose(1, 2)
+    lin = ref.float() @ w.permute(0, 2, 3, 1).reshape(32, -1).t()
+    assert _rel(lin, conv) <= 1e-5
+    sc = torch.tensor([0.0, 1.25], device=DEV)
+    br = _r(B, H * W, C, seed=13).to(dtype).to(DEV)
+    xx = xd.view(B, H * W, C)
+    out = T.row_scale_add(xx, br, sc, torch.empty_like(br))
+    ref2 = xx.float().cpu() + sc.cpu().view(B, 1, 1) * br.float().cpu()
+    assert _rel(out.float().cpu(), ref2) <= (1e-6 if dtype == torch.float32 else 4e-3)
+    gb = T.row_scale_add(None, br, sc, torch.empty_like(br))
+    assert float(gb[0].float().abs().max()) == 0.0 and _rel(gb[1].float().cpu(), 1.25 * br[1].float().cpu()) <= 4e-3
+
+
+def _build_pvt(C, B, dtype=torch.float32):
+    from cavp_amd.cavp_model import CAVP
+    args = types.SimpleNamespace(seg_model="PVT", last_three_dilation_stride=[False, False, False], audio_backbone="vgg",
+                                 num_classes=C, batch_size=B, local_rank="cpu", allow_random_pvt=True)
+    m = CAVP(50, None, num_classes=C, args=args)
+    sd = synth_state_dict({k: tuple(v.shape) for k, v in m.state_dict().items()}, seed=1)
+    m.load_state_dict(sd, strict=True)
+    m.train().to(DEV).set_compute_dtype(dtype)
+    return m, sd
+
+
+def _scales(m, B, seed):
+    """DropPath factors as the reference's timm draws them: one torch.rand((B,1,1)) per branch with probability > 0."""
+    from cavp_amd.pvt_train import draw_drop_path_scales
+    torch.manual_seed(seed)
+    return draw_drop_path_scales(m.backbone, B, torch.device("cpu"))
+
+
+def test_pvt_train_step_vs_oracle_autograd():
+    """forward_train + CE + full backward through the PVTv2-B5 backbone (f32) against the CPU oracle's autograd over the same
+    graph with the same DropPath masks: loss, logits and every parameter gradient."""
+    from oracle import cavp_oracle as O
+    from cavp_amd import train_ops as T
+    C, B, hw = 5, 2, (64, 96)
+    m, sd = _build_pvt(C, B)
+    image, audio, label = synth_inputs(B, hw, audio_batch=2 * B, num_classes=C, seed=3)
+    scales = _scales(m, B, 99)
+    assert sum(s is not None for s in scales) >= 100 and any(float(s.min()) == 0.0 for s in scales if s is not None)
+    m._pvt_drop_scales = [None if s is None else s.to(DEV) for s in scales]
+    out, fus, pack = m(image.to(DEV), audio.to(DEV), None, False)
+    loss, dl = T.ce_loss(out.detach(), label.to(DEV), B)
+    out.backward(dl)
+    torch.cuda.synchronize()
+    params = {k: v.clone().requires_grad_(True) for k, v in sd.items() if v.is_floating_point() and "running_" not in k}
+    sd2 = dict(sd)
+    sd2.update(params)
+    ro, rf, _ = O.cavp_forward(sd2, image, audio, eval_mode=False, seg_model="PVT", drop_scales=scales)
+    rl = O.ce_loss_train(ro, label, B)
+    rl.backward()
+    assert float((out.detach().cpu() - ro.detach()).abs().max()) <= 1e-3 * max(1.0, float(ro.detach().abs().max()))
+    assert abs(float(loss.item()) - float(rl.item())) <= 1e-4 * max(1.0, abs(float(rl.item())))
+    mine = dict(m.named_parameters())
+    gmax = max(float(p.grad.norm()) for p in params.values() if p.grad is not None)
+    worst, errs = (0.0, None), []
+    for k, p in params.items():
+        if p.grad is None:
+            assert mine[k].grad is None or float(mine[k].grad.abs().max()) == 0.0, k
+            continue
+        assert mine[k].grad is not None, k
+        a, b = mine[k].grad.detach().double().cpu().flatten(), p.grad.double().flatten()
+        err = float((a - b).norm() / max(float(b.norm()), 1e-4 * gmax))
+        worst = max(worst, (err, k))
+        errs.append(err)
+    print("PVT train step vs oracle autograd: relative L2 gradient error worst", worst, "median", float(np.median(errs)),
+          "over", len(errs), "parameters")
+    # 2-sample BatchNorm in the ASPP pooling branch (B = 2) makes the step's own f32-vs-f64 discrepancy ~1e-2
+    assert worst[0] <= 3e-2 and float(np.median(errs)) <= 1e-2, worst
