@@ -814,6 +814,9 @@ class CAVP(nn.Module):
 
         def replay():
             self.params_changed()   # the graph updates the running statistics (and is usually followed by an optimiser step)
+            if self.seg_model == "PVT" and getattr(self, "_pvt_drop_scales", None) is None:
+                from .pvt_train import refresh_drop_path
+                refresh_drop_path(self.backbone, image.shape[0], image.device)   # the graph reads the persistent mask buffer
             graphs[0].replay()
             if len(graphs) == 2:
                 work = allreduce_arena_early(arena)

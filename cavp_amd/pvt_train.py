@@ -143,21 +143,35 @@ def _residual_drop_path(tp: TrainPass, x: V, branch: V, scale: torch.Tensor) -> 
 def draw_drop_path_scales(bb, B: int, device) -> List[Optional[torch.Tensor]]:
     """One f32 [B] factor (mask / keep) per residual branch, in forward order (attention, MLP of every block); None where
     the block's probability is 0 or the backbone is in eval mode.  Drawn like timm 0.4.9's drop_path - `floor(keep +
-    torch.rand((B, 1, 1)))`, one draw per branch from the default CPU generator - then moved to the device in ONE copy."""
+    torch.rand((B, 1, 1)))`, one draw per branch from the default CPU generator - then moved in ONE copy into a persistent
+    device buffer (`bb._dp_buf`).  While a hipGraph is being captured nothing is drawn: the graph reads that buffer, and
+    `CAVP.capture_train_step`'s replay() refreshes it before every launch (refresh_drop_path)."""
     probs = [blk.drop_prob for i in range(4) for blk in getattr(bb, f"block{i + 1}") for _ in range(2)]
     if not bb.training or not any(probs):
         return [None] * len(probs)
-    rows = []
-    for p in probs:
-        if p > 0:
-            keep = 1.0 - p
-            rows.append((keep + torch.rand((B, 1, 1), dtype=torch.float32)).floor_().view(B) / keep)
-    dev = torch.stack(rows).to(device)
+    n = sum(1 for p in probs if p > 0)
+    buf = getattr(bb, "_dp_buf", None)
+    dev = torch.device(device)
+    if buf is None or tuple(buf.shape) != (n, B) or buf.device != dev:
+        buf = torch.ones((n, B), dtype=torch.float32, device=dev)
+        bb.__dict__["_dp_buf"] = buf          # not a registered buffer: it must stay out of the state_dict
+    if not (dev.type == "cuda" and torch.cuda.is_current_stream_capturing()):
+        rows = []
+        for p in probs:
+            if p > 0:
+                keep = 1.0 - p
+                rows.append((keep + torch.rand((B, 1, 1), dtype=torch.float32)).floor_().view(B) / keep)
+        buf.copy_(torch.stack(rows))
     out, k = [], 0
     for p in probs:
-        out.append(dev[k] if p > 0 else None)
+        out.append(buf[k] if p > 0 else None)
         k += 1 if p > 0 else 0
     return out
+
+
+def refresh_drop_path(bb, B: int, device) -> None:
+    """New DropPath masks for the next replay of a captured training step."""
+    draw_drop_path_scales(bb, B, device)
 
 
 def pvt_train_forward(tp: TrainPass, bb, image: torch.Tensor, drop_scales: Optional[list] = None) -> List[V]:

@@ -142,14 +142,20 @@ def _scales(m, B, seed):
     return draw_drop_path_scales(m.backbone, B, torch.device("cpu"))
 
 
-def test_pvt_train_step_vs_oracle_autograd():
+@pytest.mark.parametrize("frozen_bn,B", [(False, 2), (False, 4), (True, 2)], ids=["batch_stat_bn_b2", "batch_stat_bn_b4", "frozen_bn"])
+def test_pvt_train_step_vs_oracle_autograd(frozen_bn, B):
     """forward_train + CE + full backward through the PVTv2-B5 backbone (f32) against the CPU oracle's autograd over the same
-    graph with the same DropPath masks: loss, logits and every parameter gradient."""
+    graph with the same DropPath masks: loss, logits and every parameter gradient.  frozen_bn: the decoder's BatchNorm modules
+    in eval() - without the 2-sample batch statistics the step is well conditioned and the gradient bar is 2e-4 (measured 1.6e-5); batch statistics: 1.2e-2 at B = 2, 1.8e-3 at B = 4."""
     from oracle import cavp_oracle as O
     from cavp_amd import train_ops as T
-    C, B, hw = 5, 2, (64, 96)
+    C, hw = 5, (64, 96)
     m, sd = _build_pvt(C, B)
     image, audio, label = synth_inputs(B, hw, audio_batch=2 * B, num_classes=C, seed=3)
+    if frozen_bn:
+        for mod in m.modules():
+            if isinstance(mod, torch.nn.modules.batchnorm._BatchNorm):
+                mod.eval()
     scales = _scales(m, B, 99)
     assert sum(s is not None for s in scales) >= 100 and any(float(s.min()) == 0.0 for s in scales if s is not None)
     m._pvt_drop_scales = [None if s is None else s.to(DEV) for s in scales]
@@ -160,7 +166,8 @@ def test_pvt_train_step_vs_oracle_autograd():
     params = {k: v.clone().requires_grad_(True) for k, v in sd.items() if v.is_floating_point() and "running_" not in k}
     sd2 = dict(sd)
     sd2.update(params)
-    ro, rf, _ = O.cavp_forward(sd2, image, audio, eval_mode=False, seg_model="PVT", drop_scales=scales)
+    ro, rf, _ = O.cavp_forward(sd2, image, audio, eval_mode=False, seg_model="PVT", drop_scales=scales,
+                               bn_train=not frozen_bn)
     rl = O.ce_loss_train(ro, label, B)
     rl.backward()
     assert float((out.detach().cpu() - ro.detach()).abs().max()) <= 1e-3 * max(1.0, float(ro.detach().abs().max()))
@@ -180,4 +187,91 @@ def test_pvt_train_step_vs_oracle_autograd():
     print("PVT train step vs oracle autograd: relative L2 gradient error worst", worst, "median", float(np.median(errs)),
           "over", len(errs), "parameters")
     # 2-sample BatchNorm in the ASPP pooling branch (B = 2) makes the step's own f32-vs-f64 discrepancy ~1e-2
-    assert worst[0] <= 3e-2 and float(np.median(errs)) <= 1e-2, worst
+    if frozen_bn:
+        assert worst[0] <= 2e-4, worst
+    else:
+        assert worst[0] <= 3e-2 and float(np.median(errs)) <= 2e-2, worst
+
+
+def test_pvt_train_step_matches_reference_golden():
+    """The same step against the fixture written by the REFERENCE's own autograd (tests/golden/pvt_train.npz, config #4's
+    model in train mode): DropPath masks re-drawn as timm draws them, loss, stage maps, logits, every parameter's gradient
+    norm and the sampled sentinel gradients."""
+    from cavp_amd import train_ops as T
+    from tests._golden_util import check_tap, load_case
+    z, cfg = load_case("pvt_train")
+    C, B, hw = cfg["C"], cfg["B"], cfg["hw"]
+    m, sd = _build_pvt(C, B)
+    image, audio, label = synth_inputs(B, hw, audio_batch=2 * B, num_classes=C, seed=3)
+    torch.manual_seed(int(z["seed"][0]))
+    m._keep_train_pass = True
+    out, fus, pack = m(image.to(DEV), audio.to(DEV), None, False)     # draws its own masks: same generator, same order
+    buf = m.backbone._dp_buf.cpu().numpy()
+    assert buf.shape == z["drop_scales"].shape and np.abs(buf - z["drop_scales"]).max() <= 1e-4
+    loss, dl = T.ce_loss(out.detach(), label.to(DEV), B)
+    out.backward(dl)
+    torch.cuda.synchronize()
+    assert abs(float(loss.item()) - float(z["loss"][0])) <= 1e-4
+    tp = m._last_train_pass
+    got = {f"stage{i + 1}": tp.named[f"stage{i + 1}"].t.permute(0, 3, 1, 2) for i in range(4)}
+    got.update(out_pred=out.detach(), out_fusion=fus.detach(), pack_visual=pack["visual"], pack_attn_v=pack["attn_v"])
+    for k, t in got.items():
+        scale = max(1.0, float(np.abs(z["sample/" + k]).max()))
+        check_tap(z, k, t, (1e-3 if k == "out_pred" else 3e-4) * scale, what="pvt train:")
+    mine = dict(m.named_parameters())
+    rels = []
+    for k, v in zip(list(z["grad_norm_keys"]), z["grad_norm_vals"]):
+        assert mine[k].grad is not None, k
+        rels.append(abs(float(mine[k].grad.double().norm()) - v) / max(v, 1e-3))
+    print(f"PVT golden: gradient-norm relative error median {np.median(rels):.2e} max {max(rels):.2e} over {len(rels)} tensors")
+    # every backbone gradient passes through the 2-sample BatchNorm of the ASPP pooling branch (B = 2), whose backward turns
+    # f32 rounding into ~1e-2 of relative gradient error (the reference's own f32-vs-f64 difference on such a step is 1.1e-2,
+    # DESIGN.md 4b); the frozen-BatchNorm variant of the oracle test above holds the same kernels to 2e-4
+    assert np.median(rels) <= 2e-2 and max(rels) <= 6e-2
+    for k in [s[len("grad_sample/"):] for s in z.files if s.startswith("grad_sample/")]:
+        g, ref = mine[k].grad.detach().cpu(), z["grad_sample/" + k]
+        s = g.flatten()[:: max(1, g.numel() // 4096)][:4096].numpy()
+        assert np.abs(s - ref).max() <= 6e-2 * max(1e-2, np.abs(ref).max()), (k, np.abs(s - ref).max(), np.abs(ref).max())
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, BF], ids=["f32", "bf16"])
+def test_pvt_native_train_step_and_graph_replay(dtype):
+    """CAVP.train_step (fused head, gradient arena) on the PVT model == the autograd route; the hipGraph replay of it draws new
+    DropPath masks before every launch (same torch seed -> same masks -> same loss as the eager step)."""
+    C, B, hw = 5, 2, (64, 64)
+    m, sd = _build_pvt(C, B, dtype)
+    image, audio, label = [t.to(DEV) for t in synth_inputs(B, hw, audio_batch=2 * B, num_classes=C, seed=4)]
+
+    def reset():
+        m.load_state_dict({k: v for k, v in sd.items() if "running_" in k or "num_batches" in k}, strict=False)
+
+    reset()
+    torch.manual_seed(7)
+    l0 = float(m.train_step(image, audio, label, all_reduce=False).item())
+    g0 = m._grad_arena.flat.clone()
+    assert np.isfinite(l0) and bool(torch.isfinite(g0).all())
+    if dtype == torch.float32:
+        from cavp_amd import train_ops as T
+        m2, _ = _build_pvt(C, B)
+        torch.manual_seed(7)
+        out, fus, pack = m2(image, audio, None, False)
+        loss, dl = T.ce_loss(out.detach(), label, B)
+        out.backward(dl)
+        assert abs(float(loss.item()) - l0) <= 1e-5 * max(1.0, abs(l0))
+        a = dict(m.named_parameters())["backbone.block3.20.attn.kv.weight"].grad
+        b = dict(m2.named_parameters())["backbone.block3.20.attn.kv.weight"].grad
+        assert _rel(a.cpu(), b.cpu()) <= 2e-2
+    reset()
+    step = m.capture_train_step(image, audio, label)
+    for seed in (7, 8, 7):
+        reset()
+        torch.manual_seed(seed)
+        l1 = float(step().item())
+        torch.cuda.synchronize()
+        assert np.isfinite(l1)
+        if seed == 7:
+            assert abs(l1 - l0) <= (1e-4 if dtype == torch.float32 else 2e-2) * max(1.0, abs(l0)), (l1, l0)
+            err = float((m._grad_arena.flat - g0).norm() / g0.norm())
+            assert err <= (5e-2 if dtype == torch.float32 else 0.5), err
+        else:
+            assert abs(l1 - l0) > 1e-7      # other masks

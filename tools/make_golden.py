@@ -230,6 +230,90 @@ def run_pvt(out_dir, hw=(256, 256), C=71, B=1, name="pvt_eval"):
           " ".join(f"{k}:{taps[k].std().item():.2f}" for k in ("stage1", "stage2", "stage3", "stage4")))
 
 
+PVT_SENTINELS = [
+    "backbone.patch_embed1.proj.weight", "backbone.patch_embed1.norm.weight", "backbone.block1.0.attn.sr.weight",
+    "backbone.block1.0.attn.q.weight", "backbone.block1.2.attn.kv.weight", "backbone.block2.3.mlp.dwconv.dwconv.weight",
+    "backbone.block2.3.mlp.dwconv.dwconv.bias", "backbone.patch_embed3.proj.weight", "backbone.block3.17.attn.proj.weight",
+    "backbone.block3.39.mlp.fc1.weight", "backbone.block3.5.attn.norm.weight", "backbone.block4.1.attn.kv.weight",
+    "backbone.block4.2.mlp.fc2.weight", "backbone.norm4.weight", "segment.aspp.red_conv.weight", "segment.reduce.0.weight",
+    "cross_att.blocks.0.attn.q.weight", "visual_projector.fc1.weight", "segment.upsample.classifier.weight",
+]
+
+
+def run_pvt_train(out_dir, hw=(64, 96), C=5, B=2, name="pvt_train", seed=99):
+    """config #4's model in TRAIN mode (batch-stat BN in the decoder, timm DropPath with drop_path_rate 0.1 in the backbone,
+    pvt.py:413-421): forward_train + CE (trainer_cavp_vpo_mono.py:171,187) + backward.  torch.manual_seed(seed) right before
+    the forward: the backbone is the first consumer of the RNG, so the DropPath draws (one torch.rand((B,1,1)) per branch
+    with probability > 0, in forward order) are reproducible; the factors mask / keep_prob are stored as well."""
+    import models.cavp_model as CM   # noqa: F401
+    from models.visual.backbones.pvt.pvt import pvt_v2_b5
+    import timm.models.layers as TL
+    real_load = torch.load
+
+    def fake_load(path, *a, **k):
+        if "pvt_v2_b5" in str(path):
+            sd = pvt_v2_b5().state_dict()
+            sd["head.weight"], sd["head.bias"] = torch.zeros(1), torch.zeros(1)
+            return sd
+        return real_load(path, *a, **k)
+    torch.load = fake_load
+    try:
+        args = EasyDict(seg_model="PVT", last_three_dilation_stride=[False, False, False], audio_backbone="vgg",
+                        num_classes=C, batch_size=B, local_rank="cpu")
+        m = CAVP(50, None, num_classes=C, audio_backbone_pretrain_path=None, visual_backbone=50, args=args)
+    finally:
+        torch.load = real_load
+    sd = synth_state_dict({k: tuple(v.shape) for k, v in m.state_dict().items()}, seed=1)
+    m.load_state_dict(sd, strict=True)
+    image, audio, label = synth_inputs(B, hw, audio_batch=2 * B, num_classes=C, seed=3)
+    drawn = []
+    for mod in m.modules():
+        if isinstance(mod, TL.DropPath):
+            def hook(mod_, inp, out, _d=drawn):
+                x = inp[0]
+                if mod_.drop_prob and mod_.training:
+                    nz = x.flatten(1).abs().sum(1) > 0
+                    ratio = (out.flatten(1).abs().sum(1) / x.flatten(1).abs().sum(1).clamp_min(1e-30))
+                    _d.append(torch.where(nz, ratio, torch.zeros_like(ratio)).detach().float())
+            mod.register_forward_hook(hook)
+    taps = {}
+    orig = m.backbone.forward_features
+
+    def ff(x):
+        outs = orig(x)
+        for i, o in enumerate(outs):
+            taps[f"stage{i + 1}"] = o
+        return outs
+    m.backbone.forward_features = ff
+    m.train()
+    torch.manual_seed(seed)
+    out, fus, pack = m(image, audio, None, False)
+    output = out[:B] + out[B:] * 0.0
+    loss = F.cross_entropy(output, label, ignore_index=255)
+    loss.backward()
+    store = {"loss": np.array([loss.item()], dtype=np.float64), "drop_scales": torch.stack(drawn).numpy(),
+             "seed": np.array([seed], dtype=np.int64)}
+    gn = {k: p.grad.double().norm().item() for k, p in m.named_parameters() if p.grad is not None}
+    store["grad_norm_keys"] = np.array(sorted(gn), dtype=object)
+    store["grad_norm_vals"] = np.array([gn[k] for k in sorted(gn)], dtype=np.float64)
+    params = dict(m.named_parameters())
+    for k in PVT_SENTINELS:
+        s_, c_ = sample(params[k].grad)
+        store["grad_sample/" + k], store["grad_cksum/" + k] = s_, c_
+    taps.update(out_pred=out, out_fusion=fus, pack_visual=pack["visual"], pack_attn_v=pack["attn_v"])
+    for k, t in taps.items():
+        s_, c_ = sample(t)
+        store["sample/" + k], store["cksum/" + k] = s_, c_
+        store["shape/" + k] = np.array(t.shape, dtype=np.int64)
+    store["cfg/CBHW"] = np.array([C, B, hw[0], hw[1]], dtype=np.int64)
+    store["cfg/lds"] = np.array([0, 0, 0], dtype=np.int64)
+    store["cfg/train"] = np.array([1], dtype=np.int64)
+    path = os.path.join(out_dir, name + ".npz")
+    np.savez_compressed(path, **store)
+    print(f"{name}: wrote {path} ({os.path.getsize(path) / 1e3:.0f} kB); loss {loss.item():.5f}; {len(drawn)} DropPath draws, "
+          f"{int((torch.stack(drawn) == 0).sum())} dropped; |out|max={out.abs().max().item():.3f}")
+
+
 def contrast_inputs(seed=7, B=2, C=304, hw=(56, 56), full=(224, 224), num_classes=4):
     """Synthetic ContrastLoss inputs: blocky label maps so that several classes keep >= max_views pixels at 56x56."""
     g = torch.Generator().manual_seed(seed)
@@ -349,5 +433,7 @@ if __name__ == "__main__":
         run_pvt(a.out)
     if not a.only or a.only == "pvt512":   # config #4 at its own resolution (config_avss.py:12-13): samples + checksums only
         run_pvt(a.out, hw=(512, 512), name="pvt_eval_512")
+    if not a.only or a.only == "pvt_train":
+        run_pvt_train(a.out)
     if not a.only or a.only == "optstep":
         run_optstep(a.out)
