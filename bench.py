@@ -44,7 +44,7 @@ def parse():
                     help="train = forward_train + CE + backward (+ gradient all-reduce when N > 1): the BASELINE.json "
                          "metric; eval = inference forward only")
     ap.add_argument("--config", choices=["c1p", "c4"], default="c1p",
-                    help="c1p = ResNet-50 224x224 (the BASELINE metric); c4 = PVTv2-B5 512x512, inference only (config #4)")
+                    help="c1p = ResNet-50 224x224 (the BASELINE metric); c4 = PVTv2-B5 512x512 (config #4; not the BASELINE metric)")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
     ap.add_argument("--split-graph", action="store_true",
                     help="force the two-graph replay of the data-parallel path (cut where the early gradients are final) on one GPU")
@@ -384,8 +384,6 @@ def main():
         _cl.set_deterministic(True, dev)
     dtype = torch.bfloat16 if a.dtype == "bf16" else torch.float32
     cfg = model_cfg(a.config)
-    if a.config == "c4":
-        a.mode = "eval"
     B = a.batch
     from cavp_amd.synth import synth_inputs
     model, sd = build_model(cfg, B, dtype, dev)
@@ -462,7 +460,10 @@ def main():
             "value": round(value, 2), "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(elapsed / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
-            "config": {"workload": (f"C1' (config_avss_binary shape): CAVP ResNet-50 OS16 + VGGish, training step = "
+            "config": {"workload": (f"C4 (config_avss shape): CAVP PVTv2-B5 (DropPath 0.1) + VGGish, training step = forward_train "
+                                    f"({B} images + {2 * B} audio clips per GPU) + cross-entropy + full backward, 512x512 RGB + "
+                                    f"96x64 mel, num_classes=71, random-init (synthetic) weights" if (train and a.config == "c4") else
+                                    f"C1' (config_avss_binary shape): CAVP ResNet-50 OS16 + VGGish, training step = "
                                     f"forward_train (batch-stat BN, {B} images + {2 * B} audio clips per GPU) + cross-entropy + "
                                     f"full backward" + (" + gradient all-reduce over RCCL in two pieces, the first overlapped with the backbone backward" if world > 1 else "") +
                                     ", 224x224 RGB + 96x64 mel, num_classes=2, random-init (synthetic) weights"

@@ -1,9 +1,8 @@
 // Backward kernels of the PVTv2-B5 backbone (models/visual/backbones/pvt/pvt.py) for gfx950: spatial-reduction attention
 // (dq | dk, dv), depth-wise 3x3 conv weight gradient, weight gradient of the 7x7 / stride-4 patch embedding, the sr x sr
 // space-to-depth rearrangement that turns the spatial-reduction conv (kernel = stride) into a token GEMM, and the
-// stochastic-depth residual add.  All matrix products run on the f32 matrix pipe (v_mfma_f32_16x16x4f32) whatever the
-// storage type: the attention backward is ~10 % of the backbone's FLOPs and its K / V / Q tiles are converted once when
-// they are staged into LDS.
+// stochastic-depth residual add.  The attention backward exists twice: on the f32 matrix pipe (v_mfma_f32_16x16x4f32, the
+// f32 parity path) and on v_mfma_f32_16x16x32_bf16 for bf16 storage.
 #include "common.h"
 
 namespace {
@@ -240,17 +239,229 @@ __global__ __launch_bounds__(256) void sra_bwd_kv_kernel(const T* __restrict__ q
 }
 
 // ------------------------------------------------------------------------------------------------------------------------
+// bf16 storage: the same two kernels on v_mfma_f32_16x16x32_bf16 (8x the f32 matrix rate).  Tiles stay bf16 in LDS; an
+// operand that is multiplied along its ROWS (K in dQ = dS K, Q / dO in dK = dS^T Q, dV = P^T dO) is read with the
+// transposing LDS load (ds_read_b64_tr_b16) from a second, un-swizzled copy of the tile - the same idiom as V^T in the
+// forward kernel (pvt_ops.hip); P and dS go from the f32 accumulators to the B operand as bf16 without a layout change
+// (MFMA k index = an arbitrary but shared permutation of the keys / queries).
+// ------------------------------------------------------------------------------------------------------------------------
+typedef short s16x4_t __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ u32x4_t btile_ld(const char* base, int row, int slot) {
+  return *(const u32x4_t*)(base + row * 128 + ((slot ^ (row & 7)) << 4));
+}
+// A operand X^T[i = channel db*16 + lrow][k <-> rows r0 + {0..3} and r0 + 16 + {0..3}] from a linear bf16 tile (128-byte rows)
+__device__ __forceinline__ bf16x8_t btile_tr(const char* base, int r0, int db, int lrow) {
+  const int ra = r0 + (lrow >> 2);
+  const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+      (__attribute__((address_space(3))) s16x4_t*)(base + ra * 128 + db * 32 + (lrow & 3) * 8));
+  const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+      (__attribute__((address_space(3))) s16x4_t*)(base + (ra + 16) * 128 + db * 32 + (lrow & 3) * 8));
+  const uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
+  return __builtin_bit_cast(bf16x8_t, (u32x4_t){l2.x, l2.y, h2.x, h2.y});
+}
+__device__ __forceinline__ bf16x8_t pack8(const f32x4_t& a, const f32x4_t& b) {
+  return __builtin_bit_cast(bf16x8_t, (u32x4_t){pack2bf(a[0], a[1]), pack2bf(a[2], a[3]), pack2bf(b[0], b[1]), pack2bf(b[2], b[3])});
+}
+// stage rows of 64 bf16 channels: swizzled copy `sw` and (optional) linear copy `lin`; zero fill up to `cap` rows
+__device__ __forceinline__ void bstage(char* sw, char* lin, const bf16_t* src, size_t ld, int rows, int cap, int tid) {
+  for (int i = tid; i < cap * 8; i += 256) {
+    const int r = i >> 3, sl = i & 7;
+    u32x4_t v = (u32x4_t){0, 0, 0, 0};
+    if (r < rows) v = *(const u32x4_t*)(src + (size_t)r * ld + sl * 8);
+    *(u32x4_t*)(sw + r * 128 + ((sl ^ (r & 7)) << 4)) = v;
+    if (lin) *(u32x4_t*)(lin + r * 128 + (sl << 4)) = v;
+  }
+}
+
+__global__ __launch_bounds__(256) void sra_bwd_q_bf16_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kv,
+                                                             const bf16_t* __restrict__ dout, bf16_t* __restrict__ dq,
+                                                             float* __restrict__ stats, int Nq, int Nk, int heads, float scale) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* ks = smem;                 // K, swizzled rows (A operand of S^T = K Q^T)
+  char* vs = smem + 256 * 128;     // V, swizzled rows (A operand of dP^T = V dO^T)
+  char* kl = smem + 2 * 256 * 128; // K, linear (transposed reads for dQ^T = K^T dS^T)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int bh = blockIdx.y, b = bh / heads, h = bh - b * heads;
+  const int C = heads * 64;
+  const bf16_t* kvb = kv + (size_t)b * Nk * 2 * C + h * 64;
+  bstage(ks, kl, kvb, (size_t)2 * C, Nk, 256, tid);
+  bstage(vs, nullptr, kvb + C, (size_t)2 * C, Nk, 256, tid);
+  __syncthreads();
+  const int lrow = lane & 15, lgrp = lane >> 4;
+  const int qi = blockIdx.x * 64 + wave * 16 + lrow;
+  const bool qok = qi < Nq;
+  const size_t qoff = ((size_t)b * Nq + (qok ? qi : 0)) * C + h * 64;
+  u32x4_t qf[2], gf[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    qf[j] = qok ? *(const u32x4_t*)(q + qoff + j * 32 + lgrp * 8) : (u32x4_t){0, 0, 0, 0};
+    gf[j] = qok ? *(const u32x4_t*)(dout + qoff + j * 32 + lgrp * 8) : (u32x4_t){0, 0, 0, 0};
+  }
+  f32x4_t s[16], dp[16];
+#pragma unroll
+  for (int kb = 0; kb < 16; ++kb) {
+    s[kb] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    dp[kb] = s[kb];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int key = kb * 16 + lrow;
+      s[kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, btile_ld(ks, key, j * 4 + lgrp)),
+                                                      __builtin_bit_cast(bf16x8_t, qf[j]), s[kb], 0, 0, 0);
+      dp[kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, btile_ld(vs, key, j * 4 + lgrp)),
+                                                       __builtin_bit_cast(bf16x8_t, gf[j]), dp[kb], 0, 0, 0);
+    }
+  }
+  float m = -INFINITY;
+#pragma unroll
+  for (int kb = 0; kb < 16; ++kb)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int key = kb * 16 + lgrp * 4 + r;
+      const float v = key < Nk ? s[kb][r] * scale : -INFINITY;
+      s[kb][r] = v;
+      m = fmaxf(m, v);
+    }
+  m = fmaxf(m, __shfl_xor(m, 16, 64));
+  m = fmaxf(m, __shfl_xor(m, 32, 64));
+  float sum = 0.f;
+#pragma unroll
+  for (int kb = 0; kb < 16; ++kb)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float e = expf(s[kb][r] - m);
+      s[kb][r] = e;
+      sum += e;
+    }
+  sum += __shfl_xor(sum, 16, 64);
+  sum += __shfl_xor(sum, 32, 64);
+  const float inv = 1.f / sum;
+  float delta = 0.f;
+#pragma unroll
+  for (int kb = 0; kb < 16; ++kb)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      s[kb][r] *= inv;
+      delta += s[kb][r] * dp[kb][r];
+    }
+  delta += __shfl_xor(delta, 16, 64);
+  delta += __shfl_xor(delta, 32, 64);
+#pragma unroll
+  for (int kb = 0; kb < 16; ++kb)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) s[kb][r] = s[kb][r] * (dp[kb][r] - delta) * scale;   // dS^T
+  f32x4_t acc[4];
+#pragma unroll
+  for (int db = 0; db < 4; ++db) acc[db] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int kp = 0; kp < 8; ++kp) {   // one k step = 32 keys = the 16-key blocks 2 kp, 2 kp + 1
+    const bf16x8_t df = pack8(s[2 * kp], s[2 * kp + 1]);
+#pragma unroll
+    for (int db = 0; db < 4; ++db)
+      acc[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(btile_tr(kl, 32 * kp + 4 * lgrp, db, lrow), df, acc[db], 0, 0, 0);
+  }
+  if (qok) {
+#pragma unroll
+    for (int db = 0; db < 4; ++db) st4<bf16_t>(dq + qoff + db * 16 + lgrp * 4, acc[db][0], acc[db][1], acc[db][2], acc[db][3]);
+    if (lgrp == 0) {
+      stats[(size_t)bh * Nq + qi] = m + logf(sum);
+      stats[(size_t)gridDim.y * Nq + (size_t)bh * Nq + qi] = delta;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void sra_bwd_kv_bf16_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kv,
+                                                              const bf16_t* __restrict__ dout, const float* __restrict__ stats,
+                                                              float* __restrict__ dkv, int Nq, int Nk, int heads, float scale) {
+  __shared__ __attribute__((aligned(16))) char qs[64 * 128];
+  __shared__ __attribute__((aligned(16))) char ql[64 * 128];
+  __shared__ __attribute__((aligned(16))) char gs[64 * 128];
+  __shared__ __attribute__((aligned(16))) char gl[64 * 128];
+  __shared__ float lse_s[64], del_s[64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lrow = lane & 15, lgrp = lane >> 4;
+  const int bh = blockIdx.y, b = bh / heads, h = bh - b * heads;
+  const int C = heads * 64;
+  const int key = blockIdx.z * 64 + wave * 16 + lrow;
+  const bool kok = key < Nk;
+  u32x4_t kr[2], vr[2];
+  {
+    const bf16_t* kp = kv + ((size_t)b * Nk + (kok ? key : 0)) * 2 * C + h * 64;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      kr[j] = kok ? *(const u32x4_t*)(kp + j * 32 + lgrp * 8) : (u32x4_t){0, 0, 0, 0};
+      vr[j] = kok ? *(const u32x4_t*)(kp + C + j * 32 + lgrp * 8) : (u32x4_t){0, 0, 0, 0};
+    }
+  }
+  f32x4_t dk[4], dv[4];
+#pragma unroll
+  for (int db = 0; db < 4; ++db) { dk[db] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; dv[db] = dk[db]; }
+  const int chunks = (Nq + 63) / 64;
+  for (int ch = blockIdx.x; ch < chunks; ch += gridDim.x) {
+    const int q0 = ch * 64, rows = min(64, Nq - q0);
+    __syncthreads();
+    bstage(qs, ql, q + ((size_t)b * Nq + q0) * C + h * 64, (size_t)C, rows, 64, tid);
+    bstage(gs, gl, dout + ((size_t)b * Nq + q0) * C + h * 64, (size_t)C, rows, 64, tid);
+    if (tid < 64) {
+      const bool ok = tid < rows;
+      lse_s[tid] = ok ? stats[(size_t)bh * Nq + q0 + tid] : 0.f;
+      del_s[tid] = ok ? stats[(size_t)gridDim.y * Nq + (size_t)bh * Nq + q0 + tid] : 0.f;
+    }
+    __syncthreads();
+    f32x4_t p[4], ds[4];
+#pragma unroll
+    for (int qb = 0; qb < 4; ++qb) {
+      f32x4_t sa = (f32x4_t){0.f, 0.f, 0.f, 0.f}, da = sa;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        sa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, btile_ld(qs, qb * 16 + lrow, j * 4 + lgrp)),
+                                                     __builtin_bit_cast(bf16x8_t, kr[j]), sa, 0, 0, 0);
+        da = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, btile_ld(gs, qb * 16 + lrow, j * 4 + lgrp)),
+                                                     __builtin_bit_cast(bf16x8_t, vr[j]), da, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int qlr = qb * 16 + lgrp * 4 + r;
+        const bool ok = kok && qlr < rows;
+        p[qb][r] = ok ? expf(sa[r] * scale - lse_s[qlr]) : 0.f;
+        ds[qb][r] = p[qb][r] * (da[r] - del_s[qlr]) * scale;
+      }
+    }
+#pragma unroll
+    for (int qp = 0; qp < 2; ++qp) {   // one k step = 32 queries = the 16-query blocks 2 qp, 2 qp + 1
+      const bf16x8_t pf = pack8(p[2 * qp], p[2 * qp + 1]), df = pack8(ds[2 * qp], ds[2 * qp + 1]);
+#pragma unroll
+      for (int db = 0; db < 4; ++db) {
+        dv[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(btile_tr(gl, 32 * qp + 4 * lgrp, db, lrow), pf, dv[db], 0, 0, 0);
+        dk[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(btile_tr(ql, 32 * qp + 4 * lgrp, db, lrow), df, dk[db], 0, 0, 0);
+      }
+    }
+  }
+  if (kok) {
+    float* op = dkv + ((size_t)b * Nk + key) * 2 * C + h * 64;
+#pragma unroll
+    for (int db = 0; db < 4; ++db)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        atomicAdd(op + db * 16 + lgrp * 4 + r, dk[db][r]);
+        atomicAdd(op + C + db * 16 + lgrp * 4 + r, dv[db][r]);
+      }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
 // Depth-wise 3x3 (pad 1) weight + bias gradient: dw[c][t] += sum_p x[p + off_t][c] g[p][c], db[c] += sum_p g[p][c].
-// thread = 4 channels x one of 4 pixel lanes; workgroup = 64 channel quads x `ppb` pixels; LDS reduce over the pixel lanes,
-// then one atomic per (channel, tap) and workgroup.
+// thread = 4 channels x one of 16 pixel lanes (a wave = 16 channel quads x 4 pixel lanes: 128 contiguous bytes per pixel);
+// workgroup = 16 channel quads x `ppb` pixels; the 16 pixel lanes are reduced with two cross-lane shuffles and a pass through
+// LDS, then one atomic per (channel, tap) and workgroup.
 // ------------------------------------------------------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void dwconv3x3_wgrad_kernel(const T* __restrict__ x, const T* __restrict__ g,
                                                               float* __restrict__ dw, float* __restrict__ db, int N, int H,
                                                               int W, int C, int ppb) {
-  __shared__ float red[3][64][41];
-  const int cl = threadIdx.x & 63, pl = threadIdx.x >> 6;
-  const int cv = blockIdx.x * 64 + cl;
+  __shared__ float red[4][16][41];
+  const int cl = threadIdx.x & 15, pl = threadIdx.x >> 4, wave = threadIdx.x >> 6;
+  const int cv = blockIdx.x * 16 + cl;
   const bool cok = cv * 4 < C;
   const long long total = (long long)N * H * W;
   const long long p0 = (long long)blockIdx.y * ppb, p1 = min(total, p0 + ppb);
@@ -258,7 +469,7 @@ __global__ __launch_bounds__(256) void dwconv3x3_wgrad_kernel(const T* __restric
 #pragma unroll
   for (int i = 0; i < 40; ++i) acc[i] = 0.f;
   if (cok)
-    for (long long p = p0 + pl; p < p1; p += 4) {
+    for (long long p = p0 + pl; p < p1; p += 16) {
       const int wi = (int)(p % W), hi = (int)((p / W) % H);
       const float4 gv = ld4<T>(g + (size_t)p * C + cv * 4);
       const float ga[4] = {gv.x, gv.y, gv.z, gv.w};
@@ -267,32 +478,37 @@ __global__ __launch_bounds__(256) void dwconv3x3_wgrad_kernel(const T* __restric
 #pragma unroll
       for (int kh = 0; kh < 3; ++kh) {
         const int h2 = hi - 1 + kh;
-        if ((unsigned)h2 >= (unsigned)H) continue;
 #pragma unroll
         for (int kw = 0; kw < 3; ++kw) {
           const int w2 = wi - 1 + kw;
-          if ((unsigned)w2 >= (unsigned)W) continue;
-          const float4 xv = ld4<T>(x + ((size_t)p + (long long)(kh - 1) * W + (kw - 1)) * C + cv * 4);
+          const bool ok = (unsigned)h2 < (unsigned)H && (unsigned)w2 < (unsigned)W;
+          // branch-free: an out-of-image tap reads the centre pixel and is multiplied by 0 (keeps the 9 loads in flight together)
+          const long long off = ok ? (long long)(kh - 1) * W + (kw - 1) : 0;
+          const float4 xv = ld4<T>(x + ((size_t)p + off) * C + cv * 4);
+          const float m = ok ? 1.f : 0.f;
           const float xa[4] = {xv.x, xv.y, xv.z, xv.w};
 #pragma unroll
-          for (int e = 0; e < 4; ++e) acc[(kh * 3 + kw) * 4 + e] += xa[e] * ga[e];
+          for (int e = 0; e < 4; ++e) acc[(kh * 3 + kw) * 4 + e] += xa[e] * (ga[e] * m);
         }
       }
     }
-  if (pl > 0)
 #pragma unroll
-    for (int i = 0; i < 40; ++i) red[pl - 1][cl][i] = acc[i];
+  for (int i = 0; i < 40; ++i) {   // the wave's 4 pixel lanes (lane bits 4, 5)
+    acc[i] += __shfl_xor(acc[i], 16, 64);
+    acc[i] += __shfl_xor(acc[i], 32, 64);
+  }
+  if ((threadIdx.x & 63) < 16)
+#pragma unroll
+    for (int i = 0; i < 40; ++i) red[wave][cl][i] = acc[i];
   __syncthreads();
-  if (pl == 0 && cok) {
-#pragma unroll
-    for (int i = 0; i < 40; ++i) acc[i] += red[0][cl][i] + red[1][cl][i] + red[2][cl][i];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int c = cv * 4 + e;
-#pragma unroll
-      for (int t = 0; t < 9; ++t) atomicAdd(dw + c * 9 + t, acc[t * 4 + e]);
-      if (db) atomicAdd(db + c, acc[36 + e]);
-    }
+  for (int i = threadIdx.x; i < 16 * 40; i += 256) {
+    const int c4 = i / 40, k = i - c4 * 40;
+    const int c0 = (blockIdx.x * 16 + c4) * 4;
+    if (c0 >= C) continue;
+    const float v = red[0][c4][k] + red[1][c4][k] + red[2][c4][k] + red[3][c4][k];
+    const int t = k >> 2, e = k & 3;
+    if (t < 9) atomicAdd(dw + (c0 + e) * 9 + t, v);
+    else if (db) atomicAdd(db + c0 + e, v);
   }
 }
 
@@ -330,10 +546,13 @@ __global__ __launch_bounds__(256) void smallcin_kxk_wgrad_kernel(const float* __
 #pragma unroll
     for (int t = 0; t < PE_MAXT; ++t) {
       const int code = tap_code[t];
-      if (code < 0) continue;
+      if (code < 0) continue;   // uniform per tap group: the last group's tail
       const int ci = code >> 16, kh = (code >> 8) & 255, kw = code & 255;
       const int hi = ho * stride - pad + kh, wi = wo * stride - pad + kw;
-      if ((unsigned)hi < (unsigned)H && (unsigned)wi < (unsigned)W) acc[t] = fmaf(gv, xn[((size_t)ci * H + hi) * W + wi], acc[t]);
+      const bool ok = (unsigned)hi < (unsigned)H && (unsigned)wi < (unsigned)W;
+      // branch-free (clamped address, zero weight): the loads of one pixel's taps are issued together
+      const float xv = xn[((size_t)ci * H + (ok ? hi : 0)) * W + (ok ? wi : 0)];
+      acc[t] = fmaf(ok ? gv : 0.f, xv, acc[t]);
     }
   }
 #pragma unroll
@@ -408,7 +627,7 @@ extern "C" int cavp_sra_attention_bwd(int32_t dtype, const void* q, const void* 
   static bool attr = false;
   if (!attr) {
     (void)hipFuncSetAttribute((const void*)sra_bwd_q_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 256 * 256);
-    (void)hipFuncSetAttribute((const void*)sra_bwd_q_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 256 * 256);
+    (void)hipFuncSetAttribute((const void*)sra_bwd_q_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 256 * 128);
     attr = true;
   }
   float* stats = (float*)workspace;
@@ -428,10 +647,10 @@ extern "C" int cavp_sra_attention_bwd(int32_t dtype, const void* q, const void* 
     sra_bwd_kv_kernel<float><<<gb, 256, 0, s>>>((const float*)q, (const float*)kv, (const float*)dout, stats, dkv, Nq, Nk, heads,
                                                 scale);
   } else {
-    sra_bwd_q_kernel<bf16_t><<<ga, 256, 2 * 256 * 256, s>>>((const bf16_t*)q, (const bf16_t*)kv, (const bf16_t*)dout, (bf16_t*)dq,
-                                                           stats, Nq, Nk, heads, scale);
-    sra_bwd_kv_kernel<bf16_t><<<gb, 256, 0, s>>>((const bf16_t*)q, (const bf16_t*)kv, (const bf16_t*)dout, stats, dkv, Nq, Nk,
-                                                 heads, scale);
+    sra_bwd_q_bf16_kernel<<<ga, 256, 3 * 256 * 128, s>>>((const bf16_t*)q, (const bf16_t*)kv, (const bf16_t*)dout, (bf16_t*)dq, stats,
+                                                        Nq, Nk, heads, scale);
+    sra_bwd_kv_bf16_kernel<<<gb, 256, 0, s>>>((const bf16_t*)q, (const bf16_t*)kv, (const bf16_t*)dout, stats, dkv, Nq, Nk, heads,
+                                              scale);
   }
   CHECK_LAUNCH();
 }
@@ -441,9 +660,9 @@ extern "C" int cavp_dwconv3x3_wgrad(int32_t dtype, const void* x, const void* dy
   if (!x || !dy || !dw_c133 || N <= 0 || H <= 0 || W <= 0 || C <= 0) return CAVP_ERR_BAD_ARG;
   if (!dt_ok(dtype) || C % 8) return CAVP_ERR_UNSUPPORTED;
   const long long total = (long long)N * H * W;
-  const int gx = (C / 4 + 63) / 64;
+  const int gx = (C / 4 + 15) / 16;
   int ppb = 256;
-  while ((total + ppb - 1) / ppb * gx > 4096) ppb *= 2;
+  while ((total + ppb - 1) / ppb * gx > 8192) ppb *= 2;
   const dim3 grid(gx, (unsigned)((total + ppb - 1) / ppb));
   hipStream_t s = (hipStream_t)stream;
   if (dtype == CAVP_F32)
@@ -462,7 +681,7 @@ extern "C" int cavp_conv_smallcin_kxk_wgrad(int32_t dtype, const float* x_nchw, 
   const int Ho = (H + 2 * pad - KS) / stride + 1, Wo = (W + 2 * pad - KS) / stride + 1;
   const long long total = (long long)N * Ho * Wo;
   int ppb = 64;
-  while ((total + ppb - 1) / ppb > 2048) ppb *= 2;
+  while ((total + ppb - 1) / ppb > 256) ppb *= 2;   // 9408 atomics per workgroup: few, long workgroups
   const int nb = (int)((total + ppb - 1) / ppb);
   hipStream_t s = (hipStream_t)stream;
   if (dtype == CAVP_F32)
