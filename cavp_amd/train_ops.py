@@ -424,12 +424,23 @@ def dwconv3x3_wgrad(x, dy, dw, dbias) -> None:
 
 
 def conv_smallcin_kxk_wgrad(x_nchw, dy, dw_oihw, ks: int, stride: int, pad: int) -> None:
+    """dw_oihw (f32 [Cout, Cin, ks, ks]) += weight gradient of ops.conv_smallcin_kxk: im2col rows x dy on the MFMA
+    weight-gradient kernel (a 1x1 layer with K = Cin*ks*ks padded to a multiple of 8)."""
     _need_gpu(x_nchw, dy, dw_oihw)
     n, cin, h, w = x_nchw.shape
-    if not (x_nchw.is_contiguous() and dy.is_contiguous() and dw_oihw.is_contiguous()) or x_nchw.dtype != torch.float32:
+    cout = dy.shape[-1]
+    if not (x_nchw.is_contiguous() and dy.is_contiguous() and dw_oihw.is_contiguous()) or x_nchw.dtype != torch.float32 \
+            or dw_oihw.dtype != torch.float32 or dw_oihw.numel() != cout * cin * ks * ks:
         raise _lib.CavpError("conv_smallcin_kxk_wgrad: contiguous f32 NCHW input, NHWC dy, OIHW f32 gradient required")
-    _check(_lib.load().cavp_conv_smallcin_kxk_wgrad(dtype_code(dy.dtype), _ptr(x_nchw), _ptr(dy), _ptr(dw_oihw), n, cin, h, w,
-                                                    dy.shape[-1], ks, stride, pad, _s()), "cavp_conv_smallcin_kxk_wgrad")
+    k = cin * ks * ks
+    kpad = (k + 7) // 8 * 8
+    rows = dy.numel() // cout
+    cols = torch.empty((1, 1, rows, kpad), dtype=dy.dtype, device=dy.device)
+    _check(_lib.load().cavp_smallcin_kxk_im2col(dtype_code(dy.dtype), _ptr(x_nchw), _ptr(cols), n, cin, h, w, ks, stride, pad, kpad,
+                                                _s()), "cavp_smallcin_kxk_im2col")
+    tmp = torch.empty((cout, 1, 1, kpad), dtype=torch.float32, device=dy.device)
+    conv2d_wgrad(cols, dy.reshape(1, 1, rows, cout), tmp, kh=1, kw=1, stride=1, pad=0, dil=1, overwrite=True)
+    dw_oihw.view(cout, k).add_(tmp.view(cout, kpad)[:, :k])     # 9408 values: gradient accumulation, not compute
 
 
 def space_to_depth(src, dst, b: int, h: int, w: int, c: int, s: int, inverse: bool = False):

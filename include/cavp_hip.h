@@ -360,9 +360,11 @@ int cavp_sra_attention_bwd(int32_t dtype, const void* q, const void* kv, const v
  * cavp_dwconv3x3_nhwc with the taps reversed. */
 int cavp_dwconv3x3_wgrad(int32_t dtype, const void* x, const void* dy, float* dw_c133, float* dbias, int32_t N, int32_t H,
                          int32_t W, int32_t C, void* stream);
-/* Weight gradient of cavp_conv_smallcin_kxk_nchw: dw_oihw f32 += . */
-int cavp_conv_smallcin_kxk_wgrad(int32_t dtype, const float* x_nchw, const void* dy_nhwc, float* dw_oihw, int32_t N, int32_t Cin,
-                                 int32_t H, int32_t W, int32_t Cout, int32_t KS, int32_t stride, int32_t pad, void* stream);
+/* Weight gradient of cavp_conv_smallcin_kxk_nchw, step 1: im2col of the NCHW f32 input into cols [N*Ho*Wo][Kpad] (dtype;
+ * column order (ci, kh, kw) = the OIHW weight's, zero beyond Cin*KS*KS; Kpad a multiple of 8).  Step 2 is
+ * cavp_conv2d_wgrad_nhwc as a 1x1 layer with x = cols, giving dw [Cout][Kpad]. */
+int cavp_smallcin_kxk_im2col(int32_t dtype, const float* x_nchw, void* cols, int32_t N, int32_t Cin, int32_t H, int32_t W,
+                             int32_t KS, int32_t stride, int32_t pad, int32_t Kpad, void* stream);
 /* [B][H][W][C] -> [B][H/s][W/s][s*s*C] (inverse != 0: back): the spatial-reduction conv (kernel = stride = s,
  * pvt.py:76-79) becomes a token GEMM over the rearranged rows, forward and backward. */
 int cavp_space_to_depth(int32_t dtype, const void* src, void* dst, int32_t B, int32_t H, int32_t W, int32_t C, int32_t s,
