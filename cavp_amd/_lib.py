@@ -35,6 +35,7 @@ _vp, _i32, _i64, _f32, _sz = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_si
 PROTOTYPES = {
     "cavp_abi_version": (_i32, []),
     "cavp_set_deterministic": (_i32, [_vp, _sz]),
+    "cavp_zero_ranges_f32": (_i32, [_vp, _vp, _i32, _i64, _vp]),
     "cavp_get_deterministic": (_i32, []),
     "cavp_error_string": (C.c_char_p, [_i32]),
     "cavp_conv2d_workspace_bytes": (_sz, [C.POINTER(ConvDesc)]),

@@ -485,3 +485,21 @@ extern "C" int cavp_cast(int32_t sdt, const void* src, int32_t ddt, void* dst, i
     cast_kernel<bf16_t, bf16_t><<<nb, 256, 0, s>>>((const bf16_t*)src, (bf16_t*)dst, n);
   CHECK_LAUNCH();
 }
+
+
+// clear n [start, end) element ranges of one f32 buffer in ONE launch (the gradient arena's per-step reset: ~30 ranges)
+static __global__ __launch_bounds__(256) void zero_ranges_kernel(float* __restrict__ base, const long long* __restrict__ table) {
+  const long long a = table[2 * blockIdx.y], b = table[2 * blockIdx.y + 1];
+  float4* p4 = (float4*)(base + a);          // ranges are 16-byte aligned and a multiple of 4 floats long
+  const long long n4 = (b - a) >> 2;
+  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) p4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+extern "C" int cavp_zero_ranges_f32(float* base, const int64_t* table_dev, int32_t nranges, int64_t max_len, void* stream) {
+  if (!base || !table_dev || nranges <= 0 || max_len <= 0) return CAVP_ERR_BAD_ARG;
+  if ((uintptr_t)base & 15) return CAVP_ERR_ALIGN;
+  long long nb = (max_len / 4 + 255) / 256;
+  nb = nb < 1 ? 1 : (nb > 512 ? 512 : nb);
+  zero_ranges_kernel<<<dim3((unsigned)nb, (unsigned)nranges), 256, 0, (hipStream_t)stream>>>(base, (const long long*)table_dev);
+  return hipGetLastError() == hipSuccess ? CAVP_OK : CAVP_ERR_LAUNCH;
+}

@@ -42,6 +42,9 @@ typedef enum {
 
 int cavp_abi_version(void);
 
+/* Clear nranges [start, end) element ranges (table_dev: int64 pairs in device memory; 4-float aligned) of one f32 buffer in one
+ * launch: the per-step reset of the flat gradient arena.  max_len = the longest range (sizes the grid). */
+int cavp_zero_ranges_f32(float* base, const int64_t* table_dev, int32_t nranges, int64_t max_len, void* stream);
 /* Opt-in deterministic training (the reference runs with cudnn.deterministic = True, main_vpo_mono.py:39-41).  With a scratch
  * buffer registered (>= 1 MiB, 16-byte aligned device memory that stays alive; 8 MiB covers every CAVP shape) the reductions
  * that otherwise finish with f32 atomics - cavp_colsum / cavp_colstats / cavp_bn_act_bwd_reduce, the dgamma / dbeta of

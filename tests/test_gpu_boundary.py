@@ -124,7 +124,7 @@ def test_trainer_call_sequence():
         loss.backward()
         opt_v.step()
         opt_a.step()
-        losses.append(float(loss))
+        losses.append(float(loss.detach()))
         m.eval()
         with torch.no_grad():
             ev, _, _ = m(image, audio[:B], eval_mode=True)
