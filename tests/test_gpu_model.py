@@ -142,5 +142,6 @@ def test_pvt_forward_matches_reference_golden(dtype, tol, case):
             s, _ = sample(t)
             rel = float(np.abs(s - ref).max() / scale)
             rep[k] = rel
-            assert rel <= 0.12, (k, rel)
+            # measured: <= 2.9e-2 of the tap's largest value (stage 3: 40 blocks deep, sampled elements), logits 9e-3
+            assert rel <= 0.05, (k, rel)
     print("pvt", dtype, {k: f"{v:.2e}" for k, v in rep.items()})
