@@ -163,16 +163,6 @@ def allreduce_arena_late(arena: GradArena, early_work) -> None:
         early_work.wait()
 
 
-def allreduce_bn_stats(bn, buf: torch.Tensor, count: int) -> int:
-    """SyncBatchNorm statistics exchange (main_vpo_mono.py:130): SUM the per-channel partial sums over ranks and return
-    the global sample count; plain BatchNorm2d (or a single process) is left local."""
-    import torch.distributed as dist
-    if isinstance(bn, nn.SyncBatchNorm) and dist_world() > 1:
-        dist.all_reduce(buf)
-        return count * dist.get_world_size()
-    return count
-
-
 def gather_bn_moments(local: torch.Tensor) -> torch.Tensor:
     """SyncBatchNorm forward exchange: every rank's per-channel (mean, M2) [C, 2] -> [world, C, 2] on every rank, ONE
     collective per layer.  RCCL: all-gather.  Other backends (gloo in the tests, which has no device all-gather): the same
@@ -461,9 +451,6 @@ class TrainPass:
         self.tape.append(bwd)
         return y
 
-    def _allreduce_stats(self, bn, buf: torch.Tensor, count: int) -> int:
-        return allreduce_bn_stats(bn, buf, count)
-
     def bn_act(self, z: V, bn, act: int, residual: Optional[V] = None, out: Optional[V] = None) -> V:
         """y = act(BN_train(z) + residual); `out` may be a channel slice of a concat buffer."""
         c = bn.num_features
@@ -471,7 +458,7 @@ class TrainPass:
         scale, shift, mean, rstd = (self.empty((c,), torch.float32) for _ in range(4))
         track = bn.track_running_stats and bn.running_mean is not None
         mom = bn.momentum if bn.momentum is not None else 0.1
-        sync = isinstance(bn, nn.SyncBatchNorm) and dist_world() > 1
+        sync = isinstance(bn, nn.SyncBatchNorm) and collectives_on()   # (a forced single-rank group runs the collectives too)
         frozen = (not bn.training) and bn.running_mean is not None   # torch: eval-mode BatchNorm normalises with the running statistics
         if frozen:
             # fine-tuning with frozen statistics: y = gamma (z - running_mean) rstd + beta, no update of the running buffers;
@@ -529,7 +516,7 @@ class TrainPass:
             dy = y.g
             if dy is None:
                 return
-            direct = (count == rows and id(bn.weight) not in self.grads and id(bn.bias) not in self.grads)
+            direct = (not sync and id(bn.weight) not in self.grads and id(bn.bias) not in self.grads)
             if direct:
                 # local BatchNorm: sum g -> dbeta and sum g*zhat -> dgamma ARE the affine gradients: reduce straight
                 # into their (zeroed) gradient buffers and let the apply kernel read them from there
@@ -540,11 +527,12 @@ class TrainPass:
             yb = y.t if (residual is not None or _BN_BWD_READ_Y) else None
             T.bn_act_bwd_reduce(dy, yb, z.t, mean, rstd, act, sums[0], sums[1], fwd_scale=scale, fwd_shift=shift)
             local = sums
-            if count != rows:
+            if sync:
                 # SyncBatchNorm: dz uses the GLOBAL sums / count, the affine gradients stay the LOCAL sums (DDP
                 # reduces them with every other parameter gradient) - same split as torch's SyncBatchNorm backward
+                import torch.distributed as dist
                 local = sums.clone()
-                self._allreduce_stats(bn, sums, rows)
+                dist.all_reduce(sums)
                 sums = sums * (float(rows) / float(count))
             if frozen:
                 sums = self.zeros_f32(2, c)     # the batch-mean terms of dz vanish; `local` keeps the affine gradients

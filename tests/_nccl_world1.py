@@ -1,7 +1,8 @@
 """Child process of tests/test_gpu_nccl_world1.py: the data-parallel training path on the REAL RCCL backend with a process
 group of one rank (a 1-GPU box cannot host two), collectives forced on (cavp_amd.train.FORCE_COLLECTIVES).  Exercises what
 gloo runs cannot: ncclCommInit, all-reduce of the flat f32 gradient arena (early range asynchronously on RCCL's stream, late
-range, join), and both interleaved with hipGraph replays of the two-graph training step."""
+range, join), both interleaved with hipGraph replays of the two-graph training step, and the SyncBatchNorm exchanges (one
+all-gather forward + one all-reduce backward per layer) issued eagerly and captured inside those graphs."""
 import os
 import sys
 import types
@@ -54,6 +55,26 @@ def main():
         l2 = float(step().item())
         torch.cuda.synchronize()
         errs.append(float((m._grad_arena.flat - ref).abs().max() / ref.abs().max()))
+    # SyncBatchNorm (main_vpo_mono.py:130) on RCCL: one all-gather per layer forward + one all-reduce backward, eagerly AND inside
+    # the captured graphs (RCCL collectives are capturable; with one rank they are identities, so the result must not move)
+    import torch.nn as nn
+    ms = nn.SyncBatchNorm.convert_sync_batchnorm(CAVP(50, None, num_classes=C, args=args))
+    ms.load_state_dict(sd, strict=True)
+    ms.train().to(dev)
+    ls0 = float(ms.train_step(image, audio, label).item())
+    torch.cuda.synchronize()
+    es = float((ms._grad_arena.flat - ref).abs().max() / ref.abs().max())
+    ms.load_state_dict({k: v for k, v in sd.items() if "running_" in k or "num_batches" in k}, strict=False)
+    sstep = ms.capture_train_step(image, audio, label)
+    serrs = []
+    for _ in range(2):
+        ms.load_state_dict({k: v for k, v in sd.items() if "running_" in k or "num_batches" in k}, strict=False)
+        ls1 = float(sstep().item())
+        torch.cuda.synchronize()
+        serrs.append(float((ms._grad_arena.flat - ref).abs().max() / ref.abs().max()))
+    print(f"SYNCBN_RCCL loss {ls0:.6f} {ls1:.6f} eager_err {es:.2e} replay_err {max(serrs):.2e}")
+    assert abs(ls0 - l0) <= 1e-4 * max(1.0, abs(l0)) and abs(ls1 - l0) <= 1e-4 * max(1.0, abs(l0))
+    assert es <= 0.1 and max(serrs) <= 0.1
     # a plain all-reduce of a known buffer really goes through RCCL
     t = torch.arange(1 << 20, dtype=torch.float32, device=dev)
     dist.all_reduce(t)
