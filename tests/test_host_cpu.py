@@ -155,3 +155,28 @@ def test_reference_import_paths_and_signatures():
     assert params(MC.CAVP.forward_audio) == [("audio", E), ("shuffle_info", None), ("ow_flag", False)]
     assert [n for n, _ in params(LC.ContrastLoss.forward)] == ["embeds_match", "gt_match", "embeds_shuffle", "gt_shuffle"]
     assert [n for n, _ in params(LC.ContrastLoss.__init__)][:3] == ["temperature", "ignore_idx", "max_views"]
+
+
+def test_pvt_drop_path_schedule_and_draws_follow_timm():
+    """PVTv2-B5's stochastic-depth schedule (pvt.py:229: linspace(0, 0.1, 52), one DropPath per residual branch) and the mask
+    draws of the training pass: one torch.rand((B, 1, 1)) per branch with probability > 0 from the default CPU generator,
+    factor = floor(keep + u) / keep - the sequence timm 0.4.9's drop_path consumes (tests/golden/pvt_train.npz holds the
+    factors the reference applied under seed 99)."""
+    import numpy as np
+    from cavp_amd.pvt import pvt_v2_b5
+    from cavp_amd.pvt_train import draw_drop_path_scales
+    bb = pvt_v2_b5()
+    probs = [blk.drop_prob for i in range(4) for blk in getattr(bb, f"block{i + 1}")]
+    assert len(probs) == 52 and probs[0] == 0.0 and abs(probs[-1] - 0.1) < 1e-7
+    assert all(abs(p - 0.1 * i / 51) < 1e-6 for i, p in enumerate(probs))
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "pvt_train.npz"), allow_pickle=True)
+    B = int(z["cfg/CBHW"][1])
+    bb.train()
+    torch.manual_seed(int(z["seed"][0]))
+    scales = draw_drop_path_scales(bb, B, "cpu")
+    assert len(scales) == 104 and scales[0] is None and scales[1] is None
+    drawn = torch.stack([s for s in scales if s is not None]).numpy()
+    assert drawn.shape == z["drop_scales"].shape and np.abs(drawn - z["drop_scales"]).max() <= 1e-4
+    bb.eval()
+    assert all(s is None for s in draw_drop_path_scales(bb, B, "cpu"))     # DropPath is the identity in eval mode
+    assert "_dp_buf" not in bb.state_dict()
