@@ -52,6 +52,7 @@ def parse():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--deterministic", action="store_true", help="opt-in bit-reproducible reductions (cavp_set_deterministic)")
     ap.add_argument("--no-token-fusion", action="store_true", help="A/B: GELU as a separate pass, duplicated token tensors copied")
+    ap.add_argument("--no-side-stream", action="store_true", help="A/B: the audio encoder on the main stream instead of a second one")
     ap.add_argument("--no-f32", action="store_true", help="skip the secondary f32 (parity path) training-step measurement")
     ap.add_argument("--cpu-sample-batch", type=int, default=8)
     return ap.parse_args()
@@ -372,6 +373,9 @@ def main():
     if a.no_token_fusion:
         import cavp_amd.train as _tr
         _tr._FUSE_TOKEN_PATH = False
+    if a.no_side_stream:
+        import cavp_amd.train as _tr
+        _tr._SIDE_STREAM = False
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

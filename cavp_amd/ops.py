@@ -67,6 +67,25 @@ def _nhwc(t: torch.Tensor) -> Tuple[int, int, int, int, int]:
     return n, h, w, c, ld
 
 
+_ws_slot = [0]
+
+
+class workspace_slot:
+    """Kernels launched on a second stream concurrently with the main one (TrainPass side sections) must not share the split-K /
+    weight-gradient slab scratch: inside this context `workspace()` hands out slot `k`'s own buffer."""
+
+    def __init__(self, k: int):
+        self.k = k
+
+    def __enter__(self):
+        self.prev = _ws_slot[0]
+        _ws_slot[0] = self.k
+
+    def __exit__(self, *exc):
+        _ws_slot[0] = self.prev
+        return False
+
+
 def workspace(nbytes: int, device) -> Optional[torch.Tensor]:
     """Grow-only scratch buffer per device (split-K slabs).  Must not grow while a graph is being captured.  A buffer that
     is outgrown later (say validation at another resolution after capture_train_step) is RETIRED, not freed: graphs captured
@@ -74,7 +93,7 @@ def workspace(nbytes: int, device) -> Optional[torch.Tensor]:
     else.  Sizes at least double, so the retired buffers sum to less than the live one."""
     if nbytes <= 0:
         return None
-    key = torch.device(device).index or 0
+    key = (torch.device(device).index or 0, _ws_slot[0])
     ws = _workspace.get(key)
     if ws is None or ws.numel() < nbytes:
         if torch.cuda.is_current_stream_capturing():

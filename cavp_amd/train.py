@@ -181,6 +181,7 @@ def gather_bn_moments(local: torch.Tensor) -> torch.Tensor:
 
 # False (tests / A-B only): GELU as a separate pass with the pre-activation stored, and the duplicated token tensors copied
 _FUSE_TOKEN_PATH = True
+_SIDE_STREAM = True      # False (tests / A-B only): the audio encoder on the main stream
 _BN_BWD_READ_Y = False   # True (tests / A-B only): the BatchNorm backward always re-reads y instead of re-deriving the mask from z
 
 
@@ -190,8 +191,6 @@ class TrainPass:
         self.dt = dtype
         self.arena = arena
         self.touched = set()
-        self._zpool = None
-        self._zoff = 0
         self.tape: List[Callable[[], None]] = []
         self.grads: Dict[int, torch.Tensor] = {}
         self.P: Dict[str, _P] = {}
@@ -200,6 +199,11 @@ class TrainPass:
         self.on_early_final: Optional[Callable[[], None]] = None   # called in backward once head / attention / audio grads are final
         self.dev = next(model.parameters()).device
         self.named: Dict[str, V] = {}   # debug taps (activations + their gradients after backward)
+        # side section (the audio encoder): tape range run on a second stream, concurrently with the visual backbone
+        self.side_range: Optional[tuple] = None
+        self._side_done = None
+        self._slot = 0
+        self._zpools: Dict[int, list] = {}
 
     # ---- parameter helpers -----------------------------------------------------------------------------------
     def pack(self, key: str, mod, need_dgrad: bool = True, raw: bool = False, pad_cout_to: int = 0) -> _P:
@@ -296,11 +300,12 @@ class TrainPass:
             n *= d
         if n > (1 << 16):
             return torch.zeros(shape, dtype=torch.float32, device=self.dev)
-        if self._zpool is None or self._zoff + n + 4 > self._zpool.numel():
-            self._zpool = torch.zeros(1 << 21, dtype=torch.float32, device=self.dev)
-            self._zoff = 0
-        t = self._zpool[self._zoff:self._zoff + n].view(shape)
-        self._zoff += (n + 3) // 4 * 4     # keep every carve 16-byte aligned
+        st = self._zpools.setdefault(self._slot, [None, 0])   # one pool per stream slot: a pool's fill is ordered on ITS stream only
+        if st[0] is None or st[1] + n + 4 > st[0].numel():
+            st[0] = torch.zeros(1 << 21 if self._slot == 0 else 1 << 18, dtype=torch.float32, device=self.dev)
+            st[1] = 0
+        t = st[0][st[1]:st[1] + n].view(shape)
+        st[1] += (n + 3) // 4 * 4     # keep every carve 16-byte aligned
         return t
 
     # ---- gradient accumulation -------------------------------------------------------------------------------
@@ -723,12 +728,50 @@ class TrainPass:
         def bwd():
             self.finish_padded()            # the zero-padded classifier's gradient rows -> its real .grad view
             if self.on_early_final is not None:
+                self.join_side()            # the audio encoder's gradients are part of the early range
                 self.on_early_final()
         self.tape.append(bwd)
 
+    # ---- side section ------------------------------------------------------------------------------------------
+    def side_stream(self):
+        """Second stream for the side section, or None (CPU tensors, deterministic mode: its scratch is process-wide)."""
+        if self.dev.type != "cuda" or not _SIDE_STREAM or _lib_load().cavp_get_deterministic():
+            return None
+        s = getattr(self.m, "_side_stream", None)
+        if s is None or s.device != self.dev:
+            s = torch.cuda.Stream(device=self.dev)
+            self.m.__dict__["_side_stream"] = s
+        return s
+
+    def join_side(self) -> None:
+        """Make the current stream wait for the side section's backward (its parameter gradients are final after this)."""
+        if self._side_done is not None:
+            torch.cuda.current_stream().wait_event(self._side_done)
+            self._side_done = None
+
     def backward(self) -> None:
-        for fn in reversed(self.tape):
-            fn()
+        side = self.side_stream() if self.side_range is not None else None
+        i0, i1 = self.side_range if side is not None else (-1, -1)
+        i = len(self.tape) - 1
+        while i >= 0:
+            if i == i1 - 1:
+                # fork: everything recorded after the side section (fusion, head) has been issued; its gradients feed both
+                # the side section's backward and the rest of the main tape, which now run concurrently
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream())
+                side.wait_event(ev)
+                with torch.cuda.stream(side), ops.workspace_slot(1):
+                    self._slot = 1
+                    for j in range(i1 - 1, i0 - 1, -1):
+                        self.tape[j]()
+                    self._slot = 0
+                    self._side_done = torch.cuda.Event()
+                    self._side_done.record(side)
+                i = i0 - 1
+                continue
+            self.tape[i]()
+            i -= 1
+        self.join_side()
         self.tape = []
 
 
@@ -784,6 +827,10 @@ def run_train_forward(model, image: torch.Tensor, audio: torch.Tensor, tp: Train
     tp.pack("ca.fc1", blk.mlp.fc1)
     tp.pack("ca.fc2", blk.mlp.fc2)
     tp.flush_packs()
+    ev_start = None
+    if tp.dev.type == "cuda":
+        ev_start = torch.cuda.Event()
+        ev_start.record(torch.cuda.current_stream())
 
     dt = tp.dt
     if pvt:
@@ -833,18 +880,37 @@ def run_train_forward(model, image: torch.Tensor, audio: torch.Tensor, tp: Train
     if audio.shape[0] != (B if shuffle is not None else 2 * B):
         raise CavpError(f"train mode expects audio of {'B' if shuffle is not None else '2B'} clips (cavp_model.py:181,160-173), "
                         f"got {audio.shape[0]} for {B} images")
-    a = tp.conv_smallcin(audio, "a.conv0", 1, ACT_RELU)
-    ci = 1
-    for v in VGG.CFG[1:]:
-        if v == "M":
-            a = tp.maxpool(a, 2, 2, 0)
-        else:
-            a = tp.conv(a, f"a.conv{ci}", act=ACT_RELU)
-            ci += 1
-    a = tp.flatten(a)
-    a = tp.conv(a, "a.fc0", act=ACT_RELU)
-    a = tp.conv(a, "a.fc1", act=ACT_RELU)
-    fea_a = tp.conv(a, "a.fc2", act=ACT_RELU)
+    def audio_encoder():
+        a = tp.conv_smallcin(audio, "a.conv0", 1, ACT_RELU)
+        ci = 1
+        for v in VGG.CFG[1:]:
+            if v == "M":
+                a = tp.maxpool(a, 2, 2, 0)
+            else:
+                a = tp.conv(a, f"a.conv{ci}", act=ACT_RELU)
+                ci += 1
+        a = tp.flatten(a)
+        a = tp.conv(a, "a.fc0", act=ACT_RELU)
+        a = tp.conv(a, "a.fc1", act=ACT_RELU)
+        return tp.conv(a, "a.fc2", act=ACT_RELU)
+
+    # The audio encoder depends on nothing but its input and feeds only the fusion: it runs on a second stream, concurrently
+    # with the visual backbone (whose 14 x 14 layers and small BatchNorm kernels leave most of the chip idle), forward and
+    # backward.  The kernels are ISSUED after the backbone's but wait only for the weight re-pack (`ev_start`).
+    side = tp.side_stream()
+    t0 = len(tp.tape)
+    if side is None:
+        fea_a = audio_encoder()
+    else:
+        side.wait_event(ev_start)
+        with torch.cuda.stream(side), ops.workspace_slot(1):
+            tp._slot = 1
+            fea_a = audio_encoder()
+            tp._slot = 0
+            ev_audio = torch.cuda.Event()
+            ev_audio.record(side)
+        torch.cuda.current_stream().wait_event(ev_audio)
+        tp.side_range = (t0, len(tp.tape))
     if shuffle is not None:   # forward_audio (cavp_model.py:156-173): features | the same features gathered by shuffle_idx
         fea_a = tp.gather_cat(fea_a, model._bank_and_shuffle(fea_a.t, shuffle[0], shuffle[1]))
     # ---- fusion (cavp_model.py:143-154; attn.py:232-244) ----
