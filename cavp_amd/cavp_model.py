@@ -586,13 +586,31 @@ class CAVP(nn.Module):
         P = self.packed()
         input_shape = tuple(image.shape[-2:])
         B = image.shape[0]
+        # the audio encoder depends on nothing but its input: second stream, concurrent with the visual backbone (own scratch slot)
+        from . import train as _tr
+        side = None
+        if _tr._SIDE_STREAM:
+            side = getattr(self, "_side_stream", None)
+            if side is None or side.device != image.device:
+                side = self.__dict__["_side_stream"] = torch.cuda.Stream(device=image.device)
+            main = torch.cuda.current_stream()
+            ev0 = torch.cuda.Event()
+            ev0.record(main)
+            side.wait_event(ev0)
+            with torch.cuda.stream(side), ops.workspace_slot(1):
+                fea_a = self._audio_hip(audio, P)
+                ev1 = torch.cuda.Event()
+                ev1.record(side)
         if self.seg_model == "PVT":
             from .pvt import pvt_forward_hip
             feats = pvt_forward_hip(self.backbone, image, P["pvt"], self.compute_dtype)
         else:
             feats = self._backbone_hip(image, P)
         fea_v, aspp = self._forward_feature_hip(feats, P)
-        fea_a = self._audio_hip(audio, P)
+        if side is None:
+            fea_a = self._audio_hip(audio, P)
+        else:
+            torch.cuda.current_stream().wait_event(ev1)
         if shuffle is not None:   # forward_audio (cavp_model.py:156-173): B clips -> features | shuffled features
             idx = self._bank_and_shuffle(fea_a, shuffle[0], shuffle[1])
             fea_a = torch.cat((fea_a, fea_a.index_select(0, idx)), dim=0)
