@@ -115,3 +115,38 @@ def test_label_free_half_gets_zero_head_gradient():
     lo2[B:] = torch.randn_like(lo2[B:])          # the label-free half does not reach the loss through the head
     loss2, _ = T.upsample_ce_head(lo2, label, B, C, 255, want_grad=False)
     assert float(loss.item()) == float(loss2.item())
+
+
+def test_pvt_train_step_at_config4_size():
+    """Config #4 at its own size (PVTv2-B5, 512 x 512, 71 classes; B = 2 images + 4 clips): the f32 training step through all 52
+    blocks is finite, its gradients are linear in the loss scale under identical DropPath masks, the frozen-mask eval-mode
+    DropPath is the identity (masks None), and every parameter the forward touches gets a gradient."""
+    from cavp_amd.cavp_model import CAVP
+    Bp, hw, Cp = 2, (512, 512), 71
+    args = types.SimpleNamespace(seg_model="PVT", last_three_dilation_stride=[False, False, False], audio_backbone="vgg",
+                                 num_classes=Cp, batch_size=Bp, local_rank="cpu", allow_random_pvt=True)
+    image, audio, label = [t.to(DEV) for t in synth_inputs(Bp, hw, audio_batch=2 * Bp, num_classes=Cp, seed=7)]
+
+    def run(scale):
+        m = CAVP(50, None, num_classes=Cp, args=args)
+        m.load_state_dict(synth_state_dict({k: tuple(v.shape) for k, v in m.state_dict().items()}, seed=1), strict=True)
+        m.train().to(DEV).set_compute_dtype(torch.float32)
+        torch.manual_seed(123)                      # same DropPath masks in both runs
+        loss = float(m.train_step(image, audio, label, loss_scale=scale).item())
+        torch.cuda.synchronize()
+        assert int((m.backbone._dp_buf == 0).sum()) > 0      # some branches really were dropped
+        missing = [k for k, p in m.named_parameters() if p.grad is None and p not in set(m.params_without_grad())]
+        assert not missing, missing[:5]
+        return loss, _grads(m)
+
+    l1, g1 = run(1.0)
+    l2, g2 = run(2.0)
+    assert l1 == pytest.approx(l2, rel=1e-5) and 0.0 < l1 < 20.0
+    worst = 0.0
+    for k in g1:
+        assert torch.isfinite(g1[k]).all(), k
+        n1 = float(g1[k].norm())
+        if n1 > 0:
+            worst = max(worst, float((g2[k] - 2.0 * g1[k]).norm()) / (2.0 * n1))
+    # the only non-determinism is the order of f32 atomics (BatchNorm reductions in the decoder, dK / dV, depth-wise weights)
+    assert worst <= 2e-2, worst
