@@ -275,3 +275,42 @@ def test_pvt_native_train_step_and_graph_replay(dtype):
             assert err <= (5e-2 if dtype == torch.float32 else 0.5), err
         else:
             assert abs(l1 - l0) > 1e-7      # other masks
+
+
+def test_pvt_train_entry_points_fail_loudly():
+    """Error paths of the PVT training entry points: unsupported geometry, short workspace, misaligned or missing operands and
+    shape mismatches surface as CAVP_ERR_* / CavpError."""
+    import ctypes as C
+    from cavp_amd import _lib, train_ops as T
+    from cavp_amd._lib import CavpError
+    lib = _lib.load()
+    p = lambda t: C.c_void_p(t.data_ptr())
+    s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    q = torch.zeros((1, 64, 128), dtype=BF, device=DEV)
+    kv = torch.zeros((1, 32, 256), dtype=BF, device=DEV)
+    dq, dkv = torch.empty_like(q), torch.empty(kv.shape, dtype=torch.float32, device=DEV)
+    need = lib.cavp_sra_attention_bwd_workspace_bytes(1, 64, 2)
+    ws = torch.empty(need, dtype=torch.uint8, device=DEV)
+    args = lambda **k: [k.get("dt", 1), p(k.get("q", q)), p(kv), p(q), p(dq), p(dkv), 1, 64, k.get("nk", 32), 2, k.get("hd", 64),
+                        C.c_float(0.125), k.get("ws", p(ws)), C.c_size_t(k.get("wsb", need)), s]
+    from cavp_amd import ops
+    bf = ops.dtype_code(BF)
+    assert lib.cavp_sra_attention_bwd(*args(dt=bf)) == 0
+    for bad, word in ((dict(dt=bf, hd=32), b"unsupported"), (dict(dt=bf, nk=300), b"unsupported"), (dict(dt=bf, wsb=need // 2), b"workspace"),
+                      (dict(dt=bf, q=q.view(-1)[1:]), b"align"), (dict(dt=bf, ws=None), None)):
+        st = lib.cavp_sra_attention_bwd(*args(**bad))
+        assert st != 0 and (word is None or word in lib.cavp_error_string(st).lower()), (bad, st)
+    with pytest.raises(CavpError):   # dkv must be f32 of kv's shape
+        T.sra_attention_bwd(q, kv, q, dq, torch.empty_like(kv), 2, 0.125)
+    x = torch.zeros((1, 8, 8, 64), dtype=BF, device=DEV)
+    with pytest.raises(CavpError):   # gradient of the wrong size
+        T.dwconv3x3_wgrad(x, x, torch.zeros((32, 1, 3, 3), device=DEV), None)
+    with pytest.raises(CavpError):   # channel count not a multiple of 8
+        T.dwconv3x3_wgrad(x[..., :60].contiguous(), x[..., :60].contiguous(), torch.zeros((60, 1, 3, 3), device=DEV), None)
+    with pytest.raises(CavpError):   # H not divisible by the reduction ratio
+        T.space_to_depth(torch.zeros((1, 6, 8, 64), dtype=BF, device=DEV), torch.zeros((1, 3, 4 * 4 * 64), dtype=BF, device=DEV), 1, 6, 8, 64, 4)
+    with pytest.raises(CavpError):   # one scale per batch item
+        T.row_scale_add(None, x, torch.ones(3, device=DEV), torch.empty_like(x))
+    with pytest.raises(CavpError):   # image must be f32 NCHW
+        T.conv_smallcin_kxk_wgrad(torch.zeros((1, 3, 32, 32), dtype=BF, device=DEV), torch.zeros((1, 8, 8, 64), dtype=BF, device=DEV),
+                                  torch.zeros((64, 3, 7, 7), device=DEV), 7, 4, 3)
