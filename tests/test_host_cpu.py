@@ -180,3 +180,20 @@ def test_pvt_drop_path_schedule_and_draws_follow_timm():
     bb.eval()
     assert all(s is None for s in draw_drop_path_scales(bb, B, "cpu"))     # DropPath is the identity in eval mode
     assert "_dp_buf" not in bb.state_dict()
+
+
+def test_conv_desc_binding_matches_header():
+    """The ctypes mirror of `struct cavp_conv_desc` (and the stub printed in INTEGRATION.md) lists the header's fields in order."""
+    import re
+    from cavp_amd._lib import ConvDesc
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hdr = open(os.path.join(root, "include", "cavp_hip.h")).read()
+    body = hdr[hdr.index("typedef struct cavp_conv_desc"):hdr.index("} cavp_conv_desc;")]
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    names = []
+    for decl in re.findall(r"int32_t\s+([^;]+);", body):
+        names += [n.strip() for n in decl.split(",")]
+    assert names == [f[0] for f in ConvDesc._fields_]
+    doc = open(os.path.join(root, "INTEGRATION.md")).read()
+    stub = doc[doc.index("class ConvDesc"):doc.index("lib.cavp_conv2d_nhwc.restype")]
+    assert re.findall(r'"(\w+)"', stub) == names
