@@ -589,7 +589,7 @@ class CAVP(nn.Module):
         # the audio encoder depends on nothing but its input: second stream, concurrent with the visual backbone (own scratch slot)
         from . import train as _tr
         side = None
-        if _tr._SIDE_STREAM:
+        if _tr._SIDE_STREAM and self.seg_model != "PVT":   # (PVTv2: measured slower with the second branch, 9.89 -> 10.17 ms)
             side = getattr(self, "_side_stream", None)
             if side is None or side.device != image.device:
                 side = self.__dict__["_side_stream"] = torch.cuda.Stream(device=image.device)
