@@ -476,3 +476,49 @@ def test_deterministic_mode_is_bit_reproducible(dtype):
     finally:
         _lib.set_deterministic(False)
     assert not _lib.is_deterministic()
+
+
+def test_second_stream_equals_single_stream():
+    """The audio encoder runs on a second stream (forward and backward).  With every BatchNorm frozen the step has no chaotic
+    amplifier and its only run-to-run noise is the order of a few f32 atomics (~1e-6), so a missing dependency or a shared scratch
+    buffer between the streams would show: gradients with the second stream == gradients without, eagerly and as graph replays."""
+    import cavp_amd.train as TR
+    cfg = dict(C=3, B=4, hw=(96, 96), lds=[False, False, False])
+    image, audio, label = [t.to(DEV) for t in synth_inputs(cfg["B"], cfg["hw"], audio_batch=2 * cfg["B"], num_classes=cfg["C"], seed=8)]
+
+    def build():
+        m, _ = _build(cfg)
+        for mod in m.modules():
+            if isinstance(mod, torch.nn.modules.batchnorm._BatchNorm):
+                mod.eval()
+        return m
+
+    old = TR._SIDE_STREAM
+    try:
+        TR._SIDE_STREAM = False
+        m0 = build()
+        l0 = float(m0.train_step(image, audio, label, all_reduce=False).item())
+        ref = m0._grad_arena.flat.clone()
+        TR._SIDE_STREAM = True
+        m1 = build()
+        for _ in range(3):
+            l1 = float(m1.train_step(image, audio, label, all_reduce=False).item())
+            torch.cuda.synchronize()
+            assert m1._side_stream is not None
+            err = float((m1._grad_arena.flat - ref).norm() / ref.norm())
+            assert abs(l1 - l0) <= 1e-6 * max(1.0, abs(l0)) and err <= 1e-5, (l1, l0, err)
+        step = m1.capture_train_step(image, audio, label)
+        for _ in range(3):
+            l2 = float(step().item())
+            torch.cuda.synchronize()
+            err = float((m1._grad_arena.flat - ref).norm() / ref.norm())
+            assert abs(l2 - l0) <= 1e-6 * max(1.0, abs(l0)) and err <= 1e-5, (l2, l0, err)
+        # inference forward: bit-identical with and without the second stream
+        m1.eval()
+        with torch.no_grad():
+            a = m1(image, audio[:cfg["B"]], eval_mode=True)[0].clone()
+            TR._SIDE_STREAM = False
+            b = m1(image, audio[:cfg["B"]], eval_mode=True)[0]
+        assert torch.equal(a, b)
+    finally:
+        TR._SIDE_STREAM = old
