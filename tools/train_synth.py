@@ -35,6 +35,8 @@ def main():
     ap.add_argument("--momentum", type=float, default=0.9)
     ap.add_argument("--weight-decay", type=float, default=1e-4)
     ap.add_argument("--total-iters", type=int, default=1000)
+    ap.add_argument("--seg-model", choices=["DeepLabV3Plus", "PVT"], default="DeepLabV3Plus", help="PVT = config #4's PVTv2-B5 backbone")
+    ap.add_argument("--fixed-batch", action="store_true", help="train on ONE batch (over-fit sanity: the loss must fall)")
     ap.add_argument("--from-waveform", action="store_true", help="start from 16 kHz waveforms (HIP log-mel front-end)")
     a = ap.parse_args()
 
@@ -54,9 +56,9 @@ def main():
     from cavp_amd.optim import FusedSGDAdam, warmup_poly_lr
     from cavp_amd.synth import synth_state_dict
 
-    hyp = types.SimpleNamespace(seg_model="DeepLabV3Plus", last_three_dilation_stride=[False, False, False],
+    hyp = types.SimpleNamespace(seg_model=a.seg_model, last_three_dilation_stride=[False, False, False],
                                 audio_backbone="vgg", num_classes=a.num_classes, batch_size=a.batch, local_rank=local,
-                                audio_len=1.0, spec_min=-100, spec_max=100)
+                                audio_len=1.0, spec_min=-100, spec_max=100, allow_random_pvt=True)
     model = CAVP(50, None, num_classes=a.num_classes, args=hyp)
     model.load_state_dict(synth_state_dict({k: tuple(v.shape) for k, v in model.state_dict().items()}, seed=1))
     model.train().to(dev).set_compute_dtype(torch.bfloat16 if a.dtype == "bf16" else torch.float32)
@@ -67,7 +69,10 @@ def main():
     B = a.batch
     opt = None
     t0 = None
+    first = None
     for it in range(a.steps):
+        if a.fixed_batch:
+            g = torch.Generator().manual_seed(1234 + rank)      # the same batch every step
         image = torch.randn(B, 3, a.hw, a.hw, generator=g).to(dev)
         label = torch.randint(0, a.num_classes, (B, a.hw, a.hw), generator=g).to(dev)
         if front is not None:                                   # matched clips ‖ shuffled clips = 2B (cavp_model.py:181)
@@ -84,6 +89,8 @@ def main():
         if it == 1:                                             # skip the first two (allocation / warm-up) steps
             torch.cuda.synchronize()
             t0 = time.time()
+        if first is None:
+            first = float(loss.item())
         if rank == 0 and (it % 5 == 0 or it == a.steps - 1):
             print(f"iter {it:4d}  lr {sched(it):.3e}  loss {float(loss.item()):.4f}", flush=True)
     torch.cuda.synchronize()
@@ -91,6 +98,8 @@ def main():
         dt = (time.time() - t0) / (a.steps - 2)
         print(f"{B * world / dt:.1f} frames/s over {world} GPU(s) ({dt * 1e3:.1f} ms/step incl. host-side input generation, "
               f"eager launches, optimiser step)")
+    if rank == 0 and a.fixed_batch:
+        print(f"fixed batch: loss {first:.4f} -> {float(loss.item()):.4f} after {a.steps} steps")
     if world > 1:
         import torch.distributed as dist
         dist.destroy_process_group()
