@@ -148,6 +148,113 @@ __global__ __launch_bounds__(256) void attn_gate_bwd_kernel(const T* __restrict_
   }
 }
 
+// ---- 4-head variants (every CAVP configuration: 4 x 76 and 4 x 28 channels) ------------------------------------------------
+// A 16-lane DPP row owns one head: lane (g, i) holds the head's channel quads i and i + 16, so the four per-head dot products are
+// ONE row reduction (4 DPP steps) instead of `heads` masked 64-lane reductions (24 steps) per token row.
+__device__ __forceinline__ float row_sum16(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true));   // quad_perm [1,0,3,2]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, true));   // quad_perm [2,3,0,1]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, true));  // row_half_mirror
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xf, 0xf, true));  // row_mirror
+  return v;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void attn_gate4_kernel(const T* __restrict__ q, const T* __restrict__ k,
+                                                         const T* __restrict__ v, T* __restrict__ o,
+                                                         float* __restrict__ attn, int B, int Tn, int hd, float scale,
+                                                         long long q_rows) {
+  const int lane = threadIdx.x & 63, g = lane >> 4, i = lane & 15;
+  const int C = 4 * hd, qh = hd >> 2;
+  const bool ok0 = i < qh, ok1 = i + 16 < qh;
+  const int c0 = g * hd + 4 * i, c1 = c0 + 64;
+  const long long rows = (long long)B * Tn;
+  for (long long row = blockIdx.x * 4ll + (threadIdx.x >> 6); row < rows; row += (long long)gridDim.x * 4) {
+    const int b = (int)(row / Tn), t = (int)(row - (long long)b * Tn);
+    const T* qp = q + (size_t)(row >= q_rows ? row % q_rows : row) * C;   // q_batch < B: the query rows repeat
+    const T* kp = k + (size_t)b * C;
+    const T* vp = v + (size_t)b * C;
+    float q0[4] = {0.f, 0.f, 0.f, 0.f}, q1[4] = {0.f, 0.f, 0.f, 0.f}, k0[4] = {0.f, 0.f, 0.f, 0.f}, k1[4] = {0.f, 0.f, 0.f, 0.f};
+    float v0[4] = {0.f, 0.f, 0.f, 0.f}, v1[4] = {0.f, 0.f, 0.f, 0.f};
+    if (ok0) { Quad<T>::load(qp + c0, q0); Quad<T>::load(kp + c0, k0); Quad<T>::load(vp + c0, v0); }
+    if (ok1) { Quad<T>::load(qp + c1, q1); Quad<T>::load(kp + c1, k1); Quad<T>::load(vp + c1, v1); }
+    const float d = (q0[0] * k0[0] + q0[1] * k0[1] + q0[2] * k0[2] + q0[3] * k0[3]) +
+                    (q1[0] * k1[0] + q1[1] * k1[1] + q1[2] * k1[2] + q1[3] * k1[3]);
+    const float gt = 1.f / (1.f + expf(-row_sum16(d) * scale));
+    if (i == 0) attn[((size_t)b * 4 + g) * Tn + t] = gt;
+    T* op = o + (size_t)row * C;
+    if (ok0) {
+      const float r[4] = {gt * v0[0], gt * v0[1], gt * v0[2], gt * v0[3]};
+      Quad<T>::store(op + c0, r);
+    }
+    if (ok1) {
+      const float r[4] = {gt * v1[0], gt * v1[1], gt * v1[2], gt * v1[3]};
+      Quad<T>::store(op + c1, r);
+    }
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void attn_gate4_bwd_kernel(const T* __restrict__ dout, const T* __restrict__ q,
+                                                             const T* __restrict__ k, const T* __restrict__ v,
+                                                             const float* __restrict__ attn,
+                                                             const float* __restrict__ dattn, T* __restrict__ dq,
+                                                             float* __restrict__ dk, float* __restrict__ dv, int Tn, int hd,
+                                                             float scale, int tok_per_block, int q_batch,
+                                                             float* __restrict__ det_part) {
+  __shared__ float part[2][4][512];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, b = blockIdx.y, g = lane >> 4, i = lane & 15;
+  const int C = 4 * hd, qh = hd >> 2;
+  const bool ok0 = i < qh, ok1 = i + 16 < qh;
+  const int c0 = g * hd + 4 * i, c1 = c0 + 64;
+  float k0[4] = {0.f, 0.f, 0.f, 0.f}, k1[4] = {0.f, 0.f, 0.f, 0.f}, v0[4] = {0.f, 0.f, 0.f, 0.f}, v1[4] = {0.f, 0.f, 0.f, 0.f};
+  if (ok0) { Quad<T>::load(k + (size_t)b * C + c0, k0); Quad<T>::load(v + (size_t)b * C + c0, v0); }
+  if (ok1) { Quad<T>::load(k + (size_t)b * C + c1, k1); Quad<T>::load(v + (size_t)b * C + c1, v1); }
+  float adk0[4] = {0.f, 0.f, 0.f, 0.f}, adk1[4] = {0.f, 0.f, 0.f, 0.f}, adv0[4] = {0.f, 0.f, 0.f, 0.f}, adv1[4] = {0.f, 0.f, 0.f, 0.f};
+  const int t_begin = blockIdx.x * tok_per_block;
+  int t_end = t_begin + tok_per_block;
+  if (t_end > Tn) t_end = Tn;
+  for (int t = t_begin + wv; t < t_end; t += 4) {
+    const size_t row = ((size_t)b * Tn + t) * C;
+    const size_t qrow = ((size_t)(b % q_batch) * Tn + t) * C;   // q_batch < B: the query rows repeat
+    float d0[4] = {0.f, 0.f, 0.f, 0.f}, d1[4] = {0.f, 0.f, 0.f, 0.f}, q0[4] = {0.f, 0.f, 0.f, 0.f}, q1[4] = {0.f, 0.f, 0.f, 0.f};
+    if (ok0) { Quad<T>::load(dout + row + c0, d0); Quad<T>::load(q + qrow + c0, q0); }
+    if (ok1) { Quad<T>::load(dout + row + c1, d1); Quad<T>::load(q + qrow + c1, q1); }
+    const size_t ai = ((size_t)b * 4 + g) * Tn + t;
+    const float gt = attn[ai];
+    float sdot = row_sum16((d0[0] * v0[0] + d0[1] * v0[1] + d0[2] * v0[2] + d0[3] * v0[3]) +
+                           (d1[0] * v1[0] + d1[1] * v1[1] + d1[2] * v1[2] + d1[3] * v1[3]));
+    if (dattn) sdot += dattn[ai];
+    const float da = sdot * gt * (1.f - gt) * scale;
+    if (ok0) {
+      const float r[4] = {da * k0[0], da * k0[1], da * k0[2], da * k0[3]};
+      Quad<T>::store(dq + row + c0, r);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { adk0[e] += da * q0[e]; adv0[e] += gt * d0[e]; }
+    }
+    if (ok1) {
+      const float r[4] = {da * k1[0], da * k1[1], da * k1[2], da * k1[3]};
+      Quad<T>::store(dq + row + c1, r);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { adk1[e] += da * q1[e]; adv1[e] += gt * d1[e]; }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    if (ok0) { part[0][wv][c0 + e] = adk0[e]; part[1][wv][c0 + e] = adv0[e]; }
+    if (ok1) { part[0][wv][c1 + e] = adk1[e]; part[1][wv][c1 + e] = adv1[e]; }
+  }
+  __syncthreads();
+  for (int j = threadIdx.x; j < 2 * C; j += 256) {
+    const int st = j / C, c = j - st * C;
+    const float s = (part[st][0][c] + part[st][1][c]) + (part[st][2][c] + part[st][3][c]);
+    if (det_part)
+      det_part[((size_t)st * gridDim.x + blockIdx.x) * ((size_t)gridDim.y * C) + (size_t)b * C + c] = s;
+    else
+      atomicAdd((st == 0 ? dk : dv) + (size_t)b * C + c, s);
+  }
+}
+
 inline bool dt_ok(int dt) { return dt == CAVP_F32 || dt == CAVP_BF16; }
 inline bool shape_ok(int dtype, int heads, int hd, const void* a, const void* b, const void* c, const void* d) {
   const uintptr_t al = dtype == CAVP_F32 ? 15 : 7;
@@ -165,6 +272,13 @@ extern "C" int cavp_attn_gate(int32_t dtype, const void* q, const void* k, const
   long long nbl = ((long long)B * T + 3) / 4;
   if (nbl > 16384) nbl = 16384;
   hipStream_t s = (hipStream_t)stream;
+  if (heads == 4 && hd <= 128) {   // one DPP row per head
+    if (dtype == CAVP_F32)
+      attn_gate4_kernel<float><<<(int)nbl, 256, 0, s>>>((const float*)q, (const float*)k, (const float*)v, (float*)o, attn, B, T, hd, scale, q_rows);
+    else
+      attn_gate4_kernel<bf16_t><<<(int)nbl, 256, 0, s>>>((const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)o, attn, B, T, hd, scale, q_rows);
+    return hipGetLastError() == hipSuccess ? CAVP_OK : CAVP_ERR_LAUNCH;
+  }
   if (dtype == CAVP_F32)
     attn_gate_kernel<float><<<(int)nbl, 256, 0, s>>>((const float*)q, (const float*)k, (const float*)v, (float*)o, attn, B, T, heads, hd, scale, q_rows);
   else
@@ -190,7 +304,12 @@ extern "C" int cavp_attn_gate_bwd(int32_t dtype, const void* dout, const void* q
   bool det_err;
   float* det = cavp_det_scratch(gx, B * heads * hd, &det_err);
   if (det_err) return CAVP_ERR_WORKSPACE;
-  if (dtype == CAVP_F32)
+  if (heads == 4 && hd <= 128) {
+    if (dtype == CAVP_F32)
+      attn_gate4_bwd_kernel<float><<<dim3(gx, B), 256, 0, s>>>((const float*)dout, (const float*)q, (const float*)k, (const float*)v, attn, dattn, (float*)dq, dk, dv, T, hd, scale, tpb, q_batch, det);
+    else
+      attn_gate4_bwd_kernel<bf16_t><<<dim3(gx, B), 256, 0, s>>>((const bf16_t*)dout, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, attn, dattn, (bf16_t*)dq, dk, dv, T, hd, scale, tpb, q_batch, det);
+  } else if (dtype == CAVP_F32)
     attn_gate_bwd_kernel<float><<<dim3(gx, B), 256, 0, s>>>((const float*)dout, (const float*)q, (const float*)k, (const float*)v, attn, dattn, (float*)dq, dk, dv, T, heads, hd, scale, tpb, q_batch, det);
   else
     attn_gate_bwd_kernel<bf16_t><<<dim3(gx, B), 256, 0, s>>>((const bf16_t*)dout, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, attn, dattn, (bf16_t*)dq, dk, dv, T, heads, hd, scale, tpb, q_batch, det);

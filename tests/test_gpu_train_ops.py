@@ -198,10 +198,11 @@ def test_layernorm_bwd(rows, C, dt):
     _check(db, b.grad, dt, "ln dbeta", 1e-4, 1e-2)
 
 
+@pytest.mark.parametrize("H,hd", [(4, 76), (4, 28), (4, 128), (2, 64), (8, 32)], ids=["4x76", "4x28", "4x128", "2x64", "8x32"])
 @pytest.mark.parametrize("dt", DTYPES, ids=IDS)
-def test_attn_gate_bwd(dt):
+def test_attn_gate_bwd(dt, H, hd):
     ops, T = _mods()
-    B, Tn, H, hd = 3, 150, 4, 76
+    B, Tn = 3, 150
     q = _q(_rand(B, Tn, H * hd, seed=20), dt).requires_grad_(True)
     k = _q(_rand(B, H * hd, seed=21), dt).requires_grad_(True)
     v = _q(_rand(B, H * hd, seed=22), dt).requires_grad_(True)
