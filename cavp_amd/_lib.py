@@ -77,6 +77,7 @@ PROTOTYPES = {
     "cavp_act_bwd": (_i32, [_i32, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _vp]),
     "cavp_add": (_i32, [_i32, _vp, _vp, _vp, _i64, _vp]),
     "cavp_colsum": (_i32, [_i32, _vp, _i64, _i32, _i32, _vp, _vp]),
+    "cavp_colsum_groups": (_i32, [_i32, _vp, _i32, _i32, _i32, _i32, _vp, _vp]),
     "cavp_layernorm_bwd": (_i32, [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _vp]),
     "cavp_attn_gate_bwd": (_i32, [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _i32, _vp]),
     "cavp_maxpool_bwd_nhwc": (_i32, [_i32, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),

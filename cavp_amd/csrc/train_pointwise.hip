@@ -1448,6 +1448,54 @@ extern "C" int cavp_colsum(int32_t dtype, const void* x, int64_t rows, int32_t C
   return launch_col_reduce<2>(dtype, a, (hipStream_t)stream);
 }
 
+// out[g][c] += sum over the `rpg` rows of group g (the per-image bias gradient of the ASPP pooled branch: one group per image).
+// One workgroup per (group, 16 channel vectors): 16 row lanes x 16 vectors, LDS reduce, single owner per output -> no atomics.
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_groups_kernel(const T* __restrict__ x, float* __restrict__ out, int rpg, int C, int ld) {
+  constexpr int VE = VecT<T>::VE;
+  __shared__ float red[16][16 * VE + 1];
+  const int cg = threadIdx.x & 15, rl = threadIdx.x >> 4;
+  const int c0 = (blockIdx.y * 16 + cg) * VE;
+  const bool ok = c0 < C;
+  float acc[VE];
+#pragma unroll
+  for (int e = 0; e < VE; ++e) acc[e] = 0.f;
+  const T* xg = x + (size_t)blockIdx.x * rpg * ld;
+  if (ok)
+    for (int r = rl; r < rpg; r += 16) {
+      float v[VE];
+      VecT<T>::load(xg + (size_t)r * ld + c0, v);
+#pragma unroll
+      for (int e = 0; e < VE; ++e) acc[e] += v[e];
+    }
+#pragma unroll
+  for (int e = 0; e < VE; ++e) red[rl][cg * VE + e] = acc[e];
+  __syncthreads();
+  for (int i = threadIdx.x; i < 16 * VE; i += 256) {
+    const int c = blockIdx.y * 16 * VE + i;
+    if (c >= C) continue;
+    float sum = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) sum += red[k][i];
+    out[(size_t)blockIdx.x * C + c] += sum;
+  }
+}
+
+extern "C" int cavp_colsum_groups(int32_t dtype, const void* x, int32_t groups, int32_t rows_per_group, int32_t C, int32_t ldx,
+                                  float* out, void* stream) {
+  if (!x || !out || groups <= 0 || rows_per_group <= 0 || C <= 0 || ldx < C) return CAVP_ERR_BAD_ARG;
+  if (!dt_ok(dtype)) return CAVP_ERR_UNSUPPORTED;
+  const int VE = dtype == CAVP_F32 ? 4 : 8;
+  if (C % VE || ldx % VE) return CAVP_ERR_UNSUPPORTED;
+  if (!al16(x)) return CAVP_ERR_ALIGN;
+  const dim3 grid(groups, cdiv_h(C, 16 * VE));
+  if (dtype == CAVP_F32)
+    colsum_groups_kernel<float><<<grid, 256, 0, (hipStream_t)stream>>>((const float*)x, out, rows_per_group, C, ldx);
+  else
+    colsum_groups_kernel<bf16_t><<<grid, 256, 0, (hipStream_t)stream>>>((const bf16_t*)x, out, rows_per_group, C, ldx);
+  CHECK_LAUNCH();
+}
+
 extern "C" int cavp_maxpool_bwd_nhwc(int32_t dtype, const uint8_t* argmax, const void* dy, void* dx, int32_t N, int32_t H,
                                      int32_t W, int32_t C, int32_t k, int32_t stride, int32_t pad, void* stream) {
   const void* x = argmax;

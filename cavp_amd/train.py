@@ -408,9 +408,7 @@ class TrainPass:
                     self.acc_add(residual, g)
             if nbias is not None:
                 nb = self.zeros_f32(*nbias.t.shape)
-                g4 = _as4(g)
-                for i in range(g4.shape[0]):
-                    T.colsum(g4[i], nb[i])
+                T.colsum_groups(_as4(g), nb)      # one launch for all images (was one column-sum launch per image)
                 self.acc_add(nbias, nb)
             self.wgrad(p, x4, _as4(g))      # (+ the bias gradient: column sums of g taken inside the same kernel)
             if x.needs_grad:

@@ -300,6 +300,17 @@ def colsum(x, out) -> torch.Tensor:
     return out
 
 
+def colsum_groups(x, out) -> torch.Tensor:
+    """out[g] += column sums of x[g] for every leading index g in ONE launch (x: [G, ..., C] dense or channel-sliced, out f32 [G, C])."""
+    _need_gpu(x, out)
+    g = x.shape[0]
+    rows, c, ld = _rows(x)
+    if rows % g or out.dtype != torch.float32 or tuple(out.shape) != (g, c) or not out.is_contiguous():
+        raise _lib.CavpError("colsum_groups: x [G, ..., C] and a contiguous f32 [G, C] output required")
+    _check(_lib.load().cavp_colsum_groups(dtype_code(x.dtype), _ptr(x), g, rows // g, c, ld, _ptr(out), _s()), "cavp_colsum_groups")
+    return out
+
+
 def layernorm_bwd(dy, x, gamma, dx, dgamma, dbeta, eps: float) -> torch.Tensor:
     rows, c, ld_dy = _rows(dy)
     _, _, ld_x = _rows(x)

@@ -248,6 +248,10 @@ int cavp_act_bwd(int32_t dtype, const void* dy, const void* ref, void* dx, int64
 int cavp_add(int32_t dtype, const void* a, const void* b, void* out, int64_t n, void* stream);
 /* out[c] += sum_rows x[r][c]  (bias gradients; f32 atomics, caller zeroes) */
 int cavp_colsum(int32_t dtype, const void* x, int64_t rows, int32_t C, int32_t ldx, float* out, void* stream);
+/* out[g][c] += sum of rows g*rows_per_group .. (g+1)*rows_per_group - 1: the per-image bias gradient of the ASPP pooled branch
+ * (encoder_decoder.py:150-154) for all images in one launch.  Deterministic (one owner per output). */
+int cavp_colsum_groups(int32_t dtype, const void* x, int32_t groups, int32_t rows_per_group, int32_t C, int32_t ldx, float* out,
+                       void* stream);
 /* nn.LayerNorm backward; dgamma / dbeta are accumulated with f32 atomics (caller zeroes). */
 int cavp_layernorm_bwd(int32_t dtype, const void* dy, const void* x, const float* gamma, void* dx, float* dgamma,
                        float* dbeta, int32_t rows, int32_t C, int32_t ld_dy, int32_t ld_x, int32_t ld_dx, float eps,

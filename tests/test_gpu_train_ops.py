@@ -459,3 +459,16 @@ def test_training_entry_points_fail_loudly():
     finally:
         assert lib.cavp_set_deterministic(None, C.c_size_t(0)) == 0
     assert lib.cavp_set_deterministic(C.c_void_p(small.data_ptr() + 4), C.c_size_t(1 << 20)) != 0   # misaligned scratch
+
+
+@pytest.mark.parametrize("dt", DTYPES, ids=IDS)
+def test_colsum_groups(dt):
+    """Per-image column sums in one launch (the ASPP pooled branch's per-image bias gradient), accumulating, on a channel slice."""
+    ops, T = _mods()
+    G, H, W, C = 5, 14, 13, 256
+    x = _q(_rand(G, H, W, C + 16, seed=40), dt)
+    xd = x.to(dt).to(DEV)[..., 8:8 + C]
+    out = torch.full((G, C), 0.5, device=DEV)
+    T.colsum_groups(xd, out)
+    ref = x[..., 8:8 + C].double().sum((1, 2)).float() + 0.5
+    _check(out, ref, torch.float32, "colsum_groups", 1e-4, 1e-4)
