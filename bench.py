@@ -205,7 +205,10 @@ class KernelTimer:
 
 def measure_roofline(model, run_step, image, dtype_name, reps=3):
     from cavp_amd import ops, train_ops
+    import cavp_amd.train as _tr
     kt = KernelTimer().wrap(ops, train_ops)
+    side_was = _tr._SIDE_STREAM
+    _tr._SIDE_STREAM = False   # per-launch durations are taken with one stream: a co-running branch would inflate them
     try:
         with torch.no_grad():
             for _ in range(reps):
@@ -217,6 +220,7 @@ def measure_roofline(model, run_step, image, dtype_name, reps=3):
                 f.write(kt.per_layer(reps) + "\n")
     finally:
         kt.unwrap(ops)
+        _tr._SIDE_STREAM = side_was
     # dominant kernel = igemm_kernel: forward convs / linears (conv2d) + data gradients (conv2d_dgrad, same kernel)
     launches, ms, flops, nbytes = agg["conv2d"]
     if "conv2d_dgrad" in agg:
