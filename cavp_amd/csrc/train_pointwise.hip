@@ -1448,6 +1448,86 @@ extern "C" int cavp_colsum(int32_t dtype, const void* x, int64_t rows, int32_t C
   return launch_col_reduce<2>(dtype, a, (hipStream_t)stream);
 }
 
+// Per-tile (mean, M2) of 128-row tiles of a [rows][C] tensor in ONE pass (the tile is held in registers: sum -> mean -> centred
+// squares), in the layout the conv epilogue writes (ts[tile][C][2]), for BatchNorm inputs whose producer could not fuse the
+// statistics (split-K convs, the small-Cin stem, channel slices).  Replaces column sum -> mean -> centred column squares (two passes
+// over the tensor, four launches) by one pass + cavp_bn_finalize_tiles; equally cancellation-free.
+template <typename T>
+__global__ __launch_bounds__(256) void col_tile_stats_kernel(const T* __restrict__ x, float* __restrict__ ts, long long rows, int C,
+                                                             int ld) {
+  constexpr int VE = VecT<T>::VE, CW = 16 * VE;
+  __shared__ float red[16][CW + 1];
+  __shared__ float mean_s[CW];
+  const int cg = threadIdx.x & 15, rl = threadIdx.x >> 4;
+  const int c0 = (blockIdx.y * 16 + cg) * VE;
+  const bool ok = c0 < C;
+  const long long r0 = (long long)blockIdx.x * 128;
+  const int nb = (int)(rows - r0 < 128 ? rows - r0 : 128);
+  float v[8][VE];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int r = rl + 16 * j;
+    if (ok && r < nb) {
+      VecT<T>::load(x + (r0 + r) * ld + c0, v[j]);
+    } else {
+#pragma unroll
+      for (int e = 0; e < VE; ++e) v[j][e] = 0.f;
+    }
+  }
+  float acc[VE];
+#pragma unroll
+  for (int e = 0; e < VE; ++e) {
+    acc[e] = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[e] += v[j][e];
+    red[rl][cg * VE + e] = acc[e];
+  }
+  __syncthreads();
+  if (threadIdx.x < CW) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t += red[k][threadIdx.x];
+    mean_s[threadIdx.x] = t / (float)nb;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int e = 0; e < VE; ++e) {
+    const float m = mean_s[cg * VE + e];
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float d = (rl + 16 * j < nb) ? v[j][e] - m : 0.f;
+      q += d * d;
+    }
+    red[rl][cg * VE + e] = q;
+  }
+  __syncthreads();
+  if (threadIdx.x < CW) {
+    const int c = blockIdx.y * CW + threadIdx.x;
+    if (c < C) {
+      float q = 0.f;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) q += red[k][threadIdx.x];
+      *(float2*)(ts + ((size_t)blockIdx.x * C + c) * 2) = make_float2(mean_s[threadIdx.x], q);
+    }
+  }
+}
+
+extern "C" int cavp_col_tile_stats(int32_t dtype, const void* x, int64_t rows, int32_t C, int32_t ldx, float* tile_stats,
+                                   void* stream) {
+  if (!x || !tile_stats || rows <= 0 || C <= 0 || ldx < C) return CAVP_ERR_BAD_ARG;
+  if (!dt_ok(dtype) || rows > 0x7fffffff) return CAVP_ERR_UNSUPPORTED;
+  const int VE = dtype == CAVP_F32 ? 4 : 8;
+  if (C % VE || ldx % VE) return CAVP_ERR_UNSUPPORTED;
+  if (!al16(x) || ((uintptr_t)tile_stats & 7)) return CAVP_ERR_ALIGN;
+  const dim3 grid((unsigned)((rows + 127) / 128), cdiv_h(C, 16 * VE));
+  if (dtype == CAVP_F32)
+    col_tile_stats_kernel<float><<<grid, 256, 0, (hipStream_t)stream>>>((const float*)x, tile_stats, rows, C, ldx);
+  else
+    col_tile_stats_kernel<bf16_t><<<grid, 256, 0, (hipStream_t)stream>>>((const bf16_t*)x, tile_stats, rows, C, ldx);
+  CHECK_LAUNCH();
+}
+
 // out[g][c] += sum over the `rpg` rows of group g (the per-image bias gradient of the ASPP pooled branch: one group per image).
 // One workgroup per (group, 16 channel vectors): 16 row lanes x 16 vectors, LDS reduce, single owner per output -> no atomics.
 template <typename T>

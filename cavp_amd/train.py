@@ -472,44 +472,27 @@ class TrainPass:
             one, zero = self.empty((c,), torch.float32).fill_(1.0), self.zeros_f32(c)
             O.bn_fold(one, zero, bn.running_mean, bn.running_var, bn.eps, rstd, zero.clone())
             mean = bn.running_mean
-        elif z.tile_stats is not None and not sync:
-            # statistics came out of the producing conv's epilogue (per-tile mean / M2): just combine them
-            ts, tiles, rpt = z.tile_stats
+        elif not sync:
+            # per-tile (mean, M2) - out of the producing conv's epilogue, or (split-K convs, the small-Cin stem, channel slices of a
+            # concat buffer) from one pass over z - combined by Chan's formula: cancellation-free, also for the M = B rows of the
+            # ASPP pooled branch
+            ts, tiles, rpt = z.tile_stats if z.tile_stats is not None else T.col_tile_stats(z.t)
             count = rows
             T.bn_finalize_tiles(ts, tiles, rpt, rows, bn.weight.detach(), bn.bias.detach(), bn.eps, mom,
                                 bn.running_mean if track else None, bn.running_var if track else None, scale, shift,
                                 mean, rstd)
-        elif sync:
+        else:
             # SyncBatchNorm (main_vpo_mono.py:130): this rank's (mean, M2) -> ONE all-gather -> Chan combine over the ranks (the
             # same kernel that combines tiles; every rank holds `rows` samples).  Round 1 issued three all-reduces per layer.
             world = dist_world()
-            if z.tile_stats is not None:
-                ts, tiles, rpt = z.tile_stats
-                local = self.empty((c, 2), torch.float32)
-                T.bn_tiles_to_moments(ts, tiles, rpt, rows, local)
-            else:
-                s1 = self.zeros_f32(c)
-                T.colsum(z.t, s1)
-                m0 = T.scale_f32(s1, 1.0 / rows, self.empty((c,), torch.float32))
-                st = self.zeros_f32(2, c)
-                T.colstats(z.t, st[0], st[1], shift=m0)
-                local = torch.stack((m0, st[1]), dim=-1).contiguous()   # (mean, sum (x - mean)^2): data movement only
+            ts, tiles, rpt = z.tile_stats if z.tile_stats is not None else T.col_tile_stats(z.t)
+            local = self.empty((c, 2), torch.float32)
+            T.bn_tiles_to_moments(ts, tiles, rpt, rows, local)
             gathered = gather_bn_moments(local)
             count = rows * world
             T.bn_finalize_tiles(gathered, world, rows, count, bn.weight.detach(), bn.bias.detach(), bn.eps, mom,
                                 bn.running_mean if track else None, bn.running_var if track else None, scale, shift,
                                 mean, rstd)
-        else:
-            # two-pass statistics: sum -> mean, then centred second moment (cancellation-free)
-            s1 = self.zeros_f32(c)
-            T.colsum(z.t, s1)
-            count = rows
-            m0 = T.scale_f32(s1, 1.0 / count, self.empty((c,), torch.float32))
-            stats = self.zeros_f32(2, c)
-            T.colstats(z.t, stats[0], stats[1], shift=m0)
-            T.bn_finalize(stats[0], stats[1], count, bn.weight.detach(), bn.bias.detach(), bn.eps, mom,
-                          bn.running_mean if track else None, bn.running_var if track else None, scale, shift, mean,
-                          rstd, stat_shift=m0)
         if track and bn.num_batches_tracked is not None:
             self._nbt.append(bn.num_batches_tracked)
         y = out if out is not None else V(self.empty(z.t.shape, z.t.dtype))

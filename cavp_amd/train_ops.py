@@ -300,6 +300,16 @@ def colsum(x, out) -> torch.Tensor:
     return out
 
 
+def col_tile_stats(x) -> Tuple[torch.Tensor, int, int]:
+    """(tile_stats f32 [tiles, C, 2], tiles, 128): per-tile (mean, M2) of x viewed as [rows][C], one pass."""
+    _need_gpu(x)
+    rows, c, ld = _rows(x)
+    tiles = (rows + 127) // 128
+    ts = torch.empty((tiles, c, 2), dtype=torch.float32, device=x.device)
+    _check(_lib.load().cavp_col_tile_stats(dtype_code(x.dtype), _ptr(x), rows, c, ld, _ptr(ts), _s()), "cavp_col_tile_stats")
+    return ts, tiles, 128
+
+
 def colsum_groups(x, out) -> torch.Tensor:
     """out[g] += column sums of x[g] for every leading index g in ONE launch (x: [G, ..., C] dense or channel-sliced, out f32 [G, C])."""
     _need_gpu(x, out)

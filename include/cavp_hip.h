@@ -248,6 +248,9 @@ int cavp_act_bwd(int32_t dtype, const void* dy, const void* ref, void* dx, int64
 int cavp_add(int32_t dtype, const void* a, const void* b, void* out, int64_t n, void* stream);
 /* out[c] += sum_rows x[r][c]  (bias gradients; f32 atomics, caller zeroes) */
 int cavp_colsum(int32_t dtype, const void* x, int64_t rows, int32_t C, int32_t ldx, float* out, void* stream);
+/* BatchNorm batch statistics of a tensor whose producer could not fuse them: per-tile (mean, M2) of 128-row tiles in one pass,
+ * tile_stats f32 [ceil(rows / 128)][C][2] - the layout cavp_bn_finalize_tiles(tiles, rows_per_tile = 128) combines. */
+int cavp_col_tile_stats(int32_t dtype, const void* x, int64_t rows, int32_t C, int32_t ldx, float* tile_stats, void* stream);
 /* out[g][c] += sum of rows g*rows_per_group .. (g+1)*rows_per_group - 1: the per-image bias gradient of the ASPP pooled branch
  * (encoder_decoder.py:150-154) for all images in one launch.  Deterministic (one owner per output). */
 int cavp_colsum_groups(int32_t dtype, const void* x, int32_t groups, int32_t rows_per_group, int32_t C, int32_t ldx, float* out,

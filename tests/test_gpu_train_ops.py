@@ -472,3 +472,25 @@ def test_colsum_groups(dt):
     T.colsum_groups(xd, out)
     ref = x[..., 8:8 + C].double().sum((1, 2)).float() + 0.5
     _check(out, ref, torch.float32, "colsum_groups", 1e-4, 1e-4)
+
+
+@pytest.mark.parametrize("dt", DTYPES, ids=IDS)
+@pytest.mark.parametrize("rows,C", [(32, 256), (1000, 64), (6272, 1024), (130, 48)], ids=["pooled_B32", "ragged", "aspp_slice", "narrow"])
+def test_col_tile_stats(rows, C, dt):
+    """One-pass per-tile (mean, M2) of a channel slice + cavp_bn_finalize_tiles == mean / biased variance of the tensor, also for a
+    large common offset (the cancellation case) and the M = B rows of the ASPP pooled branch."""
+    ops, T = _mods()
+    if C % (8 if dt == torch.bfloat16 else 4):
+        pytest.skip("channel count must be a multiple of the 16-byte vector")
+    x = _q(_rand(rows, C + 16, seed=41) * 0.5 + 30.0, dt)
+    xd = x.to(dt).to(DEV)[:, 8:8 + C]
+    ts, tiles, rpt = T.col_tile_stats(xd)
+    assert rpt == 128 and tiles == (rows + 127) // 128
+    scale, shift, mean, rstd = (torch.empty(C, device=DEV) for _ in range(4))
+    T.bn_finalize_tiles(ts, tiles, rpt, rows, torch.ones(C, device=DEV), torch.zeros(C, device=DEV), 1e-5, 0.1, None, None, scale, shift,
+                        mean, rstd)
+    ref = x[:, 8:8 + C].double()
+    assert float((mean.cpu().double() - ref.mean(0)).abs().max()) <= 1e-4
+    var = ref.var(0, unbiased=False)
+    got_var = 1.0 / rstd.cpu().double() ** 2 - 1e-5
+    assert float(((got_var - var).abs() / var).max()) <= 2e-4
