@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Random model-level configurations (batch, image extent incl. odd sizes, classes, dilation flags): MI355X eval forward and training
-step (f32) against the CPU oracle.  GPU box only.  usage: python tools/fuzz_model.py [--cases 6] [--seed 0]"""
+step (f32) against the CPU oracle.  GPU box only.  usage: python tests/_fuzz_model.py [--cases 6] [--seed 0]"""
 import argparse
 import os
 import random

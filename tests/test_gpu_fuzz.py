@@ -22,7 +22,7 @@ def test_fuzz_conv(args):
 def test_fuzz_model_vs_oracle():
     """Random model-level configurations (odd image extents such as 33 x 112 or 70 x 81, 2 .. 71 classes, the dilation variants):
     eval forward within 1e-3 of the CPU oracle, training loss within 2e-4, every parameter gradient's cosine >= 0.97."""
-    r = subprocess.run([sys.executable, os.path.join(REPO, "tools", "fuzz_model.py"), "--cases", "3", "--seed", "5"], cwd=REPO,
+    r = subprocess.run([sys.executable, os.path.join(REPO, "tests", "_fuzz_model.py"), "--cases", "3", "--seed", "5"], cwd=REPO,
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=1200)
     tail = "\n".join(r.stdout.splitlines()[-8:])
     assert r.returncode == 0 and ", 0 bad" in r.stdout, tail
