@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py — frames/s of the CAVP hot path on MI355X (driver contract in the task statement).
 
-    python bench.py --gpus 1 --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W                  (N > 1 without a launcher: bench.py starts its own N ranks)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
 A "step" is one pass of the hot path (`CAVP.forward`) over one batch of B=32 synthetic frames
@@ -372,8 +372,33 @@ def cpu_baseline(sd, cfg, sample_batch):
                       f"same C1' model and synthetic inputs"}
 
 
+def _free_port() -> int:
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def self_launch(a) -> int:
+    """`python bench.py --gpus N` without a launcher (the reference spawns one process per GPU itself, main_vpo_mono.py:274-275
+    `mp.spawn`; engine/engine.py:50-54): re-run this command line under torch.distributed.run with N ranks on 127.0.0.1 and
+    pass the ranks' output through.  Returns the launcher's exit code."""
+    import subprocess
+    if os.environ.get("CAVP_BENCH_SHARE_GPU") != "1" and torch.cuda.is_available() and torch.cuda.device_count() < a.gpus:
+        print(f"[bench] --gpus {a.gpus} but this node has {torch.cuda.device_count()} GPU(s)", file=sys.stderr)
+        return 2
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(a))
     if a.no_token_fusion:
         import cavp_amd.train as _tr
         _tr._FUSE_TOKEN_PATH = False
@@ -383,6 +408,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        raise SystemExit(f"bench.py: --gpus {a.gpus} but the launcher started WORLD_SIZE={world} rank(s); they must agree")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
     # CAVP_BENCH_SHARE_GPU=1 (plumbing check on a 1-GPU box only): every rank uses cuda:0 and the collectives run on gloo
@@ -396,6 +423,8 @@ def main():
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=dev)
+        if dist.get_world_size() != a.gpus:
+            raise SystemExit(f"bench.py: process group of {dist.get_world_size()} rank(s) for --gpus {a.gpus}")
     if a.deterministic:
         from cavp_amd import _lib as _cl
         _cl.set_deterministic(True, dev)
@@ -490,6 +519,8 @@ def main():
                                      f"C1' (config_avss_binary shape): CAVP ResNet-50 OS16 + VGGish, eval forward, "
                                      f"B={B}/GPU, 224x224 RGB + 96x64 mel, num_classes=2, random-init (synthetic) weights")),
                        "global_batch": world * B, "per_gpu_batch": B, "parallelism": f"dp{world}",
+                       "ranks": dist.get_world_size() if world > 1 else 1,
+                       "collective_backend": (dist.get_backend() if world > 1 else None),
                        "launch": "eager" if a.no_graph else "hipGraph replay", "deterministic": bool(a.deterministic)},
         }
         if not a.no_roofline:

@@ -875,7 +875,13 @@ extern "C" int cavp_conv2d_tile_stats_layout(const cavp_conv_desc* d, int32_t* t
 
 extern "C" size_t cavp_conv2d_workspace_bytes(const cavp_conv_desc* d) {
   Plan pl = make_plan(d);
-  return pl.status == CAVP_OK ? pl.ws_bytes : 0;
+  if (pl.status != CAVP_OK) return 0;
+  size_t need = pl.ws_bytes;
+  if (tile_is_big(pl.tile_id)) {   // the launch re-plans without the 256x256 tile when an operand is not 16-byte aligned: that
+    Plan alt = make_plan(d, false);   // plan may split K
+    if (alt.status == CAVP_OK && alt.ws_bytes > need) need = alt.ws_bytes;
+  }
+  return need;
 }
 
 extern "C" int cavp_conv2d_nhwc(const cavp_conv_desc* d, const void* x, const void* w, const float* scale,

@@ -648,14 +648,18 @@ extern "C" int cavp_dwconv3x3_wgrad(int32_t dtype, const void* x, const void* dy
   if (!dt_ok(dtype) || C % 8) return CAVP_ERR_UNSUPPORTED;
   const long long total = (long long)N * H * W;
   const int gx = (C / 4 + 15) / 16;
-  int ppb = 256;
+  long long ppb = 256;
   while ((total + ppb - 1) / ppb * gx > 8192) ppb *= 2;
+  // deterministic mode (cavp_set_deterministic): ONE pixel split, i.e. one contribution per (channel, tap) - the atomics then
+  // have a single, ordered writer per address (slow: C / 64 workgroups; the mode is opt-in)
+  if (g_cavp_det.scratch) ppb = total;
+  if (ppb > 0x7fffffffll) return CAVP_ERR_UNSUPPORTED;
   const dim3 grid(gx, (unsigned)((total + ppb - 1) / ppb));
   hipStream_t s = (hipStream_t)stream;
   if (dtype == CAVP_F32)
-    dwconv3x3_wgrad_kernel<float><<<grid, 256, 0, s>>>((const float*)x, (const float*)dy, dw_c133, dbias, N, H, W, C, ppb);
+    dwconv3x3_wgrad_kernel<float><<<grid, 256, 0, s>>>((const float*)x, (const float*)dy, dw_c133, dbias, N, H, W, C, (int)ppb);
   else
-    dwconv3x3_wgrad_kernel<bf16_t><<<grid, 256, 0, s>>>((const bf16_t*)x, (const bf16_t*)dy, dw_c133, dbias, N, H, W, C, ppb);
+    dwconv3x3_wgrad_kernel<bf16_t><<<grid, 256, 0, s>>>((const bf16_t*)x, (const bf16_t*)dy, dw_c133, dbias, N, H, W, C, (int)ppb);
   CHECK_LAUNCH();
 }
 

@@ -144,7 +144,7 @@ def draw_drop_path_scales(bb, B: int, device) -> List[Optional[torch.Tensor]]:
     """One f32 [B] factor (mask / keep) per residual branch, in forward order (attention, MLP of every block); None where
     the block's probability is 0 or the backbone is in eval mode.  Drawn like timm 0.4.9's drop_path - `floor(keep +
     torch.rand((B, 1, 1)))`, one draw per branch from the default CPU generator - then moved in ONE copy into a persistent
-    device buffer (`bb._dp_buf`).  While a hipGraph is being captured nothing is drawn: the graph reads that buffer, and
+    device buffer (`bb._dp_buf`); an eager pass works on a private clone of it.  While a hipGraph is being captured nothing is drawn: the graph reads that buffer, and
     `CAVP.capture_train_step`'s replay() refreshes it before every launch (refresh_drop_path)."""
     probs = [blk.drop_prob for i in range(4) for blk in getattr(bb, f"block{i + 1}") for _ in range(2)]
     if not bb.training or not any(probs):
@@ -162,9 +162,15 @@ def draw_drop_path_scales(bb, B: int, device) -> List[Optional[torch.Tensor]]:
                 keep = 1.0 - p
                 rows.append((keep + torch.rand((B, 1, 1), dtype=torch.float32)).floor_().view(B) / keep)
         buf.copy_(torch.stack(rows))
+        # an eager pass gets its OWN copy of the masks: its backward closures may run after a later forward (two forwards before
+        # one backward, gradient accumulation with a deferred backward) has redrawn the persistent buffer.  Only a captured
+        # graph reads the persistent buffer itself (replay() refreshes it before every launch).
+        use = buf.clone()
+    else:
+        use = buf
     out, k = [], 0
     for p in probs:
-        out.append(buf[k] if p > 0 else None)
+        out.append(use[k] if p > 0 else None)
         k += 1 if p > 0 else 0
     return out
 

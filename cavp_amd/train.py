@@ -513,7 +513,7 @@ class TrainPass:
             yb = y.t if (residual is not None or _BN_BWD_READ_Y) else None
             T.bn_act_bwd_reduce(dy, yb, z.t, mean, rstd, act, sums[0], sums[1], fwd_scale=scale, fwd_shift=shift)
             local = sums
-            if sync:
+            if sync and not frozen:   # (frozen statistics: dz has no batch-mean terms, nothing to exchange)
                 # SyncBatchNorm: dz uses the GLOBAL sums / count, the affine gradients stay the LOCAL sums (DDP
                 # reduces them with every other parameter gradient) - same split as torch's SyncBatchNorm backward
                 import torch.distributed as dist
