@@ -43,8 +43,13 @@ def parse():
     ap.add_argument("--mode", choices=["train", "eval"], default="train",
                     help="train = forward_train + CE + backward (+ gradient all-reduce when N > 1): the BASELINE.json "
                          "metric; eval = inference forward only")
-    ap.add_argument("--config", choices=["c1p", "c4"], default="c1p",
-                    help="c1p = ResNet-50 224x224 (the BASELINE metric); c4 = PVTv2-B5 512x512 (config #4; not the BASELINE metric)")
+    ap.add_argument("--config", choices=["c1p", "c1", "c4"], default="c1p",
+                    help="c1p = ResNet-50 224x224 OS16, 2 classes (config_avss_binary shape: the BASELINE metric's default); c1 = the same "
+                         "model in BASELINE config #1's VPO-SS plumbing (OS8: layer3 / layer4 / ASPP at 28x28, 22 classes); "
+                         "c4 = PVTv2-B5 512x512 (config #4; not the BASELINE metric)")
+    ap.add_argument("--pmc", action="store_true",
+                    help="measure roofline.traffic live: two extra rocprofv3 --pmc passes of this command (FETCH_SIZE, WRITE_SIZE) "
+                         "through tools/pmc_traffic.py; default: the committed profiles/ figure, labelled as such")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
     ap.add_argument("--split-graph", action="store_true",
                     help="force the two-graph replay of the data-parallel path (cut where the early gradients are final) on one GPU")
@@ -53,6 +58,7 @@ def parse():
     ap.add_argument("--deterministic", action="store_true", help="opt-in bit-reproducible reductions (cavp_set_deterministic)")
     ap.add_argument("--no-token-fusion", action="store_true", help="A/B: GELU as a separate pass, duplicated token tensors copied")
     ap.add_argument("--no-side-stream", action="store_true", help="A/B: the audio encoder on the main stream instead of a second one")
+    ap.add_argument("--no-group-wgrad", action="store_true", help="A/B: one weight-gradient launch (+ slab reduce) per layer instead of grouped launches")
     ap.add_argument("--no-f32", action="store_true", help="skip the secondary f32 (parity path) training-step measurement")
     ap.add_argument("--cpu-sample-batch", type=int, default=8)
     return ap.parse_args()
@@ -61,6 +67,8 @@ def parse():
 def model_cfg(name="c1p"):
     if name == "c4":   # config_avss.py shape: PVTv2-B5, 512x512, 71 classes
         return dict(C=71, lds=[False, False, False], hw=(512, 512), seg_model="PVT")
+    if name == "c1":   # C1: config_vpo_ss.py plumbing at 224x224 - OS8 ([False, True, True]), 22 classes
+        return dict(C=22, lds=[False, True, True], hw=(224, 224), seg_model="DeepLabV3Plus")
     # C1' (SURVEY.md §8d): config_avss_binary.py shape — 224x224, OS16, VGGish audio, num_classes=2
     return dict(C=2, lds=[False, False, False], hw=(224, 224), seg_model="DeepLabV3Plus")
 
@@ -90,6 +98,9 @@ def live_taps(h_in, w_in, h_out, w_out, kh, kw, stride, pad, dil):
 # x 3 (forward: every activation written once and read once; backward: every saved activation read once, every gradient
 # written once and read once; weights and their f32 gradients are < 3 % of that and are left out).
 FUSED_MIN_MB_PER_FRAME_BF16 = {"train": 147.4 * (57.8 / 39.41) * 3.0, "eval": 147.4}
+# C1 (OS8, 22 classes): 221.9 MB per frame; its train-mode forward adds the same 18.39 GFLOP of 2B work
+# (audio, projector, fusion, head) to 82.75 GFLOP
+FUSED_MIN_MB_PER_FRAME_BF16_C1 = {"train": 221.9 * ((82.75 + 57.8 - 39.41) / 82.75) * 3.0, "eval": 221.9}
 
 
 class KernelTimer:
@@ -120,7 +131,7 @@ class KernelTimer:
             self._orig[(ops_mod, name)] = fn
             setattr(ops_mod, name, self._timed(name, fn))
         if train_mod is not None:
-            for name in ("conv2d_dgrad", "conv2d_wgrad", "colstats", "colsum", "scale_shift_act", "bn_act_bwd_reduce",
+            for name in ("conv2d_dgrad", "conv2d_wgrad", "conv2d_wgrad_group", "colstats", "colsum", "scale_shift_act", "bn_act_bwd_reduce",
                          "bn_act_bwd_apply", "act_bwd", "add", "layernorm_bwd", "attn_gate_bwd", "maxpool_bwd",
                          "bilinear_bwd", "bilinear_bwd_from_nchw", "bcast_add", "ce_loss", "upsample_ce_head", "smallcin_wgrad",
                          "unpack_weight_grad", "pack_weight_dgrad"):
@@ -155,6 +166,12 @@ class KernelTimer:
                     m_dy = t1.shape[0] * t1.shape[1] * t1.shape[2]
                     flops = 2 * m_dy * t1.shape[3] * t0.shape[3] * kk
                     nbytes = (t0.numel() + t1.numel()) * es + t2.numel() * 4
+            if name == "conv2d_wgrad_group":   # one launch for up to 16 layers: sum over its jobs
+                for j in a[0]:
+                    t0, t1 = j["x"], j["dy"]
+                    kk = live_taps(t0.shape[1], t0.shape[2], t1.shape[1], t1.shape[2], j["kh"], j["kw"], j["stride"], j["pad"], j["dil"])
+                    flops += 2 * t1.shape[0] * t1.shape[1] * t1.shape[2] * t1.shape[3] * t0.shape[3] * kk
+                    nbytes += (t0.numel() + t1.numel()) * t0.element_size() + j["dw"].numel() * 4
             if name == "conv2d":
                 x, w, out = a[0], a[1], a[2]
                 es = x.element_size()
@@ -168,6 +185,8 @@ class KernelTimer:
             desc = ""
             if name in ("conv2d_dgrad", "conv2d_wgrad"):
                 desc = f"{tuple(a[0].shape)} {tuple(a[1].shape)} -> {tuple(a[2].shape)} k{k.get('kh', 1)} s{k.get('stride', 1)} d{k.get('dil', 1)}"
+            if name == "conv2d_wgrad_group":
+                desc = f"{len(a[0])} weight gradients: " + " ".join(f"{tuple(j['dw'].shape)}" for j in a[0])
             if name == "conv2d":
                 desc = (f"x{tuple(a[0].shape)} -> y{tuple(a[2].shape)} k{k.get('kh', 1)} s{k.get('stride', 1)} "
                         f"d{k.get('dil', 1)}")
@@ -203,7 +222,7 @@ class KernelTimer:
         return sum(max(fl / peak_flops, nb / peak_bytes) for name, _, _, fl, nb, _ in self.records if name in names) * 1e3
 
 
-def measure_roofline(model, run_step, image, dtype_name, reps=3):
+def measure_roofline(model, run_step, image, dtype_name, reps=3, config="c1p", live_pmc=False):
     from cavp_amd import ops, train_ops
     import cavp_amd.train as _tr
     kt = KernelTimer().wrap(ops, train_ops)
@@ -246,15 +265,25 @@ def measure_roofline(model, run_step, image, dtype_name, reps=3):
     roof["intensity_flop_per_byte"] = round(flops / max(nbytes, 1), 1)
     roof["ridge_flop_per_byte"] = round(ridge, 1)
     traffic = None
-    tname = f"traffic_{dtype_name}.json" if not getattr(model, "training", False) else f"traffic_train_{dtype_name}.json"
-    tpath = next((q for q in (os.path.join(REPO, "profiles", r + tname) for r in ("r02_", "r01_")) if os.path.exists(q)), "")
-    if tpath:  # PMC counters cannot be read from inside the process: measured with rocprofv3 --pmc
-        with open(tpath) as f:
-            tj = json.load(f)
-        if tj.get("batch") == image.shape[0] and tj.get("dtype") == dtype_name:
-            traffic = {"hbm_bytes_per_step": tj["hbm_bytes_per_step"], "hbm_bytes_per_launch": tj["hbm_bytes_per_launch"],
-                       "all_kernels_hbm_bytes_per_step": tj.get("all_kernels_hbm_bytes_per_step"),
-                       "vs_algorithmic": round(tj["hbm_bytes_per_step"] / nbytes, 3), "source": "profiles/" + os.path.basename(tpath)}
+    mode_name = "train" if getattr(model, "training", False) else "eval"
+    tj = None
+    if live_pmc:   # two rocprofv3 --pmc passes of this very command (tools/pmc_traffic.py); PMC counters cannot be read in-process
+        sys.path.insert(0, os.path.join(REPO, "tools"))
+        import pmc_traffic
+        tj = pmc_traffic.measure(mode_name, config=config, batch=image.shape[0], dtype=dtype_name)
+        tsrc = "live: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (tools/pmc_traffic.py)"
+    else:
+        cname = "" if config == "c1p" else config + "_"
+        tname = f"traffic_{cname}{dtype_name}.json" if mode_name == "eval" else f"traffic_{cname}train_{dtype_name}.json"
+        tpath = next((q for q in (os.path.join(REPO, "profiles", r + tname) for r in ("r03_", "r02_", "r01_")) if os.path.exists(q)), "")
+        if tpath:
+            with open(tpath) as f:
+                tj = json.load(f)
+            tsrc = "profiles/" + os.path.basename(tpath) + " (committed measurement, not taken in this run; --pmc measures it live)"
+    if tj is not None and tj.get("batch") == image.shape[0] and tj.get("dtype") == dtype_name:
+        traffic = {"hbm_bytes_per_step": tj["hbm_bytes_per_step"], "hbm_bytes_per_launch": tj["hbm_bytes_per_launch"],
+                   "all_kernels_hbm_bytes_per_step": tj.get("all_kernels_hbm_bytes_per_step"),
+                   "vs_algorithmic": round(tj["hbm_bytes_per_step"] / nbytes, 3), "source": tsrc}
     roof.update({
         "traffic": traffic,
         "kernel": "igemm_kernel (cavp_conv2d_nhwc: all conv / linear launches of one step)",
@@ -272,8 +301,8 @@ def measure_roofline(model, run_step, image, dtype_name, reps=3):
         "other_kernels_ms": {k: round(v[1] / reps, 3) for k, v in agg.items() if k not in ("conv2d", "conv2d_dgrad")},
     })
     step_flops = flops
-    if "conv2d_wgrad" in agg:
-        wl, wms, wf, wb = agg["conv2d_wgrad"]
+    if "conv2d_wgrad" in agg or "conv2d_wgrad_group" in agg:
+        wl, wms, wf, wb = (sum(agg[k][i] for k in ("conv2d_wgrad", "conv2d_wgrad_group") if k in agg) for i in range(4))
         wms /= reps
         step_flops += wf // reps
         roof["wgrad_kernel"] = {"launches_per_step": wl // reps, "ms_per_step": round(wms, 3),
@@ -320,8 +349,10 @@ def _timed_iters(fn, budget_s, min_iters, max_iters, warm=True):
 
 
 def cpu_baseline_train(sd, cfg, sample_batch):
-    """Oracle forward_train + CE + autograd backward on the host cores: bounded sample, one warm-up + >= 5 timed iterations on
-    all physical cores, plus a single-thread figure on a smaller batch."""
+    """Oracle forward_train + CE + autograd backward on the host cores, bounded sample.  torch's CPU convolutions do not scale
+    to a whole two-socket box on this model (round 2 measured 128 threads at 1.1 frames/s against 0.9 on ONE), so the thread
+    count is swept - one timed step each at {16, 32, 64, all cores} - and the best count is then timed properly (median of
+    >= 3 further steps).  `cores` = the threads of the reported figure; the sweep and a single-thread figure travel with it."""
     from cavp_amd.synth import synth_inputs
     from oracle import cavp_oracle as O
     cores, cpu_model, sockets = _host_cpu()
@@ -339,18 +370,30 @@ def cpu_baseline_train(sd, cfg, sample_batch):
             O.ce_loss_train(out, label, batch).backward()
         return step
 
+    step = make(sample_batch)
     torch.set_num_threads(cores)
-    n, secs, med = _timed_iters(make(sample_batch), budget_s=18.0, min_iters=5, max_iters=12)
+    step()   # warm-up (allocator, oneDNN primitive caches)
+    sweep = {}
+    for nt in sorted({t for t in (16, 32, 64, cores) if t <= cores}):
+        torch.set_num_threads(nt)
+        t0 = time.perf_counter()
+        step()
+        sweep[nt] = time.perf_counter() - t0
+    best_nt = min(sweep, key=sweep.get)
+    torch.set_num_threads(best_nt)
+    n, secs, med = _timed_iters(step, budget_s=12.0, min_iters=3, max_iters=8, warm=False)
     torch.set_num_threads(1)
     # (B = 2 is the smallest batch the reference's training step accepts: the ASPP image-pooling BatchNorm sees B values per channel)
-    n1, secs1, med1 = _timed_iters(make(2), budget_s=8.0, min_iters=1, max_iters=2, warm=False)
+    n1, secs1, med1 = _timed_iters(make(2), budget_s=6.0, min_iters=1, max_iters=2, warm=False)
     torch.set_num_threads(cores)
-    return {"value": round(sample_batch / med, 2), "unit": "frames/s", "cores": cores, "kind": "port",
-            "cpu_model": cpu_model, "sockets": sockets, "iterations": n, "warmup_iterations": 1,
+    return {"value": round(sample_batch / med, 2), "unit": "frames/s", "cores": best_nt, "kind": "port",
+            "cpu_model": cpu_model, "sockets": sockets, "physical_cores": cores, "iterations": n, "warmup_iterations": 1,
+            "thread_sweep_frames_per_s": {str(k): round(sample_batch / v, 2) for k, v in sorted(sweep.items())},
             "single_thread": {"value": round(2.0 / med1, 3), "unit": "frames/s", "cores": 1, "iterations": n1,
                               "sample": "B=2 frames (audio 4), same step, no warm-up"},
-            "sample": f"median of {n} x (forward_train + CE + backward) of B={sample_batch} frames (audio {2 * sample_batch}) after one "
-                      f"warm-up, fp32, torch CPU autograd over the oracle ({cores} threads), same C1' model and synthetic inputs"}
+            "sample": f"median of {n} x (forward_train + CE + backward) of B={sample_batch} frames (audio {2 * sample_batch}) on {best_nt} "
+                      f"threads (the best of a one-step sweep over {sorted(sweep)} threads, after one warm-up step), fp32, torch CPU "
+                      f"autograd over the oracle, same model and synthetic inputs"}
 
 
 def cpu_baseline(sd, cfg, sample_batch):
@@ -405,6 +448,9 @@ def main():
     if a.no_side_stream:
         import cavp_amd.train as _tr
         _tr._SIDE_STREAM = False
+    if a.no_group_wgrad:
+        import cavp_amd.train as _tr
+        _tr._GROUP_WGRAD = False
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -500,6 +546,8 @@ def main():
 
     if rank == 0:
         value = world * B * a.steps / elapsed
+        c1name = ("C1 (config_vpo_ss plumbing at 224x224): CAVP ResNet-50 OS8 + VGGish" if a.config == "c1" else
+                  "C1' (config_avss_binary shape): CAVP ResNet-50 OS16 + VGGish")
         line = {
             "metric": (f"frames/sec end-to-end CAVP fwd+bwd, B={B} {cfg['hw'][0]}x{cfg['hw'][1]}" if train else
                        f"frames/sec end-to-end CAVP forward (inference), B={B} {cfg['hw'][0]}x{cfg['hw'][1]}"),
@@ -509,28 +557,28 @@ def main():
             "config": {"workload": (f"C4 (config_avss shape): CAVP PVTv2-B5 (DropPath 0.1) + VGGish, training step = forward_train "
                                     f"({B} images + {2 * B} audio clips per GPU) + cross-entropy + full backward, 512x512 RGB + "
                                     f"96x64 mel, num_classes=71, random-init (synthetic) weights" if (train and a.config == "c4") else
-                                    f"C1' (config_avss_binary shape): CAVP ResNet-50 OS16 + VGGish, training step = "
+                                    f"{c1name}, training step = "
                                     f"forward_train (batch-stat BN, {B} images + {2 * B} audio clips per GPU) + cross-entropy + "
                                     f"full backward" + (" + gradient all-reduce over RCCL in two pieces, the first overlapped with the backbone backward" if world > 1 else "") +
-                                    ", 224x224 RGB + 96x64 mel, num_classes=2, random-init (synthetic) weights"
+                                    f", 224x224 RGB + 96x64 mel, num_classes={cfg['C']}, random-init (synthetic) weights"
                                     if train else
                                     (f"C4 (config_avss shape): CAVP PVTv2-B5 + VGGish, eval forward, B={B}/GPU, 512x512 RGB + 96x64 "
                                      f"mel, num_classes=71, random-init (synthetic) weights" if a.config == "c4" else
-                                     f"C1' (config_avss_binary shape): CAVP ResNet-50 OS16 + VGGish, eval forward, "
-                                     f"B={B}/GPU, 224x224 RGB + 96x64 mel, num_classes=2, random-init (synthetic) weights")),
+                                     f"{c1name}, eval forward, "
+                                     f"B={B}/GPU, 224x224 RGB + 96x64 mel, num_classes={cfg['C']}, random-init (synthetic) weights")),
                        "global_batch": world * B, "per_gpu_batch": B, "parallelism": f"dp{world}",
                        "ranks": dist.get_world_size() if world > 1 else 1,
                        "collective_backend": (dist.get_backend() if world > 1 else None),
                        "launch": "eager" if a.no_graph else "hipGraph replay", "deterministic": bool(a.deterministic)},
         }
         if not a.no_roofline:
-            roof = measure_roofline(model, run_step_local, image, a.dtype)
+            roof = measure_roofline(model, run_step_local, image, a.dtype, config=a.config, live_pmc=a.pmc)
             step_gflop, meas_bytes = roof.pop("_step_gflop"), roof.pop("_measured_step_bytes")
             ms_step = elapsed / a.steps * 1e3
-            if a.config == "c1p" and a.dtype == "bf16":
+            if a.config in ("c1p", "c1") and a.dtype == "bf16":
                 # the WHOLE step against both roofs (north_star: "fraction of the conv-bound HBM roofline"): algorithmic FLOPs of
                 # every conv / linear launch incl. weight gradients, and the perfectly-fused byte minimum
-                min_gb = FUSED_MIN_MB_PER_FRAME_BF16["train" if train else "eval"] * B / 1e3
+                min_gb = (FUSED_MIN_MB_PER_FRAME_BF16 if a.config == "c1p" else FUSED_MIN_MB_PER_FRAME_BF16_C1)["train" if train else "eval"] * B / 1e3
                 roof["step"] = {
                     "bound": "hbm", "ms_per_step": round(ms_step, 3),
                     "algorithmic_gflop": round(step_gflop, 1), "fused_min_gb": round(min_gb, 2),
@@ -540,7 +588,7 @@ def main():
                     "measured_vs_fused_min": round(meas_bytes / 1e9 / min_gb, 2) if meas_bytes else None,
                 }
             line["roofline"] = roof
-        if train and a.dtype == "bf16" and a.config == "c1p" and world == 1 and not a.no_f32:
+        if train and a.dtype == "bf16" and a.config in ("c1p", "c1") and world == 1 and not a.no_f32:
             # the same step on the f32 parity path (every kernel within 1e-3 of the reference, tests/): a throughput at the
             # north-star tolerance next to the bf16 headline
             del step
@@ -560,8 +608,8 @@ def main():
             line["f32_parity_path"] = {"value": round(B / ms32 * 1e3, 2), "unit": "frames/s", "ms_per_step": round(ms32, 3), "steps": 5,
                                        "dtype": "f32", "note": "same training step, exact-f32 MFMA kernels (logits within 1e-3 of the reference)"}
         if world == 1 and not a.no_cpu_baseline:
-            if a.config == "c1p":
-                line["cpu_baseline"] = (cpu_baseline_train(sd, cfg, max(2, a.cpu_sample_batch // 2)) if train
+            if a.config in ("c1p", "c1"):
+                line["cpu_baseline"] = (cpu_baseline_train(sd, cfg, max(2, a.cpu_sample_batch)) if train
                                         else cpu_baseline(sd, cfg, a.cpu_sample_batch))
         print(json.dumps(line), flush=True)
     if world > 1:

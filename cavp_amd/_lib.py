@@ -15,7 +15,8 @@ LIB_PATH = os.path.join(HERE, "libcavp_hip.so")
 
 F32, BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_LEAKY, ACT_GELU = 0, 1, 2, 3
-ABI_VERSION = 6
+ABI_VERSION = 7
+WGRAD_GROUP_MAX = 16   # CAVP_WGRAD_GROUP_MAX
 
 
 class CavpError(RuntimeError):
@@ -27,6 +28,11 @@ class ConvDesc(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "dtype", "N", "H", "W", "Cin", "ldx", "Cout", "ldy", "KH", "KW", "stride", "pad", "dil", "ldr", "act",
         "splitk", "tile", "up", "Ho", "Wo", "stride_w", "dw_oihw", "dw_overwrite", "res_rows", "aux_mode", "ld_aux")]
+
+
+class WgradJob(C.Structure):
+    """struct cavp_wgrad_job (include/cavp_hip.h)."""
+    _fields_ = [("desc", ConvDesc), ("x", C.c_void_p), ("dy", C.c_void_p), ("dw", C.c_void_p), ("dbias", C.c_void_p)]
 
 
 _vp, _i32, _i64, _f32, _sz = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_size_t
@@ -57,6 +63,8 @@ PROTOTYPES = {
     # ---- training side ----
     "cavp_conv2d_wgrad_workspace_bytes": (_sz, [C.POINTER(ConvDesc)]),
     "cavp_conv2d_wgrad_nhwc": (_i32, [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "cavp_conv2d_wgrad_group_workspace_bytes": (_sz, [_vp, _i32]),
+    "cavp_conv2d_wgrad_group": (_i32, [_vp, _i32, _vp, _sz, _vp]),
     "cavp_pack_weight_dgrad": (_i32, [_i32, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "cavp_pack_weights_multi": (_i32, [_i32, _vp, _i32, _vp]),
     "cavp_optimizer_blocks": (_i32, [C.c_int64]),

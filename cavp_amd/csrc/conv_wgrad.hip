@@ -41,12 +41,27 @@ struct WgradParams {
   float* dbias;        // optional: dbias[co] += sum_pix dY[pix][co] (bias gradient), taken from the dY tiles streamed anyway
   float* bias_slabs;   // ksplit > 1: [ksplit][Cout] partial column sums
   float* slabs;        // ksplit > 1: per-split partial gradients [ksplit][Cout][taps][Cin] (plain stores, then reduced)
+  int red_zg;          // grouped launches: split groups per workgroup of this job's slab reduce (1, 2, 4, 8, 16)
+  int pad_;
 };
+
+// Kernel-argument block of a grouped launch (cavp_conv2d_wgrad_group): up to CAVP_WGRAD_GROUP_MAX independent weight gradients
+// walked by ONE grid.  Logical workgroup b belongs to job j with blk_end[j-1] <= b < blk_end[j]; the slab reduces of the jobs
+// that split their pixel range form a second grouped launch (red_end).  The whole block travels as kernel arguments (< 4 KiB),
+// so a grouped launch is hipGraph-capturable like any other and needs no device-side table.
+struct WgradGroupArgs {
+  int njobs;
+  int blk_end[CAVP_WGRAD_GROUP_MAX];
+  int red_end[CAVP_WGRAD_GROUP_MAX];
+  WgradParams job[CAVP_WGRAD_GROUP_MAX];
+};
+static_assert(sizeof(WgradGroupArgs) <= 4096, "kernel-argument segment");
 
 typedef short s16x4_t __attribute__((ext_vector_type(4)));
 
+// One logical workgroup `bid` of one weight gradient (shared by the single and the grouped launch).
 template <typename T, int BK, bool BIAS>   // BK = pixel rows per stage; BIAS: also the bias gradient (column sums of dY) (64: two 64 KiB workgroups per CU; 32: four 32 KiB ones)
-__global__ __launch_bounds__(256, (BK == 32 ? 4 : 2)) void wgrad_kernel(const WgradParams p) {
+__device__ __forceinline__ void wgrad_tile(const WgradParams& p, const int bid, char* smem) {
   constexpr int ES = (int)sizeof(T);
   constexpr int TCH = 256 / ES;      // channels per tile row (256 bytes)
   constexpr int NI = BK / 16;        // DMA instructions per operand per thread and stage
@@ -55,10 +70,8 @@ __global__ __launch_bounds__(256, (BK == 32 ? 4 : 2)) void wgrad_kernel(const Wg
   constexpr int MB = WT / 16;        // 16x16 blocks per wave edge
   constexpr unsigned kOOB = 0x80000000u;
 
-  extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
-  const int bid = xcd_remap(blockIdx.x, gridDim.x);
   // (multiply + shift: integer division is a ~40-instruction VALU sequence even for wave-uniform values)
   const int b1 = fast_div(bid, p.dv_co[0], p.dv_co[1]), tco = bid - b1 * p.tiles_co;
   const int b2 = fast_div(b1, p.dv_ci[0], p.dv_ci[1]), tci = b1 - b2 * p.tiles_ci;
@@ -139,7 +152,7 @@ __global__ __launch_bounds__(256, (BK == 32 ? 4 : 2)) void wgrad_kernel(const Wg
 
   // bias gradient: the workgroups of the first ci tile and first live tap see every dY element exactly once; their
   // waves with wci0 == 0 add up the dY fragments they load for the MFMAs anyway (no extra pass over dY).
-  const bool do_bias = BIAS && tci == 0 && ti == 0 && (wave & 1) == 0;
+  const bool do_bias = BIAS && p.dbias != nullptr && tci == 0 && ti == 0 && (wave & 1) == 0;
   float bsum[MB];
 #pragma unroll
   for (int b = 0; b < MB; ++b) bsum[b] = 0.f;
@@ -271,20 +284,37 @@ __global__ __launch_bounds__(256, (BK == 32 ? 4 : 2)) void wgrad_kernel(const Wg
   }
 }
 
+template <typename T, int BK, bool BIAS>
+__global__ __launch_bounds__(256, (BK == 32 ? 4 : 2)) void wgrad_kernel(const WgradParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  wgrad_tile<T, BK, BIAS>(p, xcd_remap(blockIdx.x, gridDim.x), smem);
+}
+
+// Grouped launch: the logical workgroups of up to 16 weight gradients in one grid.  The backward of a stage of small layers
+// (layer3: 19 convs on 6272 pixels) used to be 19 launches that each split their 98 pixel chunks ~8 ways to find 1024
+// workgroups - 19 x (slab write + slab read + reduce launch); together the same layers fill the chip with 2 splits.
+template <typename T, bool BIAS>
+__global__ __launch_bounds__(256, 4) void wgrad_group_kernel(const WgradGroupArgs g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int bid = xcd_remap(blockIdx.x, gridDim.x);
+  int j = 0;
+  while (j + 1 < g.njobs && bid >= g.blk_end[j]) ++j;
+  wgrad_tile<T, 32, BIAS>(g.job[j], bid - (j ? g.blk_end[j - 1] : 0), smem);
+}
+
 // dw += sum_z slabs[z] over the live taps only (dead-tap regions of the slabs are never written).
 // 256 threads = QPB output quads x ZG split groups: group zg sums the splits zg, zg + ZG, ... and the groups are
 // combined through LDS in a fixed order (deterministic).  Small dW (16 K elements from 392 splits) needs the split
 // dimension spread over threads: one thread per quad walking all splits left 16 workgroups each chasing 392
 // dependent-latency loads (50 us of an 83 us launch).
 template <int ZG>
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradParams p) {
-  constexpr int QPB = 256 / ZG;
-  __shared__ float4 part[ZG][QPB];
+__device__ __forceinline__ void wgrad_reduce_body(const WgradParams& p, const int blk, const int nblk, float4* part) {
+  constexpr int QPB = 256 / ZG;   // part: [ZG][QPB]
   const int cq = p.Cin >> 2;
   const long long total = (long long)p.Cout * p.ntaps * cq;
   const size_t slab = (size_t)p.Cout * p.ntaps_all * p.Cin;
   const int ql = threadIdx.x % QPB, zg = threadIdx.x / QPB;
-  for (long long i0 = (long long)blockIdx.x * QPB; i0 < total; i0 += (long long)gridDim.x * QPB) {
+  for (long long i0 = (long long)blk * QPB; i0 < total; i0 += (long long)nblk * QPB) {
     const long long i = i0 + ql;
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
     size_t off = 0;
@@ -315,12 +345,12 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradParams p) 
       }
     }
     if constexpr (ZG > 1) {
-      part[zg][ql] = s;
+      part[zg * QPB + ql] = s;
       __syncthreads();
       if (zg == 0 && i < total) {
 #pragma unroll
         for (int g = 1; g < ZG; ++g) {
-          const float4 v = part[g][ql];
+          const float4 v = part[g * QPB + ql];
           s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
         }
       }
@@ -343,7 +373,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradParams p) 
     }
   }
   if (p.dbias) {   // bias partials: one thread per output channel, splits in order
-    for (int c = blockIdx.x * 256 + threadIdx.x; c < p.Cout; c += gridDim.x * 256) {
+    for (int c = blk * 256 + threadIdx.x; c < p.Cout; c += nblk * 256) {
       float s = 0.f;
       for (int z = 0; z < p.ksplit; ++z) s += p.bias_slabs[(size_t)z * p.Cout + c];
       p.dbias[c] += s;
@@ -351,10 +381,35 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradParams p) 
   }
 }
 
-namespace {
-struct WgradPlan { WgradParams p; int nblk; size_t ws_bytes; int status; };
+template <int ZG>
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradParams p) {
+  __shared__ float4 part[256];
+  wgrad_reduce_body<ZG>(p, blockIdx.x, gridDim.x, part);
+}
 
-WgradPlan make_wgrad_plan(const cavp_conv_desc* d) {
+// the slab reduces of a grouped launch, one grid
+__global__ __launch_bounds__(256) void wgrad_reduce_group_kernel(const WgradGroupArgs g) {
+  __shared__ float4 part[256];
+  const int bid = blockIdx.x;
+  int j = 0;
+  while (j + 1 < g.njobs && bid >= g.red_end[j]) ++j;
+  const int b0 = j ? g.red_end[j - 1] : 0;
+  const WgradParams& p = g.job[j];
+  const int blk = bid - b0, nblk = g.red_end[j] - b0;
+  switch (p.red_zg) {   // (wave-uniform)
+    case 1: wgrad_reduce_body<1>(p, blk, nblk, part); break;
+    case 2: wgrad_reduce_body<2>(p, blk, nblk, part); break;
+    case 4: wgrad_reduce_body<4>(p, blk, nblk, part); break;
+    case 8: wgrad_reduce_body<8>(p, blk, nblk, part); break;
+    default: wgrad_reduce_body<16>(p, blk, nblk, part); break;
+  }
+}
+
+namespace {
+struct WgradPlan { WgradParams p; int nblk; size_t ws_bytes; int status; int base, chunks; };
+
+// force_ks > 0: the group planner's split count (cavp_conv_desc.splitk still wins)
+WgradPlan make_wgrad_plan(const cavp_conv_desc* d, int force_ks = 0) {
   WgradPlan pl{};
   pl.status = CAVP_OK;
   if (!d || d->N <= 0 || d->H <= 0 || d->W <= 0 || d->Cin <= 0 || d->Cout <= 0 || d->KH <= 0 || d->KW <= 0 || d->stride <= 0 ||
@@ -398,6 +453,7 @@ WgradPlan make_wgrad_plan(const cavp_conv_desc* d) {
   fast_div_prepare(p.Ho * p.Wo, &p.dv_hw[0], &p.dv_hw[1]);
   fast_div_prepare(p.Wo, &p.dv_w[0], &p.dv_w[1]);
   const int chunks = (p.M + 63) / 64;
+  pl.base = base; pl.chunks = chunks;
   // Split count from a small time model fitted to tools/bench_wgrad.py on MI355X (profiles/r01_notes.md):
   //   t(ks) = rounds * steps * 1.08 us  +  ks * |dW| * 8 B / 5 TB/s (the slabs mostly live in the 256 MB MALL)  (+ reduce launch)
   // rounds = ceil(base * ks / 1024 resident workgroups: four 32 KiB workgroups per CU), steps = 32-row K tiles per
@@ -407,6 +463,8 @@ WgradPlan make_wgrad_plan(const cavp_conv_desc* d) {
   int ks = 1;
   if (d->splitk > 0) {
     ks = d->splitk;
+  } else if (force_ks > 0) {
+    ks = force_ks;
   } else {
     const double dw_bytes = (double)d->Cout * p.ntaps * d->Cin * 4.0;
     double best = 1e30;
@@ -498,6 +556,149 @@ extern "C" int cavp_conv2d_wgrad_nhwc(const cavp_conv_desc* d, const void* x, co
       case 8: wgrad_reduce_kernel<8><<<(int)nb, 256, 0, s>>>(p); break;
       default: wgrad_reduce_kernel<16><<<(int)nb, 256, 0, s>>>(p); break;
     }
+    if (hipGetLastError() != hipSuccess) return CAVP_ERR_LAUNCH;
+  }
+  return CAVP_OK;
+}
+
+// --------------------------------------------------------------------------------------------------------------------------
+// Grouped launch (ABI 7)
+// --------------------------------------------------------------------------------------------------------------------------
+namespace {
+struct GroupPlan {
+  WgradPlan pl[CAVP_WGRAD_GROUP_MAX];
+  size_t slab_off[CAVP_WGRAD_GROUP_MAX];   // byte offsets into the workspace
+  size_t ws_bytes;
+  int status;
+};
+
+// One pixel-range length L (in 64-row chunks) for the whole group: job j splits its chunks_j into ks_j = ceil(chunks_j / L)
+// slices, so every workgroup of the launch runs about L chunk steps.  L minimises the single-launch model of make_wgrad_plan
+// applied to the sum:  rounds(L) * steps(L) * 2.16 us  +  slab traffic  (+ the reduce launch).
+GroupPlan make_group_plan(const cavp_wgrad_job* jobs, int njobs) {
+  GroupPlan gp{};
+  gp.status = CAVP_OK;
+  if (!jobs || njobs <= 0 || njobs > CAVP_WGRAD_GROUP_MAX) { gp.status = CAVP_ERR_BAD_ARG; return gp; }
+  int max_chunks = 1;
+  for (int j = 0; j < njobs; ++j) {
+    if (jobs[j].desc.dtype != jobs[0].desc.dtype) { gp.status = CAVP_ERR_BAD_ARG; return gp; }
+    gp.pl[j] = make_wgrad_plan(&jobs[j].desc, 1);
+    if (gp.pl[j].status != CAVP_OK) { gp.status = gp.pl[j].status; return gp; }
+    if (gp.pl[j].nblk > 0 && gp.pl[j].chunks > max_chunks) max_chunks = gp.pl[j].chunks;
+  }
+  static const double slab_bw = cavp_knob_double("CAVP_WGRAD_SLAB_TBS", 5.0) * 1e12;
+  double best = 1e30;
+  int bestL = max_chunks;
+  for (int L = 1; L <= max_chunks; ++L) {
+    long long wgs = 0;
+    int steps = 0;
+    double slab = 0.0;
+    bool split = false;
+    for (int j = 0; j < njobs; ++j) {
+      const WgradPlan& q = gp.pl[j];
+      if (q.nblk == 0) continue;
+      int ks = jobs[j].desc.splitk > 0 ? jobs[j].desc.splitk : (q.chunks + L - 1) / L;
+      if (ks > 512) ks = 512;
+      if (ks > q.chunks) ks = q.chunks;
+      const int st = (q.chunks + ks - 1) / ks;
+      ks = (q.chunks + st - 1) / st;
+      wgs += (long long)q.base * ks;
+      if (st > steps) steps = st;
+      if (ks > 1) {
+        split = true;
+        slab += (double)ks * q.p.Cout * q.p.ntaps * q.p.Cin * 4.0 * 2.0;
+      }
+    }
+    const long long rounds = (wgs + 1023) / 1024;
+    const double t = (double)rounds * (2 * steps) * 1.08e-6 + slab / slab_bw + (split ? 6e-6 : 0.0);
+    if (t < best) { best = t; bestL = L; }
+  }
+  size_t off = 0;
+  for (int j = 0; j < njobs; ++j) {
+    WgradPlan& q = gp.pl[j];
+    if (q.nblk == 0) continue;
+    int ks = (q.chunks + bestL - 1) / bestL;
+    if (ks > 512) ks = 512;
+    q = make_wgrad_plan(&jobs[j].desc, ks);
+    gp.slab_off[j] = off;
+    off += (q.ws_bytes + 255) & ~(size_t)255;
+  }
+  gp.ws_bytes = off;
+  return gp;
+}
+}  // namespace
+
+extern "C" size_t cavp_conv2d_wgrad_group_workspace_bytes(const cavp_wgrad_job* jobs, int32_t njobs) {
+  const GroupPlan gp = make_group_plan(jobs, njobs);
+  return gp.status == CAVP_OK ? gp.ws_bytes : 0;
+}
+
+extern "C" int cavp_conv2d_wgrad_group(const cavp_wgrad_job* jobs, int32_t njobs, void* workspace, size_t workspace_bytes,
+                                       void* stream) {
+  GroupPlan gp = make_group_plan(jobs, njobs);
+  if (gp.status != CAVP_OK) return gp.status;
+  if (gp.ws_bytes > 0 && (!workspace || workspace_bytes < gp.ws_bytes || ((uintptr_t)workspace & 15))) return CAVP_ERR_WORKSPACE;
+  hipStream_t s = (hipStream_t)stream;
+  WgradGroupArgs g{};
+  int nj = 0, blocks = 0, rblocks = 0;
+  bool any_bias = false, any_split = false;
+  for (int j = 0; j < njobs; ++j) {
+    const cavp_wgrad_job& jb = jobs[j];
+    const cavp_conv_desc* d = &jb.desc;
+    if (!jb.x || !jb.dy || !jb.dw) return CAVP_ERR_BAD_ARG;
+    for (int i = 0; i < j; ++i)   // two jobs adding into one gradient would race inside the launch
+      if (jobs[i].dw == jb.dw || (jb.dbias && jobs[i].dbias == jb.dbias)) return CAVP_ERR_BAD_ARG;
+    WgradPlan& pl = gp.pl[j];
+    const size_t dw_bytes = (size_t)d->Cout * d->KH * d->KW * d->Cin * sizeof(float);
+    if (pl.nblk == 0) {   // every tap is outside the image: the gradient is zero
+      if (d->dw_overwrite && cavp_zero_f32_async(jb.dw, dw_bytes, s) != hipSuccess) return CAVP_ERR_LAUNCH;
+      continue;
+    }
+    if (((uintptr_t)jb.x & 15) || ((uintptr_t)jb.dy & 15) || ((uintptr_t)jb.dw & 15)) return CAVP_ERR_ALIGN;
+    WgradParams& p = pl.p;
+    p.x = jb.x; p.dy = jb.dy; p.dw = jb.dw; p.dbias = jb.dbias;
+    p.slabs = pl.ws_bytes ? (float*)((char*)workspace + gp.slab_off[j]) : nullptr;
+    p.oihw = d->dw_oihw != 0 && p.ntaps_all > 1;
+    p.overwrite = d->dw_overwrite != 0;
+    if (p.overwrite && p.ntaps < p.ntaps_all) {   // dead taps of a dilated kernel are never visited: clear, then accumulate
+      if (cavp_zero_f32_async(jb.dw, dw_bytes, s) != hipSuccess) return CAVP_ERR_LAUNCH;
+      p.overwrite = 0;
+    }
+    p.bias_slabs = p.slabs ? p.slabs + (size_t)p.ksplit * d->Cout * p.ntaps_all * d->Cin : nullptr;
+    p.dbg = 0;
+    p.red_zg = 1;
+    blocks += pl.nblk;
+    if (p.ksplit > 1) {
+      const long long quads = (long long)p.Cout * p.ntaps * (p.Cin / 4);
+      if (quads > 0x7fffffffll) return CAVP_ERR_UNSUPPORTED;
+      int zgrp = 1;
+      while (zgrp < 16 && zgrp * 2 <= p.ksplit && quads * zgrp < 131072) zgrp *= 2;
+      long long nb = (quads + (256 / zgrp) - 1) / (256 / zgrp);
+      if (nb > 2048) nb = 2048;
+      p.red_zg = zgrp;
+      rblocks += (int)nb;
+      any_split = true;
+    }
+    any_bias = any_bias || jb.dbias != nullptr;
+    g.job[nj] = p;
+    g.blk_end[nj] = blocks;
+    g.red_end[nj] = rblocks;
+    ++nj;
+  }
+  if (nj == 0) return CAVP_OK;
+  g.njobs = nj;
+  const int lds = 2 * 2 * 32 * 256;
+  const bool f32 = jobs[0].desc.dtype == CAVP_F32;
+  if (f32) {
+    if (any_bias) wgrad_group_kernel<float, true><<<blocks, 256, lds, s>>>(g);
+    else wgrad_group_kernel<float, false><<<blocks, 256, lds, s>>>(g);
+  } else {
+    if (any_bias) wgrad_group_kernel<bf16_t, true><<<blocks, 256, lds, s>>>(g);
+    else wgrad_group_kernel<bf16_t, false><<<blocks, 256, lds, s>>>(g);
+  }
+  if (hipGetLastError() != hipSuccess) return CAVP_ERR_LAUNCH;
+  if (any_split) {
+    wgrad_reduce_group_kernel<<<rblocks, 256, 0, s>>>(g);
     if (hipGetLastError() != hipSuccess) return CAVP_ERR_LAUNCH;
   }
   return CAVP_OK;

@@ -182,6 +182,9 @@ def gather_bn_moments(local: torch.Tensor) -> torch.Tensor:
 # False (tests / A-B only): GELU as a separate pass with the pre-activation stored, and the duplicated token tensors copied
 _FUSE_TOKEN_PATH = True
 _SIDE_STREAM = True      # False (tests / A-B only): the audio encoder on the main stream
+# Weight gradients are not consumed inside the backward: TrainPass collects them and issues up to 16 per launch
+# (cavp_conv2d_wgrad_group).  False (tests / A-B only): one launch (+ one slab reduce) per layer, where the layer's backward runs.
+_GROUP_WGRAD = True
 _BN_BWD_READ_Y = False   # True (tests / A-B only): the BatchNorm backward always re-reads y instead of re-deriving the mask from z
 
 
@@ -204,6 +207,9 @@ class TrainPass:
         self._side_done = None
         self._slot = 0
         self._zpools: Dict[int, list] = {}
+        self._wg_jobs: list = []       # deferred weight gradients (main stream only), see wgrad() / flush_wgrads()
+        self._wg_dst: set = set()
+        self._wg_src: set = set()      # storages of their dy operands (see _pinned)
 
     # ---- parameter helpers -----------------------------------------------------------------------------------
     def pack(self, key: str, mod, need_dgrad: bool = True, raw: bool = False, pad_cout_to: int = 0) -> _P:
@@ -247,6 +253,7 @@ class TrainPass:
         self._pack_jobs = []
 
     def finish_padded(self) -> None:
+        self.flush_wgrads()
         for p in self.P.values():
             if p.real_weight is None:
                 continue
@@ -328,6 +335,10 @@ class TrainPass:
             g = self.empty(x.t.shape, x.t.dtype)
             compute(g, None)
             x.set_g(g)
+        elif self._pinned(x.g):   # a pending weight gradient still reads x.g (see wgrad()): accumulate out of place
+            g = self.empty(x.t.shape, x.t.dtype)
+            compute(g, x.g)
+            x.set_g(g)
         else:
             compute(x.g, x.g)
 
@@ -340,7 +351,18 @@ class TrainPass:
             x.set_g(g if g.is_contiguous() else self._dense_copy(g))
         else:
             gg = g if g.is_contiguous() else self._dense_copy(g)
-            T.add(x.g, gg, x.g)
+            if self._pinned(x.g):
+                out = self.empty(x.g.shape, x.g.dtype)
+                T.add(x.g, gg, out)
+                x.set_g(out)
+            else:
+                T.add(x.g, gg, x.g)
+
+    def _pinned(self, t: torch.Tensor) -> bool:
+        """True while a deferred weight gradient reads t's storage: a conv with a fused residual hands its output gradient to
+        the residual branch WITHOUT a copy (acc_add: x.g = g), so a later in-place accumulation into that branch's gradient
+        would change the dy of the pending job.  The accumulation then goes into a fresh tensor (same traffic, no extra pass)."""
+        return bool(self._wg_src) and t.untyped_storage().data_ptr() in self._wg_src
 
     def _dense_copy(self, g: torch.Tensor) -> torch.Tensor:
         out = self.empty(g.shape, g.dtype)
@@ -426,11 +448,32 @@ class TrainPass:
         ow = self.arena is not None and k in self.arena.no_zero and k not in self.grads and k not in self.touched
         dw = self.grad_buffer(p.weight, _overwrite=ow)
         if p.kh * p.kw == 1:   # OHWI == OIHW for 1x1 / linear: straight into the gradient
-            T.conv2d_wgrad(x4, g4, dw.view(p.cout, 1, 1, p.cin), kh=1, kw=1, stride=p.stride, pad=p.pad, dil=p.dil, dbias=db,
-                           overwrite=ow)
+            job = dict(x=x4, dy=g4, dw=dw.view(p.cout, 1, 1, p.cin), kh=1, kw=1, stride=p.stride, pad=p.pad, dil=p.dil, dbias=db,
+                       overwrite=ow)
         else:   # k x k: the kernel writes the torch-layout gradient directly (no OHWI temporary + unpack pass)
-            T.conv2d_wgrad(x4, g4, dw, kh=p.kh, kw=p.kw, stride=p.stride, pad=p.pad, dil=p.dil, dbias=db, dw_oihw=True,
-                           overwrite=ow)
+            job = dict(x=x4, dy=g4, dw=dw, kh=p.kh, kw=p.kw, stride=p.stride, pad=p.pad, dil=p.dil, dbias=db, dw_oihw=True,
+                       overwrite=ow)
+        if not _GROUP_WGRAD or self._slot != 0 or x4.dtype != self.dt:
+            T.conv2d_wgrad(job.pop("x"), job.pop("dy"), job.pop("dw"), **job)   # (the side stream keeps its per-layer launches)
+            return
+        # Deferred: nothing in the backward chain reads a weight gradient, so the jobs wait (holding x and dy alive) until 16
+        # are pending or a flush point is reached, and go out as ONE launch.  A second contribution to a destination that is
+        # already pending would race inside the launch: flush first.
+        dst = {dw.data_ptr()} | ({db.data_ptr()} if db is not None else set())
+        if dst & self._wg_dst:
+            self.flush_wgrads()
+        self._wg_jobs.append(job)
+        self._wg_dst |= dst
+        self._wg_src.add(g4.untyped_storage().data_ptr())
+        if len(self._wg_jobs) >= 16:
+            self.flush_wgrads()
+
+    def flush_wgrads(self) -> None:
+        """Issue the pending weight gradients (before anything reads a parameter gradient: finish_padded, the early / late
+        gradient collectives, the end of the backward)."""
+        if self._wg_jobs:
+            jobs, self._wg_jobs, self._wg_dst, self._wg_src = self._wg_jobs, [], set(), set()
+            T.conv2d_wgrad_group(jobs)
 
     def conv_smallcin(self, x_nchw: torch.Tensor, key: str, stride: int, act: int) -> V:
         """First stem conv (raw, BN follows) / first VGG conv (bias + ReLU fused).  Input needs no gradient."""
@@ -578,6 +621,8 @@ class TrainPass:
                 return
             if x.g is None:
                 x.set_g(torch.zeros(x.t.shape, dtype=x.t.dtype, device=self.dev))
+            elif self._pinned(x.g):
+                self.flush_wgrads()   # in-place update of a gradient a pending weight gradient reads
             T.bcast_add(x.g, y.g, 1.0 / (h * w))
         self.tape.append(bwd)
         return y
@@ -707,6 +752,7 @@ class TrainPass:
         """Tape marker: everything recorded AFTER this point in the forward (audio encoder, projector, cross attention,
         decoder head) has its parameter gradients complete when the backward reaches it."""
         def bwd():
+            self.flush_wgrads()
             self.finish_padded()            # the zero-padded classifier's gradient rows -> its real .grad view
             if self.on_early_final is not None:
                 self.join_side()            # the audio encoder's gradients are part of the early range
@@ -754,6 +800,7 @@ class TrainPass:
                 continue
             self.tape[i]()
             i -= 1
+        self.flush_wgrads()
         self.join_side()
         self.tape = []
 

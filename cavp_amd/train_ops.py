@@ -112,6 +112,44 @@ def conv2d_wgrad(x: torch.Tensor, dy: torch.Tensor, dw_ohwi: torch.Tensor, *, kh
     return dw_ohwi
 
 
+def _wgrad_desc(x, dy, dw, kh, kw, stride, pad, dil, splitk, dbias, dw_oihw, overwrite) -> ConvDesc:
+    _need_gpu(x, dy, dw, dbias)
+    n, h, w, cin, ldx = _nhwc(x)
+    n2, ho, wo, cout, ldy = _nhwc(dy)
+    if n2 != n or x.dtype != dy.dtype or dw.dtype != torch.float32 or dw.numel() != cout * kh * kw * cin or not dw.is_contiguous():
+        raise _lib.CavpError("conv2d_wgrad: shape / dtype mismatch")
+    eho = (h + 2 * pad - dil * (kh - 1) - 1) // stride + 1
+    ewo = (w + 2 * pad - dil * (kw - 1) - 1) // stride + 1
+    if (ho, wo) != (eho, ewo):
+        raise _lib.CavpError("conv2d_wgrad: dy extent does not match the forward conv")
+    if dbias is not None and (dbias.dtype != torch.float32 or dbias.numel() != cout or not dbias.is_contiguous()):
+        raise _lib.CavpError("conv2d_wgrad: dbias must be a dense f32 [Cout] tensor")
+    return ConvDesc(dtype=dtype_code(x.dtype), N=n, H=h, W=w, Cin=cin, ldx=ldx, Cout=cout, ldy=ldy, KH=kh, KW=kw,
+                    stride=stride, pad=pad, dil=dil, ldr=0, act=0, splitk=splitk, tile=0, up=0, Ho=0, Wo=0, stride_w=0,
+                    dw_oihw=int(dw_oihw), dw_overwrite=int(overwrite))
+
+
+def conv2d_wgrad_group(jobs) -> None:
+    """Up to _lib.WGRAD_GROUP_MAX independent weight gradients in ONE launch (cavp_conv2d_wgrad_group).  jobs: list of dicts
+    with the arguments of conv2d_wgrad (x, dy, dw, kh, kw, stride, pad, dil and optionally splitk, dbias, dw_oihw, overwrite).
+    Two jobs must not share a dw / dbias."""
+    if not jobs:
+        return
+    if len(jobs) > _lib.WGRAD_GROUP_MAX:
+        raise _lib.CavpError(f"conv2d_wgrad_group: at most {_lib.WGRAD_GROUP_MAX} jobs per launch")
+    arr = (_lib.WgradJob * len(jobs))()
+    for i, j in enumerate(jobs):
+        db = j.get("dbias")
+        d = _wgrad_desc(j["x"], j["dy"], j["dw"], j["kh"], j["kw"], j["stride"], j["pad"], j["dil"], j.get("splitk", 0), db,
+                        j.get("dw_oihw", False), j.get("overwrite", False))
+        arr[i] = _lib.WgradJob(d, j["x"].data_ptr(), j["dy"].data_ptr(), j["dw"].data_ptr(), db.data_ptr() if db is not None else None)
+    lib = _lib.load()
+    pa = C.cast(arr, C.c_void_p)
+    ws = ops.workspace(lib.cavp_conv2d_wgrad_group_workspace_bytes(pa, len(jobs)), jobs[0]["x"].device)
+    _check(lib.cavp_conv2d_wgrad_group(pa, len(jobs), _ptr(ws), C.c_size_t(ws.numel() if ws is not None else 0), _s()),
+           f"cavp_conv2d_wgrad_group ({len(jobs)} jobs)")
+
+
 def linear_wgrad(x: torch.Tensor, dy: torch.Tensor, dw: torch.Tensor, dbias: Optional[torch.Tensor] = None) -> torch.Tensor:
     """x: [..., Cin], dy: [..., Cout] -> dw f32 [Cout][Cin] (pre-zeroed) += dy^T x."""
     rx, cin, ldx = _rows(x)

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define CAVP_ABI_VERSION 6
+#define CAVP_ABI_VERSION 7
 
 typedef enum { CAVP_F32 = 0, CAVP_BF16 = 1 } cavp_dtype_t;
 typedef enum { CAVP_ACT_NONE = 0, CAVP_ACT_RELU = 1, CAVP_ACT_LEAKY = 2, CAVP_ACT_GELU = 3 } cavp_act_t;
@@ -178,6 +178,25 @@ int cavp_cast(int32_t src_dtype, const void* src, int32_t dst_dtype, void* dst, 
 size_t cavp_conv2d_wgrad_workspace_bytes(const cavp_conv_desc* d);
 int cavp_conv2d_wgrad_nhwc(const cavp_conv_desc* d, const void* x, const void* dy, float* dw_ohwi, float* dbias,
                            void* workspace, size_t workspace_bytes, void* stream);
+
+/* ABI 7: up to CAVP_WGRAD_GROUP_MAX independent weight gradients (the jobs of cavp_conv2d_wgrad_nhwc, one dtype) in ONE launch
+ * (+ one launch for the slab reduces of the jobs that split their pixel range).  torch.autograd computes every weight
+ * gradient where its layer's backward runs (trainer_cavp_vpo_mono.py:168-193 `loss.backward()`); nothing in the backward
+ * chain consumes them, so the host defers the weight gradients of a stage of small layers (ResNet layer3: 19 convs on
+ * 32 x 14 x 14 pixels, resnet.py:75-98; the 52 PVTv2 blocks, pvt.py:137-170) and issues them together: the launches fill the
+ * chip with far fewer pixel splits (less slab traffic, one reduce instead of 19).  `jobs` is a HOST array; the job table
+ * travels as kernel arguments.  Two jobs must not share a dw or dbias (CAVP_ERR_BAD_ARG).  The split reduction stays a
+ * fixed-order slab sum: deterministic. */
+#define CAVP_WGRAD_GROUP_MAX 16
+typedef struct cavp_wgrad_job {
+  cavp_conv_desc desc;   /* the FORWARD conv, as for cavp_conv2d_wgrad_nhwc (dw_oihw / dw_overwrite / splitk honoured per job) */
+  const void* x;
+  const void* dy;
+  float* dw;
+  float* dbias;          /* optional */
+} cavp_wgrad_job;
+size_t cavp_conv2d_wgrad_group_workspace_bytes(const cavp_wgrad_job* jobs, int32_t njobs);
+int cavp_conv2d_wgrad_group(const cavp_wgrad_job* jobs, int32_t njobs, void* workspace, size_t workspace_bytes, void* stream);
 
 /* OIHW f32 -> [Cin][KH][KW][Cout] (dtype), taps rotated by 180 degrees: the OHWI weight of the transposed conv. */
 /* All weight re-packs of one training step in one launch per <= 48 tensors (the per-tensor entry points cost ~170

@@ -98,6 +98,53 @@ def test_conv_dgrad_wgrad(case, dt):
 
 
 @pytest.mark.parametrize("dt", DTYPES, ids=IDS)
+def test_conv_wgrad_group(dt):
+    """cavp_conv2d_wgrad_group: all CONV cases (strides, dilations with dead taps, 304 / 48 channels) as ONE launch, mixed
+    destinations (OHWI / torch layout, accumulate / overwrite, with / without bias) - each job against torch.autograd, and
+    bit-identical to the per-layer launch when both are given the same split count."""
+    ops, T = _mods()
+    from cavp_amd._lib import CavpError
+    jobs, refs = [], []
+    for i, (name, n, h, w, cin, cout, k, s, p, d) in enumerate(CONV):
+        x = _q(_rand(n, cin, h, w, seed=10 + i), dt).requires_grad_(True)
+        wt = _q(_rand(cout, cin, k, k, seed=30 + i, scale=(cin * k * k) ** -0.5), dt).requires_grad_(True)
+        y = F.conv2d(x, wt, None, s, p, d)
+        dy = _q(_rand(*y.shape, seed=50 + i), dt)
+        y.backward(dy)
+        oihw, over, bias = bool(i & 1), bool(i & 2), bool(i % 3 == 0)
+        shape = (cout, cin, k, k) if oihw else (cout, k, k, cin)
+        dw = torch.full(shape, 7.5 if over else 0.25, dtype=torch.float32, device=DEV)
+        db = torch.full((cout,), 0.5, dtype=torch.float32, device=DEV) if bias else None
+        jobs.append(dict(x=_nhwc(x.detach(), dt), dy=_nhwc(dy, dt), dw=dw, kh=k, kw=k, stride=s, pad=p, dil=d, dbias=db,
+                         dw_oihw=oihw, overwrite=over, splitk=(0, 1, 3)[i % 3]))
+        refs.append((name, wt.grad, dy.sum(dim=(0, 2, 3)), oihw, over))
+    T.conv2d_wgrad_group(jobs)
+    for j, (name, gw, gb, oihw, over) in zip(jobs, refs):
+        got = j["dw"] if oihw else j["dw"].permute(0, 3, 1, 2)
+        _check(got, gw + (0.0 if over else 0.25), dt, name + ".group.wgrad", f32_tol=5e-5, bf16_tol=2e-2)
+        if j["dbias"] is not None:
+            _check(j["dbias"], gb + 0.5, dt, name + ".group.dbias", f32_tol=5e-5, bf16_tol=2e-2)
+    # same split count -> the same slab sums in the same order as the per-layer launch: bit-identical
+    for j in jobs:
+        if j["splitk"] == 0:
+            continue
+        single = torch.full_like(j["dw"], 7.5 if j["overwrite"] else 0.25)
+        T.conv2d_wgrad(j["x"], j["dy"], single, kh=j["kh"], kw=j["kw"], stride=j["stride"], pad=j["pad"], dil=j["dil"],
+                       dw_oihw=j["dw_oihw"], overwrite=j["overwrite"], splitk=j["splitk"])
+        assert torch.equal(single, j["dw"]), "group vs single launch"
+    # a group of one, and the limits
+    one = dict(jobs[1], dw=torch.zeros_like(jobs[1]["dw"]), overwrite=False, dbias=None)
+    T.conv2d_wgrad_group([one])
+    name, gw, _, oihw, _ = refs[1]
+    _check(one["dw"] if oihw else one["dw"].permute(0, 3, 1, 2), gw, dt, "group of one", f32_tol=5e-5, bf16_tol=2e-2)
+    with pytest.raises(CavpError):
+        T.conv2d_wgrad_group([jobs[0], dict(jobs[2], dw=jobs[0]["dw"])] if jobs[0]["dw"].numel() == jobs[2]["dw"].numel()
+                             else [jobs[0], jobs[0]])          # two jobs adding into one gradient
+    with pytest.raises(CavpError):
+        T.conv2d_wgrad_group([jobs[0]] * 17)                    # more than CAVP_WGRAD_GROUP_MAX
+
+
+@pytest.mark.parametrize("dt", DTYPES, ids=IDS)
 @pytest.mark.parametrize("rows,cin,cout", [(6272, 304, 1216), (64, 4096, 304), (4, 12288, 512), (6272, 256, 304)])
 def test_linear_wgrad(rows, cin, cout, dt):
     ops, T = _mods()
