@@ -59,6 +59,7 @@ def parse():
     ap.add_argument("--no-token-fusion", action="store_true", help="A/B: GELU as a separate pass, duplicated token tensors copied")
     ap.add_argument("--no-side-stream", action="store_true", help="A/B: the audio encoder on the main stream instead of a second one")
     ap.add_argument("--no-group-wgrad", action="store_true", help="A/B: one weight-gradient launch (+ slab reduce) per layer instead of grouped launches")
+    ap.add_argument("--no-tail-split", action="store_true", help="A/B: never split a 256x256-tile launch with a nearly empty last round")
     ap.add_argument("--no-f32", action="store_true", help="skip the secondary f32 (parity path) training-step measurement")
     ap.add_argument("--cpu-sample-batch", type=int, default=8)
     return ap.parse_args()
@@ -351,7 +352,7 @@ def _timed_iters(fn, budget_s, min_iters, max_iters, warm=True):
 def cpu_baseline_train(sd, cfg, sample_batch):
     """Oracle forward_train + CE + autograd backward on the host cores, bounded sample.  torch's CPU convolutions do not scale
     to a whole two-socket box on this model (round 2 measured 128 threads at 1.1 frames/s against 0.9 on ONE), so the thread
-    count is swept - one timed step each at {16, 32, 64, all cores} - and the best count is then timed properly (median of
+    count is swept - one timed step each at {4, 8, 16, 32, 64, all cores} - and the best count is then timed properly (median of
     >= 3 further steps).  `cores` = the threads of the reported figure; the sweep and a single-thread figure travel with it."""
     from cavp_amd.synth import synth_inputs
     from oracle import cavp_oracle as O
@@ -374,7 +375,7 @@ def cpu_baseline_train(sd, cfg, sample_batch):
     torch.set_num_threads(cores)
     step()   # warm-up (allocator, oneDNN primitive caches)
     sweep = {}
-    for nt in sorted({t for t in (16, 32, 64, cores) if t <= cores}):
+    for nt in sorted({t for t in (4, 8, 16, 32, 64, cores) if t <= cores}):
         torch.set_num_threads(nt)
         t0 = time.perf_counter()
         step()
@@ -451,6 +452,9 @@ def main():
     if a.no_group_wgrad:
         import cavp_amd.train as _tr
         _tr._GROUP_WGRAD = False
+    if a.no_tail_split:
+        from cavp_amd import _lib as _cl0
+        _cl0.load().cavp_set_tail_split(0)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

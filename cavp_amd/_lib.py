@@ -47,6 +47,7 @@ PROTOTYPES = {
     "cavp_conv2d_workspace_bytes": (_sz, [C.POINTER(ConvDesc)]),
     "cavp_conv2d_nhwc": (_i32, [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _vp]),
     "cavp_conv2d_nhwc_aux": (_i32, [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _vp]),
+    "cavp_set_tail_split": (_i32, [_i32]),
     "cavp_conv2d_tile_stats_layout": (_i32, [C.POINTER(ConvDesc), C.POINTER(_i32), C.POINTER(_i32)]),
     "cavp_bn_finalize_tiles": (_i32, [_vp, _i32, _i32, _i64, _vp, _vp, _f32, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp]),
     "cavp_bn_tiles_to_moments": (_i32, [_vp, _i32, _i32, _i64, _vp, _i32, _vp]),

@@ -163,18 +163,22 @@ struct CavpDetState {
   size_t floats;
 };
 extern CavpDetState g_cavp_det;
-// out0[i] += sum_p part[p][i], out1[i] += sum_p part[nparts + p][i]  (p ascending: fixed summation order)
+// out0[i] += sum_p part[p][i], out1[i] += sum_p part[nparts + p][i] in a FIXED order: one wave per output element, lane l adds
+// the partials l, l + 64, ... (ascending), then a fixed butterfly over the 64 lanes.  (Round 2 used one THREAD per element
+// walking all nparts (up to 768) partials one dependent-latency load at a time: ~150 us per call, 9 ms per C1' step - the
+// deterministic mode cost +59 %, measured in round 3.)
 static __global__ __launch_bounds__(256) void cavp_det_finish_kernel(const float* __restrict__ part, int nparts, int n,
                                                                     float* __restrict__ out0, float* __restrict__ out1) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
-  float s0 = 0.f, s1 = 0.f;
-  for (int q = 0; q < nparts; ++q) s0 += part[(size_t)q * n + i];
-  out0[i] += s0;
-  if (out1) {
-    for (int q = 0; q < nparts; ++q) s1 += part[(size_t)(nparts + q) * n + i];
-    out1[i] += s1;
-  }
+  const int w = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int total = out1 ? 2 * n : n;
+  if (w >= total) return;
+  const int st = w >= n ? 1 : 0, i = w - st * n;
+  const float* src = part + (size_t)st * nparts * n + i;
+  float s = 0.f;
+  for (int q = lane; q < nparts; q += 64) s += src[(size_t)q * n];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  if (lane == 0) (st ? out1 : out0)[i] += s;
 }
 // scratch for 2 x nparts x n floats, or nullptr when the mode is off; *err is set when it is on but the buffer is too small
 static inline float* cavp_det_scratch(int nparts, int n, bool* err) {
@@ -184,7 +188,7 @@ static inline float* cavp_det_scratch(int nparts, int n, bool* err) {
   return g_cavp_det.scratch;
 }
 static inline hipError_t cavp_det_finish(const float* part, int nparts, int n, float* out0, float* out1, hipStream_t s) {
-  cavp_det_finish_kernel<<<dim3((n + 255) / 256), dim3(256), 0, s>>>(part, nparts, n, out0, out1);
+  cavp_det_finish_kernel<<<dim3(((out1 ? 2 * n : n) + 3) / 4), dim3(256), 0, s>>>(part, nparts, n, out0, out1);
   return hipGetLastError();
 }
 

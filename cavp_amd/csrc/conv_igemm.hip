@@ -853,6 +853,33 @@ inline bool aligned(const void* ptr, size_t a) { return ((uintptr_t)ptr % a) == 
 
 }  // namespace
 
+// Tail split of a 256x256-tile launch.  The persistent grid runs whole rounds of 256 tiles; the head 3x3 convs of the
+// training step (2B x 56 x 56 pixels, 256 channels: 784 tiles) leave a fourth round with 16 tiles - 86 us of a 335 us launch
+// for 2 % of the work.  When the last round is at most a quarter full, the leading images that fill the whole rounds go to
+// the big tile and the remaining images (here 2 of 64) to an ordinary launch of the small tiles (~25 us).  Returns the number
+// of leading images, 0 = no split.
+static bool g_tail_split = true;
+extern "C" int cavp_set_tail_split(int on) { g_tail_split = on != 0; return CAVP_OK; }
+
+static int tail_split_images(const cavp_conv_desc* d, const Plan& pl, bool with_tile_stats) {
+  if (!g_tail_split) return 0;
+  if (!tile_is_big(pl.tile_id) || d->tile % 100 != 0 || d->N < 2 || d->res_rows > 0) return 0;
+  const long long nb = (long long)pl.p.tiles_c * pl.p.tiles_p;
+  const long long rounds = (nb + 255) / 256, last = nb - (rounds - 1) * 256;
+  if (rounds < 2 || last > 64) return 0;
+  const long long hw = (long long)pl.p.Ho * pl.p.Wo;
+  const long long ptiles = (rounds - 1) * 256 / pl.p.tiles_c;   // pixel tiles that fit the whole rounds
+  long long n1 = ptiles * 256 / hw;
+  if (n1 >= d->N) n1 = d->N - 1;
+  // per-tile statistics: the tail's first pixel must start a 128-row statistics tile
+  while (with_tile_stats && n1 > 0 && (n1 * hw) % 128) --n1;
+  if (n1 < 1 || (d->N - n1) * hw > 65536) return 0;   // the tail must stay a small problem
+  cavp_conv_desc da = *d;
+  da.N = (int)n1;
+  if (!tile_is_big(make_plan(&da).tile_id)) return 0;   // (the leading part must keep the tile the caller's layouts assume)
+  return (int)n1;
+}
+
 // Fused BatchNorm statistics are available when the launch uses the LDS-staged epilogue: no split-K, vector-aligned
 // Cout / ldy.  Returns 1 and the tile geometry, else 0 (caller falls back to cavp_colsum / cavp_colstats).
 extern "C" int cavp_conv2d_tile_stats_layout(const cavp_conv_desc* d, int32_t* tiles, int32_t* rows_per_tile) {
@@ -880,6 +907,17 @@ extern "C" size_t cavp_conv2d_workspace_bytes(const cavp_conv_desc* d) {
   if (tile_is_big(pl.tile_id)) {   // the launch re-plans without the 256x256 tile when an operand is not 16-byte aligned: that
     Plan alt = make_plan(d, false);   // plan may split K
     if (alt.status == CAVP_OK && alt.ws_bytes > need) need = alt.ws_bytes;
+    const int n1 = tail_split_images(d, pl, true);   // ... and the tail of a split launch runs on the small tiles
+    if (n1 > 0) {
+      cavp_conv_desc db = *d;
+      db.N = d->N - n1;
+      for (int forced = 0; forced <= 2; forced += 2) {   // (tile 2, unsplit, when the launch carries per-tile statistics)
+        db.tile = forced;
+        db.splitk = forced ? 1 : d->splitk;
+        Plan tail = make_plan(&db);
+        if (tail.status == CAVP_OK && tail.ws_bytes > need) need = tail.ws_bytes;
+      }
+    }
   }
   return need;
 }
@@ -891,9 +929,21 @@ extern "C" int cavp_conv2d_nhwc(const cavp_conv_desc* d, const void* x, const vo
   return cavp_conv2d_nhwc_aux(d, x, w, scale, shift, nbias, residual, y, nullptr, workspace, workspace_bytes, tile_stats, stream);
 }
 
+static int conv2d_launch(const cavp_conv_desc* d, const void* x, const void* w, const float* scale, const float* shift,
+                         const float* nbias, const void* residual, void* y, void* aux, void* workspace, size_t workspace_bytes,
+                         float* tile_stats, void* stream,
+                         bool allow_split = true);
+
 extern "C" int cavp_conv2d_nhwc_aux(const cavp_conv_desc* d, const void* x, const void* w, const float* scale,
                                     const float* shift, const float* nbias, const void* residual, void* y, void* aux,
                                     void* workspace, size_t workspace_bytes, float* tile_stats, void* stream) {
+  return conv2d_launch(d, x, w, scale, shift, nbias, residual, y, aux, workspace, workspace_bytes, tile_stats, stream);
+}
+
+static int conv2d_launch(const cavp_conv_desc* d, const void* x, const void* w, const float* scale, const float* shift,
+                         const float* nbias, const void* residual, void* y, void* aux, void* workspace, size_t workspace_bytes,
+                         float* tile_stats, void* stream,
+                         bool allow_split) {
   if (!d || !x || !w || !y) return CAVP_ERR_BAD_ARG;
   const bool fused = d->aux_mode != 0 || (residual && d->res_rows > 0);
   if (d->aux_mode < 0 || d->aux_mode > 2 || (d->aux_mode != 0) != (aux != nullptr) || (d->aux_mode == 1 && d->act != CAVP_ACT_GELU) ||
@@ -912,6 +962,26 @@ extern "C" int cavp_conv2d_nhwc_aux(const cavp_conv_desc* d, const void* x, cons
     if (pl.status != CAVP_OK) return pl.status;
   }
   if (residual && d->ldr < d->Cout) return CAVP_ERR_BAD_ARG;
+  if (allow_split && d->up <= 1) {
+    const int n1 = tail_split_images(d, pl, tile_stats != nullptr);
+    if (n1 > 0) {
+      const size_t es_ = d->dtype == CAVP_F32 ? 4 : 2;
+      const size_t xin = (size_t)n1 * d->H * d->W * d->ldx * es_;
+      const size_t opix = (size_t)n1 * pl.p.Ho * pl.p.Wo;
+      cavp_conv_desc da = *d, db = *d;
+      da.N = n1;
+      db.N = d->N - n1;
+      // per-tile BatchNorm statistics: the big tile writes one pair per 128-row slab; the tail launch continues that tile
+      // sequence (its first pixel is a multiple of 128, see tail_split_images) on a tile with 128 pixel rows
+      if (tile_stats) { db.tile = 2; db.splitk = 1; }
+      int st = conv2d_launch(&da, x, w, scale, shift, nbias, residual, y, aux, workspace, workspace_bytes, tile_stats, stream, false);
+      if (st != CAVP_OK) return st;
+      return conv2d_launch(&db, (const char*)x + xin, w, scale, shift, nbias ? nbias + (size_t)n1 * d->Cout : nullptr,
+                           residual ? (const char*)residual + opix * d->ldr * es_ : nullptr, (char*)y + opix * d->ldy * es_,
+                           aux ? (char*)aux + opix * d->ld_aux * es_ : nullptr, workspace, workspace_bytes,
+                           tile_stats ? tile_stats + (opix / 128) * (size_t)d->Cout * 2 : nullptr, stream, false);
+    }
+  }
   if (pl.ws_bytes > 0 && (!workspace || workspace_bytes < pl.ws_bytes || !aligned(workspace, 16)))
     return CAVP_ERR_WORKSPACE;
   IgemmParams& p = pl.p;

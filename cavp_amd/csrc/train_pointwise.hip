@@ -46,12 +46,15 @@ struct ColArgs {
 // MODE 0: out0 += sum a, out1 += sum a^2       (BN forward statistics)
 // MODE 1: g = a * act'(b); out0 += sum g, out1 += sum g * (c - mean) * rstd   (BN backward reduce)
 // MODE 2: out0 += sum a                        (bias gradient)
-template <typename T, int MODE>
+// CG column groups x RL = 256 / CG row lanes: 16 x 16 for C >= 128 (bf16), 8 x 32 for the 64- / 48-channel tensors of the stem and
+// layer1, where half of a 16-group workgroup idled (23 us per reduce on tensors the apply kernel walks in 7)
+template <typename T, int MODE, int CG>
 __global__ __launch_bounds__(256) void col_reduce_kernel(const ColArgs p) {
   constexpr int VE = VecT<T>::VE;
-  __shared__ float red[2][16][16 * VE + 1];
-  const int cg = threadIdx.x & 15, rl = threadIdx.x >> 4;
-  const int c0 = (blockIdx.y * 16 + cg) * VE;
+  constexpr int RL = 256 / CG;
+  __shared__ float red[2][RL][CG * VE + 1];
+  const int cg = threadIdx.x % CG, rl = threadIdx.x / CG;
+  const int c0 = (blockIdx.y * CG + cg) * VE;
   const bool col_ok = c0 < p.C;
   float s0[VE], s1[VE];
 #pragma unroll
@@ -84,13 +87,13 @@ __global__ __launch_bounds__(256) void col_reduce_kernel(const ColArgs p) {
       // UR rows per trip: all 2 UR (3 UR with y) 16-byte loads are issued before the first is consumed - with one row per trip the
       // loop carried 2 loads in flight per lane and the reduce ran at 1.7 TB/s where the apply kernels reach 3.7
       constexpr int UR = 4;   // 8: 25 % slower (registers), 1: the round-1 loop
-      for (; r + 16 * (UR - 1) < r_end; r += 16 * UR) {
+      for (; r + RL * (UR - 1) < r_end; r += RL * UR) {
         float a4[UR][VE], z4[UR][VE], y4[UR][VE];
 #pragma unroll
         for (int u = 0; u < UR; ++u) {
-          VecT<T>::load((const T*)p.a + (r + 16 * u) * p.lda + c0, a4[u]);
-          VecT<T>::load((const T*)p.c + (r + 16 * u) * p.ldc + c0, z4[u]);
-          if (!from_z) VecT<T>::load((const T*)p.b + (r + 16 * u) * p.ldb + c0, y4[u]);
+          VecT<T>::load((const T*)p.a + (r + RL * u) * p.lda + c0, a4[u]);
+          VecT<T>::load((const T*)p.c + (r + RL * u) * p.ldc + c0, z4[u]);
+          if (!from_z) VecT<T>::load((const T*)p.b + (r + RL * u) * p.ldb + c0, y4[u]);
         }
 #pragma unroll
         for (int u = 0; u < UR; ++u)
@@ -103,7 +106,7 @@ __global__ __launch_bounds__(256) void col_reduce_kernel(const ColArgs p) {
           }
       }
     }
-    for (; r < r_end; r += 16) {
+    for (; r < r_end; r += RL) {
       float a[VE];
       VecT<T>::load((const T*)p.a + r * p.lda + c0, a);
       if (MODE == 0) {
@@ -136,15 +139,15 @@ __global__ __launch_bounds__(256) void col_reduce_kernel(const ColArgs p) {
     red[1][rl][cg * VE + e] = s1[e];
   }
   __syncthreads();
-  // 16*VE channels x (1 or 2) stats: thread t sums the 16 row lanes of one (stat, channel)
-  for (int i = threadIdx.x; i < 2 * 16 * VE; i += 256) {
-    const int st = i / (16 * VE), ch = i - st * (16 * VE);
+  // CG*VE channels x (1 or 2) stats: thread t sums the RL row lanes of one (stat, channel)
+  for (int i = threadIdx.x; i < 2 * CG * VE; i += 256) {
+    const int st = i / (CG * VE), ch = i - st * (CG * VE);
     if (MODE == 2 && st == 1) continue;
-    const int c = blockIdx.y * 16 * VE + ch;
+    const int c = blockIdx.y * CG * VE + ch;
     if (c >= p.C) continue;
     float s = 0.f;
 #pragma unroll
-    for (int k = 0; k < 16; ++k) s += red[st][k][ch];
+    for (int k = 0; k < RL; ++k) s += red[st][k][ch];
     if (p.part)
       p.part[((size_t)st * gridDim.x + blockIdx.x) * p.C + c] = s;
     else
@@ -244,7 +247,8 @@ int launch_col_reduce(int dtype, ColArgs& a, hipStream_t s) {
       col_reduce_flat_kernel<bf16_t, MODE><<<gx, 256, 0, s>>>(a, CV);
     CHECK_LAUNCH();
   }
-  const int gy = cdiv_h(a.C, 16 * VE);
+  const int CG = a.C <= 8 * VE ? 8 : 16;   // column groups per workgroup
+  const int gy = cdiv_h(a.C, CG * VE);
   // workgroups per launch: every one ends with 2 x 128 device-scope f32 atomics, which are served memory-side (the L2s of
   // the 8 XCDs are not coherent): at 2048 workgroups the atomics were 40 % of the BN backward reduce (1.60 ms per step,
   // 0.95 without them); 512 keeps enough loads in flight and costs 1.27 ms (sweep: 2048 / 1024 / 512 / 256 -> 1.61 / 1.31 /
@@ -255,16 +259,19 @@ int launch_col_reduce(int dtype, ColArgs& a, hipStream_t s) {
   if (gx < 1) gx = 1;
   int rpb = cdiv_h(a.rows, gx);
   if (rpb < 64) rpb = 64;
-  rpb = (rpb + 15) / 16 * 16;
+  rpb = (rpb + 31) / 32 * 32;
   gx = cdiv_h(a.rows, rpb);
   a.rows_per_block = rpb;
   bool det_err;
   a.part = cavp_det_scratch(gx, a.C, &det_err);
   if (det_err) return CAVP_ERR_WORKSPACE;
-  if (dtype == CAVP_F32)
-    col_reduce_kernel<float, MODE><<<dim3(gx, gy), 256, 0, s>>>(a);
-  else
-    col_reduce_kernel<bf16_t, MODE><<<dim3(gx, gy), 256, 0, s>>>(a);
+  if (dtype == CAVP_F32) {
+    if (CG == 8) col_reduce_kernel<float, MODE, 8><<<dim3(gx, gy), 256, 0, s>>>(a);
+    else col_reduce_kernel<float, MODE, 16><<<dim3(gx, gy), 256, 0, s>>>(a);
+  } else {
+    if (CG == 8) col_reduce_kernel<bf16_t, MODE, 8><<<dim3(gx, gy), 256, 0, s>>>(a);
+    else col_reduce_kernel<bf16_t, MODE, 16><<<dim3(gx, gy), 256, 0, s>>>(a);
+  }
   if (a.part) {
     if (hipGetLastError() != hipSuccess) return CAVP_ERR_LAUNCH;
     return cavp_det_finish(a.part, gx, a.C, a.out0, MODE == 2 ? nullptr : a.out1, s) == hipSuccess ? CAVP_OK : CAVP_ERR_LAUNCH;

@@ -78,3 +78,21 @@ def synth_inputs(batch: int, image_hw=(224, 224), audio_batch: int | None = None
     ign = torch.rand((batch,) + tuple(image_hw), generator=g) < 0.02
     label[ign] = 255
     return image, audio, label
+
+
+def learnable_inputs(batch: int, image_hw=(96, 96), num_classes: int = 3, seed: int = 0):
+    """A synthetic batch a network can LEARN (uniformly random labels, as in synth_inputs, can only be answered with the class
+    prior: after a few training steps the logits collapse to a constant): low-frequency random images, label = the quantised
+    low-pass of channel 0 (equal-population classes), 2B audio clips as in synth_inputs.  Used to condition the synthetic
+    weights by a short training run (tools/conditioned_probe.py, tests/test_gpu_conditioned_parity.py)."""
+    H, W = image_hw
+    g = torch.Generator(device="cpu")
+    g.manual_seed(seed)
+    low = torch.randn(batch, 3, max(1, H // 8), max(1, W // 8), generator=g)
+    image = torch.nn.functional.interpolate(low, size=(H, W), mode="bilinear", align_corners=False) * 1.5 \
+        + 0.3 * torch.randn(batch, 3, H, W, generator=g)
+    smooth = torch.nn.functional.avg_pool2d(image[:, :1], 9, 1, 4).squeeze(1)
+    edges = torch.quantile(smooth.flatten()[:1 << 20], torch.linspace(0, 1, num_classes + 1)[1:-1])
+    label = torch.bucketize(smooth, edges).long()
+    audio = (torch.rand((2 * batch, 1, 96, 64), generator=g) * 2 - 1).clamp_(-1, 1)
+    return image.contiguous(), audio, label.contiguous()

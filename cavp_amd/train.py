@@ -373,7 +373,8 @@ class TrainPass:
     def conv(self, x: V, key: str, *, act: int = ACT_NONE, residual: Optional[V] = None, nbias: Optional[V] = None,
              out: Optional[V] = None, stats: bool = False, residual_periodic: bool = False) -> V:
         """y = act(conv(x) + nbias[n] + bias + residual); fused epilogue forward, tape entry for backward.
-        stats=True: a plain conv feeding a BatchNorm - ask the epilogue for the per-tile batch statistics.
+        stats=True or the BatchNorm module the conv feeds: ask the epilogue for the per-tile batch statistics (a module in eval
+        mode normalises with its running statistics: nothing is collected).
         act=ACT_GELU (timm Mlp's fc1, attn.py:136-150): y = gelu(t) and gelu'(t) are both written by the epilogue; the
         pre-activation never reaches HBM and the backward multiplier is applied inside the GEMM that produces dy.
         residual_periodic: `residual` holds the first 1/k of the batch and is added to every k-th part (the un-duplicated half
@@ -386,7 +387,10 @@ class TrainPass:
         if out is None:
             out = V(self.empty(x.t.shape[:-1] + (p.cout,)) if x.t.dim() != 4 else self.empty((n, ho, wo, p.cout)))
         bias = p.bias.detach() if p.bias is not None else None
-        fuse = stats and bias is None and nbias is None and residual is None and act == ACT_NONE and out.parent is None
+        bn_mod = stats if isinstance(stats, nn.modules.batchnorm._BatchNorm) else None
+        if bn_mod is not None and (not bn_mod.training) and bn_mod.running_mean is not None:
+            stats = False   # frozen statistics (eval-mode module): nobody reads batch statistics
+        fuse = bool(stats) and bias is None and nbias is None and residual is None and act == ACT_NONE and out.parent is None
         deriv = self.empty(out.t.shape, out.t.dtype) if act == ACT_GELU else None
         res_rows = 0
         if residual_periodic:
@@ -871,18 +875,18 @@ def run_train_forward(model, image: torch.Tensor, audio: torch.Tensor, tp: Train
         # ---- backbone (resnet.py:186-201) ----
         z = tp.conv_smallcin(image, "stem0", 2, ACT_NONE)
         x = tp.bn_act(z, rn.conv1[1], ACT_RELU)
-        x = tp.bn_act(tp.conv(x, "stem1", stats=True), rn.conv1[4], ACT_RELU)
-        x = tp.bn_act(tp.conv(x, "stem2", stats=True), rn.bn1, ACT_RELU)
+        x = tp.bn_act(tp.conv(x, "stem1", stats=rn.conv1[4]), rn.conv1[4], ACT_RELU)
+        x = tp.bn_act(tp.conv(x, "stem2", stats=rn.bn1), rn.bn1, ACT_RELU)
         x = tp.maxpool(x, 3, 2, 1)
         feats = []
         for si, stage in enumerate(rn.block_table):
             for bi, (_, _, _, has_ds) in enumerate(stage):
                 blkm = getattr(rn, f"layer{si + 1}")[bi]
                 key = f"l{si + 1}.{bi}"
-                o = tp.bn_act(tp.conv(x, key + ".c1", stats=True), blkm.bn1, ACT_RELU)
-                o = tp.bn_act(tp.conv(o, key + ".c2", stats=True), blkm.bn2, ACT_RELU)
-                res = tp.bn_act(tp.conv(x, key + ".ds", stats=True), blkm.downsample[1], ACT_NONE) if has_ds else x
-                x = tp.bn_act(tp.conv(o, key + ".c3", stats=True), blkm.bn3, ACT_RELU, residual=res)
+                o = tp.bn_act(tp.conv(x, key + ".c1", stats=blkm.bn1), blkm.bn1, ACT_RELU)
+                o = tp.bn_act(tp.conv(o, key + ".c2", stats=blkm.bn2), blkm.bn2, ACT_RELU)
+                res = tp.bn_act(tp.conv(x, key + ".ds", stats=blkm.downsample[1]), blkm.downsample[1], ACT_NONE) if has_ds else x
+                x = tp.bn_act(tp.conv(o, key + ".c3", stats=blkm.bn3), blkm.bn3, ACT_RELU, residual=res)
                 tp.named[key] = x
             feats.append(x)
     for i, f in enumerate(feats):
@@ -974,9 +978,9 @@ def run_train_forward(model, image: torch.Tensor, audio: torch.Tensor, tp: Train
     fus_tok = tp.layernorm(r2, ca.norm)
     fusion = tp.reshape(fus_tok, (B2, hh, ww, Cc))
     # ---- decoder head (encoder_decoder.py:62-75) ----
-    z0h = tp.conv(fusion, "head0", stats=True)
+    z0h = tp.conv(fusion, "head0", stats=up.last_conv[1])
     c1 = tp.bn_act(z0h, up.last_conv[1], ACT_RELU)
-    z1h = tp.conv(c1, "head1", stats=True)
+    z1h = tp.conv(c1, "head1", stats=up.last_conv[4])
     c2 = tp.bn_act(z1h, up.last_conv[4], ACT_RELU)
     lo = tp.conv(c2, "cls")   # [2B, h, w, Cpad]; channels >= num_classes are exact zeros
     tp.named.update(fusion=fusion, z0h=z0h, c1=c1, z1h=z1h, c2=c2, lo=lo, r2=r2, r1=r1, vn=vn, q=q, o=o, fea_v2=fea_v2,

@@ -115,6 +115,11 @@ int cavp_conv2d_nhwc(const cavp_conv_desc* d, const void* x, const void* w, cons
 int cavp_conv2d_nhwc_aux(const cavp_conv_desc* d, const void* x, const void* w, const float* scale, const float* shift,
                          const float* nbias, const void* residual, void* y, void* aux, void* workspace,
                          size_t workspace_bytes, float* tile_stats, void* stream);
+/* An automatically planned launch of the 256x256 tile whose last round of 256 tiles is at most a quarter full (the decoder head
+ * convs, encoder_decoder.py:62-75, at 2B x 56 x 56: 784 tiles = 3.06 rounds) is issued as the leading images on the 256x256 tile
+ * + the remaining images on the small tiles.  Process-wide switch for A/B runs and tests (default on); results are identical
+ * either way up to the summation order inside the tail images. */
+int cavp_set_tail_split(int32_t on);
 
 /* Direct 3x3 conv for Cin in {1,2,3} reading an NCHW f32 tensor and writing NHWC (dtype) with scale/shift + act:
  * the ResNet deep-stem first conv (resnet.py:108-110, stride 2) and the first VGGish conv (vgg.py:26-36). */

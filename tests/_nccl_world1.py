@@ -18,8 +18,12 @@ def main():
     torch.cuda.set_device(0)
     dev = torch.device("cuda", 0)
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    from cavp_amd import _lib as CL
     from cavp_amd import train as TR
     from cavp_amd.cavp_model import CAVP
+    # deterministic reductions (main_vpo_mono.py:39-41 sets cudnn.deterministic): the comparisons below are then held to rounding;
+    # with the default f32 atomics they needed 10 % of the largest gradient (round 2)
+    CL.set_deterministic(True, dev)
     from cavp_amd.synth import synth_inputs, synth_state_dict
     C, B, hw = 3, 4, (64, 64)
     args = types.SimpleNamespace(seg_model="DeepLabV3Plus", last_three_dilation_stride=[False, False, False], audio_backbone="vgg",
@@ -74,17 +78,19 @@ def main():
         serrs.append(float((ms._grad_arena.flat - ref).abs().max() / ref.abs().max()))
     print(f"SYNCBN_RCCL loss {ls0:.6f} {ls1:.6f} eager_err {es:.2e} replay_err {max(serrs):.2e}")
     assert abs(ls0 - l0) <= 1e-4 * max(1.0, abs(l0)) and abs(ls1 - l0) <= 1e-4 * max(1.0, abs(l0))
-    assert es <= 0.1 and max(serrs) <= 0.1
+    # SyncBatchNorm combines (mean, M2) through a gather + a second Chan pass: same statistics, other rounding, then ~1e3 of
+    # amplification through the batch-statistics trunk at B = 4
+    assert es <= 5e-3 and max(serrs) <= 5e-3 and max(serrs) == min(serrs)
     # a plain all-reduce of a known buffer really goes through RCCL
     t = torch.arange(1 << 20, dtype=torch.float32, device=dev)
     dist.all_reduce(t)
     torch.cuda.synchronize()
     assert float(t[12345]) == 12345.0
     print(f"NCCL_WORLD1_OK backend={dist.get_backend()} loss {l0:.6f} {l1:.6f} {l2:.6f} eager_err {e1:.2e} replay_err {max(errs):.2e}")
-    # f32 atomics in the BatchNorm reductions: run-to-run differences of a few 1e-2 of the largest gradient are the documented
-    # noise floor; a missing / misordered collective would leave garbage or zeros
-    assert abs(l1 - l0) <= 1e-4 * max(1.0, abs(l0)) and abs(l2 - l0) <= 1e-4 * max(1.0, abs(l0))
-    assert e1 <= 0.1 and max(errs) <= 0.1
+    # SUM over one rank is the identity and the reductions run in a fixed order: the eager step with the collectives and every
+    # replay of the two-graph capture reproduce the collective-free step exactly
+    assert l1 == l0 and l2 == l0
+    assert e1 <= 1e-6 and max(errs) <= 1e-6
     dist.destroy_process_group()
 
 

@@ -15,3 +15,16 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return os.path.join(REPO, "tests", "golden")
+
+
+@pytest.fixture
+def deterministic():
+    """cavp_set_deterministic for the duration of one test (fixed-order reductions: run-to-run bit-reproducible steps), so that
+    comparisons between two runs of the training step can be held to rounding instead of to the f32-atomics noise."""
+    import torch
+    from cavp_amd import _lib
+    _lib.set_deterministic(True, torch.device("cuda", 0))
+    try:
+        yield
+    finally:
+        _lib.set_deterministic(False)

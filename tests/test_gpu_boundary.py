@@ -50,7 +50,7 @@ def test_stage_methods_compose_to_the_forward():
     assert pack2["audio"].shape == rp["audio"].shape == (CFG["B"], 304, 1, 1)
 
 
-def test_forward_audio_and_audio_func_path():
+def test_forward_audio_and_audio_func_path(deterministic):
     """forward_audio: [features | features[shuffle_idx]] + SoundBank update under ow_flag; forward_train(audio_func=True) on B
     clips == forward_train on the explicitly concatenated 2B clips (forward and every parameter gradient)."""
     m, sd = _model()
@@ -84,22 +84,17 @@ def test_forward_audio_and_audio_func_path():
     o1, g1 = step(audio=audio, shuffle_info=info, ow_flag=False, audio_func=True)
     o2, g2 = step(audio=torch.cat((audio, audio[idx])), shuffle_info=None, ow_flag=False)
     assert o1.shape == (2 * B, CFG["C"]) + CFG["hw"]
-    # (B = 2 batch-statistics BatchNorm amplifies the different summation order of the audio encoder's GEMMs: M = B vs 2B rows)
-    assert float((o1 - o2).abs().max()) <= 5e-3 * max(1.0, float(o2.abs().max()))
+    # deterministic mode (fixed-order reductions): what is left is the different summation order of the audio encoder's GEMMs
+    # (M = B vs 2B rows pick different tiles) - measured: logits identical, gradients within 2.2e-6 (tools/det_bars_probe.py).
+    # Round 2 ran this with the default f32 atomics and had to allow 25 % on the backbone gradients.
+    assert float((o1 - o2).abs().max()) <= 1e-5 * max(1.0, float(o2.abs().max()))
     assert g1.keys() == g2.keys()
     for k in g1:
         a, b = g1[k].double().flatten(), g2[k].double().flatten()
         if float(b.norm()) == 0.0:
             continue
-        # the audio encoder sees every clip once (B) instead of twice (2B): same gradient, different summation order
-        # Two runs of the SAME step already differ by a few % of the gradient norm at the far end of the backward (f32 atomics in
-        # the reductions, amplified through 50 batch-statistics BatchNorm layers at B = 2: DESIGN.md 6c), so the backbone gets a
-        # direction check and everything the audio path feeds directly (audio encoder, attention, head) a tight one
-        rel, cos = float((a - b).norm() / b.norm()), float((a @ b) / (a.norm() * b.norm()))
-        if k.startswith("backbone.") or k.startswith("segment.aspp") or k.startswith("segment.reduce"):
-            assert rel <= 0.25 and cos >= 0.97, (k, rel, cos)
-        else:
-            assert rel <= 6e-2 and cos >= 0.998, (k, rel, cos)
+        rel = float((a - b).norm() / b.norm())
+        assert rel <= 1e-4, (k, rel)
 
 
 def test_trainer_call_sequence():

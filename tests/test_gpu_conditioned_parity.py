@@ -1,0 +1,109 @@
+"""End-to-end parity of the bf16 training step - the dtype the headline frames/s is measured in - against the CPU ORACLE
+(f32, pinned to the reference by tests/golden) on CONDITIONED weights.
+
+On the synthetic random weights the batch-statistics BatchNorm trunk amplifies every perturbation layer by layer (bf16 storage
+rounding included: the un-forced bf16 logits sit 60 % away from the oracle's, tools/conditioned_probe.py), so the model-level
+bf16 tests on those weights can only pin loss and gradient-norm statistics.  Here the synthetic set is first trained for 100
+f32 steps on a learnable synthetic task with the repo's own fused step + fused SGD / Adam (cavp_amd.optim.FusedSGDAdam), then
+frozen; on these weights the bf16 step is held to the oracle's logits, loss and gradient direction.  Measured (MI355X, round
+3): logits 3e-3 .. 5e-3 relative L2 (the f32 path: 5e-7), loss within 1e-4 .. 9e-4, whole-gradient cosine 0.979, per-parameter
+cosine median 0.958 / 5th percentile 0.89 (f32 path: >= 0.9999): at a trained point the gradient is a small residual of
+near-cancelling terms, so bf16 storage rounding shows in its direction before it shows in the logits."""
+import types
+
+import pytest
+import torch
+
+from cavp_amd.synth import learnable_inputs, synth_state_dict
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+CFG = dict(C=3, B=8, hw=(96, 96), lds=[False, False, False])
+
+
+def _build(sd, dtype):
+    from cavp_amd.cavp_model import CAVP
+    args = types.SimpleNamespace(seg_model="DeepLabV3Plus", last_three_dilation_stride=CFG["lds"], audio_backbone="vgg",
+                                 num_classes=CFG["C"], batch_size=CFG["B"], local_rank="cpu")
+    m = CAVP(50, None, num_classes=CFG["C"], args=args)
+    if sd is None:
+        sd = synth_state_dict({k: tuple(v.shape) for k, v in m.state_dict().items()}, seed=1)
+    m.load_state_dict(sd, strict=True)
+    m.train().to(DEV).set_compute_dtype(dtype)
+    return m
+
+
+@pytest.fixture(scope="module")
+def conditioned():
+    """(state_dict on the CPU, first loss, last loss) after 100 f32 training steps over four learnable batches."""
+    from cavp_amd.optim import FusedSGDAdam
+    m = _build(None, torch.float32)
+    batches = [[t.to(DEV) for t in learnable_inputs(CFG["B"], CFG["hw"], CFG["C"], seed=3 + i)] for i in range(4)]
+    opt, losses = None, []
+    for it in range(100):
+        image, audio, label = batches[it % 4]
+        loss = m.train_step(image, audio, label)
+        if opt is None:
+            opt = FusedSGDAdam(m, m._grad_arena, 1e-2, momentum=0.9, weight_decay=1e-4)
+        opt.step(1e-2)
+        losses.append(float(loss.item()))
+    torch.cuda.synchronize()
+    return {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}, losses[0], losses[-1]
+
+
+@pytest.fixture(scope="module")
+def oracle_step(conditioned):
+    from oracle import cavp_oracle as O
+    sd = conditioned[0]
+    image, audio, label = learnable_inputs(CFG["B"], CFG["hw"], CFG["C"], seed=11)   # a batch the training run never saw
+    params = {k: v.clone().requires_grad_(True) for k, v in sd.items() if v.is_floating_point() and "running_" not in k}
+    sd2 = dict(sd)
+    sd2.update(params)
+    out, _, _ = O.cavp_forward(sd2, image, audio, CFG["lds"], eval_mode=False)
+    loss = O.ce_loss_train(out, label, CFG["B"])
+    loss.backward()
+    return (image, audio, label), out.detach(), float(loss.item()), {k: p.grad for k, p in params.items() if p.grad is not None}
+
+
+def _compare(sd, dtype, oracle_step):
+    (image, audio, label), ref, ref_loss, ref_g = oracle_step
+    m = _build(sd, dtype)
+    loss = m.train_step(image.to(DEV), audio.to(DEV), label.to(DEV), want_pred=True)
+    torch.cuda.synchronize()
+    pred = m._last_outputs[0].float().cpu()
+    rel = float((pred - ref).norm() / ref.norm())
+    dot = na = nb = 0.0
+    cos = []
+    big = max(float(g.norm()) for g in ref_g.values())
+    for k, p in m.named_parameters():
+        if p.grad is None or k not in ref_g:
+            continue
+        a, b = p.grad.double().cpu().flatten(), ref_g[k].double().flatten()
+        dot, na, nb = dot + float(a @ b), na + float(a @ a), nb + float(b @ b)
+        if float(b.norm()) >= 1e-3 * big:   # (directions of gradients that are ~0 in the oracle are noise on both sides)
+            cos.append(float((a @ b) / (a.norm() * b.norm())))
+    cos.sort()
+    return dict(logits_rel=rel, loss=float(loss.item()), ref_loss=ref_loss, whole_cos=dot / (na * nb) ** 0.5,
+                cos_med=cos[len(cos) // 2], cos_p05=cos[len(cos) // 20], n=len(cos), logit_std=float(ref.std()))
+
+
+def test_training_conditions_the_weights(conditioned):
+    _, first, last = conditioned
+    assert last < 0.5 * first, (first, last)   # measured 2.39 -> ~0.2: the task is learnable and the fused step + optimiser learn it
+
+
+def test_f32_step_vs_oracle_on_conditioned_weights(conditioned, oracle_step):
+    r = _compare(conditioned[0], torch.float32, oracle_step)
+    print("f32 :", r)
+    assert r["logit_std"] > 1.0                                   # a real prediction, not a collapsed constant
+    assert r["logits_rel"] <= 1e-4 and abs(r["loss"] - r["ref_loss"]) <= 1e-4 * max(1.0, r["ref_loss"])
+    assert r["whole_cos"] >= 0.9999 and r["cos_p05"] >= 0.999
+
+
+def test_bf16_step_vs_oracle_on_conditioned_weights(conditioned, oracle_step):
+    r = _compare(conditioned[0], torch.bfloat16, oracle_step)
+    print("bf16:", r)
+    assert r["logits_rel"] <= 2e-2, r                             # measured 3e-3 .. 5e-3 (VERDICT r02 target: <= 2 %)
+    assert abs(r["loss"] - r["ref_loss"]) <= 5e-3 * max(1.0, r["ref_loss"]), r
+    assert r["whole_cos"] >= 0.96, r                              # measured 0.979
+    assert r["cos_med"] >= 0.93 and r["cos_p05"] >= 0.80, r       # measured 0.958 / 0.891

@@ -47,40 +47,60 @@ def test_eval_forward_is_per_sample_at_full_size():
     assert float((full[8:16] - part).abs().max()) <= 2e-4 * scale
 
 
-def test_train_step_full_size_properties():
-    """f32 path (the parity path): run-to-run differences are only the order of the f32 atomics in the BatchNorm column
-    reductions, so the linearity in the loss scale can be pinned tightly.  (In bf16 the same rounding noise is amplified
-    by 50 batch-statistics BatchNorm layers on random weights to ~1 % of the loss: see the last test.)"""
+def test_train_step_full_size_properties(deterministic):
+    """f32 path (the parity path) at the BASELINE size, deterministic mode (fixed-order reductions; the reference trains with
+    cudnn.deterministic = True, main_vpo_mono.py:39-41): two runs of the step are bit-identical, so linearity in the loss scale
+    (a power of two: exact in binary floating point) is held to rounding.  Round 2 ran this with the default atomics and had
+    to leave 8 % of the gradient norm for their re-association noise."""
     image, audio, label = [t.to(DEV) for t in synth_inputs(B, HW, audio_batch=2 * B, num_classes=C, seed=5)]
-    m1, m2 = _build(torch.float32, True), _build(torch.float32, True)
+    m1, m2, m3 = _build(torch.float32, True), _build(torch.float32, True), _build(torch.float32, True)
     l1 = float(m1.train_step(image, audio, label, loss_scale=1.0).item())
     g1 = _grads(m1)
     l2 = float(m2.train_step(image, audio, label, loss_scale=4.0).item())
     g2 = _grads(m2)
+    l3 = float(m3.train_step(image, audio, label, loss_scale=1.0).item())
+    g3 = _grads(m3)
     torch.cuda.synchronize()
-    assert l1 == pytest.approx(l2, rel=1e-3) and 0.0 < l1 < 20.0
+    assert l1 == l2 == l3 and 0.0 < l1 < 20.0
     assert set(g1) == set(g2) and len(g1) > 200
-    tot1 = torch.sqrt(sum((v ** 2).sum() for v in g1.values()))
-    tot2 = torch.sqrt(sum((v ** 2).sum() for v in g2.values()))
-    assert float(tot2 / tot1) == pytest.approx(4.0, rel=2e-3)
-    # two runs of the same f32 step already differ by ~2.5 % of the gradient norm on these random weights (the f32 atomics of
-    # the column reductions re-associate, 50 batch-statistics BatchNorm layers amplify it): the bar sits above that noise
-    err = torch.sqrt(sum(((4.0 * g1[k] - g2[k]) ** 2).sum() for k in g1))
-    assert float(err / tot2) <= 8e-2, float(err / tot2)
+    assert all(torch.equal(g1[k], g3[k]) for k in g1), "two runs of the same deterministic step must be bit-identical"
+    tot2 = torch.sqrt(sum((v.double() ** 2).sum() for v in g2.values()))
+    err = torch.sqrt(sum(((4.0 * g1[k].double() - g2[k].double()) ** 2).sum() for k in g1))
+    assert float(err / tot2) <= 1e-6, float(err / tot2)   # measured 0.0 (tools/det_bars_probe.py)
 
 
-def test_graph_replay_equals_eager_at_full_size():
+def test_graph_replay_equals_eager_at_full_size(deterministic):
     image, audio, label = [t.to(DEV) for t in synth_inputs(B, HW, audio_batch=2 * B, num_classes=C, seed=6)]
     m1, m2 = _build(torch.float32, True), _build(torch.float32, True)
     l1 = float(m1.train_step(image, audio, label).item())
     replay = m2.capture_train_step(image, audio, label)
     l2 = float(replay().item())
     torch.cuda.synchronize()
-    assert l1 == pytest.approx(l2, rel=1e-3)
+    assert l1 == l2
     g1, g2 = _grads(m1), _grads(m2)
-    tot = torch.sqrt(sum((v ** 2).sum() for v in g1.values()))
-    err = torch.sqrt(sum(((g1[k] - g2[k]) ** 2).sum() for k in g1))
-    assert float(err / tot) <= 8e-2, float(err / tot)   # run-to-run noise of the eager step itself: ~2.5e-2 (see above)
+    tot = torch.sqrt(sum((v.double() ** 2).sum() for v in g1.values()))
+    err = torch.sqrt(sum(((g1[k].double() - g2[k].double()) ** 2).sum() for k in g1))
+    assert float(err / tot) <= 1e-6, float(err / tot)   # deterministic mode: the replay is the eager step, bit for bit
+
+
+def test_default_mode_noise_band_at_full_size():
+    """The DEFAULT step (reductions finish with f32 atomics) against the deterministic one: what the re-association noise costs
+    on these random weights, as a band - loss to 1e-4, gradient within 8 % of its norm (measured ~2.5 %)."""
+    from cavp_amd import _lib
+    image, audio, label = [t.to(DEV) for t in synth_inputs(B, HW, audio_batch=2 * B, num_classes=C, seed=6)]
+    m1, m2 = _build(torch.float32, True), _build(torch.float32, True)
+    l1 = float(m1.train_step(image, audio, label).item())
+    g1 = _grads(m1)
+    _lib.set_deterministic(True, torch.device(DEV))
+    try:
+        l2 = float(m2.train_step(image, audio, label).item())
+        g2 = _grads(m2)
+    finally:
+        _lib.set_deterministic(False)
+    assert l1 == pytest.approx(l2, rel=1e-4)
+    tot = torch.sqrt(sum((v.double() ** 2).sum() for v in g2.values()))
+    err = torch.sqrt(sum(((g1[k].double() - g2[k].double()) ** 2).sum() for k in g1))
+    assert float(err / tot) <= 8e-2, float(err / tot)
 
 
 def test_bf16_step_tracks_f32_at_full_size():

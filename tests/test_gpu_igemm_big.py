@@ -154,3 +154,41 @@ def test_token_path_epilogue_fusions(tile, dtype):
     ops.conv2d(xv, wp, out, shift=bias.to(DEV), residual=rv, res_rows=(n // 2) * t, aux=mv, aux_mode=2, tile=tile)
     ref = pre * _q(mul, dtype) + torch.cat((_q(res, dtype), _q(res, dtype)), 0)
     _check(out.permute(0, 3, 1, 2), ref, dtype, f"mul + periodic residual tile{tile}")
+
+
+def test_tail_split_of_a_nearly_empty_last_round():
+    """An automatically planned 256x256-tile launch whose last round of 256 tiles is nearly empty (66 images of 32 x 32 pixels:
+    264 tiles) is issued as the 64 images that fill a whole round on the big tile + the 2 remaining images on the small tiles
+    (conv_igemm.hip: tail_split_images).  Per-image bias, residual, scale / shift, activation and the accumulated BatchNorm
+    sums must all follow the image offset."""
+    ops = _ops()
+    from cavp_amd import train_ops as T
+    n, h, w, cin, cout = 66, 32, 32, 64, 256
+    x, wt = _rand(n, cin, h, w, seed=21), _rand(cout, cin, 3, 3, seed=22, scale=(cin * 9) ** -0.5)
+    sc, sh = torch.rand(cout, generator=torch.Generator().manual_seed(23)) + 0.5, _rand(cout, seed=24)
+    nb, res = _rand(n, cout, seed=25), _rand(n, cout, h, w, seed=26)
+    xv, _ = _to_nhwc_dev(x, BF)
+    rv, _ = _to_nhwc_dev(res, BF)
+    wp = ops.pack_weight(wt.to(DEV), BF)
+    conv = F.conv2d(_q(x, BF), _q(wt, BF), None, 1, 1)
+    ref = _act((conv + nb[:, :, None, None]) * sc[None, :, None, None] + sh[None, :, None, None] + _q(res, BF), 1)
+    out = torch.empty((n, h, w, cout), dtype=BF, device=DEV)
+    ops.conv2d(xv, wp, out, kh=3, kw=3, pad=1, scale=sc.to(DEV), shift=sh.to(DEV), nbias=nb.to(DEV), residual=rv, act=1)
+    _check(out.permute(0, 3, 1, 2), ref, BF, "tail split / fused epilogue")
+    forced = torch.empty_like(out)   # the same conv as ONE launch of the big tile (an explicit tile request never splits)
+    ops.conv2d(xv, wp, forced, kh=3, kw=3, pad=1, scale=sc.to(DEV), shift=sh.to(DEV), nbias=nb.to(DEV), residual=rv, act=1, tile=BIG)
+    assert torch.equal(out[:64], forced[:64]), "the leading images run on the same tile: bit-identical"
+    assert float((out[64:].float() - forced[64:].float()).abs().max()) <= 2e-2 * float(ref.abs().max())
+    # per-tile BatchNorm statistics across both launches: the tail continues the 128-row tile sequence of the big tile
+    z = torch.empty_like(out)
+    _, stats = ops.conv2d(xv, wp, z, kh=3, kw=3, pad=1, want_tile_stats=True)
+    assert stats is not None
+    ts, tiles, rpt = stats
+    assert (tiles, rpt) == (n * h * w // 128, 128)
+    g, b = torch.ones(cout, device=DEV), torch.zeros(cout, device=DEV)
+    f = lambda: torch.empty(cout, device=DEV)
+    scale, shift, mean, rstd = f(), f(), f(), f()
+    T.bn_finalize_tiles(ts, tiles, rpt, n * h * w, g, b, 1e-5, 0.1, None, None, scale, shift, mean, rstd)
+    assert float((mean.cpu() - conv.mean((0, 2, 3))).abs().max()) <= 2e-4, "mean over both launches"
+    v_ref = conv.var((0, 2, 3), unbiased=False)
+    assert float((rstd.cpu() - 1 / torch.sqrt(v_ref + 1e-5)).abs().max()) <= 2e-4 * float((1 / torch.sqrt(v_ref + 1e-5)).max())

@@ -91,7 +91,7 @@ def test_fused_optimizer_vs_torch_optim():
 
 
 @pytest.mark.gpu
-def test_two_train_steps_vs_reference_weights():
+def test_two_train_steps_vs_reference_weights(deterministic):
     from cavp_amd.optim import FusedSGDAdam, warmup_poly_lr
     from cavp_amd.synth import synth_inputs
     ref, z = _golden()
@@ -148,10 +148,11 @@ def test_two_train_steps_vs_reference_weights():
             else:
                 # second step: the gradient is re-evaluated at weights that already differ in the last bits and by
                 # +-2 lr wherever Adam's sign step met a near-zero gradient; with batch-statistics BN at B = 4 that is
-                # enough to decorrelate the gradients of the early layers (the momentum / bias-correction / schedule
-                # arithmetic itself is pinned exactly by test_fused_optimizer_vs_torch_optim), so only a sanity band here
-                # (24 runs on one box, tools/flaky_probe.py: the worst sentinel of a run lands at cosine 0.44 .. 0.50 in one run
-                # out of six, with or without the second stream - the band below is a sanity band, not a parity bar)
-                assert cos >= 0.3 and 0.5 <= ratio <= 1.7, (it, k, cos, ratio)
+                # enough to move the gradients of the early layers (the momentum / bias-correction / schedule arithmetic
+                # itself is pinned exactly by test_fused_optimizer_vs_torch_optim).  The test runs in deterministic mode
+                # (fixed-order reductions), so the figures are reproducible run to run - measured: worst sentinel cosine
+                # 0.663, norm ratios 0.93 .. 1.13 (round 2, with the default f32 atomics, saw 0.44 .. 0.99 across runs and
+                # could only keep a 0.3 band)
+                assert cos >= 0.6 and 0.85 <= ratio <= 1.2, (it, k, cos, ratio)
         print(f"step {it}: loss {got:.5f} (reference {float(z['loss'][it]):.5f}); weight-update cosine min "
               f"{min(r[1] for r in rep):.4f}, norm ratio in [{min(r[2] for r in rep):.3f}, {max(r[2] for r in rep):.3f}]")

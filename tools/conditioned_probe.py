@@ -32,6 +32,11 @@ def build(sd, cfg, dtype, dev):
     return m, sd
 
 
+def blob_batch(cfg, seed):
+    from cavp_amd.synth import learnable_inputs
+    return learnable_inputs(cfg["B"], cfg["hw"], cfg["C"], seed)
+
+
 def condition(cfg, steps, lr, dev, damp=1.0, seed=3):
     """Synthetic weights -> `steps` f32 training steps on ONE synthetic batch (fused step + fused SGD / Adam) -> CPU state_dict."""
     from cavp_amd.optim import FusedSGDAdam
@@ -42,10 +47,10 @@ def condition(cfg, steps, lr, dev, damp=1.0, seed=3):
             for k, p in m.named_parameters():
                 if ".bn3.weight" in k:
                     p.mul_(damp)
-    image, audio, label = [t.to(dev) for t in synth_inputs(cfg["B"], cfg["hw"], audio_batch=2 * cfg["B"], num_classes=cfg["C"], seed=seed)]
     opt = None
     losses = []
     for it in range(steps):
+        image, audio, label = [t.to(dev) for t in blob_batch(cfg, seed + it % 4)]   # four batches in turn
         loss = m.train_step(image, audio, label)
         if opt is None:
             opt = FusedSGDAdam(m, m._grad_arena, lr, momentum=0.9, weight_decay=1e-4)
@@ -59,7 +64,7 @@ def compare(sd, cfg, dev, seed=11):
     """bf16 HIP train step vs the oracle's f32 autograd on the weights `sd`: (logits rel L2, loss pair, gradient cosines)."""
     from cavp_amd.synth import synth_inputs
     from oracle import cavp_oracle as O
-    image, audio, label = synth_inputs(cfg["B"], cfg["hw"], audio_batch=2 * cfg["B"], num_classes=cfg["C"], seed=seed)
+    image, audio, label = blob_batch(cfg, seed)
     params = {k: v.clone().requires_grad_(True) for k, v in sd.items() if v.is_floating_point() and "running_" not in k}
     sd2 = dict(sd)
     sd2.update(params)
@@ -75,17 +80,19 @@ def compare(sd, cfg, dev, seed=11):
         ref = out.detach()
         rel = float((pred - ref).norm() / ref.norm())
         cos, nr = [], []
+        dot = na = nb = 0.0
         for k, p in m.named_parameters():
             if p.grad is None or params[k].grad is None:
                 continue
             a, b = p.grad.double().cpu().flatten(), params[k].grad.double().flatten()
             if float(b.norm()) < 1e-12:
                 continue
+            dot, na, nb = dot + float(a @ b), na + float(a @ a), nb + float(b @ b)
             cos.append((float((a @ b) / (a.norm() * b.norm() + 1e-300)), k))
             nr.append(float(a.norm() / b.norm()))
         cos.sort()
         nr.sort()
-        res[name] = dict(logits_rel=rel, loss=float(loss.item()), oracle_loss=float(o_loss.item()), cos_min=cos[0], cos_p05=cos[len(cos) // 20][0],
+        res[name] = dict(whole_cos=dot / (na * nb) ** 0.5, logits_rel=rel, logit_range=(float(ref.min()), float(ref.max()), float(ref.std())), loss=float(loss.item()), oracle_loss=float(o_loss.item()), cos_min=cos[0], cos_p05=cos[len(cos) // 20][0],
                          cos_med=cos[len(cos) // 2][0], norm_ratio=(nr[0], nr[len(nr) // 2], nr[-1]))
     return res
 
@@ -102,7 +109,7 @@ def main():
     from cavp_amd.synth import synth_state_dict
     m0, sd0 = build(None, cfg, torch.float32, dev)
     variants = [("synthetic (untrained)", {k: v.cpu().clone() for k, v in sd0.items()}, None)]
-    for steps, damp in ((a.steps, 1.0), (a.steps, 0.2), (0, 0.2)):
+    for steps, damp in ((a.steps, 1.0), (2 * a.steps, 1.0), (a.steps, 0.2)):
         sd, losses = condition(cfg, steps, a.lr, dev, damp=damp)
         variants.append((f"{steps} f32 steps at lr {a.lr}, bn3 gamma x{damp}", sd, losses))
     for name, sd, losses in variants:
@@ -112,7 +119,7 @@ def main():
         else:
             print(f"== {name}")
         for dt, v in r.items():
-            print(f"   {dt}: logits rel L2 {v['logits_rel']:.3e}  loss {v['loss']:.5f} (oracle {v['oracle_loss']:.5f})  grad cosine min {v['cos_min'][0]:.4f} "
+            print(f"   {dt}: oracle logits min/max/std {v['logit_range'][0]:.2f}/{v['logit_range'][1]:.2f}/{v['logit_range'][2]:.2f}  logits rel L2 {v['logits_rel']:.3e}  loss {v['loss']:.5f} (oracle {v['oracle_loss']:.5f})  whole-gradient cosine {v['whole_cos']:.5f}  per-parameter cosine min {v['cos_min'][0]:.4f} "
                   f"({v['cos_min'][1]}) p05 {v['cos_p05']:.4f} median {v['cos_med']:.4f}  norm ratio min/med/max {v['norm_ratio'][0]:.3f}/{v['norm_ratio'][1]:.3f}/{v['norm_ratio'][2]:.3f}")
 
 
