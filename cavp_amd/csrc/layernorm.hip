@@ -268,7 +268,11 @@ extern "C" int cavp_layernorm_bwd(int32_t dtype, const void* dy, const void* x, 
   int G, PLV;
   if (!ln_geometry(C, VE, &G, &PLV)) return CAVP_ERR_UNSUPPORTED;
   const int rpi = 4 * (64 / G);  // rows per workgroup iteration
-  int gx = 1024;
+  // workgroups: every one ends with 2 x C f32 atomics into the SAME dgamma / dbeta (served memory-side, ~26 ns per workgroup once
+  // they queue up, tools/microbench/atomic_spread.hip): 1024 workgroups only where the tensor gives each of them >= 8 K elements
+  // (the PVTv2 stage-3 / stage-4 norms are 8192 x 320 / 2048 x 512: 1024 workgroups left them 8 rows each and 26 us of queueing)
+  long long want = (long long)rows * C / 8192;
+  int gx = want > 1024 ? 1024 : (want < 64 ? 64 : (int)want);
   int rpb = (rows + gx - 1) / gx;
   rpb = (rpb + rpi - 1) / rpi * rpi;
   gx = (rows + rpb - 1) / rpb;

@@ -217,6 +217,93 @@ __global__ __launch_bounds__(256) void dwconv3x3_kernel(const T* __restrict__ x,
   }
 }
 
+// The same conv with a thread owning one 16-byte channel vector of SW = 4 (bf16) / 8 (f32) consecutive output pixels of a row:
+// 3 x (SW + 2) input vectors serve SW outputs (4.5 / 3.75 loads per output instead of 9; SW = 8 for bf16 needed 200 VGPRs), the 9 x VE weights of the vector are fetched once per row of taps
+// with 16-byte loads (the pixel-per-thread kernel above issued 72 scalar weight loads and four 64-bit divisions per output),
+// and the index arithmetic is paid once per strip.  Lanes run along the channel vectors, so loads and stores stay coalesced.
+template <typename T>
+__global__ __launch_bounds__(256) void dwconv3x3_strip_kernel(const T* __restrict__ x, const float* __restrict__ w9c,
+                                                              const float* __restrict__ bias, T* __restrict__ y, int N, int H,
+                                                              int W, int C, int act) {
+  constexpr int VE = 16 / (int)sizeof(T), SW = 32 / VE;   // 32 accumulators per thread: 8 pixels x 4 (f32) / 4 pixels x 8 (bf16)
+  const int CV = C / VE, strips = (W + SW - 1) / SW;
+  const long long total = (long long)N * H * strips * CV;
+  for (long long idx = blockIdx.x * 256ll + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+    const unsigned u = (unsigned)idx;   // (total < 2^31 checked by the launcher)
+    const unsigned r1 = u / (unsigned)CV, cv = u - r1 * (unsigned)CV;
+    const unsigned r2 = r1 / (unsigned)strips, st = r1 - r2 * (unsigned)strips;
+    const unsigned n = r2 / (unsigned)H, hi = r2 - n * (unsigned)H;
+    const int w0 = (int)st * SW, c0 = (int)cv * VE;
+    float acc[SW][VE];
+    {
+      float b[VE];
+#pragma unroll
+      for (int e = 0; e < VE; ++e) b[e] = 0.f;
+      if (bias) {
+#pragma unroll
+        for (int q = 0; q < VE; q += 4) VecT<float>::load(bias + c0 + q, b + q);
+      }
+#pragma unroll
+      for (int p = 0; p < SW; ++p)
+#pragma unroll
+        for (int e = 0; e < VE; ++e) acc[p][e] = b[e];
+    }
+#pragma unroll 1
+    for (int kh = 0; kh < 3; ++kh) {   // (not unrolled: one row of taps' inputs and weights live at a time)
+      const int h2 = (int)hi - 1 + kh;
+      if ((unsigned)h2 >= (unsigned)H) continue;
+      float wt[3][VE];
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+        for (int q = 0; q < VE; q += 4) VecT<float>::load(w9c + (size_t)(kh * 3 + kw) * C + c0 + q, wt[kw] + q);
+      const T* row = x + ((size_t)(n * H + h2) * W) * C + c0;
+      // (the 10 input vectors stay PACKED - 4 registers each for bf16 - and are widened where they are used: with them held as
+      // f32 the kernel needed 204 VGPRs, two waves per SIMD)
+      uint4 xr[SW + 2];
+#pragma unroll
+      for (int p = 0; p < SW + 2; ++p) {
+        const int w2 = w0 - 1 + p;
+        xr[p] = (unsigned)w2 < (unsigned)W ? *(const uint4*)(row + (size_t)w2 * C) : make_uint4(0u, 0u, 0u, 0u);
+      }
+      // input-major: every input vector is widened ONCE and scattered into the (up to 3) outputs it feeds
+#pragma unroll
+      for (int p = 0; p < SW + 2; ++p) {
+        float xv[VE];
+        const unsigned q[4] = {xr[p].x, xr[p].y, xr[p].z, xr[p].w};
+        if constexpr (sizeof(T) == 4) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) xv[e] = __uint_as_float(q[e]);
+        } else {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            xv[2 * i] = __uint_as_float(q[i] << 16);
+            xv[2 * i + 1] = __uint_as_float(q[i] & 0xffff0000u);
+          }
+        }
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+          const int o = p - kw;   // output pixel of the strip that reads input p through tap kw
+          if (o >= 0 && o < SW) {
+#pragma unroll
+            for (int e = 0; e < VE; ++e) acc[o][e] = fmaf(xv[e], wt[kw][e], acc[o][e]);
+          }
+        }
+      }
+    }
+    T* yp = y + ((size_t)(n * H + hi) * W + w0) * C + c0;
+#pragma unroll
+    for (int p = 0; p < SW; ++p) {
+      if (w0 + p < W) {
+        float o[VE];
+#pragma unroll
+        for (int e = 0; e < VE; ++e) o[e] = apply_act(acc[p][e], act);
+        VecT<T>::store(yp + (size_t)p * C, o);
+      }
+    }
+  }
+}
+
 // torch depth-wise weight [C][1][3][3] -> [9][C] f32
 __global__ void pack_dw_kernel(const float* __restrict__ w, float* __restrict__ o, int C) {
   const int i = blockIdx.x * 256 + threadIdx.x;
@@ -300,9 +387,20 @@ extern "C" int cavp_dwconv3x3_nhwc(int32_t dtype, const void* x, const float* w9
   if (!dt_ok(dtype)) return CAVP_ERR_UNSUPPORTED;
   const int VE = dtype == CAVP_F32 ? 4 : 8;
   if (C % VE) return CAVP_ERR_UNSUPPORTED;
+  hipStream_t s = (hipStream_t)stream;
+  const int SW = 32 / VE;
+  const long long strips_total = (long long)N * H * ((W + SW - 1) / SW) * (C / VE);
+  if (W >= SW && strips_total < 0x7fffffffll && (((uintptr_t)w9c | (uintptr_t)bias) & 15) == 0 && C % 4 == 0) {
+    long long nb = (strips_total + 255) / 256;
+    if (nb > 32768) nb = 32768;
+    if (dtype == CAVP_F32)
+      dwconv3x3_strip_kernel<float><<<(int)nb, 256, 0, s>>>((const float*)x, w9c, bias, (float*)y, N, H, W, C, act);
+    else
+      dwconv3x3_strip_kernel<bf16_t><<<(int)nb, 256, 0, s>>>((const bf16_t*)x, w9c, bias, (bf16_t*)y, N, H, W, C, act);
+    CHECK_LAUNCH();
+  }
   long long nb = ((long long)N * H * W * (C / VE) + 255) / 256;
   if (nb > 32768) nb = 32768;
-  hipStream_t s = (hipStream_t)stream;
   if (dtype == CAVP_F32)
     dwconv3x3_kernel<float><<<(int)nb, 256, 0, s>>>((const float*)x, w9c, bias, (float*)y, N, H, W, C, act);
   else
