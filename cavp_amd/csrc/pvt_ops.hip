@@ -167,7 +167,7 @@ __global__ __launch_bounds__(256) void sra_attention_kernel(const T* __restrict_
 template <typename T>
 __global__ __launch_bounds__(256) void dwconv3x3_kernel(const T* __restrict__ x, const float* __restrict__ w9c,
                                                         const float* __restrict__ bias, T* __restrict__ y, int N, int H,
-                                                        int W, int C, int act) {
+                                                        int W, int C, int act, T* __restrict__ aux) {
   constexpr int VE = 16 / (int)sizeof(T);
   const int CV = C / VE;
   const long long total = (long long)N * H * W * CV;
@@ -204,6 +204,14 @@ __global__ __launch_bounds__(256) void dwconv3x3_kernel(const T* __restrict__ x,
       }
     }
     T* yp = y + (size_t)pix * C + cv * VE;
+    if (aux) {   // GELU with its derivative as second output (see dwconv3x3_strip_kernel)
+      float dg[VE];
+#pragma unroll
+      for (int e = 0; e < VE; ++e) gelu_and_grad(acc[e], acc[e], dg[e]);
+      VecT<T>::store(yp, acc);
+      VecT<T>::store(aux + (size_t)pix * C + cv * VE, dg);
+      continue;
+    }
     if constexpr (sizeof(T) == 4) {
       *(float4*)yp = make_float4(apply_act(acc[0], act), apply_act(acc[1], act), apply_act(acc[2], act), apply_act(acc[3], act));
     } else {
@@ -224,7 +232,7 @@ __global__ __launch_bounds__(256) void dwconv3x3_kernel(const T* __restrict__ x,
 template <typename T>
 __global__ __launch_bounds__(256) void dwconv3x3_strip_kernel(const T* __restrict__ x, const float* __restrict__ w9c,
                                                               const float* __restrict__ bias, T* __restrict__ y, int N, int H,
-                                                              int W, int C, int act) {
+                                                              int W, int C, int act, T* __restrict__ aux) {
   constexpr int VE = 16 / (int)sizeof(T), SW = 32 / VE;   // 32 accumulators per thread: 8 pixels x 4 (f32) / 4 pixels x 8 (bf16)
   const int CV = C / VE, strips = (W + SW - 1) / SW;
   const long long total = (long long)N * H * strips * CV;
@@ -291,7 +299,24 @@ __global__ __launch_bounds__(256) void dwconv3x3_strip_kernel(const T* __restric
         }
       }
     }
-    T* yp = y + ((size_t)(n * H + hi) * W + w0) * C + c0;
+    const size_t off = ((size_t)(n * H + hi) * W + w0) * C + c0;
+    T* yp = y + off;
+    if (aux) {
+      // Mlp.forward (pvt.py:46-55) dwconv -> GELU with gelu'(t) as second output: the backward multiplies it into the epilogue of
+      // the GEMM that produces d(hidden) (cavp_conv_desc.aux_mode 2), so neither the pre-activation nor a separate GELU /
+      // GELU-backward pass exists
+#pragma unroll
+      for (int p = 0; p < SW; ++p) {
+        if (w0 + p < W) {
+          float o[VE], dg[VE];
+#pragma unroll
+          for (int e = 0; e < VE; ++e) gelu_and_grad(acc[p][e], o[e], dg[e]);
+          VecT<T>::store(yp + (size_t)p * C, o);
+          VecT<T>::store(aux + off + (size_t)p * C, dg);
+        }
+      }
+      continue;
+    }
 #pragma unroll
     for (int p = 0; p < SW; ++p) {
       if (w0 + p < W) {
@@ -383,7 +408,14 @@ extern "C" int cavp_sra_attention(int32_t dtype, const void* q, const void* kv, 
 
 extern "C" int cavp_dwconv3x3_nhwc(int32_t dtype, const void* x, const float* w9c, const float* bias, void* y, int32_t N,
                                    int32_t H, int32_t W, int32_t C, int32_t act, void* stream) {
+  return cavp_dwconv3x3_nhwc_aux(dtype, x, w9c, bias, y, nullptr, N, H, W, C, act, stream);
+}
+
+extern "C" int cavp_dwconv3x3_nhwc_aux(int32_t dtype, const void* x, const float* w9c, const float* bias, void* y, void* aux,
+                                       int32_t N, int32_t H, int32_t W, int32_t C, int32_t act, void* stream) {
   if (!x || !w9c || !y || N <= 0 || H <= 0 || W <= 0 || C <= 0) return CAVP_ERR_BAD_ARG;
+  if (aux && act != CAVP_ACT_GELU) return CAVP_ERR_BAD_ARG;   // the second output is gelu'(t)
+  if (((uintptr_t)x | (uintptr_t)y | (uintptr_t)aux) & 15) return CAVP_ERR_ALIGN;
   if (!dt_ok(dtype)) return CAVP_ERR_UNSUPPORTED;
   const int VE = dtype == CAVP_F32 ? 4 : 8;
   if (C % VE) return CAVP_ERR_UNSUPPORTED;
@@ -394,17 +426,17 @@ extern "C" int cavp_dwconv3x3_nhwc(int32_t dtype, const void* x, const float* w9
     long long nb = (strips_total + 255) / 256;
     if (nb > 32768) nb = 32768;
     if (dtype == CAVP_F32)
-      dwconv3x3_strip_kernel<float><<<(int)nb, 256, 0, s>>>((const float*)x, w9c, bias, (float*)y, N, H, W, C, act);
+      dwconv3x3_strip_kernel<float><<<(int)nb, 256, 0, s>>>((const float*)x, w9c, bias, (float*)y, N, H, W, C, act, (float*)aux);
     else
-      dwconv3x3_strip_kernel<bf16_t><<<(int)nb, 256, 0, s>>>((const bf16_t*)x, w9c, bias, (bf16_t*)y, N, H, W, C, act);
+      dwconv3x3_strip_kernel<bf16_t><<<(int)nb, 256, 0, s>>>((const bf16_t*)x, w9c, bias, (bf16_t*)y, N, H, W, C, act, (bf16_t*)aux);
     CHECK_LAUNCH();
   }
   long long nb = ((long long)N * H * W * (C / VE) + 255) / 256;
   if (nb > 32768) nb = 32768;
   if (dtype == CAVP_F32)
-    dwconv3x3_kernel<float><<<(int)nb, 256, 0, s>>>((const float*)x, w9c, bias, (float*)y, N, H, W, C, act);
+    dwconv3x3_kernel<float><<<(int)nb, 256, 0, s>>>((const float*)x, w9c, bias, (float*)y, N, H, W, C, act, (float*)aux);
   else
-    dwconv3x3_kernel<bf16_t><<<(int)nb, 256, 0, s>>>((const bf16_t*)x, w9c, bias, (bf16_t*)y, N, H, W, C, act);
+    dwconv3x3_kernel<bf16_t><<<(int)nb, 256, 0, s>>>((const bf16_t*)x, w9c, bias, (bf16_t*)y, N, H, W, C, act, (bf16_t*)aux);
   CHECK_LAUNCH();
 }
 

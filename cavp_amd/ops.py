@@ -353,13 +353,17 @@ def pack_dwconv_weight(w: torch.Tensor) -> torch.Tensor:
     return out
 
 
-def dwconv3x3(x: torch.Tensor, w9c: torch.Tensor, bias: Optional[torch.Tensor], out: torch.Tensor, act: int = ACT_NONE):
-    _need_gpu(x, w9c, bias, out)
+def dwconv3x3(x: torch.Tensor, w9c: torch.Tensor, bias: Optional[torch.Tensor], out: torch.Tensor, act: int = ACT_NONE,
+              aux: Optional[torch.Tensor] = None):
+    """aux (out's shape, act must be ACT_GELU): receives gelu'(pre-activation) for the backward (cavp_dwconv3x3_nhwc_aux)."""
+    _need_gpu(x, w9c, bias, out, aux)
     n, h, w, c, ld = _nhwc(x)
     if ld != c or not out.is_contiguous() or out.shape != x.shape:
         raise _lib.CavpError("dwconv3x3: dense NHWC tensors required")
-    st = _lib.load().cavp_dwconv3x3_nhwc(dtype_code(x.dtype), _ptr(x), _ptr(w9c), _ptr(bias), _ptr(out), n, h, w, c, act,
-                                         C.c_void_p(_stream()))
+    if aux is not None and (not aux.is_contiguous() or aux.shape != out.shape or aux.dtype != out.dtype):
+        raise _lib.CavpError("dwconv3x3: aux must be a dense tensor of the output's shape and dtype")
+    st = _lib.load().cavp_dwconv3x3_nhwc_aux(dtype_code(x.dtype), _ptr(x), _ptr(w9c), _ptr(bias), _ptr(out), _ptr(aux), n, h, w, c,
+                                             act, C.c_void_p(_stream()))
     _lib.check(st, "cavp_dwconv3x3_nhwc")
     return out
 

@@ -5,7 +5,7 @@ embeddings, the LayerNorms and timm's DropPath (stochastic depth, pvt.py:143-144
 
 Differences from the eval forward (cavp_amd/pvt.py): the spatial-reduction conv (kernel = stride = sr) runs as a token GEMM
 over a space-to-depth rearrangement of the normalised tokens, so that its data and weight gradients are plain GEMMs as
-well; GELU is a separate pass over the depth-wise conv's output (the pre-activation is the backward's input)."""
+well; the depth-wise conv applies the GELU itself and stores gelu' for the backward (_dwconv_gelu)."""
 from __future__ import annotations
 
 from typing import List, Optional
@@ -14,7 +14,7 @@ import torch
 
 from . import ops
 from . import train_ops as T
-from ._lib import ACT_NONE, CavpError
+from ._lib import ACT_GELU, ACT_NONE, CavpError
 from .train import V, TrainPass, _P, _as4
 
 
@@ -103,17 +103,25 @@ def _sra_attention(tp: TrainPass, q: V, kv: V, heads: int, scale: float) -> V:
     return o
 
 
-def _dwconv(tp: TrainPass, x: V, conv, B: int, H: int, W: int) -> V:
-    """DWConv (pvt.py:320-326): depth-wise 3x3 + bias on the tokens viewed as NHWC pixels."""
+def _dwconv_gelu(tp: TrainPass, x: V, conv, B: int, H: int, W: int) -> V:
+    """GELU(DWConv(x)) (pvt.py:46-55,320-326): depth-wise 3x3 + bias on the tokens viewed as NHWC pixels, GELU in the same
+    kernel with gelu'(t) as second output.  The returned activation carries that tensor as `grad_mul`: the data-gradient GEMM
+    of fc2 multiplies it into its epilogue (TrainPass.acc), so this op's backward receives d(pre-activation) directly - no
+    separate GELU / GELU-backward pass, the pre-activation itself is never stored."""
     hid = x.t.shape[-1]
     w9c = ops.pack_dwconv_weight(conv.weight)
     y = V(tp.empty(x.t.shape))
-    ops.dwconv3x3(x.t.view(B, H, W, hid), w9c, conv.bias.detach(), y.t.view(B, H, W, hid), act=ACT_NONE)
+    deriv = tp.empty(x.t.shape)
+    ops.dwconv3x3(x.t.view(B, H, W, hid), w9c, conv.bias.detach(), y.t.view(B, H, W, hid), act=ACT_GELU,
+                  aux=deriv.view(B, H, W, hid))
+    y.grad_mul = deriv
 
     def bwd():
         g = y.g
         if g is None:
             return
+        if not y.g_premul:
+            raise CavpError("fused GELU: the gradient must come from a data-gradient GEMM (TrainPass.acc)")
         g4 = g.view(B, H, W, hid)
         T.dwconv3x3_wgrad(x.t.view(B, H, W, hid), g4, tp.grad_buffer(conv.weight), tp.grad_buffer(conv.bias))
         if x.needs_grad:
@@ -231,7 +239,7 @@ def pvt_train_forward(tp: TrainPass, bb, image: torch.Tensor, drop_scales: Optio
                 x = _residual_drop_path(tp, x, tp.conv(o, k + "proj"), s_att)
             n2 = tp.layernorm(x, blk.norm2)
             h1 = tp.conv(n2, k + "fc1")
-            h2 = tp.gelu(_dwconv(tp, h1, blk.mlp.dwconv.dwconv, B, H, W))
+            h2 = _dwconv_gelu(tp, h1, blk.mlp.dwconv.dwconv, B, H, W)
             if s_mlp is None:
                 x = tp.conv(h2, k + "fc2", residual=x)
             else:

@@ -376,6 +376,11 @@ int cavp_sra_attention(int32_t dtype, const void* q, const void* kv, void* o, in
 /* DWConv (pvt.py:315-326): depth-wise 3x3 pad 1 + bias on NHWC, optional fused act (GELU of Mlp.forward :46-55). */
 int cavp_dwconv3x3_nhwc(int32_t dtype, const void* x, const float* w9c, const float* bias, void* y, int32_t N, int32_t H,
                         int32_t W, int32_t C, int32_t act, void* stream);
+/* ABI 7: the same with act = CAVP_ACT_GELU and gelu'(t) stored into aux (y's shape; NULL = plain call): what the backward of
+ * Mlp.forward (pvt.py:46-55) needs - it is multiplied into the data-gradient GEMM of fc2 (cavp_conv_desc.aux_mode 2), so the
+ * training pass has no separate GELU and GELU-backward launches and the pre-activation is never stored. */
+int cavp_dwconv3x3_nhwc_aux(int32_t dtype, const void* x, const float* w9c, const float* bias, void* y, void* aux, int32_t N,
+                            int32_t H, int32_t W, int32_t C, int32_t act, void* stream);
 int cavp_pack_dwconv_weight(const float* w_c133, float* w9c, int32_t C, void* stream); /* [C][1][3][3] -> [9][C] */
 /* OverlapPatchEmbed.proj of stage 1 (pvt.py:187-188): KSxKS conv, Cin <= 3, NCHW f32 in, NHWC out, + bias. */
 int cavp_conv_smallcin_kxk_nchw(int32_t dtype, const float* x_nchw, const float* w_oihw, const float* bias, void* y_nhwc,

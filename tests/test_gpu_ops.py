@@ -293,6 +293,18 @@ def test_dwconv_and_patch_embed_and_sr_conv(dtype):
     out = torch.empty((2, 13, 17, 64), dtype=dtype, device=DEV)
     ops.dwconv3x3(xv.contiguous(), ops.pack_dwconv_weight(w.to(DEV)), b.to(DEV), out, act=ops.ACT_GELU)
     _check(out.permute(0, 3, 1, 2), ref, dtype, "dwconv3x3+gelu")
+    # GELU with its derivative as second output (training pass of pvt.py:46-55), on the strip kernel (W >= 8) and, with a narrow
+    # map, on the pixel-per-thread kernel
+    for (hh, ww) in ((13, 17), (9, 3)):
+        xs = x[:, :, :hh, :ww].contiguous()
+        pre = F.conv2d(_q(xs, dtype), w, b, 1, 1, 1, 64).requires_grad_(True)
+        F.gelu(pre).sum().backward()
+        xv2, _ = _to_nhwc_dev(xs, dtype)
+        o2 = torch.empty((2, hh, ww, 64), dtype=dtype, device=DEV)
+        aux = torch.empty_like(o2)
+        ops.dwconv3x3(xv2.contiguous(), ops.pack_dwconv_weight(w.to(DEV)), b.to(DEV), o2, act=ops.ACT_GELU, aux=aux)
+        _check(o2.permute(0, 3, 1, 2), F.gelu(pre.detach()), dtype, f"dwconv3x3+gelu (aux call, W={ww})")
+        _check(aux.permute(0, 3, 1, 2), pre.grad, dtype, f"gelu' second output (W={ww})")
     # 7x7 stride-4 overlapping patch embedding (Cin = 3)
     img, w7, b7 = _rand(2, 3, 64, 96, seed=55), _rand(64, 3, 7, 7, seed=56, scale=0.1), _rand(64, seed=57)
     ref = F.conv2d(img, w7, b7, 4, 3)
