@@ -153,12 +153,14 @@ __global__ __launch_bounds__(256) void sra_bwd_q_kernel(const T* __restrict__ q,
 // K / V rows stay in registers; chunks of 64 queries (Q, dO as f32 tiles in LDS) stream past them:
 //   S[query][key] = Q K^T, P = exp(scale S - lse), dP = dO V^T, dS = scale P (dP - delta),
 //   dV^T[d][key] += sum_query dO^T[d][query] P[query][key],  dK^T[d][key] += sum_query Q^T[d][query] dS[query][key].
-// The per-split partial sums are added into the f32 gradient with atomics (one split: plain adds, deterministic).
+// Each query split stores its partial sums into its own f32 slab; sra_bwd_kv_reduce_kernel adds the slabs in split order
+// (deterministic; a single split writes the gradient itself).
 // ------------------------------------------------------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void sra_bwd_kv_kernel(const T* __restrict__ q, const T* __restrict__ kv,
                                                          const T* __restrict__ dout, const float* __restrict__ stats,
-                                                         float* __restrict__ dkv, int Nq, int Nk, int heads, float scale) {
+                                                         float* __restrict__ dkv, int Nq, int Nk, int heads, float scale,
+                                                         size_t slab_stride) {
   __shared__ __attribute__((aligned(16))) char qs[64 * 256];
   __shared__ __attribute__((aligned(16))) char gs[64 * 256];
   __shared__ float lse_s[64], del_s[64];
@@ -227,14 +229,16 @@ __global__ __launch_bounds__(256) void sra_bwd_kv_kernel(const T* __restrict__ q
     }
   }
   if (kok) {
-    float* op = dkv + ((size_t)b * Nk + key) * 2 * C + h * 64;
+    // every (key, channel) of this (batch, head, key block) is owned by ONE lane of one workgroup per query split: each split
+    // stores its partial into its own slab with 16-byte stores (split 0 of a single-split launch writes dkv itself) and
+    // sra_bwd_kv_reduce_kernel adds the slabs in split order.  (Round 2 added every partial with scalar f32 atomics onto a
+    // zero-filled dkv: 2 M atomics per launch at 8 splits, and atomics even with one split.)
+    float* op = dkv + (size_t)blockIdx.x * slab_stride + ((size_t)b * Nk + key) * 2 * C + h * 64;
 #pragma unroll
-    for (int db = 0; db < 4; ++db)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        atomicAdd(op + db * 16 + lgrp * 4 + r, dk[db][r]);
-        atomicAdd(op + C + db * 16 + lgrp * 4 + r, dv[db][r]);
-      }
+    for (int db = 0; db < 4; ++db) {
+      *(float4*)(op + db * 16 + lgrp * 4) = make_float4(dk[db][0], dk[db][1], dk[db][2], dk[db][3]);
+      *(float4*)(op + C + db * 16 + lgrp * 4) = make_float4(dv[db][0], dv[db][1], dv[db][2], dv[db][3]);
+    }
   }
 }
 
@@ -372,7 +376,8 @@ __global__ __launch_bounds__(256) void sra_bwd_q_bf16_kernel(const bf16_t* __res
 
 __global__ __launch_bounds__(256) void sra_bwd_kv_bf16_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kv,
                                                               const bf16_t* __restrict__ dout, const float* __restrict__ stats,
-                                                              float* __restrict__ dkv, int Nq, int Nk, int heads, float scale) {
+                                                              float* __restrict__ dkv, int Nq, int Nk, int heads, float scale,
+                                                              size_t slab_stride) {
   __shared__ __attribute__((aligned(16))) char qs[64 * 128];
   __shared__ __attribute__((aligned(16))) char ql[64 * 128];
   __shared__ __attribute__((aligned(16))) char gs[64 * 128];
@@ -438,14 +443,16 @@ __global__ __launch_bounds__(256) void sra_bwd_kv_bf16_kernel(const bf16_t* __re
     }
   }
   if (kok) {
-    float* op = dkv + ((size_t)b * Nk + key) * 2 * C + h * 64;
+    // every (key, channel) of this (batch, head, key block) is owned by ONE lane of one workgroup per query split: each split
+    // stores its partial into its own slab with 16-byte stores (split 0 of a single-split launch writes dkv itself) and
+    // sra_bwd_kv_reduce_kernel adds the slabs in split order.  (Round 2 added every partial with scalar f32 atomics onto a
+    // zero-filled dkv: 2 M atomics per launch at 8 splits, and atomics even with one split.)
+    float* op = dkv + (size_t)blockIdx.x * slab_stride + ((size_t)b * Nk + key) * 2 * C + h * 64;
 #pragma unroll
-    for (int db = 0; db < 4; ++db)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        atomicAdd(op + db * 16 + lgrp * 4 + r, dk[db][r]);
-        atomicAdd(op + C + db * 16 + lgrp * 4 + r, dv[db][r]);
-      }
+    for (int db = 0; db < 4; ++db) {
+      *(float4*)(op + db * 16 + lgrp * 4) = make_float4(dk[db][0], dk[db][1], dk[db][2], dk[db][3]);
+      *(float4*)(op + C + db * 16 + lgrp * 4) = make_float4(dv[db][0], dv[db][1], dv[db][2], dv[db][3]);
+    }
   }
 }
 
@@ -593,12 +600,27 @@ __global__ __launch_bounds__(256) void row_scale_add_kernel(const T* __restrict_
   }
 }
 
+// dkv[i] = sum_s slabs[s][i] (split order), 16-byte vectors
+__global__ __launch_bounds__(256) void sra_bwd_kv_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ dkv,
+                                                                long long n4, int splits, size_t slab_stride) {
+  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+    float4 a = *(const float4*)(slabs + 4 * i);
+    for (int s = 1; s < splits; ++s) {
+      const float4 v = *(const float4*)(slabs + (size_t)s * slab_stride + 4 * i);
+      a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+    }
+    *(float4*)(dkv + 4 * i) = a;
+  }
+}
+
 inline bool dt_ok(int dt) { return dt == CAVP_F32 || dt == CAVP_BF16; }
 }  // namespace
 #define CHECK_LAUNCH() return hipGetLastError() == hipSuccess ? CAVP_OK : CAVP_ERR_LAUNCH
 
+// row statistics (log-sum-exp, delta) + the dK / dV slabs of the query splits: splits * B * Nk * 2C floats with
+// splits <= 256 / (B * heads) and Nk <= 256, i.e. at most 256 * 256 * 128 floats whatever the shape
 extern "C" size_t cavp_sra_attention_bwd_workspace_bytes(int32_t B, int32_t Nq, int32_t heads) {
-  return (size_t)2 * B * heads * Nq * sizeof(float);
+  return ((size_t)2 * B * heads * Nq + (size_t)256 * 256 * 128 + 64) * sizeof(float);
 }
 
 extern "C" int cavp_sra_attention_bwd(int32_t dtype, const void* q, const void* kv, const void* dout, void* dq, float* dkv,
@@ -619,25 +641,32 @@ extern "C" int cavp_sra_attention_bwd(int32_t dtype, const void* q, const void* 
   }
   float* stats = (float*)workspace;
   const int C = heads * 64;
-  if (cavp_zero_f32_async(dkv, (size_t)B * Nk * 2 * C * sizeof(float), s) != hipSuccess) return CAVP_ERR_LAUNCH;
   const dim3 ga((Nq + 63) / 64, B * heads);
   const int chunks = (Nq + 63) / 64, kblocks = (Nk + 63) / 64;
-  int splits = 1;
-  if (!g_cavp_det.scratch) {   // deterministic mode: one split = one contribution per element, in a fixed order
-    splits = 256 / (B * heads * kblocks);   // every split adds B * Nk * 2C atomics: just enough workgroups to fill the chip
-    splits = splits < 1 ? 1 : (splits > chunks ? chunks : splits);
-  }
+  int splits = 256 / (B * heads * kblocks);   // query splits of the dK / dV pass: just enough workgroups to fill the chip
+  splits = splits < 1 ? 1 : (splits > chunks ? chunks : splits);
+  const size_t slab = (size_t)B * Nk * 2 * C;                     // floats per split
+  float* slabs = stats + (((size_t)2 * B * heads * Nq + 3) & ~(size_t)3);
+  if (splits > 1 && (size_t)((slabs - stats) + splits * slab) * sizeof(float) > workspace_bytes) return CAVP_ERR_WORKSPACE;
+  float* kv_out = splits > 1 ? slabs : dkv;   // a single split writes the gradient itself
   const dim3 gb(splits, B * heads, kblocks);
   if (dtype == CAVP_F32) {
     sra_bwd_q_kernel<float><<<ga, 256, 2 * 256 * 256, s>>>((const float*)q, (const float*)kv, (const float*)dout, (float*)dq, stats,
                                                           Nq, Nk, heads, scale);
-    sra_bwd_kv_kernel<float><<<gb, 256, 0, s>>>((const float*)q, (const float*)kv, (const float*)dout, stats, dkv, Nq, Nk, heads,
-                                                scale);
+    sra_bwd_kv_kernel<float><<<gb, 256, 0, s>>>((const float*)q, (const float*)kv, (const float*)dout, stats, kv_out, Nq, Nk, heads,
+                                                scale, slab);
   } else {
     sra_bwd_q_bf16_kernel<<<ga, 256, 3 * 256 * 128, s>>>((const bf16_t*)q, (const bf16_t*)kv, (const bf16_t*)dout, (bf16_t*)dq, stats,
                                                         Nq, Nk, heads, scale);
-    sra_bwd_kv_bf16_kernel<<<gb, 256, 0, s>>>((const bf16_t*)q, (const bf16_t*)kv, (const bf16_t*)dout, stats, dkv, Nq, Nk, heads,
-                                              scale);
+    sra_bwd_kv_bf16_kernel<<<gb, 256, 0, s>>>((const bf16_t*)q, (const bf16_t*)kv, (const bf16_t*)dout, stats, kv_out, Nq, Nk, heads,
+                                              scale, slab);
+  }
+  if (hipGetLastError() != hipSuccess) return CAVP_ERR_LAUNCH;
+  if (splits > 1) {
+    const long long n4 = (long long)(slab / 4);
+    long long nb = (n4 + 255) / 256;
+    if (nb > 2048) nb = 2048;
+    sra_bwd_kv_reduce_kernel<<<(int)nb, 256, 0, s>>>(slabs, dkv, n4, splits, slab);
   }
   CHECK_LAUNCH();
 }
