@@ -43,10 +43,12 @@ def parse():
     ap.add_argument("--mode", choices=["train", "eval"], default="train",
                     help="train = forward_train + CE + backward (+ gradient all-reduce when N > 1): the BASELINE.json "
                          "metric; eval = inference forward only")
-    ap.add_argument("--config", choices=["c1p", "c1", "c4"], default="c1p",
+    ap.add_argument("--config", choices=["c1p", "c1", "c4", "c5"], default="c1p",
                     help="c1p = ResNet-50 224x224 OS16, 2 classes (config_avss_binary shape: the BASELINE metric's default); c1 = the same "
                          "model in BASELINE config #1's VPO-SS plumbing (OS8: layer3 / layer4 / ASPP at 28x28, 22 classes); "
-                         "c4 = PVTv2-B5 512x512 (config #4; not the BASELINE metric)")
+                         "c4 = PVTv2-B5 512x512 (config #4; not the BASELINE metric); c5 = clip-shaped step of config #5: the c1p model on "
+                         "--batch = 5 x clips frames (use --batch 30), loss = CE + ContrastLoss on the fusion halves, through the "
+                         "autograd boundary (eager: the class-balanced sampling runs on the host)")
     ap.add_argument("--pmc", action="store_true",
                     help="measure roofline.traffic live: two extra rocprofv3 --pmc passes of this command (FETCH_SIZE, WRITE_SIZE) "
                          "through tools/pmc_traffic.py; default: the committed profiles/ figure, labelled as such")
@@ -486,7 +488,27 @@ def main():
     train = a.mode == "train"
     image, audio, label = synth_inputs(B, cfg["hw"], audio_batch=2 * B if train else B, num_classes=cfg["C"], seed=100 + rank)
     image, audio, label = image.to(dev), audio.to(dev), label.to(dev)
-    if train:
+    if a.config == "c5":
+        # config #5 (AVSBench-MS): 5-frame clips batched as B = 5 x clips (the reference loops the frames at B = 1,
+        # trainer_cavp_avs_obj.py:317-330); loss = CE on out[:B] + out[B:]*0 + ContrastLoss(temperature 0.1, max_views 512) on the
+        # fusion halves (trainer_cavp_vpo_mono.py:171-189), back-propagated through the model's autograd node
+        if not train or B % 5:
+            raise SystemExit("bench.py --config c5: training step only, --batch must be a multiple of 5 (frames per clip)")
+        import torch.nn.functional as F
+        from cavp_amd.contrast import ContrastLoss
+        crit = ContrastLoss(temperature=0.1, ignore_idx=255, max_views=512)
+        label_shuf = synth_inputs(B, cfg["hw"], audio_batch=2 * B, num_classes=cfg["C"], seed=900 + rank)[2].to(dev)
+        a.no_graph = True
+        model.train()
+
+        def run_step():
+            model.zero_grad(set_to_none=True)
+            out, fus, _ = model(image, audio, None, False)
+            loss = F.cross_entropy(out[:B] + out[B:] * 0.0, label, ignore_index=255) + crit(fus[:B], label, fus[B:], label_shuf)
+            loss.backward()
+            return loss
+        run_step_local = run_step
+    elif train:
         model.train()
 
         def run_step():
@@ -499,7 +521,7 @@ def main():
             return model(image, audio, eval_mode=True)
         run_step_local = run_step
 
-    with torch.no_grad():
+    with torch.set_grad_enabled(a.config == "c5"):
         run_step()      # eager warm-up: packs weights, sizes the workspace
         torch.cuda.synchronize()
         if train and not a.no_graph:
@@ -551,6 +573,8 @@ def main():
     if rank == 0:
         value = world * B * a.steps / elapsed
         c1name = ("C1 (config_vpo_ss plumbing at 224x224): CAVP ResNet-50 OS8 + VGGish" if a.config == "c1" else
+                  f"C5 (config #5, AVSBench-MS clip shape: {B // 5} clips x 5 frames; loss = CE + ContrastLoss(T 0.1, 512 views) on the "
+                  f"fusion halves through the model's autograd node, eager): CAVP ResNet-50 OS16 + VGGish" if a.config == "c5" else
                   "C1' (config_avss_binary shape): CAVP ResNet-50 OS16 + VGGish")
         line = {
             "metric": (f"frames/sec end-to-end CAVP fwd+bwd, B={B} {cfg['hw'][0]}x{cfg['hw'][1]}" if train else

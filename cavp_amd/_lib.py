@@ -98,6 +98,7 @@ PROTOTYPES = {
     "cavp_upsample_ce_head": (_i32, [_i32, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _vp, _vp,
                               _vp, _vp, _vp]),
     # ---- contrastive loss ----
+    "cavp_label_nearest": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
     "cavp_gather_l2norm": (_i32, [_vp, _i64, _i64, _i64, _vp, _vp, _i32, _i32, _f32, _vp, _vp, _vp]),
     "cavp_infonce_rows": (_i32, [_vp, _vp, _i32, _i32, _f32, _vp, _vp, _vp, _f32, _vp]),
     "cavp_symm_add": (_i32, [_vp, _vp, _i32, _f32, _vp]),

@@ -134,6 +134,31 @@ __global__ __launch_bounds__(256) void l2norm_bwd_scatter_kernel(const float* __
 }  // namespace
 #define CHECK_LAUNCH() return hipGetLastError() == hipSuccess ? CAVP_OK : CAVP_ERR_LAUNCH
 
+// F.interpolate(mode='nearest') of the label maps to the feature resolution (contrastive_aud.py:18-22): source index
+// min(floor(dst * float32(in / out)), in - 1) per axis, as ATen computes it.  int64 [B][H][W] -> int32 [B][h][w].
+static __global__ __launch_bounds__(256) void label_nearest_kernel(const long long* __restrict__ gt, int* __restrict__ out, int B,
+                                                                   int H, int W, int h, int w, float sh, float sw) {
+  const long long total = (long long)B * h * w;
+  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int x = (int)(i % w), y = (int)((i / w) % h), b = (int)(i / ((long long)w * h));
+    int ys = (int)floorf((float)y * sh), xs = (int)floorf((float)x * sw);
+    ys = ys < H - 1 ? ys : H - 1;
+    xs = xs < W - 1 ? xs : W - 1;
+    out[i] = (int)gt[((size_t)b * H + ys) * W + xs];
+  }
+}
+
+extern "C" int cavp_label_nearest(const int64_t* gt, int32_t* out, int32_t B, int32_t H, int32_t W, int32_t h, int32_t w,
+                                  void* stream) {
+  if (!gt || !out || B <= 0 || H <= 0 || W <= 0 || h <= 0 || w <= 0) return CAVP_ERR_BAD_ARG;
+  const long long total = (long long)B * h * w;
+  long long nb = (total + 255) / 256;
+  if (nb > 4096) nb = 4096;
+  label_nearest_kernel<<<(int)nb, 256, 0, (hipStream_t)stream>>>((const long long*)gt, out, B, H, W, h, w, (float)H / (float)h,
+                                                                 (float)W / (float)w);
+  return hipGetLastError() == hipSuccess ? CAVP_OK : CAVP_ERR_LAUNCH;
+}
+
 extern "C" int cavp_gather_l2norm(const float* x, int64_t stride_b, int64_t stride_c, int64_t stride_p,
                                   const int32_t* idx_b, const int32_t* idx_p, int32_t N, int32_t C, float eps, float* A,
                                   float* norms, void* stream) {

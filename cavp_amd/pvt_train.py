@@ -46,8 +46,10 @@ def _sr_linear(tp: TrainPass, x: V, p: _P) -> V:
         if g is None:
             return
         tmp = torch.empty((p.cout, 1, 1, p.cin), dtype=torch.float32, device=tp.dev)
-        T.conv2d_wgrad(_as4(x.t), _as4(g), tmp, kh=1, kw=1, stride=1, pad=0, dil=1, dbias=tp.grad_buffer(p.bias), overwrite=True)
-        T.unpack_weight_grad(tmp, tp.grad_buffer(p.weight), accumulate=True)
+        gw = tp.grad_buffer(p.weight)
+        tp.defer_wgrad(dict(x=_as4(x.t), dy=_as4(g), dw=tmp, kh=1, kw=1, stride=1, pad=0, dil=1, dbias=tp.grad_buffer(p.bias),
+                            overwrite=True),
+                       after=lambda: T.unpack_weight_grad(tmp, gw, accumulate=True))   # OHWI GEMM result -> the conv's OIHW .grad
         if x.needs_grad:
             def dg(o, r, mul=None):
                 T.conv2d_dgrad(_as4(g), p.wT, _as4(o), kh=1, kw=1, stride=1, pad=0, dil=1, residual=_as4(r) if r is not None else None)

@@ -210,6 +210,7 @@ class TrainPass:
         self._wg_jobs: list = []       # deferred weight gradients (main stream only), see wgrad() / flush_wgrads()
         self._wg_dst: set = set()
         self._wg_src: set = set()      # storages of their dy operands (see _pinned)
+        self._wg_after: list = []      # callbacks run right behind the next grouped launch (defer_wgrad)
 
     # ---- parameter helpers -----------------------------------------------------------------------------------
     def pack(self, key: str, mod, need_dgrad: bool = True, raw: bool = False, pad_cout_to: int = 0) -> _P:
@@ -457,18 +458,29 @@ class TrainPass:
         else:   # k x k: the kernel writes the torch-layout gradient directly (no OHWI temporary + unpack pass)
             job = dict(x=x4, dy=g4, dw=dw, kh=p.kh, kw=p.kw, stride=p.stride, pad=p.pad, dil=p.dil, dbias=db, dw_oihw=True,
                        overwrite=ow)
+        self.defer_wgrad(job)
+
+    def defer_wgrad(self, job: dict, after: Optional[Callable[[], None]] = None) -> None:
+        """Queue one weight-gradient job (the arguments of train_ops.conv2d_wgrad as a dict).  Nothing in the backward chain
+        reads a weight gradient, so the jobs wait (holding x and dy alive) until 16 are pending or a flush point is reached, and
+        go out as ONE launch (cavp_conv2d_wgrad_group).  `after` runs right behind that launch (e.g. the un-permutation of a
+        gradient the GEMM produced in another layout)."""
+        x4, g4, dw, db = job["x"], job["dy"], job["dw"], job.get("dbias")
         if not _GROUP_WGRAD or self._slot != 0 or x4.dtype != self.dt:
-            T.conv2d_wgrad(job.pop("x"), job.pop("dy"), job.pop("dw"), **job)   # (the side stream keeps its per-layer launches)
+            j = dict(job)
+            T.conv2d_wgrad(j.pop("x"), j.pop("dy"), j.pop("dw"), **j)   # (the side stream keeps its per-layer launches)
+            if after is not None:
+                after()
             return
-        # Deferred: nothing in the backward chain reads a weight gradient, so the jobs wait (holding x and dy alive) until 16
-        # are pending or a flush point is reached, and go out as ONE launch.  A second contribution to a destination that is
-        # already pending would race inside the launch: flush first.
+        # a second contribution to a destination that is already pending would race inside the launch: flush first
         dst = {dw.data_ptr()} | ({db.data_ptr()} if db is not None else set())
         if dst & self._wg_dst:
             self.flush_wgrads()
         self._wg_jobs.append(job)
         self._wg_dst |= dst
         self._wg_src.add(g4.untyped_storage().data_ptr())
+        if after is not None:
+            self._wg_after.append(after)
         if len(self._wg_jobs) >= 16:
             self.flush_wgrads()
 
@@ -477,7 +489,10 @@ class TrainPass:
         gradient collectives, the end of the backward)."""
         if self._wg_jobs:
             jobs, self._wg_jobs, self._wg_dst, self._wg_src = self._wg_jobs, [], set(), set()
+            after, self._wg_after = self._wg_after, []
             T.conv2d_wgrad_group(jobs)
+            for fn in after:
+                fn()
 
     def conv_smallcin(self, x_nchw: torch.Tensor, key: str, stride: int, act: int) -> V:
         """First stem conv (raw, BN follows) / first VGG conv (bias + ReLU fused).  Input needs no gradient."""

@@ -355,6 +355,10 @@ int cavp_mel_frontend(const float* wave, int32_t N, int32_t A, const float* wind
 /* ---- pixel-level audio-visual InfoNCE (loss/contrastive_aud.py::ContrastLoss, config #5 / SURVEY.md §8a row a13) ----
  * The class-balanced sampling (torch.randperm on the CPU generator, contrastive_aud.py:76-141) stays on the host; these
  * are the device stages for the N sampled anchors.  S = A A^T / T and dA = G A run on cavp_conv2d_nhwc / _wgrad. */
+/* Nearest-neighbour down-sampling of the int64 label maps [B][H][W] to the feature resolution, int32 [B][h][w]
+ * (contrastive_aud.py:18-22 `F.interpolate(gt.unsqueeze(1).float(), size, mode='nearest')`): only B*h*w int32 labels travel to the
+ * host for the class-balanced sampling instead of the full-resolution int64 maps. */
+int cavp_label_nearest(const int64_t* gt, int32_t* out, int32_t B, int32_t H, int32_t W, int32_t h, int32_t w, void* stream);
 /* A[i] = x[b_i, :, p_i] / max(||.||, eps); x addressed by element strides (works for NCHW memory and for the NHWC
  * memory behind out_fusion); also saves the norms (F.normalize, contrastive_aud.py:25-26 + gathers :97-139). */
 int cavp_gather_l2norm(const float* x, int64_t stride_b, int64_t stride_c, int64_t stride_p, const int32_t* idx_b,

@@ -38,7 +38,7 @@ def main():
             for row in csv.DictReader(fh):
                 k = row["Kernel_Name"]
                 grp = ("igemm (forward convs / linears + data gradients)" if "igemm" in k else
-                       "wgrad (weight gradients)" if "wgrad_kernel" in k else "everything else")
+                       "wgrad (weight gradients)" if ("wgrad_kernel" in k or "wgrad_group_kernel" in k) else "everything else")
                 agg[grp][row["Counter_Name"]] += float(row["Counter_Value"])
                 if row["Counter_Name"] == COUNTERS[0]:
                     calls[grp] += 1
