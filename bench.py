@@ -232,7 +232,7 @@ def measure_roofline(model, run_step, image, dtype_name, reps=3, config="c1p", l
     side_was = _tr._SIDE_STREAM
     _tr._SIDE_STREAM = False   # per-launch durations are taken with one stream: a co-running branch would inflate them
     try:
-        with torch.no_grad():
+        with torch.set_grad_enabled(config == "c5"):   # (c5 back-propagates through torch.autograd; the fused steps need none)
             for _ in range(reps):
                 run_step()
         agg = kt.summary()
