@@ -374,7 +374,7 @@ def cpu_baseline_train(sd, cfg, sample_batch):
         return step
 
     step = make(sample_batch)
-    torch.set_num_threads(cores)
+    torch.set_num_threads(min(16, cores))
     step()   # warm-up (allocator, oneDNN primitive caches)
     sweep = {}
     for nt in sorted({t for t in (4, 8, 16, 32, 64, cores) if t <= cores}):
