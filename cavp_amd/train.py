@@ -835,6 +835,19 @@ def run_train_forward(model, image: torch.Tensor, audio: torch.Tensor, tp: Train
     pvt = m.seg_model == "PVT"
     rn = None if pvt else m.backbone.backbone
     B = image.shape[0]
+    if (collectives_on() and tp.dev.type == "cuda" and not torch.cuda.is_current_stream_capturing()
+            and any(isinstance(mm, nn.SyncBatchNorm) for mm in m.modules())):
+        # SyncBatchNorm combines the ranks' moments assuming every rank holds the same number of samples per layer (bn_act):
+        # one tiny exchange per eager step verifies it (torch's SyncBatchNorm gathers per-rank counts instead; uneven last
+        # batches need drop_last=True here)
+        import torch.distributed as dist
+        allv = torch.zeros((dist.get_world_size(), 3), dtype=torch.float32, device=tp.dev)
+        allv[dist.get_rank()] = torch.tensor([B, image.shape[-2], image.shape[-1]], dtype=torch.float32)
+        dist.all_reduce(allv)   # (an all-gather every backend has, see gather_bn_moments)
+        got = allv.tolist()
+        if any(v != got[0] for v in got):
+            raise CavpError("SyncBatchNorm on the MI355X path needs the same batch and image size on every rank "
+                            f"(got {got}); use drop_last=True")
     # ---- pack ----
     if not pvt:
         tp.pack("stem0", rn.conv1[0], raw=True)
