@@ -200,6 +200,9 @@ inline bool ln_geometry(int C, int VE, int* G, int* PLV) {
   int need = (vecs + plv - 1) / plv, g = 8;
   while (g < need) g <<= 1;
   if (plv > 1) g = 64;
+  // 33 .. 48 vectors (C = 304: 38 bf16 vectors, every CAVP fusion norm): 16 lanes x 3 vectors leave 21 % of the lanes idle and put
+  // four rows on a wave; 64 lanes x 1 vector idled 41 % with one row per wave
+  if (plv == 1 && vecs > 32 && vecs <= 48) { g = 16; plv = 3; }
   *G = g;
   *PLV = plv;
   return true;
@@ -211,6 +214,7 @@ inline bool ln_geometry(int C, int VE, int* G, int* PLV) {
   switch (G * 10 + PLV) {                                                            \
     case 81: KERNEL_CALL(8, 1); break;                                               \
     case 161: KERNEL_CALL(16, 1); break;                                             \
+    case 163: KERNEL_CALL(16, 3); break;                                             \
     case 321: KERNEL_CALL(32, 1); break;                                             \
     case 641: KERNEL_CALL(64, 1); break;                                             \
     case 642: KERNEL_CALL(64, 2); break;                                             \
@@ -224,6 +228,7 @@ inline bool ln_geometry(int C, int VE, int* G, int* PLV) {
   switch (G * 10 + PLV) {                                                            \
     case 81: KERNEL_CALL(8, 1); break;                                               \
     case 161: KERNEL_CALL(16, 1); break;                                             \
+    case 163: KERNEL_CALL(16, 3); break;                                             \
     case 321: KERNEL_CALL(32, 1); break;                                             \
     case 641: KERNEL_CALL(64, 1); break;                                             \
     case 642: KERNEL_CALL(64, 2); break;                                             \
