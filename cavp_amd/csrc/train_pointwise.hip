@@ -1058,6 +1058,159 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const T* __restrict__ lo,
   if (c == 0)
     for (int k = C; k < ld; ++k) Elem<T>::st(dlo + pix * ld + k, 0.f);
 }
+// Vector forms of the two passes for heads with many classes (22 / 71): a thread reads VE = 16 B / sizeof(T) classes of
+// a corner per load instead of one, pass 2 stages the residuals of VE classes at once (workgroup = tile x image x class
+// chunk, so every label pixel costs 4 vector loads per CHUNK instead of 4 scalar loads per CLASS) and four lanes share a
+// low-res pixel's footprint rows.  71 classes at 512 x 512, B = 8: pass 1 470 -> ~150 us, pass 2 1000 -> ~250 us.
+// Needs ld % VE == 0; the padded channels C .. ld - 1 get zeros from the chunk that holds them.
+template <typename T>
+__global__ __launch_bounds__(256) void head_fwd_vec_kernel(const T* __restrict__ lo, const long long* __restrict__ label,
+                                                           int n_img, int C, int Hi, int Wi, int ld, int Ho, int Wo,
+                                                           int align, int ignore, float* __restrict__ lse,
+                                                           float* __restrict__ part) {
+  constexpr int VE = VecT<T>::VE;
+  __shared__ float red[8];
+  const long long HW = (long long)Ho * Wo, total = (long long)n_img * HW;
+  float loss = 0.f, cnt = 0.f;
+  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const long long lb = label[i];
+    if (lb == ignore) { lse[i] = 0.f; continue; }
+    if ((unsigned long long)lb >= (unsigned long long)C) { lse[i] = 0.f; loss = NAN; continue; }
+    const int wo = (int)(i % Wo);
+    const int ho = (int)((i / Wo) % Ho);
+    const int n = (int)(i / HW);
+    int h0, h1, w0, w1;
+    float lh, lw;
+    src_index_t(ho, Hi, Ho, align, h0, h1, lh);
+    src_index_t(wo, Wi, Wo, align, w0, w1, lw);
+    const T* img = lo + (size_t)n * Hi * Wi * ld;
+    const T *p00 = img + ((size_t)h0 * Wi + w0) * ld, *p01 = img + ((size_t)h0 * Wi + w1) * ld;
+    const T *p10 = img + ((size_t)h1 * Wi + w0) * ld, *p11 = img + ((size_t)h1 * Wi + w1) * ld;
+    const float k00 = (1.f - lh) * (1.f - lw), k01 = (1.f - lh) * lw, k10 = lh * (1.f - lw), k11 = lh * lw;
+    float m = -INFINITY, s = 0.f, picked = 0.f;
+    for (int q = 0; q < C; q += VE) {
+      float a[VE], b[VE], cc[VE], d[VE], v[VE];
+      VecT<T>::load(p00 + q, a);
+      VecT<T>::load(p01 + q, b);
+      VecT<T>::load(p10 + q, cc);
+      VecT<T>::load(p11 + q, d);
+      float cm = -INFINITY;
+#pragma unroll
+      for (int e = 0; e < VE; ++e) {
+        v[e] = k00 * a[e] + k01 * b[e] + k10 * cc[e] + k11 * d[e];
+        if (q + e < C) cm = fmaxf(cm, v[e]);
+        if (q + e == lb) picked = v[e];
+      }
+      const float mn = fmaxf(m, cm);
+      s *= expf(m - mn);
+#pragma unroll
+      for (int e = 0; e < VE; ++e)
+        if (q + e < C) s += expf(v[e] - mn);
+      m = mn;
+    }
+    const float l = m + logf(s);
+    lse[i] = l;
+    loss += l - picked;
+    cnt += 1.f;
+  }
+  loss = wave_sum(loss);
+  cnt = wave_sum(cnt);
+  const int wv = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) { red[wv] = loss; red[4 + wv] = cnt; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    part[2 + 2 * blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+    part[3 + 2 * blockIdx.x] = (red[4] + red[5]) + (red[6] + red[7]);
+  }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void head_bwd_vec_kernel(const T* __restrict__ lo, const long long* __restrict__ label,
+                                                           const float* __restrict__ lse, const float* __restrict__ acc,
+                                                           float gscale, int n_img, int C, int Hi, int Wi, int ld, int Ho,
+                                                           int Wo, int align, int ignore, int th, int tw, int RW,
+                                                           int tiles_w, int nchunk, T* __restrict__ dlo) {
+  constexpr int VE = VecT<T>::VE;
+  extern __shared__ float resid[];   // [RH][RW][VE]
+  const int q = (blockIdx.y % nchunk) * VE, n = blockIdx.y / nchunk;
+  const int ty0 = (blockIdx.x / tiles_w) * th, tx0 = (blockIdx.x % tiles_w) * tw;
+  const int ty1 = min(ty0 + th, Hi) - 1, tx1 = min(tx0 + tw, Wi) - 1;
+  const int ly = (threadIdx.x >> 2) / tw, lx = (threadIdx.x >> 2) % tw, sub = threadIdx.x & 3;
+  const int hi = ty0 + ly, wi = tx0 + lx;
+  const bool live = ly < th && hi < Hi && wi < Wi;
+  const size_t pix = ((size_t)n * Hi + hi) * Wi + wi;
+  float g[VE];
+#pragma unroll
+  for (int e = 0; e < VE; ++e) g[e] = 0.f;
+  if (q >= C) {   // a chunk of padding only
+    if (live && sub == 0) VecT<T>::store(dlo + pix * ld + q, g);
+    return;
+  }
+  int rh0, rh1, rw0, rw1, t0, t1;
+  dst_range(ty0, Hi, Ho, align, rh0, t1);
+  dst_range(ty1, Hi, Ho, align, t0, rh1);
+  dst_range(tx0, Wi, Wo, align, rw0, t1);
+  dst_range(tx1, Wi, Wo, align, t0, rw1);
+  const int rw = rw1 - rw0 + 1, cnt = (rh1 - rh0 + 1) * rw;
+  const T* img = lo + (size_t)n * Hi * Wi * ld + q;
+#pragma unroll 2
+  for (int e = threadIdx.x; e < cnt; e += 256) {
+    const int ho = rh0 + e / rw, wo = rw0 + e % rw;
+    const size_t at = ((size_t)n * Ho + ho) * Wo + wo;
+    const long long lb = label[at];
+    const float l = lse[at];
+    int h0, h1, w0, w1;
+    float lh, lw;
+    src_index_t(ho, Hi, Ho, align, h0, h1, lh);
+    src_index_t(wo, Wi, Wo, align, w0, w1, lw);
+    const float k00 = (1.f - lh) * (1.f - lw), k01 = (1.f - lh) * lw, k10 = lh * (1.f - lw), k11 = lh * lw;
+    float a[VE], b[VE], cc[VE], d[VE], r[VE];
+    VecT<T>::load(img + ((size_t)h0 * Wi + w0) * ld, a);
+    VecT<T>::load(img + ((size_t)h0 * Wi + w1) * ld, b);
+    VecT<T>::load(img + ((size_t)h1 * Wi + w0) * ld, cc);
+    VecT<T>::load(img + ((size_t)h1 * Wi + w1) * ld, d);
+    const bool dead = lb == ignore || (unsigned long long)lb >= (unsigned long long)C;
+#pragma unroll
+    for (int k = 0; k < VE; ++k) {
+      const float v = k00 * a[k] + k01 * b[k] + k10 * cc[k] + k11 * d[k];
+      r[k] = (dead || q + k >= C) ? 0.f : expf(v - l) - (q + k == lb ? 1.f : 0.f);
+    }
+    float4* dst = (float4*)(resid + ((size_t)(ho - rh0) * RW + (wo - rw0)) * VE);
+#pragma unroll
+    for (int k = 0; k < VE / 4; ++k) dst[k] = make_float4(r[4 * k], r[4 * k + 1], r[4 * k + 2], r[4 * k + 3]);
+  }
+  __syncthreads();
+  if (live) {
+    int hlo, hhi, wlo, whi;
+    dst_range(hi, Hi, Ho, align, hlo, hhi);
+    dst_range(wi, Wi, Wo, align, wlo, whi);
+    for (int ho = hlo + sub; ho <= hhi; ho += 4) {
+      const float wh = tap_weight(ho, hi, Hi, Ho, align);
+      if (wh == 0.f) continue;
+      const float* row = resid + ((size_t)(ho - rh0) * RW - rw0) * VE;
+      for (int wo = wlo; wo <= whi; ++wo) {
+        const float w = wh * tap_weight(wo, wi, Wi, Wo, align);
+        const float4* src = (const float4*)(row + (size_t)wo * VE);
+#pragma unroll
+        for (int k = 0; k < VE / 4; ++k) {
+          const float4 t = src[k];
+          g[4 * k] += w * t.x; g[4 * k + 1] += w * t.y; g[4 * k + 2] += w * t.z; g[4 * k + 3] += w * t.w;
+        }
+      }
+    }
+  }
+  // the four lanes of a pixel are adjacent lanes of one wave (dead pixels carry zeros)
+#pragma unroll
+  for (int e = 0; e < VE; ++e) {
+    g[e] += __shfl_xor(g[e], 1);
+    g[e] += __shfl_xor(g[e], 2);
+  }
+  if (live && sub == 0) {
+    const float inv = acc[1] > 0.f ? gscale / acc[1] : 0.f;
+#pragma unroll
+    for (int e = 0; e < VE; ++e) g[e] *= inv;
+    VecT<T>::store(dlo + pix * ld + q, g);
+  }
+}
 template <typename T>
 __global__ __launch_bounds__(256) void zero_tail_kernel(T* __restrict__ p, long long n) {
   for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (long long)gridDim.x * 256) Elem<T>::st(p + i, 0.f);
@@ -1685,23 +1838,34 @@ inline int head_region(int t, int in, int out, int align) {
 template <typename T>
 int head_launch(const T* lo, const long long* lab, int n_img, int n_total, int C, int Hi, int Wi, int ld, int Ho, int Wo,
                 int align, int ignore, float gscale, float* loss, T* dlo, float* lse, float* scratch2, hipStream_t s) {
+  constexpr int VE = VecT<T>::VE;
+  const bool vec = C >= 8 && ld % VE == 0;   // many classes: VE classes per load (head_*_vec_kernel)
   long long nb = ((long long)n_img * Ho * Wo + 255) / 256;
   if (nb > 1024) nb = 1024;   // = (CAVP_CE_SCRATCH_FLOATS - 2) / 2 partials
-  head_fwd_kernel<T><<<(int)nb, 256, 0, s>>>(lo, lab, n_img, C, Hi, Wi, ld, Ho, Wo, align, ignore, lse, scratch2);
+  if (vec)
+    head_fwd_vec_kernel<T><<<(int)nb, 256, 0, s>>>(lo, lab, n_img, C, Hi, Wi, ld, Ho, Wo, align, ignore, lse, scratch2);
+  else
+    head_fwd_kernel<T><<<(int)nb, 256, 0, s>>>(lo, lab, n_img, C, Hi, Wi, ld, Ho, Wo, align, ignore, lse, scratch2);
   ce_finish_kernel<<<1, 256, 0, s>>>(scratch2, (int)nb, loss);
   if (!dlo) return CAVP_OK;
-  int th = 16, tw = 16, RH = 0, RW = 0;
+  const int per = vec ? VE : 1;               // floats of LDS per label pixel of the region
+  int th = vec ? 8 : 16, tw = th, RH = 0, RW = 0;   // vec: four lanes per low-res pixel -> th * tw <= 64
   for (;;) {
     RH = head_region(th, Hi, Ho, align);
     RW = head_region(tw, Wi, Wo, align);
-    if ((long long)RH * RW * 4 <= 60 * 1024) break;
+    if ((long long)RH * RW * 4 * per <= 60 * 1024) break;
     if (th == 1 && tw == 1) return CAVP_ERR_UNSUPPORTED;   // one low-res pixel spans > 15 K label pixels
     if (th >= tw) th = (th + 1) / 2; else tw = (tw + 1) / 2;
   }
   const int tiles_h = (Hi + th - 1) / th, tiles_w = (Wi + tw - 1) / tw;
-  if ((long long)n_img * C > 65535) return CAVP_ERR_UNSUPPORTED;
-  head_bwd_kernel<T><<<dim3(tiles_h * tiles_w, n_img * C), 256, (size_t)RH * RW * 4, s>>>(
-      lo, lab, lse, scratch2, gscale, n_img, C, Hi, Wi, ld, Ho, Wo, align, ignore, th, tw, RW, tiles_w, dlo);
+  const int nchunk = vec ? ld / VE : C;
+  if ((long long)n_img * nchunk > 65535) return CAVP_ERR_UNSUPPORTED;
+  if (vec)
+    head_bwd_vec_kernel<T><<<dim3(tiles_h * tiles_w, n_img * nchunk), 256, (size_t)RH * RW * 4 * per, s>>>(
+        lo, lab, lse, scratch2, gscale, n_img, C, Hi, Wi, ld, Ho, Wo, align, ignore, th, tw, RW, tiles_w, nchunk, dlo);
+  else
+    head_bwd_kernel<T><<<dim3(tiles_h * tiles_w, n_img * C), 256, (size_t)RH * RW * 4, s>>>(
+        lo, lab, lse, scratch2, gscale, n_img, C, Hi, Wi, ld, Ho, Wo, align, ignore, th, tw, RW, tiles_w, dlo);
   const long long tail = (long long)(n_total - n_img) * Hi * Wi * ld;   // images >= n_img contribute `* 0`
   if (tail > 0) {
     long long nz = (tail + 255) / 256;

@@ -323,7 +323,8 @@ def test_bilinear_bwd_from_nchw_and_ce(C, dt):
 
 @pytest.mark.parametrize("dt", DTYPES, ids=IDS)
 @pytest.mark.parametrize("C,ld,hw,HW", [(2, 8, (14, 14), (56, 56)), (22, 24, (9, 13), (35, 50)), (71, 72, (8, 8), (32, 32)),
-                                        (2, 2, (7, 7), (7, 7))])
+                                        (2, 2, (7, 7), (7, 7)), (71, 72, (20, 18), (80, 72)), (24, 48, (5, 7), (23, 30)),
+                                        (9, 16, (6, 6), (50, 48))])
 def test_fused_upsample_ce_head(C, ld, hw, HW, dt):
     """one op == F.interpolate(bilinear) + CrossEntropyLoss(ignore_index) on out[:B] + out[B:]*0 and
     its gradient w.r.t. the low-resolution logits (non-integer ratios, padded channel stride, all-ignored rows)."""
