@@ -107,6 +107,7 @@ PROTOTYPES = {
     "cavp_sra_attention": (_i32, [_i32, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _vp]),
     "cavp_dwconv3x3_nhwc": (_i32, [_i32, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
     "cavp_dwconv3x3_nhwc_aux": (_i32, [_i32, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "cavp_dwconv3x3_bwd_data_nhwc": (_i32, [_i32, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "cavp_pack_dwconv_weight": (_i32, [_vp, _vp, _i32, _vp]),
     "cavp_conv_smallcin_kxk_nchw": (_i32, [_i32, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "cavp_sra_attention_bwd_workspace_bytes": (_sz, [_i32, _i32, _i32]),

@@ -167,7 +167,7 @@ __global__ __launch_bounds__(256) void sra_attention_kernel(const T* __restrict_
 template <typename T>
 __global__ __launch_bounds__(256) void dwconv3x3_kernel(const T* __restrict__ x, const float* __restrict__ w9c,
                                                         const float* __restrict__ bias, T* __restrict__ y, int N, int H,
-                                                        int W, int C, int act, T* __restrict__ aux) {
+                                                        int W, int C, int act, T* __restrict__ aux, int flip) {
   constexpr int VE = 16 / (int)sizeof(T);
   const int CV = C / VE;
   const long long total = (long long)N * H * W * CV;
@@ -188,7 +188,7 @@ __global__ __launch_bounds__(256) void dwconv3x3_kernel(const T* __restrict__ x,
         const int w2 = wi - 1 + kw;
         if ((unsigned)w2 >= (unsigned)W) continue;
         const T* xp = x + ((size_t)(n * H + h2) * W + w2) * C + cv * VE;
-        const float* wp = w9c + (kh * 3 + kw) * C + cv * VE;
+        const float* wp = w9c + (flip ? 8 - (kh * 3 + kw) : kh * 3 + kw) * C + cv * VE;
         if constexpr (sizeof(T) == 4) {
           const float4 v = *(const float4*)xp;
           acc[0] += v.x * wp[0]; acc[1] += v.y * wp[1]; acc[2] += v.z * wp[2]; acc[3] += v.w * wp[3];
@@ -232,7 +232,7 @@ __global__ __launch_bounds__(256) void dwconv3x3_kernel(const T* __restrict__ x,
 template <typename T>
 __global__ __launch_bounds__(256) void dwconv3x3_strip_kernel(const T* __restrict__ x, const float* __restrict__ w9c,
                                                               const float* __restrict__ bias, T* __restrict__ y, int N, int H,
-                                                              int W, int C, int act, T* __restrict__ aux) {
+                                                              int W, int C, int act, T* __restrict__ aux, int flip) {
   constexpr int VE = 16 / (int)sizeof(T), SW = 32 / VE;   // 32 accumulators per thread: 8 pixels x 4 (f32) / 4 pixels x 8 (bf16)
   const int CV = C / VE, strips = (W + SW - 1) / SW;
   const long long total = (long long)N * H * strips * CV;
@@ -264,7 +264,7 @@ __global__ __launch_bounds__(256) void dwconv3x3_strip_kernel(const T* __restric
 #pragma unroll
       for (int kw = 0; kw < 3; ++kw)
 #pragma unroll
-        for (int q = 0; q < VE; q += 4) VecT<float>::load(w9c + (size_t)(kh * 3 + kw) * C + c0 + q, wt[kw] + q);
+        for (int q = 0; q < VE; q += 4) VecT<float>::load(w9c + (size_t)(flip ? 8 - (kh * 3 + kw) : kh * 3 + kw) * C + c0 + q, wt[kw] + q);
       const T* row = x + ((size_t)(n * H + h2) * W) * C + c0;
       // (the 10 input vectors stay PACKED - 4 registers each for bf16 - and are widened where they are used: with them held as
       // f32 the kernel needed 204 VGPRs, two waves per SIMD)
@@ -411,8 +411,9 @@ extern "C" int cavp_dwconv3x3_nhwc(int32_t dtype, const void* x, const float* w9
   return cavp_dwconv3x3_nhwc_aux(dtype, x, w9c, bias, y, nullptr, N, H, W, C, act, stream);
 }
 
-extern "C" int cavp_dwconv3x3_nhwc_aux(int32_t dtype, const void* x, const float* w9c, const float* bias, void* y, void* aux,
-                                       int32_t N, int32_t H, int32_t W, int32_t C, int32_t act, void* stream) {
+namespace {
+int dwconv_launch(int32_t dtype, const void* x, const float* w9c, const float* bias, void* y, void* aux, int32_t N, int32_t H,
+                  int32_t W, int32_t C, int32_t act, int flip, void* stream) {
   if (!x || !w9c || !y || N <= 0 || H <= 0 || W <= 0 || C <= 0) return CAVP_ERR_BAD_ARG;
   if (aux && act != CAVP_ACT_GELU) return CAVP_ERR_BAD_ARG;   // the second output is gelu'(t)
   if (((uintptr_t)x | (uintptr_t)y | (uintptr_t)aux) & 15) return CAVP_ERR_ALIGN;
@@ -426,18 +427,30 @@ extern "C" int cavp_dwconv3x3_nhwc_aux(int32_t dtype, const void* x, const float
     long long nb = (strips_total + 255) / 256;
     if (nb > 32768) nb = 32768;
     if (dtype == CAVP_F32)
-      dwconv3x3_strip_kernel<float><<<(int)nb, 256, 0, s>>>((const float*)x, w9c, bias, (float*)y, N, H, W, C, act, (float*)aux);
+      dwconv3x3_strip_kernel<float><<<(int)nb, 256, 0, s>>>((const float*)x, w9c, bias, (float*)y, N, H, W, C, act, (float*)aux, flip);
     else
-      dwconv3x3_strip_kernel<bf16_t><<<(int)nb, 256, 0, s>>>((const bf16_t*)x, w9c, bias, (bf16_t*)y, N, H, W, C, act, (bf16_t*)aux);
+      dwconv3x3_strip_kernel<bf16_t><<<(int)nb, 256, 0, s>>>((const bf16_t*)x, w9c, bias, (bf16_t*)y, N, H, W, C, act, (bf16_t*)aux, flip);
     CHECK_LAUNCH();
   }
   long long nb = ((long long)N * H * W * (C / VE) + 255) / 256;
   if (nb > 32768) nb = 32768;
   if (dtype == CAVP_F32)
-    dwconv3x3_kernel<float><<<(int)nb, 256, 0, s>>>((const float*)x, w9c, bias, (float*)y, N, H, W, C, act, (float*)aux);
+    dwconv3x3_kernel<float><<<(int)nb, 256, 0, s>>>((const float*)x, w9c, bias, (float*)y, N, H, W, C, act, (float*)aux, flip);
   else
-    dwconv3x3_kernel<bf16_t><<<(int)nb, 256, 0, s>>>((const bf16_t*)x, w9c, bias, (bf16_t*)y, N, H, W, C, act, (bf16_t*)aux);
+    dwconv3x3_kernel<bf16_t><<<(int)nb, 256, 0, s>>>((const bf16_t*)x, w9c, bias, (bf16_t*)y, N, H, W, C, act, (bf16_t*)aux, flip);
   CHECK_LAUNCH();
+}
+}  // namespace
+
+extern "C" int cavp_dwconv3x3_nhwc_aux(int32_t dtype, const void* x, const float* w9c, const float* bias, void* y, void* aux,
+                                       int32_t N, int32_t H, int32_t W, int32_t C, int32_t act, void* stream) {
+  return dwconv_launch(dtype, x, w9c, bias, y, aux, N, H, W, C, act, 0, stream);
+}
+
+// data gradient of the depth-wise conv: dx = correlation of dy with the REVERSED taps (row 8 - t of the same [9][C] weights)
+extern "C" int cavp_dwconv3x3_bwd_data_nhwc(int32_t dtype, const void* dy, const float* w9c, void* dx, int32_t N, int32_t H,
+                                            int32_t W, int32_t C, void* stream) {
+  return dwconv_launch(dtype, dy, w9c, nullptr, dx, nullptr, N, H, W, C, CAVP_ACT_NONE, 1, stream);
 }
 
 extern "C" int cavp_pack_dwconv_weight(const float* w_c133, float* w9c, int32_t C, void* stream) {

@@ -368,6 +368,18 @@ def dwconv3x3(x: torch.Tensor, w9c: torch.Tensor, bias: Optional[torch.Tensor], 
     return out
 
 
+def dwconv3x3_bwd_data(dy: torch.Tensor, w9c: torch.Tensor, dx: torch.Tensor):
+    """dx of the depth-wise 3x3 conv from the forward's packed [9][C] weights (the taps are read in reverse order)."""
+    _need_gpu(dy, w9c, dx)
+    n, h, w, c, ld = _nhwc(dy)
+    if ld != c or not dx.is_contiguous() or dx.shape != dy.shape or dx.dtype != dy.dtype:
+        raise _lib.CavpError("dwconv3x3_bwd_data: dense NHWC tensors required")
+    st = _lib.load().cavp_dwconv3x3_bwd_data_nhwc(dtype_code(dy.dtype), _ptr(dy), _ptr(w9c), _ptr(dx), n, h, w, c,
+                                                  C.c_void_p(_stream()))
+    _lib.check(st, "cavp_dwconv3x3_bwd_data_nhwc")
+    return dx
+
+
 def conv_smallcin_kxk(x_nchw: torch.Tensor, w_oihw: torch.Tensor, bias, out: torch.Tensor, ks: int, stride: int, pad: int):
     _need_gpu(x_nchw, w_oihw, bias, out)
     n, cin, h, w = x_nchw.shape

@@ -105,13 +105,12 @@ def _sra_attention(tp: TrainPass, q: V, kv: V, heads: int, scale: float) -> V:
     return o
 
 
-def _dwconv_gelu(tp: TrainPass, x: V, conv, B: int, H: int, W: int) -> V:
+def _dwconv_gelu(tp: TrainPass, x: V, conv, w9c: torch.Tensor, B: int, H: int, W: int) -> V:
     """GELU(DWConv(x)) (pvt.py:46-55,320-326): depth-wise 3x3 + bias on the tokens viewed as NHWC pixels, GELU in the same
     kernel with gelu'(t) as second output.  The returned activation carries that tensor as `grad_mul`: the data-gradient GEMM
     of fc2 multiplies it into its epilogue (TrainPass.acc), so this op's backward receives d(pre-activation) directly - no
     separate GELU / GELU-backward pass, the pre-activation itself is never stored."""
     hid = x.t.shape[-1]
-    w9c = ops.pack_dwconv_weight(conv.weight)
     y = V(tp.empty(x.t.shape))
     deriv = tp.empty(x.t.shape)
     ops.dwconv3x3(x.t.view(B, H, W, hid), w9c, conv.bias.detach(), y.t.view(B, H, W, hid), act=ACT_GELU,
@@ -128,7 +127,7 @@ def _dwconv_gelu(tp: TrainPass, x: V, conv, B: int, H: int, W: int) -> V:
         T.dwconv3x3_wgrad(x.t.view(B, H, W, hid), g4, tp.grad_buffer(conv.weight), tp.grad_buffer(conv.bias))
         if x.needs_grad:
             dx = tp.empty(x.t.shape)
-            ops.dwconv3x3(g4, w9c.flip(0).contiguous(), None, dx.view(B, H, W, hid), act=ACT_NONE)   # correlation with the reversed taps
+            ops.dwconv3x3_bwd_data(g4, w9c, dx.view(B, H, W, hid))   # correlation with the reversed taps
             tp.acc_add(x, dx)
     tp.tape.append(bwd)
     return y
@@ -195,6 +194,7 @@ def pvt_train_forward(tp: TrainPass, bb, image: torch.Tensor, drop_scales: Optio
     DropPath factors (tests: the masks a reference run drew)."""
     B = image.shape[0]
     pre_jobs: list = []
+    dw_packed: dict = {}
     for i in range(4):
         pe = getattr(bb, f"patch_embed{i + 1}")
         if i > 0:
@@ -207,6 +207,11 @@ def pvt_train_forward(tp: TrainPass, bb, image: torch.Tensor, drop_scales: Optio
                 _pack_sr(tp, k + "sr", blk.attn.sr, pre_jobs)
             tp.pack(k + "fc1", blk.mlp.fc1)
             tp.pack(k + "fc2", blk.mlp.fc2)
+            # depth-wise taps [C][1][3][3] -> [9][C] f32: the OIHW -> OHWI permutation of a [1][C][3][3] weight
+            dw = blk.mlp.dwconv.dwconv.weight
+            w9c = torch.empty((9, dw.shape[0]), dtype=torch.float32, device=tp.dev)
+            pre_jobs.append((dw.detach().view(1, dw.shape[0], 3, 3), w9c, None))
+            dw_packed[k] = w9c
     T.pack_weights_multi(pre_jobs, torch.float32)
     tp.flush_packs()
     scales = drop_scales if drop_scales is not None else draw_drop_path_scales(bb, B, image.device)
@@ -241,7 +246,7 @@ def pvt_train_forward(tp: TrainPass, bb, image: torch.Tensor, drop_scales: Optio
                 x = _residual_drop_path(tp, x, tp.conv(o, k + "proj"), s_att)
             n2 = tp.layernorm(x, blk.norm2)
             h1 = tp.conv(n2, k + "fc1")
-            h2 = _dwconv_gelu(tp, h1, blk.mlp.dwconv.dwconv, B, H, W)
+            h2 = _dwconv_gelu(tp, h1, blk.mlp.dwconv.dwconv, dw_packed[k], B, H, W)
             if s_mlp is None:
                 x = tp.conv(h2, k + "fc2", residual=x)
             else:

@@ -385,6 +385,10 @@ int cavp_dwconv3x3_nhwc(int32_t dtype, const void* x, const float* w9c, const fl
  * training pass has no separate GELU and GELU-backward launches and the pre-activation is never stored. */
 int cavp_dwconv3x3_nhwc_aux(int32_t dtype, const void* x, const float* w9c, const float* bias, void* y, void* aux, int32_t N,
                             int32_t H, int32_t W, int32_t C, int32_t act, void* stream);
+/* data gradient of the depth-wise conv (pvt.py:46-55 backward): dx = dy correlated with the reversed taps of the same packed
+ * [9][C] weights; dense NHWC of C channels. */
+int cavp_dwconv3x3_bwd_data_nhwc(int32_t dtype, const void* dy, const float* w9c, void* dx, int32_t N, int32_t H, int32_t W,
+                                 int32_t C, void* stream);
 int cavp_pack_dwconv_weight(const float* w_c133, float* w9c, int32_t C, void* stream); /* [C][1][3][3] -> [9][C] */
 /* OverlapPatchEmbed.proj of stage 1 (pvt.py:187-188): KSxKS conv, Cin <= 3, NCHW f32 in, NHWC out, + bias. */
 int cavp_conv_smallcin_kxk_nchw(int32_t dtype, const float* x_nchw, const float* w_oihw, const float* bias, void* y_nhwc,

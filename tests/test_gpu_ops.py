@@ -305,6 +305,19 @@ def test_dwconv_and_patch_embed_and_sr_conv(dtype):
         ops.dwconv3x3(xv2.contiguous(), ops.pack_dwconv_weight(w.to(DEV)), b.to(DEV), o2, act=ops.ACT_GELU, aux=aux)
         _check(o2.permute(0, 3, 1, 2), F.gelu(pre.detach()), dtype, f"dwconv3x3+gelu (aux call, W={ww})")
         _check(aux.permute(0, 3, 1, 2), pre.grad, dtype, f"gelu' second output (W={ww})")
+        # data gradient from the SAME packed weights (reversed taps), and the weights packed through the multi-tensor pack
+        # (a [1][C][3][3] OIHW -> OHWI permutation) equal pack_dwconv_weight's
+        xg = _q(xs, dtype).requires_grad_(True)
+        dy = _rand(2, 64, hh, ww, seed=61)
+        F.conv2d(xg, w, None, 1, 1, 1, 64).backward(_q(dy, dtype))
+        dyv, _ = _to_nhwc_dev(dy, dtype)
+        from cavp_amd import train_ops as T
+        w9c = torch.empty((9, 64), dtype=torch.float32, device=DEV)
+        T.pack_weights_multi([(w.to(DEV).view(1, 64, 3, 3), w9c, None)], torch.float32)
+        assert torch.equal(w9c, ops.pack_dwconv_weight(w.to(DEV)))
+        dx = torch.empty((2, hh, ww, 64), dtype=dtype, device=DEV)
+        ops.dwconv3x3_bwd_data(dyv.contiguous(), w9c, dx)
+        _check(dx.permute(0, 3, 1, 2), xg.grad, dtype, f"dwconv3x3 data gradient (W={ww})")
     # 7x7 stride-4 overlapping patch embedding (Cin = 3)
     img, w7, b7 = _rand(2, 3, 64, 96, seed=55), _rand(64, 3, 7, 7, seed=56, scale=0.1), _rand(64, seed=57)
     ref = F.conv2d(img, w7, b7, 4, 3)
