@@ -86,7 +86,8 @@ __global__ __launch_bounds__(256) void layernorm_bwd_vec_kernel(const T* __restr
                                                                 const float* __restrict__ gamma, T* __restrict__ dx,
                                                                 float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                                 int rows, int C, int ld_dy, int ld_x, int ld_dx, float eps,
-                                                                int rows_per_block, float* __restrict__ det_part) {
+                                                                int rows_per_block, float* __restrict__ det_part,
+                                                                const T* add, int ld_add) {
   constexpr int VE = VecT<T>::VE, RW = 64 / G, CW = G * PLV * VE;  // channels covered by a row group
   __shared__ float part[2][4][CW];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -157,6 +158,12 @@ __global__ __launch_bounds__(256) void layernorm_bwd_vec_kernel(const T* __restr
         float o[VE];
 #pragma unroll
         for (int e = 0; e < VE; ++e) o[e] = rstd * (dv[i][e] - s1 - xv[i][e] * s2);
+        if (add) {   // the gradient the input already holds (residual branch): one pass instead of a separate add
+          float r[VE];
+          VecT<T>::load(add + (size_t)row * ld_add + (l + G * i) * VE, r);
+#pragma unroll
+          for (int e = 0; e < VE; ++e) o[e] += r[e];
+        }
         VecT<T>::store(dx + (size_t)row * ld_dx + (l + G * i) * VE, o);
       }
     }
@@ -265,11 +272,17 @@ extern "C" int cavp_layernorm(int32_t dtype, const void* x, const float* gamma, 
 extern "C" int cavp_layernorm_bwd(int32_t dtype, const void* dy, const void* x, const float* gamma, void* dx,
                                   float* dgamma, float* dbeta, int32_t rows, int32_t C, int32_t ld_dy, int32_t ld_x,
                                   int32_t ld_dx, float eps, void* stream) {
+  return cavp_layernorm_bwd_add(dtype, dy, x, gamma, nullptr, 0, dx, dgamma, dbeta, rows, C, ld_dy, ld_x, ld_dx, eps, stream);
+}
+
+extern "C" int cavp_layernorm_bwd_add(int32_t dtype, const void* dy, const void* x, const float* gamma, const void* dx_add,
+                                      int32_t ld_add, void* dx, float* dgamma, float* dbeta, int32_t rows, int32_t C,
+                                      int32_t ld_dy, int32_t ld_x, int32_t ld_dx, float eps, void* stream) {
   if (!dy || !x || !gamma || !dx || !dgamma || !dbeta || rows <= 0 || C <= 0) return CAVP_ERR_BAD_ARG;
   if (!dt_ok(dtype)) return CAVP_ERR_UNSUPPORTED;
   const int VE = dtype == CAVP_F32 ? 4 : 8;
-  if (C % VE || ld_dy % VE || ld_x % VE || ld_dx % VE) return CAVP_ERR_UNSUPPORTED;
-  if (!al16(x) || !al16(dy) || !al16(dx) || !al16(gamma)) return CAVP_ERR_ALIGN;
+  if (C % VE || ld_dy % VE || ld_x % VE || ld_dx % VE || (dx_add && ld_add % VE)) return CAVP_ERR_UNSUPPORTED;
+  if (!al16(x) || !al16(dy) || !al16(dx) || !al16(gamma) || !al16(dx_add)) return CAVP_ERR_ALIGN;
   int G, PLV;
   if (!ln_geometry(C, VE, &G, &PLV)) return CAVP_ERR_UNSUPPORTED;
   const int rpi = 4 * (64 / G);  // rows per workgroup iteration
@@ -286,11 +299,11 @@ extern "C" int cavp_layernorm_bwd(int32_t dtype, const void* dy, const void* x, 
   float* det = cavp_det_scratch(gx, C, &det_err);
   if (det_err) return CAVP_ERR_WORKSPACE;
   if (dtype == CAVP_F32) {
-#define CALL(g, p) layernorm_bwd_vec_kernel<float, g, p><<<gx, 256, 0, s>>>((const float*)dy, (const float*)x, gamma, (float*)dx, dgamma, dbeta, rows, C, ld_dy, ld_x, ld_dx, eps, rpb, det)
+#define CALL(g, p) layernorm_bwd_vec_kernel<float, g, p><<<gx, 256, 0, s>>>((const float*)dy, (const float*)x, gamma, (float*)dx, dgamma, dbeta, rows, C, ld_dy, ld_x, ld_dx, eps, rpb, det, (const float*)dx_add, ld_add)
     LN_DISPATCH(CALL)
 #undef CALL
   } else {
-#define CALL(g, p) layernorm_bwd_vec_kernel<bf16_t, g, p><<<gx, 256, 0, s>>>((const bf16_t*)dy, (const bf16_t*)x, gamma, (bf16_t*)dx, dgamma, dbeta, rows, C, ld_dy, ld_x, ld_dx, eps, rpb, det)
+#define CALL(g, p) layernorm_bwd_vec_kernel<bf16_t, g, p><<<gx, 256, 0, s>>>((const bf16_t*)dy, (const bf16_t*)x, gamma, (bf16_t*)dx, dgamma, dbeta, rows, C, ld_dy, ld_x, ld_dx, eps, rpb, det, (const bf16_t*)dx_add, ld_add)
     LN_DISPATCH_BF16(CALL)
 #undef CALL
   }

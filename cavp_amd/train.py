@@ -678,9 +678,21 @@ class TrainPass:
         def bwd():
             if y.g is None:
                 return
-            dx = self.empty(x.t.shape, x.t.dtype)
-            T.layernorm_bwd(y.g, x.t, ln.weight.detach(), dx, self.grad_buffer(ln.weight), self.grad_buffer(ln.bias), ln.eps)
-            self.acc_add(x, dx)
+            if not x.needs_grad:
+                dx = self.empty(x.t.shape, x.t.dtype)
+                T.layernorm_bwd(y.g, x.t, ln.weight.detach(), dx, self.grad_buffer(ln.weight), self.grad_buffer(ln.bias), ln.eps)
+                return
+            # the residual stream usually delivered its gradient already: it is added inside the kernel (into a fresh tensor while
+            # a deferred weight gradient still reads the old one, in place otherwise)
+            have = x.g if (x.parent is None and x.g is not None and x.g.is_contiguous() and x.g.dtype == x.t.dtype
+                           and x.g.shape == x.t.shape) else None
+            dx = have if (have is not None and not self._pinned(have)) else self.empty(x.t.shape, x.t.dtype)
+            T.layernorm_bwd(y.g, x.t, ln.weight.detach(), dx, self.grad_buffer(ln.weight), self.grad_buffer(ln.bias), ln.eps,
+                            add=have)
+            if have is None:
+                self.acc_add(x, dx)
+            elif dx is not have:
+                x.set_g(dx)
         self.tape.append(bwd)
         return y
 

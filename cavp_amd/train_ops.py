@@ -359,13 +359,20 @@ def colsum_groups(x, out) -> torch.Tensor:
     return out
 
 
-def layernorm_bwd(dy, x, gamma, dx, dgamma, dbeta, eps: float) -> torch.Tensor:
+def layernorm_bwd(dy, x, gamma, dx, dgamma, dbeta, eps: float, add: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """add (dx's shape and dtype, may be dx): a gradient the input already holds; dx = layernorm_bwd(dy) + add in one pass."""
     rows, c, ld_dy = _rows(dy)
     _, _, ld_x = _rows(x)
     _, _, ld_dx = _rows(dx)
-    _need_gpu(dy, x, gamma, dx, dgamma, dbeta)
-    _check(_lib.load().cavp_layernorm_bwd(dtype_code(dy.dtype), _ptr(dy), _ptr(x), _ptr(gamma), _ptr(dx), _ptr(dgamma),
-                                          _ptr(dbeta), rows, c, ld_dy, ld_x, ld_dx, C.c_float(eps), _s()), "cavp_layernorm_bwd")
+    _need_gpu(dy, x, gamma, dx, dgamma, dbeta, add)
+    ld_add = 0
+    if add is not None:
+        if add.shape != dx.shape or add.dtype != dx.dtype:
+            raise _lib.CavpError("layernorm_bwd: `add` must have dx's shape and dtype")
+        _, _, ld_add = _rows(add)
+    _check(_lib.load().cavp_layernorm_bwd_add(dtype_code(dy.dtype), _ptr(dy), _ptr(x), _ptr(gamma), _ptr(add), ld_add, _ptr(dx),
+                                              _ptr(dgamma), _ptr(dbeta), rows, c, ld_dy, ld_x, ld_dx, C.c_float(eps), _s()),
+           "cavp_layernorm_bwd_add")
     return dx
 
 

@@ -243,6 +243,16 @@ def test_layernorm_bwd(rows, C, dt):
     _check(dx, x.grad, dt, "ln dx", 5e-5, 2e-2)
     _check(dg, g.grad, dt, "ln dgamma", 1e-4, 1e-2)
     _check(db, b.grad, dt, "ln dbeta", 1e-4, 1e-2)
+    # with the gradient the input already holds added in (out of place, and in place: add is dx)
+    prior = _q(_rand(rows, C, seed=20), dt)
+    pd = prior.to(dt).to(DEV)
+    for inplace in (False, True):
+        out = pd.clone() if inplace else torch.empty((rows, C), dtype=dt, device=DEV)
+        dg2, db2 = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+        T.layernorm_bwd(dy.to(dt).to(DEV), x.detach().to(dt).to(DEV), g.detach().to(DEV), out, dg2, db2, 1e-5,
+                        add=out if inplace else pd)
+        _check(out, x.grad + prior, dt, f"ln dx + prior (inplace={inplace})", 5e-5, 2e-2)
+        _check(dg2, g.grad, dt, "ln dgamma (add)", 1e-4, 1e-2)
 
 
 @pytest.mark.parametrize("H,hd", [(4, 76), (4, 28), (4, 128), (2, 64), (8, 32)], ids=["4x76", "4x28", "4x128", "2x64", "8x32"])
