@@ -643,7 +643,10 @@ extern "C" int cavp_sra_attention_bwd(int32_t dtype, const void* q, const void* 
   const int C = heads * 64;
   const dim3 ga((Nq + 63) / 64, B * heads);
   const int chunks = (Nq + 63) / 64, kblocks = (Nk + 63) / 64;
-  int splits = 256 / (B * heads * kblocks);   // query splits of the dK / dV pass: just enough workgroups to fill the chip
+  // query splits of the dK / dV pass: ~4 workgroups per CU (a workgroup is 4 waves walking its query chunks one after the
+  // other; with 256 workgroups the stage-3 shape ran one wave per SIMD, 70 us per call); splits * B * heads <= 256 keeps the slabs
+  // inside the workspace bound above
+  int splits = 1024 / (B * heads * kblocks);
   splits = splits < 1 ? 1 : (splits > chunks ? chunks : splits);
   const size_t slab = (size_t)B * Nk * 2 * C;                     // floats per split
   float* slabs = stats + (((size_t)2 * B * heads * Nq + 3) & ~(size_t)3);
