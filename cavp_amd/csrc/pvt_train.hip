@@ -264,6 +264,16 @@ __device__ __forceinline__ bf16x8_t btile_tr(const char* base, int r0, int db, i
   const uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
   return __builtin_bit_cast(bf16x8_t, (u32x4_t){l2.x, l2.y, h2.x, h2.y});
 }
+// the same operand from the SWIZZLED tile (bstage's `sw`): a lane's 8 bytes are half of the 16-byte slot 2 db + (lrow & 3) / 2 of
+// its row, which lives at slot ^ (row & 7); rows ra and ra + 16 share the swizzle
+__device__ __forceinline__ bf16x8_t btile_tr_sw(const char* base, int r0, int db, int lrow) {
+  const int ra = r0 + (lrow >> 2);
+  const int off = ra * 128 + (((db * 2 + ((lrow & 3) >> 1)) ^ (ra & 7)) << 4) + (lrow & 1) * 8;
+  const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(base + off));
+  const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(base + off + 16 * 128));
+  const uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
+  return __builtin_bit_cast(bf16x8_t, (u32x4_t){l2.x, l2.y, h2.x, h2.y});
+}
 __device__ __forceinline__ bf16x8_t pack8(const f32x4_t& a, const f32x4_t& b) {
   return __builtin_bit_cast(bf16x8_t, (u32x4_t){pack2bf(a[0], a[1]), pack2bf(a[2], a[3]), pack2bf(b[0], b[1]), pack2bf(b[2], b[3])});
 }
@@ -282,14 +292,14 @@ __global__ __launch_bounds__(256) void sra_bwd_q_bf16_kernel(const bf16_t* __res
                                                              const bf16_t* __restrict__ dout, bf16_t* __restrict__ dq,
                                                              float* __restrict__ stats, int Nq, int Nk, int heads, float scale) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* ks = smem;                 // K, swizzled rows (A operand of S^T = K Q^T)
+  char* ks = smem;                 // K, swizzled rows (A operand of S^T = K Q^T; transposed reads for dQ^T = K^T dS^T)
   char* vs = smem + 256 * 128;     // V, swizzled rows (A operand of dP^T = V dO^T)
-  char* kl = smem + 2 * 256 * 128; // K, linear (transposed reads for dQ^T = K^T dS^T)
+  // (64 KiB: two workgroups per CU.  A third, linear copy of K for the transposed reads made it 96 KiB and one per CU.)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int bh = blockIdx.y, b = bh / heads, h = bh - b * heads;
   const int C = heads * 64;
   const bf16_t* kvb = kv + (size_t)b * Nk * 2 * C + h * 64;
-  bstage(ks, kl, kvb, (size_t)2 * C, Nk, 256, tid);
+  bstage(ks, nullptr, kvb, (size_t)2 * C, Nk, 256, tid);
   bstage(vs, nullptr, kvb + C, (size_t)2 * C, Nk, 256, tid);
   __syncthreads();
   const int lrow = lane & 15, lgrp = lane >> 4;
@@ -362,7 +372,7 @@ __global__ __launch_bounds__(256) void sra_bwd_q_bf16_kernel(const bf16_t* __res
     const bf16x8_t df = pack8(s[2 * kp], s[2 * kp + 1]);
 #pragma unroll
     for (int db = 0; db < 4; ++db)
-      acc[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(btile_tr(kl, 32 * kp + 4 * lgrp, db, lrow), df, acc[db], 0, 0, 0);
+      acc[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(btile_tr_sw(ks, 32 * kp + 4 * lgrp, db, lrow), df, acc[db], 0, 0, 0);
   }
   if (qok) {
 #pragma unroll
@@ -636,7 +646,7 @@ extern "C" int cavp_sra_attention_bwd(int32_t dtype, const void* q, const void* 
   static bool attr = false;
   if (!attr) {
     (void)hipFuncSetAttribute((const void*)sra_bwd_q_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 256 * 256);
-    (void)hipFuncSetAttribute((const void*)sra_bwd_q_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 256 * 128);
+    (void)hipFuncSetAttribute((const void*)sra_bwd_q_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 256 * 128);
     attr = true;
   }
   float* stats = (float*)workspace;
@@ -659,7 +669,7 @@ extern "C" int cavp_sra_attention_bwd(int32_t dtype, const void* q, const void* 
     sra_bwd_kv_kernel<float><<<gb, 256, 0, s>>>((const float*)q, (const float*)kv, (const float*)dout, stats, kv_out, Nq, Nk, heads,
                                                 scale, slab);
   } else {
-    sra_bwd_q_bf16_kernel<<<ga, 256, 3 * 256 * 128, s>>>((const bf16_t*)q, (const bf16_t*)kv, (const bf16_t*)dout, (bf16_t*)dq, stats,
+    sra_bwd_q_bf16_kernel<<<ga, 256, 2 * 256 * 128, s>>>((const bf16_t*)q, (const bf16_t*)kv, (const bf16_t*)dout, (bf16_t*)dq, stats,
                                                         Nq, Nk, heads, scale);
     sra_bwd_kv_bf16_kernel<<<gb, 256, 0, s>>>((const bf16_t*)q, (const bf16_t*)kv, (const bf16_t*)dout, stats, kv_out, Nq, Nk, heads,
                                               scale, slab);
