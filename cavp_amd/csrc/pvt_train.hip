@@ -388,10 +388,11 @@ __global__ __launch_bounds__(256) void sra_bwd_kv_bf16_kernel(const bf16_t* __re
                                                               const bf16_t* __restrict__ dout, const float* __restrict__ stats,
                                                               float* __restrict__ dkv, int Nq, int Nk, int heads, float scale,
                                                               size_t slab_stride) {
+  // Q and dO chunks of 64 queries, swizzled rows: row-major fragments for S = Q K^T / dP = dO V^T and (btile_tr_sw) transposed
+  // ones for dK = dS^T Q / dV = P^T dO from the same copy.  The next chunk's rows are fetched into registers while this one is
+  // multiplied (the loop used to stall on a global round trip per chunk: 16 chunks x ~2 us for the stage-3 shape).
   __shared__ __attribute__((aligned(16))) char qs[64 * 128];
-  __shared__ __attribute__((aligned(16))) char ql[64 * 128];
   __shared__ __attribute__((aligned(16))) char gs[64 * 128];
-  __shared__ __attribute__((aligned(16))) char gl[64 * 128];
   __shared__ float lse_s[64], del_s[64];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lrow = lane & 15, lgrp = lane >> 4;
@@ -412,17 +413,36 @@ __global__ __launch_bounds__(256) void sra_bwd_kv_bf16_kernel(const bf16_t* __re
 #pragma unroll
   for (int db = 0; db < 4; ++db) { dk[db] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; dv[db] = dk[db]; }
   const int chunks = (Nq + 63) / 64;
-  for (int ch = blockIdx.x; ch < chunks; ch += gridDim.x) {
+  u32x4_t pq[2], pg[2];
+  float pl = 0.f, pd = 0.f;
+  auto fetch = [&](int ch) {
     const int q0 = ch * 64, rows = min(64, Nq - q0);
-    __syncthreads();
-    bstage(qs, ql, q + ((size_t)b * Nq + q0) * C + h * 64, (size_t)C, rows, 64, tid);
-    bstage(gs, gl, dout + ((size_t)b * Nq + q0) * C + h * 64, (size_t)C, rows, 64, tid);
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int r = (tid >> 3) + 32 * k, sl = tid & 7;
+      const size_t at = ((size_t)b * Nq + q0 + r) * C + h * 64 + sl * 8;
+      pq[k] = r < rows ? *(const u32x4_t*)(q + at) : (u32x4_t){0, 0, 0, 0};
+      pg[k] = r < rows ? *(const u32x4_t*)(dout + at) : (u32x4_t){0, 0, 0, 0};
+    }
     if (tid < 64) {
       const bool ok = tid < rows;
-      lse_s[tid] = ok ? stats[(size_t)bh * Nq + q0 + tid] : 0.f;
-      del_s[tid] = ok ? stats[(size_t)gridDim.y * Nq + (size_t)bh * Nq + q0 + tid] : 0.f;
+      pl = ok ? stats[(size_t)bh * Nq + q0 + tid] : 0.f;
+      pd = ok ? stats[(size_t)gridDim.y * Nq + (size_t)bh * Nq + q0 + tid] : 0.f;
     }
+  };
+  if ((int)blockIdx.x < chunks) fetch(blockIdx.x);
+  for (int ch = blockIdx.x; ch < chunks; ch += gridDim.x) {
+    const int rows = min(64, Nq - ch * 64);
     __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int r = (tid >> 3) + 32 * k, sl = tid & 7;
+      *(u32x4_t*)(qs + r * 128 + ((sl ^ (r & 7)) << 4)) = pq[k];
+      *(u32x4_t*)(gs + r * 128 + ((sl ^ (r & 7)) << 4)) = pg[k];
+    }
+    if (tid < 64) { lse_s[tid] = pl; del_s[tid] = pd; }
+    __syncthreads();
+    if (ch + (int)gridDim.x < chunks) fetch(ch + gridDim.x);
     f32x4_t p[4], ds[4];
 #pragma unroll
     for (int qb = 0; qb < 4; ++qb) {
@@ -447,8 +467,8 @@ __global__ __launch_bounds__(256) void sra_bwd_kv_bf16_kernel(const bf16_t* __re
       const bf16x8_t pf = pack8(p[2 * qp], p[2 * qp + 1]), df = pack8(ds[2 * qp], ds[2 * qp + 1]);
 #pragma unroll
       for (int db = 0; db < 4; ++db) {
-        dv[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(btile_tr(gl, 32 * qp + 4 * lgrp, db, lrow), pf, dv[db], 0, 0, 0);
-        dk[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(btile_tr(ql, 32 * qp + 4 * lgrp, db, lrow), df, dk[db], 0, 0, 0);
+        dv[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(btile_tr_sw(gs, 32 * qp + 4 * lgrp, db, lrow), pf, dv[db], 0, 0, 0);
+        dk[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(btile_tr_sw(qs, 32 * qp + 4 * lgrp, db, lrow), df, dk[db], 0, 0, 0);
       }
     }
   }
