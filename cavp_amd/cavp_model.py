@@ -633,10 +633,21 @@ class CAVP(nn.Module):
         return out_pred, out_fusion, pack
 
     # -- reference API ------------------------------------------------------------------------------------------
-    def _stage_guard(self, what):
-        if any(m.training for m in self.modules() if isinstance(m, nn.modules.batchnorm._BatchNorm)):
-            raise CavpError(f"{what} is a forward-only stage entry point (eval-mode BatchNorm); in training mode call the "
-                            f"model itself: forward_train runs all stages as one fused pass with a hand-written backward")
+    def _stage_on_tape(self, mods, *inputs) -> bool:
+        """True when a stage entry point has to run on a training tape (CAVPStageFunction): one of its BatchNorm layers is in
+        training mode (batch statistics, running-statistics update) or autograd wants gradients through it.  Otherwise the
+        forward-only eval kernels serve it."""
+        bn_train = any(m.training for top in mods for m in top.modules() if isinstance(m, nn.modules.batchnorm._BatchNorm))
+        want = torch.is_grad_enabled() and (any(isinstance(t, torch.Tensor) and t.requires_grad for t in inputs)
+                                            or any(p.requires_grad for top in mods for p in top.parameters()))
+        return bn_train or want
+
+    def _stage_apply(self, kind, meta, mods, *inputs):
+        from .train import CAVPStageFunction
+        if not inputs[0].is_cuda:
+            raise CavpError("CAVP (MI355X path) needs inputs on a HIP device: there is no CPU fallback")
+        params = [p for top in mods for p in top.parameters() if p.requires_grad] if torch.is_grad_enabled() else []
+        return CAVPStageFunction.apply(self, kind, meta, len(inputs), *inputs, *params)
 
     @staticmethod
     def _nchw_to_nhwc(t, dtype):
@@ -652,7 +663,8 @@ class CAVP(nn.Module):
     def forward_cls(self, out, input_shape):
         """cavp_model.py:138-141: decoder head (two 3x3 conv + BN + ReLU, 1x1 classifier) + bilinear x4 (align_corners=False).
         `out`: fused features [B, 304, h, w] (NCHW-shaped, any memory layout) -> logits [B, C, *input_shape] f32."""
-        self._stage_guard("forward_cls")
+        if self._stage_on_tape((self.segment.upsample,), out):
+            return self._stage_apply("cls", tuple(input_shape), (self.segment.upsample,), out)
         with torch.no_grad():
             x = self._nchw_to_nhwc(out, self.compute_dtype)
             pred, _ = self._cls_hip(x, self.packed(), tuple(input_shape))
@@ -661,7 +673,11 @@ class CAVP(nn.Module):
     def forward_fusion(self, visual, fea_a):
         """cavp_model.py:143-154: projector MLP + sigmoid cross-modal attention.  visual [B, 304, h, w], fea_a [B, 304] ->
         (fea_v [B, 304, h, w], {"audio": [B, 304, 1, 1], "visual": projected features, "attn_v": [B, heads, h*w, 1]})."""
-        self._stage_guard("forward_fusion")
+        mods = (self.visual_projector, self.cross_att)
+        if self._stage_on_tape(mods, visual, fea_a):
+            a_in = fea_a.reshape(fea_a.shape[0], -1)
+            fus, vis, attn_v = self._stage_apply("fusion", None, mods, visual, a_in)
+            return fus, {"audio": a_in[:, :, None, None], "visual": vis, "attn_v": attn_v}
         with torch.no_grad():
             v = self._nchw_to_nhwc(visual, self.compute_dtype)
             a = fea_a.reshape(fea_a.shape[0], -1).contiguous()
@@ -685,9 +701,10 @@ class CAVP(nn.Module):
 
     def forward_audio(self, audio, shuffle_info=None, ow_flag=False):
         """cavp_model.py:156-173: audio features of the B clips followed by the same features in shuffled order ([2B, 304]);
-        with ow_flag the SoundBank is updated from the image labels.  Forward-only here; inside forward_train(audio_func=True)
-        the gather is part of the training pass and carries gradients."""
-        self._stage_guard("forward_audio")
+        with ow_flag the SoundBank is updated from the image labels.  With gradients enabled the encoder and the gather run on a
+        training tape of their own (CAVPStageFunction); inside forward_train(audio_func=True) they are part of the model's pass."""
+        if self._stage_on_tape((self.audio_backbone,), audio):
+            return self._stage_apply("audio", (shuffle_info, ow_flag), (self.audio_backbone,), audio)
         with torch.no_grad():
             a = audio.contiguous()
             fea_a = self._audio_hip(a, self.packed())

@@ -839,6 +839,103 @@ class TrainPass:
 # ---------------------------------------------------------------------------------------------------------------
 # the model graph in training mode
 # ---------------------------------------------------------------------------------------------------------------
+def _pack_head(tp: TrainPass, m) -> None:
+    up = m.segment.upsample
+    tp.pack("head0", up.last_conv[0])
+    tp.pack("head1", up.last_conv[3])
+    tp.pack("cls", up.classifier, pad_cout_to=8)
+
+
+def _pack_audio(tp: TrainPass, m) -> None:
+    vgg = m.audio_backbone.backbone
+    convs = [mm for mm in vgg.features if isinstance(mm, nn.Conv2d)]
+    tp.pack("a.conv0", convs[0], raw=True)
+    for i, cv in enumerate(convs[1:], 1):
+        tp.pack(f"a.conv{i}", cv)
+    for i, j in enumerate((0, 2, 4)):
+        tp.pack(f"a.fc{i}", vgg.embeddings[j])
+
+
+def _pack_fusion(tp: TrainPass, m) -> None:
+    tp.pack("proj.fc1", m.visual_projector.fc1)
+    tp.pack("proj.fc2", m.visual_projector.fc2)
+    ca, blk = m.cross_att, m.cross_att.blocks[0]
+    tp.pack("ca.pe_v", ca.patch_embed_v.proj)
+    tp.pack("ca.pe_a", ca.patch_embed_a.proj)
+    for nme in ("q", "k", "v", "proj"):
+        tp.pack("ca." + nme, getattr(blk.attn, nme))
+    tp.pack("ca.fc1", blk.mlp.fc1)
+    tp.pack("ca.fc2", blk.mlp.fc2)
+
+
+def _audio_stage(tp: TrainPass, audio: torch.Tensor) -> V:
+    """VGGish (vgg.py:17-36) on the tape: [N, 1, 96, 64] f32 -> features [N, latent]."""
+    from .cavp_model import VGG
+    a = tp.conv_smallcin(audio, "a.conv0", 1, ACT_RELU)
+    ci = 1
+    for v in VGG.CFG[1:]:
+        if v == "M":
+            a = tp.maxpool(a, 2, 2, 0)
+        else:
+            a = tp.conv(a, f"a.conv{ci}", act=ACT_RELU)
+            ci += 1
+    a = tp.flatten(a)
+    a = tp.conv(a, "a.fc0", act=ACT_RELU)
+    a = tp.conv(a, "a.fc1", act=ACT_RELU)
+    return tp.conv(a, "a.fc2", act=ACT_RELU)
+
+
+def _fusion_stage(tp: TrainPass, m, fea_v: V, fea_a: V, duplicate: bool):
+    """forward_fusion (cavp_model.py:143-154; attn.py:232-244) on the tape.  fea_v NHWC [Bv, h, w, C], fea_a [Ba, C].
+    duplicate=True (forward_train): Ba = 2 Bv - the reference duplicates the visual features first (`torch.cat((fea_v,
+    fea_v.clone()))`, cavp_model.py:181) and runs projector / patch_embed_v / norm1 / q on both identical halves.  Those four
+    GEMMs + LN depend only on fea_v, so they are computed ONCE on Bv rows and their results duplicated where the halves start to
+    differ (the audio-conditioned gate); in backward the duplication sums the two halves' gradients - same values, half the
+    work.  duplicate=False (the stage entry point): Ba = Bv, row for row.
+    Returns (fusion NHWC [Ba, h, w, C], fea_v_proj tokens [Bv, h*w, C], attn)."""
+    ca, blk = m.cross_att, m.cross_att.blocks[0]
+    Bv, hh, ww, Cc = fea_v.t.shape
+    Ba = fea_a.t.shape[0]
+    if Ba != (2 * Bv if duplicate else Bv):
+        raise CavpError(f"fusion: {Ba} audio feature rows for {Bv} visual maps")
+    tokB = tp.reshape(fea_v, (Bv, hh * ww, Cc))
+    hidp = tp.conv(tokB, "proj.fc1", act=ACT_GELU) if _FUSE_TOKEN_PATH else tp.gelu(tp.conv(tokB, "proj.fc1"))
+    fea_v_projB = tp.conv(hidp, "proj.fc2")
+    v0B = tp.conv(fea_v_projB, "ca.pe_v")
+    a0 = tp.conv(fea_a, "ca.pe_a")
+    vnB = tp.layernorm(v0B, blk.norm1)
+    an = tp.layernorm(a0, blk.norm1)
+    qB = tp.conv(vnB, "ca.q")
+    # the 2B rows of `vn` / `q` / pack["visual"] are never materialised: the gate reads q[b % B], ca.proj adds the residual row
+    # p % (B * T), and the output-only duplicate of fea_v_proj is made by whoever returns it (three 2 x 61 MB copies per step)
+    periodic = duplicate and (Bv * hh * ww) % 256 == 0 and _FUSE_TOKEN_PATH
+    vn, q = (vnB, qB) if (periodic or not duplicate) else (tp.dup2(vnB), tp.dup2(qB))
+    k = tp.conv(an, "ca.k")
+    vv = tp.conv(an, "ca.v")
+    o, attn = tp.attn_gate(q, k, vv, blk.attn.num_heads, blk.attn.scale)
+    r1 = tp.conv(o, "ca.proj", residual=vn, residual_periodic=periodic)
+    l2 = tp.layernorm(r1, blk.norm2)
+    hh2 = tp.conv(l2, "ca.fc1", act=ACT_GELU) if _FUSE_TOKEN_PATH else tp.gelu(tp.conv(l2, "ca.fc1"))
+    r2 = tp.conv(hh2, "ca.fc2", residual=r1)
+    fus_tok = tp.layernorm(r2, ca.norm)
+    fusion = tp.reshape(fus_tok, (Ba, hh, ww, Cc))
+    tp.named.update(fusion=fusion, r2=r2, r1=r1, vn=vn, q=q, o=o, fea_v2=fea_v)
+    return fusion, fea_v_projB, attn
+
+
+def _head_stage(tp: TrainPass, m, fusion: V) -> V:
+    """Decoder head (encoder_decoder.py:62-75) on the tape: low-resolution logits [N, h, w, Cpad]; channels >= num_classes are
+    exact zeros."""
+    up = m.segment.upsample
+    z0h = tp.conv(fusion, "head0", stats=up.last_conv[1])
+    c1 = tp.bn_act(z0h, up.last_conv[1], ACT_RELU)
+    z1h = tp.conv(c1, "head1", stats=up.last_conv[4])
+    c2 = tp.bn_act(z1h, up.last_conv[4], ACT_RELU)
+    lo = tp.conv(c2, "cls")
+    tp.named.update(z0h=z0h, c1=c1, z1h=z1h, c2=c2, lo=lo)
+    return lo
+
+
 def run_train_forward(model, image: torch.Tensor, audio: torch.Tensor, tp: TrainPass, shuffle=None):
     """Mirrors CAVP._forward_hip (eval) op by op with batch-statistics BN and a backward tape.  Returns the V's of
     (logits_lowres, fusion NHWC, fea_v_proj NHWC, fea_a, attn)."""
@@ -880,26 +977,9 @@ def run_train_forward(model, image: torch.Tensor, audio: torch.Tensor, tp: Train
     tp.pack("aspp.pool_red", aspp.pool_red_conv)
     tp.pack("aspp.red", aspp.red_conv)
     tp.pack("reduce", m.segment.reduce[0])
-    up = m.segment.upsample
-    tp.pack("head0", up.last_conv[0])
-    tp.pack("head1", up.last_conv[3])
-    tp.pack("cls", up.classifier, pad_cout_to=8)
-    vgg = m.audio_backbone.backbone
-    convs = [mm for mm in vgg.features if isinstance(mm, nn.Conv2d)]
-    tp.pack("a.conv0", convs[0], raw=True)
-    for i, cv in enumerate(convs[1:], 1):
-        tp.pack(f"a.conv{i}", cv)
-    for i, j in enumerate((0, 2, 4)):
-        tp.pack(f"a.fc{i}", vgg.embeddings[j])
-    tp.pack("proj.fc1", m.visual_projector.fc1)
-    tp.pack("proj.fc2", m.visual_projector.fc2)
-    ca, blk = m.cross_att, m.cross_att.blocks[0]
-    tp.pack("ca.pe_v", ca.patch_embed_v.proj)
-    tp.pack("ca.pe_a", ca.patch_embed_a.proj)
-    for nme in ("q", "k", "v", "proj"):
-        tp.pack("ca." + nme, getattr(blk.attn, nme))
-    tp.pack("ca.fc1", blk.mlp.fc1)
-    tp.pack("ca.fc2", blk.mlp.fc2)
+    _pack_head(tp, m)
+    _pack_audio(tp, m)
+    _pack_fusion(tp, m)
     tp.flush_packs()
     ev_start = None
     if tp.dev.type == "cuda":
@@ -955,18 +1035,7 @@ def run_train_forward(model, image: torch.Tensor, audio: torch.Tensor, tp: Train
         raise CavpError(f"train mode expects audio of {'B' if shuffle is not None else '2B'} clips (cavp_model.py:181,160-173), "
                         f"got {audio.shape[0]} for {B} images")
     def audio_encoder():
-        a = tp.conv_smallcin(audio, "a.conv0", 1, ACT_RELU)
-        ci = 1
-        for v in VGG.CFG[1:]:
-            if v == "M":
-                a = tp.maxpool(a, 2, 2, 0)
-            else:
-                a = tp.conv(a, f"a.conv{ci}", act=ACT_RELU)
-                ci += 1
-        a = tp.flatten(a)
-        a = tp.conv(a, "a.fc0", act=ACT_RELU)
-        a = tp.conv(a, "a.fc1", act=ACT_RELU)
-        return tp.conv(a, "a.fc2", act=ACT_RELU)
+        return _audio_stage(tp, audio)
 
     # The audio encoder depends on nothing but its input and feeds only the fusion: it runs on a second stream, concurrently
     # with the visual backbone (whose 14 x 14 layers and small BatchNorm kernels leave most of the chip idle), forward and
@@ -987,44 +1056,9 @@ def run_train_forward(model, image: torch.Tensor, audio: torch.Tensor, tp: Train
         tp.side_range = (t0, len(tp.tape))
     if shuffle is not None:   # forward_audio (cavp_model.py:156-173): features | the same features gathered by shuffle_idx
         fea_a = tp.gather_cat(fea_a, model._bank_and_shuffle(fea_a.t, shuffle[0], shuffle[1]))
-    # ---- fusion (cavp_model.py:143-154; attn.py:232-244) ----
-    # The reference duplicates the visual features to 2B first (`torch.cat((fea_v, fea_v.clone()))`, cavp_model.py:181)
-    # and runs projector / patch_embed_v / norm1 / q on both identical halves.  Those four GEMMs + LN depend only on
-    # fea_v, so they are computed ONCE on B and their results duplicated where the halves start to differ (the
-    # audio-conditioned gate); in backward the duplication sums the two halves' gradients - same values, half the work.
-    Bv, hh, ww, Cc = fea_v.t.shape
-    B2 = 2 * Bv
-    tokB = tp.reshape(fea_v, (Bv, hh * ww, Cc))
-    hidp = tp.conv(tokB, "proj.fc1", act=ACT_GELU) if _FUSE_TOKEN_PATH else tp.gelu(tp.conv(tokB, "proj.fc1"))
-    fea_v_projB = tp.conv(hidp, "proj.fc2")
-    v0B = tp.conv(fea_v_projB, "ca.pe_v")
-    a0 = tp.conv(fea_a, "ca.pe_a")
-    vnB = tp.layernorm(v0B, blk.norm1)
-    an = tp.layernorm(a0, blk.norm1)
-    qB = tp.conv(vnB, "ca.q")
-    # the 2B rows of `vn` / `q` / pack["visual"] are never materialised: the gate reads q[b % B], ca.proj adds the residual row
-    # p % (B * T), and the output-only duplicate of fea_v_proj is made by whoever returns it (three 2 x 61 MB copies per step)
-    periodic = (Bv * hh * ww) % 256 == 0 and _FUSE_TOKEN_PATH
-    vn, q = (vnB, qB) if periodic else (tp.dup2(vnB), tp.dup2(qB))
-    fea_v_proj = fea_v_projB
-    fea_v2 = fea_v
-    k = tp.conv(an, "ca.k")
-    vv = tp.conv(an, "ca.v")
-    o, attn = tp.attn_gate(q, k, vv, blk.attn.num_heads, blk.attn.scale)
-    r1 = tp.conv(o, "ca.proj", residual=vn, residual_periodic=periodic)
-    l2 = tp.layernorm(r1, blk.norm2)
-    hh2 = tp.conv(l2, "ca.fc1", act=ACT_GELU) if _FUSE_TOKEN_PATH else tp.gelu(tp.conv(l2, "ca.fc1"))
-    r2 = tp.conv(hh2, "ca.fc2", residual=r1)
-    fus_tok = tp.layernorm(r2, ca.norm)
-    fusion = tp.reshape(fus_tok, (B2, hh, ww, Cc))
-    # ---- decoder head (encoder_decoder.py:62-75) ----
-    z0h = tp.conv(fusion, "head0", stats=up.last_conv[1])
-    c1 = tp.bn_act(z0h, up.last_conv[1], ACT_RELU)
-    z1h = tp.conv(c1, "head1", stats=up.last_conv[4])
-    c2 = tp.bn_act(z1h, up.last_conv[4], ACT_RELU)
-    lo = tp.conv(c2, "cls")   # [2B, h, w, Cpad]; channels >= num_classes are exact zeros
-    tp.named.update(fusion=fusion, z0h=z0h, c1=c1, z1h=z1h, c2=c2, lo=lo, r2=r2, r1=r1, vn=vn, q=q, o=o, fea_v2=fea_v2,
-                    fea_v=fea_v, f4=f4, f1=f1, fea_a=fea_a, asp=asp, cat=cat, zcat=zcat)
+    fusion, fea_v_proj, attn = _fusion_stage(tp, m, fea_v, fea_a, duplicate=True)
+    lo = _head_stage(tp, m, fusion)
+    tp.named.update(fea_v=fea_v, f4=f4, f1=f1, fea_a=fea_a, asp=asp, cat=cat, zcat=zcat)
     if tp._nbt:
         torch._foreach_add_(tp._nbt, 1)   # 61 counters, one launch
         tp._nbt = []
@@ -1079,3 +1113,106 @@ class CAVPTrainFunction(torch.autograd.Function):
         ctx.model_ref.params_changed()   # the forward updated running_mean / running_var through raw pointers
         ctx.tp = None
         return (None, None, None) + tuple(grads)
+
+
+class CAVPStageFunction(torch.autograd.Function):
+    """The reference's stage entry points (cavp_model.py:138-173) as autograd nodes over a TrainPass tape of that stage only:
+    `forward_cls`, `forward_fusion`, `forward_audio` called on a model in training mode (batch-statistics BatchNorm, running
+    statistics updated) or with gradients enabled.  inputs = the stage's tensor arguments followed by the trainable parameters;
+    `kind` selects the stage, `meta` carries its non-tensor arguments."""
+
+    @staticmethod
+    def forward(ctx, model, kind, meta, n_in, *tensors):
+        ins, params = tensors[:n_in], tensors[n_in:]
+        tp = TrainPass(model, model.compute_dtype)
+        dt, dev = tp.dt, tp.dev
+        f32 = model._as_f32
+
+        def nhwc(t):   # a caller's NCHW-shaped tensor -> dense NHWC of the compute dtype
+            return model._nchw_to_nhwc(t.detach(), dt)
+
+        with torch.no_grad():
+            if kind == "cls":
+                _pack_head(tp, model)
+                tp.flush_packs()
+                x = V(nhwc(ins[0]), needs_grad=ins[0].requires_grad)
+                lo = _head_stage(tp, model, x)
+                C = model.num_classes
+                out = torch.empty((lo.t.shape[0], C) + tuple(meta), dtype=torch.float32, device=dev)
+                ops.bilinear_to_nchw(lo.t[..., :C], out, align_corners=False)
+                ctx.vin, ctx.vout, outs = [x], [lo], (out,)
+            elif kind == "fusion":
+                _pack_fusion(tp, model)
+                tp.flush_packs()
+                v = V(nhwc(ins[0]), needs_grad=ins[0].requires_grad)
+                a2 = ins[1].detach().reshape(ins[1].shape[0], -1).contiguous()
+                a = V(a2 if a2.dtype == dt else ops.cast(a2, torch.empty(a2.shape, dtype=dt, device=dev)),
+                      needs_grad=ins[1].requires_grad)
+                fusion, proj, attn = _fusion_stage(tp, model, v, a, duplicate=False)
+                outs = (f32(fusion.t).permute(0, 3, 1, 2), f32(proj.t).view(fusion.t.shape).permute(0, 3, 1, 2), attn.t.unsqueeze(-1))
+                ctx.vin, ctx.vout = [v, a], [fusion, proj]
+                ctx.mark_non_differentiable(outs[2])
+            elif kind == "audio":
+                _pack_audio(tp, model)
+                tp.flush_packs()
+                fea = _audio_stage(tp, ins[0].detach().contiguous())
+                fea = tp.gather_cat(fea, model._bank_and_shuffle(fea.t, meta[0], meta[1]))
+                outs = (f32(fea.t),)
+                ctx.vin, ctx.vout = [], [fea]
+            else:
+                raise CavpError(f"unknown stage {kind!r}")
+            if tp._nbt:
+                torch._foreach_add_(tp._nbt, 1)
+                tp._nbt = []
+        model.params_changed()   # batch-statistics BatchNorm wrote running_mean / running_var through raw pointers
+        ctx.tp, ctx.kind, ctx.params, ctx.n_in, ctx.in_meta = tp, kind, params, n_in, [(t.shape, t.dtype) for t in ins]
+        return outs if len(outs) > 1 else outs[0]
+
+    @staticmethod
+    def backward(ctx, *douts):
+        tp, kind = ctx.tp, ctx.kind
+        if tp is None:
+            raise CavpError("a stage's backward can run once (its tape is released afterwards)")
+        dt = tp.dt
+
+        def to_nhwc(g):   # foreign NCHW-shaped gradient -> dense NHWC of the compute dtype
+            g = g.permute(0, 2, 3, 1).contiguous().float()
+            return g if dt == torch.float32 else ops.cast(g, tp.empty(g.shape, dt))
+
+        with torch.no_grad():
+            if kind == "cls":
+                lo = ctx.vout[0]
+                if douts[0] is not None:
+                    g = torch.zeros(lo.t.shape, dtype=lo.t.dtype, device=lo.t.device)
+                    T.bilinear_bwd_from_nchw(douts[0].contiguous().float(), g[..., :douts[0].shape[1]], n_valid=lo.t.shape[0],
+                                             align_corners=False)
+                    lo.set_g(g)
+            elif kind == "fusion":
+                fusion, proj = ctx.vout
+                if douts[0] is not None:
+                    fusion.set_g(to_nhwc(douts[0]))
+                if douts[1] is not None:
+                    proj.set_g(to_nhwc(douts[1]).view(proj.t.shape))
+            else:
+                fea = ctx.vout[0]
+                if douts[0] is not None:
+                    g = douts[0].contiguous().float()
+                    fea.set_g(g if dt == torch.float32 else ops.cast(g, tp.empty(g.shape, dt)))
+            tp.backward()
+            tp.finish_padded()
+            gin = []
+            for v, (shape, dtype) in zip(ctx.vin, ctx.in_meta):
+                if not v.needs_grad or v.g is None:
+                    gin.append(None)
+                    continue
+                g = v.g if v.g.dtype == torch.float32 else ops.cast(v.g.contiguous(), torch.empty(v.g.shape, dtype=torch.float32,
+                                                                                                   device=v.g.device))
+                g = g.permute(0, 3, 1, 2) if g.dim() == 4 else g.reshape(shape)
+                gin.append(g.to(dtype) if dtype != torch.float32 else g)
+            gin += [None] * (ctx.n_in - len(gin))
+        grads = []
+        for p in ctx.params:
+            g = tp.grads.get(id(p))
+            grads.append(None if g is None else g.view(p.shape))
+        ctx.tp = None
+        return (None, None, None, None) + tuple(gin) + tuple(grads)

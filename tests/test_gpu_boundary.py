@@ -50,6 +50,66 @@ def test_stage_methods_compose_to_the_forward():
     assert pack2["audio"].shape == rp["audio"].shape == (CFG["B"], 304, 1, 1)
 
 
+def test_stage_methods_are_differentiable(deterministic):
+    """cavp_model.py:138-173: forward_audio -> forward_fusion -> forward_cls chained through torch.autograd on a model in
+    TRAINING mode (batch-statistics BatchNorm in the head) against the oracle's stages: outputs, gradients of the tensor inputs,
+    every parameter gradient of the three stages, and the head's running statistics."""
+    from oracle import cavp_oracle as O
+    m, sd = _model(train=True)
+    B, hw = 3, (12, 12)
+    g = torch.Generator().manual_seed(11)
+    fea_v = torch.randn((B, 304) + hw, generator=g) * 0.5
+    audio = synth_inputs(B, CFG["hw"], audio_batch=B, num_classes=CFG["C"], seed=8)[1]
+    perm = torch.tensor([2, 0, 1])
+    w_out = torch.randn((2 * B, CFG["C"], 48, 48), generator=g)
+    w_vis = torch.randn((2 * B, 304) + hw, generator=g) * 0.1
+
+    # oracle (CPU, f32)
+    sdg = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running" not in k else v.clone()) for k, v in sd.items()}
+    rv = fea_v.clone().requires_grad_(True)
+    ra1 = O.audio_forward(audio, sdg)
+    ra = torch.cat((ra1, ra1[perm]), 0)
+    rv2 = torch.cat((rv, rv), 0)
+    rf, rp = O.forward_fusion(rv2, ra, sdg)
+    ro = O.forward_cls(rf, sdg, (48, 48), train=True)
+    ((ro * w_out).sum() + (rp["visual"] * w_vis).sum() + rf.square().mean()).backward()
+
+    # MI355X path
+    info = {"shuffle_idx": perm.to(DEV), "mod_idx_map": {}, "image_label": torch.zeros((B, CFG["C"]), device=DEV)}
+    xv = fea_v.to(DEV).requires_grad_(True)
+    fa = m.forward_audio(audio.to(DEV), info, ow_flag=False)
+    assert fa.requires_grad and fa.shape == (2 * B, 304)
+    fus, pack = m.forward_fusion(torch.cat((xv, xv), 0), fa)
+    out = m.forward_cls(fus, (48, 48))
+    assert not pack["attn_v"].requires_grad and pack["audio"].shape == (2 * B, 304, 1, 1)
+    ((out * w_out.to(DEV)).sum() + (pack["visual"] * w_vis.to(DEV)).sum() + fus.square().mean()).backward()
+
+    def rel(a, b):
+        return float((a.detach().cpu().double() - b.detach().double()).norm() / max(float(b.detach().double().norm()), 1e-30))
+    assert rel(fa, ra) <= 1e-5 and rel(fus, rf) <= 1e-4 and rel(out, ro) <= 1e-4 and rel(pack["visual"], rp["visual"]) <= 1e-5
+    assert rel(xv.grad, rv.grad) <= 2e-4, rel(xv.grad, rv.grad)
+    checked = 0
+    for k, p in m.named_parameters():
+        r = sdg[k].grad if isinstance(sdg.get(k), torch.Tensor) else None
+        stage = k.startswith(("audio_backbone.", "visual_projector.", "cross_att.", "segment.upsample."))
+        if r is None or float(r.norm()) == 0.0:
+            assert p.grad is None or float(p.grad.norm()) == 0.0 or not stage, k
+            continue
+        assert stage and p.grad is not None, k
+        assert rel(p.grad, r) <= 5e-4, (k, rel(p.grad, r))
+        checked += 1
+    assert checked >= 40, checked
+    # train-mode BatchNorm of the head updated its running statistics (momentum 0.1) from the batch
+    bn = m.segment.upsample.last_conv[1]
+    assert int(bn.num_batches_tracked) == int(sd["segment.upsample.last_conv.1.num_batches_tracked"]) + 1
+    assert not torch.equal(bn.running_mean.cpu(), sd["segment.upsample.last_conv.1.running_mean"])
+    # eval mode, no gradients wanted: the forward-only kernels serve the same entry points
+    m.eval()
+    with torch.no_grad():
+        f2, _ = m.forward_fusion(torch.cat((xv, xv), 0).detach(), fa.detach())
+    assert rel(f2, rf) <= 1e-4 and not f2.requires_grad
+
+
 def test_forward_audio_and_audio_func_path(deterministic):
     """forward_audio: [features | features[shuffle_idx]] + SoundBank update under ow_flag; forward_train(audio_func=True) on B
     clips == forward_train on the explicitly concatenated 2B clips (forward and every parameter gradient)."""
