@@ -149,7 +149,7 @@ def _residual_drop_path(tp: TrainPass, x: V, branch: V, scale: torch.Tensor) -> 
     return y
 
 
-def draw_drop_path_scales(bb, B: int, device) -> List[Optional[torch.Tensor]]:
+def draw_drop_path_scales(bb, B: int, device, _refresh_only: bool = False) -> List[Optional[torch.Tensor]]:
     """One f32 [B] factor (mask / keep) per residual branch, in forward order (attention, MLP of every block); None where
     the block's probability is 0 or the backbone is in eval mode.  Drawn like timm 0.4.9's drop_path - `floor(keep +
     torch.rand((B, 1, 1)))`, one draw per branch from the default CPU generator - then moved in ONE copy into a persistent
@@ -165,12 +165,30 @@ def draw_drop_path_scales(bb, B: int, device) -> List[Optional[torch.Tensor]]:
         buf = torch.ones((n, B), dtype=torch.float32, device=dev)
         bb.__dict__["_dp_buf"] = buf          # not a registered buffer: it must stay out of the state_dict
     if not (dev.type == "cuda" and torch.cuda.is_current_stream_capturing()):
-        rows = []
-        for p in probs:
-            if p > 0:
-                keep = 1.0 - p
-                rows.append((keep + torch.rand((B, 1, 1), dtype=torch.float32)).floor_().view(B) / keep)
-        buf.copy_(torch.stack(rows))
+        # one torch.rand((B, 1, 1)) per branch, in forward order (the reference's draws); the arithmetic on all rows at once
+        keeps = torch.tensor([1.0 - p for p in probs if p > 0], dtype=torch.float32).view(n, 1)
+        rows = torch.stack([torch.rand((B, 1, 1), dtype=torch.float32).view(B) for p in probs if p > 0])
+        rows = rows.add_(keeps).floor_().div_(keeps)
+        if dev.type == "cuda":
+            # through a pinned staging buffer, asynchronously: a pageable-memory copy blocks the host until the stream has drained,
+            # which put the host in lock-step with the device and exposed this function's ~1 ms of CPU work in EVERY replay of a
+            # captured step (1.1 .. 1.7 ms of idle device between two replays of the PVTv2-B5 step).  The event keeps the host
+            # from overwriting the staging buffer before the previous upload has run: at most one step ahead.
+            pin, ev = getattr(bb, "_dp_pin", None), getattr(bb, "_dp_ev", None)
+            if pin is None or pin.shape != rows.shape:
+                pin, ev = torch.empty(rows.shape, dtype=torch.float32).pin_memory(), None
+                bb.__dict__["_dp_pin"] = pin
+            if ev is not None:
+                ev.synchronize()
+            pin.copy_(rows)
+            buf.copy_(pin, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(dev))
+            bb.__dict__["_dp_ev"] = ev
+        else:
+            buf.copy_(rows)
+        if _refresh_only:
+            return []
         # an eager pass gets its OWN copy of the masks: its backward closures may run after a later forward (two forwards before
         # one backward, gradient accumulation with a deferred backward) has redrawn the persistent buffer.  Only a captured
         # graph reads the persistent buffer itself (replay() refreshes it before every launch).
@@ -186,7 +204,7 @@ def draw_drop_path_scales(bb, B: int, device) -> List[Optional[torch.Tensor]]:
 
 def refresh_drop_path(bb, B: int, device) -> None:
     """New DropPath masks for the next replay of a captured training step."""
-    draw_drop_path_scales(bb, B, device)
+    draw_drop_path_scales(bb, B, device, _refresh_only=True)
 
 
 def pvt_train_forward(tp: TrainPass, bb, image: torch.Tensor, drop_scales: Optional[list] = None) -> List[V]:
