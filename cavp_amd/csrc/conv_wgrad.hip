@@ -230,11 +230,65 @@ __device__ __forceinline__ void wgrad_tile(const WgradParams& p, const int bid, 
     gdma(0);
     __syncthreads();
     int buf = 0;
-    for (int r0 = r_begin; r0 < r_end; r0 += BK) {
-      if (r0 + BK < r_end && !CAVP_DBG(p, 4)) gdma(buf ^ 1);
-      if (!CAVP_DBG(p, 2)) compute(buf);
-      __syncthreads();
-      buf ^= 1;
+    if constexpr (ES == 2 && BK == 32) {
+      // One stage = one 32-row k step.  The fragments of the CURRENT stage are read before the next stage's DMA is issued:
+      // hipcc cannot tell the ring's two buffers apart and puts an s_waitcnt vmcnt(0) in front of every LDS read that follows
+      // a pending LDS-DMA in program order - with the DMA issued first (the generic loop below) the next tile was waited for
+      // BEFORE the current one was multiplied, i.e. a workgroup never overlapped its own loads with its own MFMAs
+      // (SQ_WAIT_ANY 58 % of the wave cycles, profiles/r03_pmc_wait_train_bf16.txt).
+      for (int r0 = r_begin; r0 < r_end; r0 += BK) {
+        const char* xb = smem + buf * STAGE;
+        const char* yb = xb + BK * 256;
+        const int ra = 8 * lgrp + (lrow >> 2), rb = ra + 4;
+        const int ka = swz_key(ra), kb = swz_key(rb);
+        const int sub = (lrow & 3) * 8;
+        u32x4_t af[MB], bfv[MB];
+#pragma unroll
+        for (int a = 0; a < MB; ++a) {
+          const int ch = (wci0 >> 4) + a;  // 32-byte chunk = 16 bf16 channels
+          const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+              (__attribute__((address_space(3))) s16x4_t*)(xb + ra * 256 + ((ch ^ ka) << 5) + sub));
+          const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+              (__attribute__((address_space(3))) s16x4_t*)(xb + rb * 256 + ((ch ^ kb) << 5) + sub));
+          const uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
+          af[a] = (u32x4_t){l2.x, l2.y, h2.x, h2.y};
+        }
+#pragma unroll
+        for (int b = 0; b < MB; ++b) {
+          const int ch = (wco0 >> 4) + b;
+          const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+              (__attribute__((address_space(3))) s16x4_t*)(yb + ra * 256 + ((ch ^ ka) << 5) + sub));
+          const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+              (__attribute__((address_space(3))) s16x4_t*)(yb + rb * 256 + ((ch ^ kb) << 5) + sub));
+          const uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
+          bfv[b] = (u32x4_t){l2.x, l2.y, h2.x, h2.y};
+        }
+        if (r0 + BK < r_end) gdma(buf ^ 1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (BIAS && do_bias) {
+#pragma unroll
+          for (int b = 0; b < MB; ++b)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              bsum[b] += __uint_as_float(bfv[b][e] << 16) + __uint_as_float(bfv[b][e] & 0xffff0000u);
+        }
+#pragma unroll
+        for (int a = 0; a < MB; ++a)
+#pragma unroll
+          for (int b = 0; b < MB; ++b)
+            acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, af[a]),
+                                                                __builtin_bit_cast(bf16x8_t, bfv[b]), acc[a][b], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);   // (the scheduler otherwise hoists the wait + barrier above the MFMAs)
+        __syncthreads();
+        buf ^= 1;
+      }
+    } else {
+      for (int r0 = r_begin; r0 < r_end; r0 += BK) {
+        if (r0 + BK < r_end && !CAVP_DBG(p, 4)) gdma(buf ^ 1);
+        if (!CAVP_DBG(p, 2)) compute(buf);
+        __syncthreads();
+        buf ^= 1;
+      }
     }
   }
 
