@@ -97,46 +97,60 @@ __device__ __forceinline__ void wgrad_tile(const WgradParams& p, const int bid, 
   const bool ci_ok = ci_base + cel < p.Cin, co_ok = co_base + cel < p.Cout;
   const unsigned xcb = (unsigned)((ci_base + cel) * ES), ycb = (unsigned)((co_base + cel) * ES);
   const bool pointwise = (p.ntaps_all == 1) && p.stride == 1 && p.pad == 0;
-  int pixr[NI], pn[NI], ph[NI], pw[NI];
+  // Per DMA row: output pixel index, its (ho, wo), the input coordinates of the current tap and the byte offsets into x / dY.
+  // Everything is advanced INCREMENTALLY by one stage (BK pixels): the issue path of a stage is adds, compares and selects - no
+  // integer multiply (quarter rate; re-deriving the offsets cost 6 v_mul_lo per stage and more: a multiply-shift re-split of
+  // the pixel index, tried instead of the wrap loops below, made the training step 0.5 ms SLOWER) and no scalar load: `p` may
+  // live in the kernel-argument segment behind a run-time job index (the grouped launch), and left to itself hipcc re-loaded
+  // every field inside the stage loop (9 s_load + s_waitcnt lgkmcnt(0) pairs per stage).  readfirstlane results stay in SGPRs.
+  const int dh = kh * p.dil - p.pad, dw = kw * p.dil - p.pad;
+  const int gH = __builtin_amdgcn_readfirstlane(p.H), gW = __builtin_amdgcn_readfirstlane(p.W);
+  const int gWo = __builtin_amdgcn_readfirstlane(p.Wo), gHo = __builtin_amdgcn_readfirstlane(p.Ho);
+  const int gStride = __builtin_amdgcn_readfirstlane(p.stride);
+  const unsigned gLdx = (unsigned)__builtin_amdgcn_readfirstlane(p.ldx * ES), gLdy = (unsigned)__builtin_amdgcn_readfirstlane(p.ldy * ES);
+  const int gWoS = gWo * gStride, gHoS = gHo * gStride;
+  const unsigned stepY = (unsigned)BK * gLdy;
+  const unsigned stepX = (unsigned)(BK * (pointwise ? 1 : gStride)) * gLdx;          // BK pixels to the right
+  const unsigned stepRow = (unsigned)((gW - gWo) * gStride) * gLdx;                   // wrap to the next output row
+  const unsigned stepImg = (unsigned)((gH - gHoS) * gW) * gLdx;                       // wrap to the next image
+  // state per row: input coordinates of the tap (which also tell when the output row / image wraps) and the two byte offsets;
+  // the pixel-range end is compared on the dY offset (yEnd), so the pixel index itself is not carried
+  int hin[NI], win[NI];
+  unsigned xo[NI], yo[NI];
+  const unsigned yEnd = (unsigned)r_end * gLdy + ycb;
+  const int hWrap = gHoS + dh, wWrap = gWoS + dw;   // first input row / column past the last output row / column
 #pragma unroll
   for (int i = 0; i < NI; ++i) {
-    pixr[i] = r_begin + drow0 + 16 * i;
-    const int pp = pixr[i] < p.M ? pixr[i] : 0;
-    pn[i] = fast_div(pp, p.dv_hw[0], p.dv_hw[1]);
-    const int rr = pp - pn[i] * HoWo;
-    ph[i] = fast_div(rr, p.dv_w[0], p.dv_w[1]);
-    pw[i] = rr - ph[i] * p.Wo;
+    const int pix = r_begin + drow0 + 16 * i;
+    yo[i] = (unsigned)pix * gLdy + ycb;
+    const int pp = pix < p.M ? pix : 0;
+    const int n = fast_div(pp, p.dv_hw[0], p.dv_hw[1]);
+    const int rr = pp - n * HoWo;
+    const int ho = fast_div(rr, p.dv_w[0], p.dv_w[1]);
+    hin[i] = ho * gStride + dh;
+    win[i] = (rr - ho * p.Wo) * gStride + dw;
+    xo[i] = pointwise ? (unsigned)pix * gLdx + xcb : (unsigned)((n * gH + hin[i]) * gW + win[i]) * gLdx + xcb;
   }
-  const int dh = kh * p.dil - p.pad, dw = kw * p.dil - p.pad;
-
+  const bool dbg_nodma = CAVP_DBG(p, 1);
   auto gdma = [&](int buf) {
     char* base = smem + buf * STAGE + wave * 1024;
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
-      const int pix = pixr[i];
-      const bool pok = pix < r_end && !CAVP_DBG(p, 1);
-      unsigned xoff;
+      const bool pok = yo[i] < yEnd && !dbg_nodma;
       bool xok = pok && ci_ok;
-      if (pointwise) {
-        xoff = (unsigned)pix * (unsigned)(p.ldx * ES) + xcb;
-      } else {
-        const int hi = ph[i] * p.stride + dh, wi = pw[i] * p.stride + dw;
-        xok = xok && ((unsigned)hi < (unsigned)p.H) && ((unsigned)wi < (unsigned)p.W);
-        xoff = (unsigned)((pn[i] * p.H + hi) * p.W + wi) * (unsigned)(p.ldx * ES) + xcb;
-      }
+      if (!pointwise) xok = xok && ((unsigned)hin[i] < (unsigned)gH) && ((unsigned)win[i] < (unsigned)gW);
       __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (__attribute__((address_space(3))) void*)(base + i * 4096), 16,
-                                               (int)(xok ? xoff : kOOB), 0, 0, 0);
-      const unsigned yoff = (unsigned)pix * (unsigned)(p.ldy * ES) + ycb;
+                                               (int)(xok ? xo[i] : kOOB), 0, 0, 0);
       __builtin_amdgcn_raw_ptr_buffer_load_lds(yrsrc,
                                                (__attribute__((address_space(3))) void*)(base + BK * 256 + i * 4096), 16,
-                                               (int)((pok && co_ok) ? yoff : kOOB), 0, 0, 0);
-      // advance this row by one K tile (64 pixels)
-      pixr[i] = pix + BK;
+                                               (int)((pok && co_ok) ? yo[i] : kOOB), 0, 0, 0);
+      // advance this row by one stage
+      yo[i] += stepY;
+      xo[i] += stepX;
       if (!pointwise) {
-        int w2 = pw[i] + BK, h2 = ph[i], n2 = pn[i];
-        while (w2 >= p.Wo) { w2 -= p.Wo; ++h2; }
-        while (h2 >= p.Ho) { h2 -= p.Ho; ++n2; }
-        pw[i] = w2; ph[i] = h2; pn[i] = n2;
+        win[i] += BK * gStride;
+        while (win[i] >= wWrap) { win[i] -= gWoS; xo[i] += stepRow; hin[i] += gStride; }
+        while (hin[i] >= hWrap) { hin[i] -= gHoS; xo[i] += stepImg; }
       }
     }
   };
@@ -231,6 +245,8 @@ __device__ __forceinline__ void wgrad_tile(const WgradParams& p, const int bid, 
     __syncthreads();
     int buf = 0;
     if constexpr (ES == 2 && BK == 32) {
+      // (A 3-stage ring behind a counted vmcnt - transposed reads as inline asm so that hipcc does not drain it - was built twice
+      // and measured: three 48 KiB workgroups per CU lose 0.5 .. 0.7 ms per step against four 32 KiB ones, profiles/r03_notes.md.)
       // One stage = one 32-row k step.  The fragments of the CURRENT stage are read before the next stage's DMA is issued:
       // hipcc cannot tell the ring's two buffers apart and puts an s_waitcnt vmcnt(0) in front of every LDS read that follows
       // a pending LDS-DMA in program order - with the DMA issued first (the generic loop below) the next tile was waited for
