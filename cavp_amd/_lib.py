@@ -113,6 +113,7 @@ PROTOTYPES = {
     "cavp_conv_smallcin_kxk_nchw": (_i32, [_i32, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "cavp_sra_attention_bwd_workspace_bytes": (_sz, [_i32, _i32, _i32]),
     "cavp_sra_attention_bwd": (_i32, [_i32, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _vp, _sz, _vp]),
+    "cavp_sra_attention_bwd_to": (_i32, [_i32, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _vp, _sz, _vp]),
     "cavp_dwconv3x3_wgrad": (_i32, [_i32, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "cavp_smallcin_kxk_im2col": (_i32, [_i32, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "cavp_space_to_depth": (_i32, [_i32, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),

@@ -630,8 +630,10 @@ __global__ __launch_bounds__(256) void row_scale_add_kernel(const T* __restrict_
   }
 }
 
-// dkv[i] = sum_s slabs[s][i] (split order), 16-byte vectors
-__global__ __launch_bounds__(256) void sra_bwd_kv_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ dkv,
+// dkv[i] = sum_s slabs[s][i] (split order), 16-byte vectors; TO = float or bf16_t (the compute dtype of the consumer: the cast pass
+// that used to follow is folded in)
+template <typename TO>
+__global__ __launch_bounds__(256) void sra_bwd_kv_reduce_kernel(const float* __restrict__ slabs, TO* __restrict__ dkv,
                                                                 long long n4, int splits, size_t slab_stride) {
   for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
     float4 a = *(const float4*)(slabs + 4 * i);
@@ -639,7 +641,7 @@ __global__ __launch_bounds__(256) void sra_bwd_kv_reduce_kernel(const float* __r
       const float4 v = *(const float4*)(slabs + (size_t)s * slab_stride + 4 * i);
       a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
     }
-    *(float4*)(dkv + 4 * i) = a;
+    st4<TO>(dkv + 4 * i, a.x, a.y, a.z, a.w);
   }
 }
 
@@ -656,8 +658,15 @@ extern "C" size_t cavp_sra_attention_bwd_workspace_bytes(int32_t B, int32_t Nq, 
 extern "C" int cavp_sra_attention_bwd(int32_t dtype, const void* q, const void* kv, const void* dout, void* dq, float* dkv,
                                       int32_t B, int32_t Nq, int32_t Nk, int32_t heads, int32_t head_dim, float scale,
                                       void* workspace, size_t workspace_bytes, void* stream) {
+  return cavp_sra_attention_bwd_to(dtype, q, kv, dout, dq, dkv, CAVP_F32, B, Nq, Nk, heads, head_dim, scale, workspace,
+                                   workspace_bytes, stream);
+}
+
+extern "C" int cavp_sra_attention_bwd_to(int32_t dtype, const void* q, const void* kv, const void* dout, void* dq, void* dkv,
+                                         int32_t dkv_dtype, int32_t B, int32_t Nq, int32_t Nk, int32_t heads, int32_t head_dim,
+                                         float scale, void* workspace, size_t workspace_bytes, void* stream) {
   if (!q || !kv || !dout || !dq || !dkv || !workspace || B <= 0 || Nq <= 0 || Nk <= 0 || heads <= 0) return CAVP_ERR_BAD_ARG;
-  if (!dt_ok(dtype) || head_dim != 64 || Nk > 256) return CAVP_ERR_UNSUPPORTED;
+  if (!dt_ok(dtype) || !dt_ok(dkv_dtype) || head_dim != 64 || Nk > 256) return CAVP_ERR_UNSUPPORTED;
   if (workspace_bytes < cavp_sra_attention_bwd_workspace_bytes(B, Nq, heads)) return CAVP_ERR_WORKSPACE;
   if (((uintptr_t)q & 15) || ((uintptr_t)kv & 15) || ((uintptr_t)dout & 15) || ((uintptr_t)dq & 15) || ((uintptr_t)dkv & 15) ||
       ((uintptr_t)workspace & 15))
@@ -680,8 +689,9 @@ extern "C" int cavp_sra_attention_bwd(int32_t dtype, const void* q, const void* 
   splits = splits < 1 ? 1 : (splits > chunks ? chunks : splits);
   const size_t slab = (size_t)B * Nk * 2 * C;                     // floats per split
   float* slabs = stats + (((size_t)2 * B * heads * Nq + 3) & ~(size_t)3);
-  if (splits > 1 && (size_t)((slabs - stats) + splits * slab) * sizeof(float) > workspace_bytes) return CAVP_ERR_WORKSPACE;
-  float* kv_out = splits > 1 ? slabs : dkv;   // a single split writes the gradient itself
+  const bool via_slabs = splits > 1 || dkv_dtype != CAVP_F32;   // a single split writes an f32 gradient itself
+  if (via_slabs && (size_t)((slabs - stats) + splits * slab) * sizeof(float) > workspace_bytes) return CAVP_ERR_WORKSPACE;
+  float* kv_out = via_slabs ? slabs : (float*)dkv;
   const dim3 gb(splits, B * heads, kblocks);
   if (dtype == CAVP_F32) {
     sra_bwd_q_kernel<float><<<ga, 256, 2 * 256 * 256, s>>>((const float*)q, (const float*)kv, (const float*)dout, (float*)dq, stats,
@@ -695,11 +705,12 @@ extern "C" int cavp_sra_attention_bwd(int32_t dtype, const void* q, const void* 
                                               scale, slab);
   }
   if (hipGetLastError() != hipSuccess) return CAVP_ERR_LAUNCH;
-  if (splits > 1) {
+  if (via_slabs) {
     const long long n4 = (long long)(slab / 4);
     long long nb = (n4 + 255) / 256;
     if (nb > 2048) nb = 2048;
-    sra_bwd_kv_reduce_kernel<<<(int)nb, 256, 0, s>>>(slabs, dkv, n4, splits, slab);
+    if (dkv_dtype == CAVP_F32) sra_bwd_kv_reduce_kernel<float><<<(int)nb, 256, 0, s>>>(slabs, (float*)dkv, n4, splits, slab);
+    else sra_bwd_kv_reduce_kernel<bf16_t><<<(int)nb, 256, 0, s>>>(slabs, (bf16_t*)dkv, n4, splits, slab);
   }
   CHECK_LAUNCH();
 }

@@ -97,10 +97,10 @@ def _sra_attention(tp: TrainPass, q: V, kv: V, heads: int, scale: float) -> V:
         if o.g is None:
             return
         dq = tp.empty(q.t.shape)
-        dkv = torch.empty(kv.t.shape, dtype=torch.float32, device=tp.dev)
+        dkv = tp.empty(kv.t.shape)   # the split partials are f32; their fixed-order sum is stored in the compute dtype
         T.sra_attention_bwd(q.t, kv.t, o.g if o.g.is_contiguous() else tp._dense_copy(o.g), dq, dkv, heads, scale)
         tp.acc_add(q, dq)
-        tp.acc_add(kv, dkv if kv.t.dtype == torch.float32 else ops.cast(dkv, tp.empty(dkv.shape)))
+        tp.acc_add(kv, dkv)
     tp.tape.append(bwd)
     return o
 

@@ -464,19 +464,21 @@ def upsample_ce_head(lo, labels, n_img: int, n_classes: int, ignore_index: int =
 
 # ---- PVTv2-B5 training pass (csrc/pvt_train.hip) ------------------------------------------------------------------------
 def sra_attention_bwd(q, kv, dout, dq, dkv, heads: int, scale: float) -> None:
-    """dq (q's dtype) and dkv (f32 [B, Nk, 2C], overwritten) of ops.sra_attention (pvt.py:120-126)."""
+    """dq (q's dtype) and dkv ([B, Nk, 2C], overwritten; f32 or q's dtype - the sum of the query splits' partials is stored in
+    the dtype its consumer wants) of ops.sra_attention (pvt.py:120-126)."""
     _need_gpu(q, kv, dout, dq, dkv)
     b, nq, c = q.shape
     nk = kv.shape[1]
-    if not all(t.is_contiguous() for t in (q, kv, dout, dq, dkv)) or dkv.dtype != torch.float32 or dkv.shape != kv.shape \
-            or dout.shape != q.shape or dq.shape != q.shape or dout.dtype != q.dtype or kv.dtype != q.dtype:
-        raise _lib.CavpError("sra_attention_bwd: contiguous [B,Nq,C] / [B,Nk,2C] tensors of one dtype + f32 dkv required")
+    if not all(t.is_contiguous() for t in (q, kv, dout, dq, dkv)) or dkv.dtype not in (torch.float32, q.dtype) \
+            or dkv.shape != kv.shape or dout.shape != q.shape or dq.shape != q.shape or dout.dtype != q.dtype or kv.dtype != q.dtype:
+        raise _lib.CavpError("sra_attention_bwd: contiguous [B,Nq,C] / [B,Nk,2C] tensors of one dtype (dkv: that dtype or f32) required")
     lib = _lib.load()
     nbytes = lib.cavp_sra_attention_bwd_workspace_bytes(b, nq, heads)
     ws = ops.workspace(nbytes, q.device)
-    _check(lib.cavp_sra_attention_bwd(dtype_code(q.dtype), _ptr(q), _ptr(kv), _ptr(dout), _ptr(dq), _ptr(dkv), b, nq, nk, heads,
-                                      c // heads, C.c_float(scale), _ptr(ws), C.c_size_t(ws.numel()), _s()),
-           f"cavp_sra_attention_bwd B{b} Nq{nq} Nk{nk} heads{heads}")
+    _check(lib.cavp_sra_attention_bwd_to(dtype_code(q.dtype), _ptr(q), _ptr(kv), _ptr(dout), _ptr(dq), _ptr(dkv),
+                                         dtype_code(dkv.dtype), b, nq, nk, heads, c // heads, C.c_float(scale), _ptr(ws),
+                                         C.c_size_t(ws.numel()), _s()),
+           f"cavp_sra_attention_bwd_to B{b} Nq{nq} Nk{nk} heads{heads}")
 
 
 def dwconv3x3_wgrad(x, dy, dw, dbias) -> None:

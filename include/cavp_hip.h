@@ -408,6 +408,11 @@ size_t cavp_sra_attention_bwd_workspace_bytes(int32_t B, int32_t Nq, int32_t hea
 int cavp_sra_attention_bwd(int32_t dtype, const void* q, const void* kv, const void* dout, void* dq, float* dkv, int32_t B,
                            int32_t Nq, int32_t Nk, int32_t heads, int32_t head_dim, float scale, void* workspace,
                            size_t workspace_bytes, void* stream);
+/* same, with dkv written in `dkv_dtype` (CAVP_F32 / CAVP_BF16): the fixed-order sum of the query splits' partials stores the
+ * consumer's dtype directly. */
+int cavp_sra_attention_bwd_to(int32_t dtype, const void* q, const void* kv, const void* dout, void* dq, void* dkv,
+                              int32_t dkv_dtype, int32_t B, int32_t Nq, int32_t Nk, int32_t heads, int32_t head_dim, float scale,
+                              void* workspace, size_t workspace_bytes, void* stream);
 /* DWConv weight / bias gradient: dw_c133 f32 [C][1][3][3] += , dbias f32 [C] += (may be NULL).  The data gradient is
  * cavp_dwconv3x3_nhwc with the taps reversed. */
 int cavp_dwconv3x3_wgrad(int32_t dtype, const void* x, const void* dy, float* dw_c133, float* dbias, int32_t N, int32_t H,

@@ -48,6 +48,10 @@ def test_sra_attention_backward(shape, dtype, tol):
     torch.cuda.synchronize()
     assert _rel(dq.float().cpu(), qr.grad) <= tol, ("dq", _rel(dq.float().cpu(), qr.grad))
     assert _rel(dkv.cpu(), kvr.grad) <= tol, ("dkv", _rel(dkv.cpu(), kvr.grad))
+    if dtype != torch.float32:   # dkv stored in the compute dtype: the f32 result rounded once
+        dkv_c = torch.empty_like(kvd)
+        T.sra_attention_bwd(qd, kvd, dod, dq, dkv_c, heads, scale)
+        assert torch.equal(dkv_c, dkv.to(dtype))
     # deterministic mode: single split, bit-identical repeats
     from cavp_amd import _lib
     _lib.set_deterministic(True, device=torch.device(DEV))
@@ -300,8 +304,8 @@ def test_pvt_train_entry_points_fail_loudly():
                       (dict(dt=bf, q=q.view(-1)[1:]), b"align"), (dict(dt=bf, ws=None), None)):
         st = lib.cavp_sra_attention_bwd(*args(**bad))
         assert st != 0 and (word is None or word in lib.cavp_error_string(st).lower()), (bad, st)
-    with pytest.raises(CavpError):   # dkv must be f32 of kv's shape
-        T.sra_attention_bwd(q, kv, q, dq, torch.empty_like(kv), 2, 0.125)
+    with pytest.raises(CavpError):   # dkv must have kv's shape (f32 or the compute dtype)
+        T.sra_attention_bwd(q, kv, q, dq, torch.empty_like(kv)[:, :-1].contiguous(), 2, 0.125)
     x = torch.zeros((1, 8, 8, 64), dtype=BF, device=DEV)
     with pytest.raises(CavpError):   # gradient of the wrong size
         T.dwconv3x3_wgrad(x, x, torch.zeros((32, 1, 3, 3), device=DEV), None)
