@@ -337,6 +337,17 @@ def _host_cpu():
     return cores, model, max(1, len(sockets))
 
 
+def _cpu_quota():
+    from cavp_amd.hostinfo import cpu_quota
+    return cpu_quota()
+
+
+def cap_host_threads():
+    """torch's intra-op pool no larger than the CPUs the container may use (cavp_amd/hostinfo.py has the story)."""
+    from cavp_amd.hostinfo import cap_torch_threads
+    return cap_torch_threads()
+
+
 def _timed_iters(fn, budget_s, min_iters, max_iters, warm=True):
     """One untimed warm-up call, then >= min_iters timed calls (more while the budget lasts); (iterations, seconds, median s)."""
     if warm:
@@ -374,10 +385,12 @@ def cpu_baseline_train(sd, cfg, sample_batch):
         return step
 
     step = make(sample_batch)
-    torch.set_num_threads(min(16, cores))
+    quota = _cpu_quota()
+    usable = cores if quota is None else min(cores, quota)   # more threads than the container's CPU quota only thrash
+    torch.set_num_threads(min(16, usable))
     step()   # warm-up (allocator, oneDNN primitive caches)
     sweep = {}
-    for nt in sorted({t for t in (4, 8, 16, 32, 64, cores) if t <= cores}):
+    for nt in sorted({t for t in (4, 8, 16, 32, 64, usable, cores) if t <= cores}):
         torch.set_num_threads(nt)
         t0 = time.perf_counter()
         step()
@@ -388,9 +401,10 @@ def cpu_baseline_train(sd, cfg, sample_batch):
     torch.set_num_threads(1)
     # (B = 2 is the smallest batch the reference's training step accepts: the ASPP image-pooling BatchNorm sees B values per channel)
     n1, secs1, med1 = _timed_iters(make(2), budget_s=6.0, min_iters=1, max_iters=2, warm=False)
-    torch.set_num_threads(cores)
+    torch.set_num_threads(usable)
     return {"value": round(sample_batch / med, 2), "unit": "frames/s", "cores": best_nt, "kind": "port",
-            "cpu_model": cpu_model, "sockets": sockets, "physical_cores": cores, "iterations": n, "warmup_iterations": 1,
+            "cpu_model": cpu_model, "sockets": sockets, "physical_cores": cores, "container_cpu_quota": quota,
+            "iterations": n, "warmup_iterations": 1,
             "thread_sweep_frames_per_s": {str(k): round(sample_batch / v, 2) for k, v in sorted(sweep.items())},
             "single_thread": {"value": round(2.0 / med1, 3), "unit": "frames/s", "cores": 1, "iterations": n1,
                               "sample": "B=2 frames (audio 4), same step, no warm-up"},
@@ -404,6 +418,8 @@ def cpu_baseline(sd, cfg, sample_batch):
     from cavp_amd.synth import synth_inputs
     from oracle import cavp_oracle as O
     cores, cpu_model, sockets = _host_cpu()
+    quota = _cpu_quota()
+    cores = cores if quota is None else min(cores, quota)   # the threads the container can actually run
     image, audio, _ = synth_inputs(sample_batch, cfg["hw"], num_classes=cfg["C"], seed=0)
     with torch.no_grad():
         torch.set_num_threads(cores)
@@ -445,6 +461,7 @@ def main():
     a = parse()
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(self_launch(a))
+    cap_host_threads()
     if a.no_token_fusion:
         import cavp_amd.train as _tr
         _tr._FUSE_TOKEN_PATH = False

@@ -10,6 +10,10 @@ if REPO not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # the oracle runs on the CPU: keep torch's thread pool within the container's CPU quota (cavp_amd/hostinfo.py - 128 threads on
+    # a 16-CPU quota made the oracle comparisons, and every eager launch sequence beside them, several times slower)
+    from cavp_amd.hostinfo import cap_torch_threads
+    cap_torch_threads()
 
 
 @pytest.fixture(scope="session")

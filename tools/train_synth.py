@@ -24,6 +24,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
 def main():
+    from cavp_amd.hostinfo import cap_torch_threads
+    cap_torch_threads()   # (container CPU quota: cavp_amd/hostinfo.py)
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--batch", type=int, default=32, help="frames per GPU per step")
