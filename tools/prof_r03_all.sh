@@ -10,6 +10,7 @@ python bench.py --config c1 --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_c
 python bench.py --config c1 --mode eval --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_c1_bf16.json 2> /dev/null
 python bench.py --config c4 --batch 8 --steps 20 --warmup 5 > $O/bench_c4_pvt_train_bf16.json 2> /dev/null
 python bench.py --config c4 --batch 8 --mode eval --steps 20 --warmup 5 > $O/bench_c4_pvt_eval_bf16.json 2> /dev/null
+python bench.py --config c5 --batch 30 --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_c5_clip_train_bf16.json 2> /dev/null
 python bench.py --deterministic --steps 20 --warmup 5 --no-cpu-baseline --no-f32 > $O/bench_train_bf16_deterministic.json 2> /dev/null
 python bench.py --no-side-stream --steps 20 --warmup 5 --no-cpu-baseline --no-f32 --no-roofline > $O/bench_train_bf16_no_side_stream.json 2> /dev/null
 python tools/pmc_traffic.py --mode train --out $O/traffic_train_bf16.json > /dev/null 2> $O/pmc_traffic.err
