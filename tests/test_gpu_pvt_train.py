@@ -84,6 +84,19 @@ def test_dwconv_backward(shape, dtype, tol):
     torch.cuda.synchronize()
     assert _rel(dx.float().cpu().permute(0, 3, 1, 2), xr.grad) <= tol
     assert _rel(dw.cpu() / 2, wr.grad) <= max(tol, 2e-5) and _rel(db.cpu() / 2, br.grad) <= max(tol, 2e-5)
+    # deterministic mode: the pixel splits' partials are added in split order - bit-identical repeats, same values
+    from cavp_amd import _lib
+    _lib.set_deterministic(True, device=torch.device(DEV))
+    try:
+        outs = []
+        for _ in range(2):
+            d2, b2 = torch.zeros((C, 1, 3, 3), device=DEV), torch.zeros(C, device=DEV)
+            T.dwconv3x3_wgrad(xd, gd, d2, b2)
+            outs.append((d2, b2))
+        assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+        assert _rel(outs[0][0].cpu(), wr.grad) <= max(tol, 2e-5) and _rel(outs[0][1].cpu(), br.grad) <= max(tol, 2e-5)
+    finally:
+        _lib.set_deterministic(False)
 
 
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (BF, 1e-2)], ids=["f32", "bf16"])
