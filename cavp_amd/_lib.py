@@ -115,6 +115,7 @@ PROTOTYPES = {
     "cavp_sra_attention_bwd": (_i32, [_i32, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _vp, _sz, _vp]),
     "cavp_sra_attention_bwd_to": (_i32, [_i32, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _vp, _sz, _vp]),
     "cavp_dwconv3x3_wgrad": (_i32, [_i32, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
+    "cavp_dwconv3x3_bwd": (_i32, [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "cavp_smallcin_kxk_im2col": (_i32, [_i32, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "cavp_space_to_depth": (_i32, [_i32, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "cavp_row_scale_add": (_i32, [_i32, _vp, _vp, _vp, _vp, _i32, _i64, _vp]),

@@ -492,11 +492,15 @@ __global__ __launch_bounds__(256) void sra_bwd_kv_bf16_kernel(const bf16_t* __re
 // workgroup = 16 channel quads x `ppb` pixels; the 16 pixel lanes are reduced with two cross-lane shuffles and a pass through
 // LDS, then one atomic per (channel, tap) and workgroup.
 // ------------------------------------------------------------------------------------------------------------------------
-template <typename T>
+// DX = true: the same walk also produces the DATA gradient.  The sum is re-indexed by the input pixel p': dw[t] = sum_p' x[p'] *
+// g[p' - off_t] and dx[p'] = sum_t w[t] * g[p' - off_t] use the same nine neighbours of g (one load of x and nine of g per pixel
+// instead of nine of x and one of g - the same traffic), so the separate data-gradient launch (a second pass over g) is gone.
+template <typename T, bool DX>
 __global__ __launch_bounds__(256) void dwconv3x3_wgrad_kernel(const T* __restrict__ x, const T* __restrict__ g,
                                                               float* __restrict__ dw, float* __restrict__ db, int N, int H,
                                                               int W, int C, int ppb, float* __restrict__ part_dw,
-                                                              float* __restrict__ part_db) {
+                                                              float* __restrict__ part_db, const float* __restrict__ w9c,
+                                                              T* __restrict__ dx) {
   __shared__ float red[4][16][41];
   const int cl = threadIdx.x & 15, pl = threadIdx.x >> 4, wave = threadIdx.x >> 6;
   const int cv = blockIdx.x * 16 + cl;
@@ -506,27 +510,63 @@ __global__ __launch_bounds__(256) void dwconv3x3_wgrad_kernel(const T* __restric
   float acc[40];
 #pragma unroll
   for (int i = 0; i < 40; ++i) acc[i] = 0.f;
+  float wt[DX ? 36 : 1];
+  if constexpr (DX) {
+    if (cok) {
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const float4 wv = *(const float4*)(w9c + (size_t)t * C + cv * 4);
+        wt[4 * t] = wv.x; wt[4 * t + 1] = wv.y; wt[4 * t + 2] = wv.z; wt[4 * t + 3] = wv.w;
+      }
+    }
+  }
   if (cok)
     for (long long p = p0 + pl; p < p1; p += 16) {
       const int wi = (int)(p % W), hi = (int)((p / W) % H);
-      const float4 gv = ld4<T>(g + (size_t)p * C + cv * 4);
-      const float ga[4] = {gv.x, gv.y, gv.z, gv.w};
+      if constexpr (DX) {
+        const float4 xv = ld4<T>(x + (size_t)p * C + cv * 4);
+        const float xa[4] = {xv.x, xv.y, xv.z, xv.w};
+        float d[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int e = 0; e < 4; ++e) acc[36 + e] += ga[e];
+        for (int kh = 0; kh < 3; ++kh) {
+          const int h2 = hi + 1 - kh;          // g at p - off_t, off_t = (kh - 1, kw - 1)
 #pragma unroll
-      for (int kh = 0; kh < 3; ++kh) {
-        const int h2 = hi - 1 + kh;
+          for (int kw = 0; kw < 3; ++kw) {
+            const int w2 = wi + 1 - kw;
+            const bool ok = (unsigned)h2 < (unsigned)H && (unsigned)w2 < (unsigned)W;
+            const long long off = ok ? (long long)(1 - kh) * W + (1 - kw) : 0;
+            const float4 gv = ld4<T>(g + ((size_t)p + off) * C + cv * 4);
+            const float m = ok ? 1.f : 0.f;
+            const float ga[4] = {gv.x * m, gv.y * m, gv.z * m, gv.w * m};
 #pragma unroll
-        for (int kw = 0; kw < 3; ++kw) {
-          const int w2 = wi - 1 + kw;
-          const bool ok = (unsigned)h2 < (unsigned)H && (unsigned)w2 < (unsigned)W;
-          // branch-free: an out-of-image tap reads the centre pixel and is multiplied by 0 (keeps the 9 loads in flight together)
-          const long long off = ok ? (long long)(kh - 1) * W + (kw - 1) : 0;
-          const float4 xv = ld4<T>(x + ((size_t)p + off) * C + cv * 4);
-          const float m = ok ? 1.f : 0.f;
-          const float xa[4] = {xv.x, xv.y, xv.z, xv.w};
+            for (int e = 0; e < 4; ++e) {
+              acc[(kh * 3 + kw) * 4 + e] += xa[e] * ga[e];
+              d[e] += wt[(kh * 3 + kw) * 4 + e] * ga[e];
+              if (kh == 1 && kw == 1) acc[36 + e] += ga[e];
+            }
+          }
+        }
+        st4<T>(dx + (size_t)p * C + cv * 4, d[0], d[1], d[2], d[3]);
+      } else {
+        const float4 gv = ld4<T>(g + (size_t)p * C + cv * 4);
+        const float ga[4] = {gv.x, gv.y, gv.z, gv.w};
 #pragma unroll
-          for (int e = 0; e < 4; ++e) acc[(kh * 3 + kw) * 4 + e] += xa[e] * (ga[e] * m);
+        for (int e = 0; e < 4; ++e) acc[36 + e] += ga[e];
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+          const int h2 = hi - 1 + kh;
+#pragma unroll
+          for (int kw = 0; kw < 3; ++kw) {
+            const int w2 = wi - 1 + kw;
+            const bool ok = (unsigned)h2 < (unsigned)H && (unsigned)w2 < (unsigned)W;
+            // branch-free: an out-of-image tap reads the centre pixel and is multiplied by 0 (keeps the 9 loads in flight together)
+            const long long off = ok ? (long long)(kh - 1) * W + (kw - 1) : 0;
+            const float4 xv = ld4<T>(x + ((size_t)p + off) * C + cv * 4);
+            const float m = ok ? 1.f : 0.f;
+            const float xa[4] = {xv.x, xv.y, xv.z, xv.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[(kh * 3 + kw) * 4 + e] += xa[e] * (ga[e] * m);
+          }
         }
       }
     }
@@ -721,8 +761,14 @@ extern "C" int cavp_sra_attention_bwd_to(int32_t dtype, const void* q, const voi
 
 extern "C" int cavp_dwconv3x3_wgrad(int32_t dtype, const void* x, const void* dy, float* dw_c133, float* dbias, int32_t N,
                                     int32_t H, int32_t W, int32_t C, void* stream) {
-  if (!x || !dy || !dw_c133 || N <= 0 || H <= 0 || W <= 0 || C <= 0) return CAVP_ERR_BAD_ARG;
+  return cavp_dwconv3x3_bwd(dtype, x, dy, nullptr, nullptr, dw_c133, dbias, N, H, W, C, stream);
+}
+
+extern "C" int cavp_dwconv3x3_bwd(int32_t dtype, const void* x, const void* dy, const float* w9c, void* dx, float* dw_c133,
+                                  float* dbias, int32_t N, int32_t H, int32_t W, int32_t C, void* stream) {
+  if (!x || !dy || !dw_c133 || N <= 0 || H <= 0 || W <= 0 || C <= 0 || ((w9c == nullptr) != (dx == nullptr))) return CAVP_ERR_BAD_ARG;
   if (!dt_ok(dtype) || C % 8) return CAVP_ERR_UNSUPPORTED;
+  if (((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dx | (uintptr_t)w9c) & 15) return CAVP_ERR_ALIGN;
   const long long total = (long long)N * H * W;
   const int gx = (C / 4 + 15) / 16;
   long long ppb = 256;
@@ -742,12 +788,11 @@ extern "C" int cavp_dwconv3x3_wgrad(int32_t dtype, const void* x, const void* dy
   const int nsplit = (int)((total + ppb - 1) / ppb);
   const dim3 grid(gx, (unsigned)nsplit);
   hipStream_t s = (hipStream_t)stream;
-  if (dtype == CAVP_F32)
-    dwconv3x3_wgrad_kernel<float><<<grid, 256, 0, s>>>((const float*)x, (const float*)dy, dw_c133, dbias, N, H, W, C, (int)ppb,
-                                                        part_dw, part_db);
-  else
-    dwconv3x3_wgrad_kernel<bf16_t><<<grid, 256, 0, s>>>((const bf16_t*)x, (const bf16_t*)dy, dw_c133, dbias, N, H, W, C, (int)ppb,
-                                                         part_dw, part_db);
+#define DW_LAUNCH(T, DX) dwconv3x3_wgrad_kernel<T, DX><<<grid, 256, 0, s>>>((const T*)x, (const T*)dy, dw_c133, dbias, N, H, W, C, \
+                                                                            (int)ppb, part_dw, part_db, w9c, (T*)dx)
+  if (dtype == CAVP_F32) { if (dx) DW_LAUNCH(float, true); else DW_LAUNCH(float, false); }
+  else { if (dx) DW_LAUNCH(bf16_t, true); else DW_LAUNCH(bf16_t, false); }
+#undef DW_LAUNCH
   if (hipGetLastError() != hipSuccess) return CAVP_ERR_LAUNCH;
   if (part_dw) {
     if (cavp_det_finish(part_dw, nsplit, 9 * C, dw_c133, nullptr, s) != hipSuccess) return CAVP_ERR_LAUNCH;

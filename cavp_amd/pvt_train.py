@@ -124,10 +124,11 @@ def _dwconv_gelu(tp: TrainPass, x: V, conv, w9c: torch.Tensor, B: int, H: int, W
         if not y.g_premul:
             raise CavpError("fused GELU: the gradient must come from a data-gradient GEMM (TrainPass.acc)")
         g4 = g.view(B, H, W, hid)
-        T.dwconv3x3_wgrad(x.t.view(B, H, W, hid), g4, tp.grad_buffer(conv.weight), tp.grad_buffer(conv.bias))
-        if x.needs_grad:
-            dx = tp.empty(x.t.shape)
-            ops.dwconv3x3_bwd_data(g4, w9c, dx.view(B, H, W, hid))   # correlation with the reversed taps
+        # weight / bias gradient and data gradient in ONE walk over g (both need its 3 x 3 neighbourhoods)
+        dx = tp.empty(x.t.shape) if x.needs_grad else None
+        T.dwconv3x3_wgrad(x.t.view(B, H, W, hid), g4, tp.grad_buffer(conv.weight), tp.grad_buffer(conv.bias),
+                          w9c if dx is not None else None, dx.view(B, H, W, hid) if dx is not None else None)
+        if dx is not None:
             tp.acc_add(x, dx)
     tp.tape.append(bwd)
     return y

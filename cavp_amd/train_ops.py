@@ -481,14 +481,18 @@ def sra_attention_bwd(q, kv, dout, dq, dkv, heads: int, scale: float) -> None:
            f"cavp_sra_attention_bwd_to B{b} Nq{nq} Nk{nk} heads{heads}")
 
 
-def dwconv3x3_wgrad(x, dy, dw, dbias) -> None:
-    """dw f32 [C,1,3,3] +=, dbias f32 [C] += of ops.dwconv3x3 (pvt.py:320-326)."""
-    _need_gpu(x, dy, dw, dbias)
+def dwconv3x3_wgrad(x, dy, dw, dbias, w9c=None, dx=None) -> None:
+    """dw f32 [C,1,3,3] +=, dbias f32 [C] += of ops.dwconv3x3 (pvt.py:320-326).  With w9c (the forward's packed [9][C] taps) and
+    dx (dy's shape and dtype, overwritten) the same walk over dy also writes the data gradient (cavp_dwconv3x3_bwd)."""
+    _need_gpu(x, dy, dw, dbias, w9c, dx)
     n, h, w, c = x.shape
     if not (x.is_contiguous() and dy.is_contiguous() and dw.is_contiguous()) or dy.shape != x.shape or dw.numel() != 9 * c:
         raise _lib.CavpError("dwconv3x3_wgrad: dense NHWC x / dy and a [C,1,3,3] f32 gradient required")
-    _check(_lib.load().cavp_dwconv3x3_wgrad(dtype_code(x.dtype), _ptr(x), _ptr(dy), _ptr(dw), _ptr(dbias), n, h, w, c, _s()),
-           "cavp_dwconv3x3_wgrad")
+    if (w9c is None) != (dx is None) or (dx is not None and (dx.shape != dy.shape or dx.dtype != dy.dtype or not dx.is_contiguous()
+                                                             or w9c.shape != (9, c) or w9c.dtype != torch.float32)):
+        raise _lib.CavpError("dwconv3x3_wgrad: the data gradient needs the packed [9][C] f32 taps and a dense dx of dy's shape")
+    _check(_lib.load().cavp_dwconv3x3_bwd(dtype_code(x.dtype), _ptr(x), _ptr(dy), _ptr(w9c), _ptr(dx), _ptr(dw), _ptr(dbias),
+                                          n, h, w, c, _s()), "cavp_dwconv3x3_bwd")
 
 
 def conv_smallcin_kxk_wgrad(x_nchw, dy, dw_oihw, ks: int, stride: int, pad: int) -> None:

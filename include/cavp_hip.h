@@ -417,6 +417,10 @@ int cavp_sra_attention_bwd_to(int32_t dtype, const void* q, const void* kv, cons
  * cavp_dwconv3x3_nhwc with the taps reversed. */
 int cavp_dwconv3x3_wgrad(int32_t dtype, const void* x, const void* dy, float* dw_c133, float* dbias, int32_t N, int32_t H,
                          int32_t W, int32_t C, void* stream);
+/* weight / bias gradient AND data gradient of the depth-wise conv in one walk over dy (w9c: the forward's packed [9][C] taps;
+ * dx: dense NHWC of x's dtype, overwritten).  w9c = dx = NULL: the weight gradient alone. */
+int cavp_dwconv3x3_bwd(int32_t dtype, const void* x, const void* dy, const float* w9c, void* dx, float* dw_c133, float* dbias,
+                       int32_t N, int32_t H, int32_t W, int32_t C, void* stream);
 /* Weight gradient of cavp_conv_smallcin_kxk_nchw, step 1: im2col of the NCHW f32 input into cols [N*Ho*Wo][Kpad] (dtype;
  * column order (ci, kh, kw) = the OIHW weight's, zero beyond Cin*KS*KS; Kpad a multiple of 8).  Step 2 is
  * cavp_conv2d_wgrad_nhwc as a 1x1 layer with x = cols, giving dw [Cout][Kpad]. */

@@ -84,6 +84,12 @@ def test_dwconv_backward(shape, dtype, tol):
     torch.cuda.synchronize()
     assert _rel(dx.float().cpu().permute(0, 3, 1, 2), xr.grad) <= tol
     assert _rel(dw.cpu() / 2, wr.grad) <= max(tol, 2e-5) and _rel(db.cpu() / 2, br.grad) <= max(tol, 2e-5)
+    # one walk: weight / bias gradient + data gradient (cavp_dwconv3x3_bwd)
+    dw3, db3, dx3 = torch.zeros((C, 1, 3, 3), device=DEV), torch.zeros(C, device=DEV), torch.empty_like(gd)
+    T.dwconv3x3_wgrad(xd, gd, dw3, db3, w9c, dx3)
+    assert _rel(dx3.float().cpu().permute(0, 3, 1, 2), xr.grad) <= tol
+    assert _rel(dw3.cpu(), wr.grad) <= max(tol, 2e-5) and _rel(db3.cpu(), br.grad) <= max(tol, 2e-5)
+    assert _rel(dx3.float(), dx.float()) <= (1e-6 if dtype == torch.float32 else 1e-2)
     # deterministic mode: the pixel splits' partials are added in split order - bit-identical repeats, same values
     from cavp_amd import _lib
     _lib.set_deterministic(True, device=torch.device(DEV))
@@ -91,7 +97,7 @@ def test_dwconv_backward(shape, dtype, tol):
         outs = []
         for _ in range(2):
             d2, b2 = torch.zeros((C, 1, 3, 3), device=DEV), torch.zeros(C, device=DEV)
-            T.dwconv3x3_wgrad(xd, gd, d2, b2)
+            T.dwconv3x3_wgrad(xd, gd, d2, b2, w9c, torch.empty_like(gd))
             outs.append((d2, b2))
         assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
         assert _rel(outs[0][0].cpu(), wr.grad) <= max(tol, 2e-5) and _rel(outs[0][1].cpu(), br.grad) <= max(tol, 2e-5)
