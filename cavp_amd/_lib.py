@@ -89,7 +89,8 @@ PROTOTYPES = {
     "cavp_colsum_groups": (_i32, [_i32, _vp, _i32, _i32, _i32, _i32, _vp, _vp]),
     "cavp_col_tile_stats": (_i32, [_i32, _vp, _i64, _i32, _i32, _vp, _vp]),
     "cavp_layernorm_bwd": (_i32, [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _vp]),
-    "cavp_layernorm_bwd_add": (_i32, [_i32, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _vp]),
+    "cavp_layernorm_bwd_add": (_i32, [_i32, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _i32, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32,
+                                      _vp]),
     "cavp_attn_gate_bwd": (_i32, [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _i32, _vp]),
     "cavp_maxpool_bwd_nhwc": (_i32, [_i32, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "cavp_bilinear_bwd_nhwc": (_i32, [_i32, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),

@@ -87,7 +87,8 @@ __global__ __launch_bounds__(256) void layernorm_bwd_vec_kernel(const T* __restr
                                                                 float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                                 int rows, int C, int ld_dy, int ld_x, int ld_dx, float eps,
                                                                 int rows_per_block, float* __restrict__ det_part,
-                                                                const T* add, int ld_add) {
+                                                                const T* add, int ld_add, T* __restrict__ dx2,
+                                                                const float* __restrict__ row_scale, int rows_per_group) {
   constexpr int VE = VecT<T>::VE, RW = 64 / G, CW = G * PLV * VE;  // channels covered by a row group
   __shared__ float part[2][4][CW];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -165,6 +166,12 @@ __global__ __launch_bounds__(256) void layernorm_bwd_vec_kernel(const T* __restr
           for (int e = 0; e < VE; ++e) o[e] += r[e];
         }
         VecT<T>::store(dx + (size_t)row * ld_dx + (l + G * i) * VE, o);
+        if (dx2) {   // second output: the same gradient times the factor of the row's group (DropPath: mask / keep of its image)
+          const float rs = row_scale[row / rows_per_group];
+#pragma unroll
+          for (int e = 0; e < VE; ++e) o[e] *= rs;
+          VecT<T>::store(dx2 + (size_t)row * C + (l + G * i) * VE, o);
+        }
       }
     }
   }
@@ -272,12 +279,16 @@ extern "C" int cavp_layernorm(int32_t dtype, const void* x, const float* gamma, 
 extern "C" int cavp_layernorm_bwd(int32_t dtype, const void* dy, const void* x, const float* gamma, void* dx,
                                   float* dgamma, float* dbeta, int32_t rows, int32_t C, int32_t ld_dy, int32_t ld_x,
                                   int32_t ld_dx, float eps, void* stream) {
-  return cavp_layernorm_bwd_add(dtype, dy, x, gamma, nullptr, 0, dx, dgamma, dbeta, rows, C, ld_dy, ld_x, ld_dx, eps, stream);
+  return cavp_layernorm_bwd_add(dtype, dy, x, gamma, nullptr, 0, dx, nullptr, nullptr, 0, dgamma, dbeta, rows, C, ld_dy, ld_x, ld_dx,
+                                eps, stream);
 }
 
 extern "C" int cavp_layernorm_bwd_add(int32_t dtype, const void* dy, const void* x, const float* gamma, const void* dx_add,
-                                      int32_t ld_add, void* dx, float* dgamma, float* dbeta, int32_t rows, int32_t C,
-                                      int32_t ld_dy, int32_t ld_x, int32_t ld_dx, float eps, void* stream) {
+                                      int32_t ld_add, void* dx, void* dx_scaled, const float* row_scale, int32_t rows_per_group,
+                                      float* dgamma, float* dbeta, int32_t rows, int32_t C, int32_t ld_dy, int32_t ld_x,
+                                      int32_t ld_dx, float eps, void* stream) {
+  if (dx_scaled && (!row_scale || rows_per_group <= 0 || rows % rows_per_group)) return CAVP_ERR_BAD_ARG;
+  if (!al16(dx_scaled)) return CAVP_ERR_ALIGN;
   if (!dy || !x || !gamma || !dx || !dgamma || !dbeta || rows <= 0 || C <= 0) return CAVP_ERR_BAD_ARG;
   if (!dt_ok(dtype)) return CAVP_ERR_UNSUPPORTED;
   const int VE = dtype == CAVP_F32 ? 4 : 8;
@@ -299,11 +310,11 @@ extern "C" int cavp_layernorm_bwd_add(int32_t dtype, const void* dy, const void*
   float* det = cavp_det_scratch(gx, C, &det_err);
   if (det_err) return CAVP_ERR_WORKSPACE;
   if (dtype == CAVP_F32) {
-#define CALL(g, p) layernorm_bwd_vec_kernel<float, g, p><<<gx, 256, 0, s>>>((const float*)dy, (const float*)x, gamma, (float*)dx, dgamma, dbeta, rows, C, ld_dy, ld_x, ld_dx, eps, rpb, det, (const float*)dx_add, ld_add)
+#define CALL(g, p) layernorm_bwd_vec_kernel<float, g, p><<<gx, 256, 0, s>>>((const float*)dy, (const float*)x, gamma, (float*)dx, dgamma, dbeta, rows, C, ld_dy, ld_x, ld_dx, eps, rpb, det, (const float*)dx_add, ld_add, (float*)dx_scaled, row_scale, rows_per_group)
     LN_DISPATCH(CALL)
 #undef CALL
   } else {
-#define CALL(g, p) layernorm_bwd_vec_kernel<bf16_t, g, p><<<gx, 256, 0, s>>>((const bf16_t*)dy, (const bf16_t*)x, gamma, (bf16_t*)dx, dgamma, dbeta, rows, C, ld_dy, ld_x, ld_dx, eps, rpb, det, (const bf16_t*)dx_add, ld_add)
+#define CALL(g, p) layernorm_bwd_vec_kernel<bf16_t, g, p><<<gx, 256, 0, s>>>((const bf16_t*)dy, (const bf16_t*)x, gamma, (bf16_t*)dx, dgamma, dbeta, rows, C, ld_dy, ld_x, ld_dx, eps, rpb, det, (const bf16_t*)dx_add, ld_add, (bf16_t*)dx_scaled, row_scale, rows_per_group)
     LN_DISPATCH_BF16(CALL)
 #undef CALL
   }

@@ -138,12 +138,15 @@ def _residual_drop_path(tp: TrainPass, x: V, branch: V, scale: torch.Tensor) -> 
     """x + DropPath(branch) with the per-sample factor `scale` = mask / keep_prob (f32 [B])."""
     y = V(tp.empty(x.t.shape))
     T.row_scale_add(x.t, branch.t, scale, y.t)
+    y.dp_scale = scale
 
     def bwd():
         if y.g is None:
             return
-        gb = tp.empty(branch.t.shape)
-        T.row_scale_add(None, y.g, scale, gb)
+        gb = y.g_scaled          # written by the LayerNorm backward that completed y.g (TrainPass.layernorm), else computed here
+        if gb is None:
+            gb = tp.empty(branch.t.shape)
+            T.row_scale_add(None, y.g, scale, gb)
         tp.acc_add(branch, gb)
         tp.acc_add(x, y.g)
     tp.tape.append(bwd)

@@ -30,7 +30,7 @@ from ._lib import load as _lib_load
 class V:
     """An activation (NHWC / token / vector tensor) and its gradient.  A channel slice of a wider buffer is a child
     whose gradient is the matching slice of the parent's gradient (free concat in both directions)."""
-    __slots__ = ("t", "_g", "parent", "lo", "hi", "needs_grad", "tile_stats", "grad_mul", "g_premul")
+    __slots__ = ("t", "_g", "parent", "lo", "hi", "needs_grad", "tile_stats", "grad_mul", "g_premul", "dp_scale", "g_scaled")
 
     def __init__(self, t: torch.Tensor, parent: Optional["V"] = None, lo: int = 0, hi: int = 0, needs_grad: bool = True):
         self.t, self._g, self.parent, self.lo, self.hi, self.needs_grad = t, None, parent, lo, hi, needs_grad
@@ -38,6 +38,10 @@ class V:
         # fused fc1 + GELU (TrainPass.conv(act=ACT_GELU)): the gelu' tensor the producer of this activation's gradient multiplies
         # into its epilogue, and whether .g already carries that factor
         self.grad_mul, self.g_premul = None, False
+        # output of `x + DropPath(branch)`: the per-image factor of the branch, and - when the LAST contributor to .g was a
+        # LayerNorm backward - the branch's gradient factor * .g, written by that kernel as a second output (any later
+        # accumulation into .g drops it again)
+        self.dp_scale, self.g_scaled = None, None
 
     @property
     def g(self) -> Optional[torch.Tensor]:
@@ -50,6 +54,7 @@ class V:
         if self.parent is not None:
             raise CavpError("gradient of a slice is owned by its parent")
         self._g = g
+        self.g_scaled = None
 
     def slice(self, lo: int, hi: int) -> "V":
         return V(self.t[..., lo:hi], parent=self, lo=lo, hi=hi)
@@ -342,6 +347,7 @@ class TrainPass:
             x.set_g(g)
         else:
             compute(x.g, x.g)
+            x.g_scaled = None
 
     def acc_add(self, x: V, g: torch.Tensor) -> None:
         if not x.needs_grad:
@@ -358,6 +364,7 @@ class TrainPass:
                 x.set_g(out)
             else:
                 T.add(x.g, gg, x.g)
+                x.g_scaled = None
 
     def _pinned(self, t: torch.Tensor) -> bool:
         """True while a deferred weight gradient reads t's storage: a conv with a fused residual hands its output gradient to
@@ -687,12 +694,19 @@ class TrainPass:
             have = x.g if (x.parent is None and x.g is not None and x.g.is_contiguous() and x.g.dtype == x.t.dtype
                            and x.g.shape == x.t.shape) else None
             dx = have if (have is not None and not self._pinned(have)) else self.empty(x.t.shape, x.t.dtype)
+            # x = residual + DropPath(branch): the branch's gradient (factor * dx) leaves the same kernel as a second output
+            # (this norm is the last contributor to x.g on a transformer block's residual stream; if it is not, the next
+            # accumulation drops the copy and the residual's backward scales x.g itself)
+            first = have is None and x.g is None
+            sc = self.empty(x.t.shape, x.t.dtype) if (x.dp_scale is not None and x.parent is None and (have is not None or first)) else None
             T.layernorm_bwd(y.g, x.t, ln.weight.detach(), dx, self.grad_buffer(ln.weight), self.grad_buffer(ln.bias), ln.eps,
-                            add=have)
+                            add=have, scaled=sc, row_scale=x.dp_scale if sc is not None else None)
             if have is None:
                 self.acc_add(x, dx)
             elif dx is not have:
                 x.set_g(dx)
+            if sc is not None:
+                x.g_scaled = sc
         self.tape.append(bwd)
         return y
 

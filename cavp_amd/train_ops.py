@@ -359,19 +359,29 @@ def colsum_groups(x, out) -> torch.Tensor:
     return out
 
 
-def layernorm_bwd(dy, x, gamma, dx, dgamma, dbeta, eps: float, add: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """add (dx's shape and dtype, may be dx): a gradient the input already holds; dx = layernorm_bwd(dy) + add in one pass."""
+def layernorm_bwd(dy, x, gamma, dx, dgamma, dbeta, eps: float, add: Optional[torch.Tensor] = None,
+                  scaled: Optional[torch.Tensor] = None, row_scale: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """add (dx's shape and dtype, may be dx): a gradient the input already holds; dx = layernorm_bwd(dy) + add in one pass.
+    scaled + row_scale (f32 [groups]): a second, dense output = dx with the rows of group g (rows / groups consecutive rows)
+    multiplied by row_scale[g]."""
     rows, c, ld_dy = _rows(dy)
     _, _, ld_x = _rows(x)
     _, _, ld_dx = _rows(dx)
-    _need_gpu(dy, x, gamma, dx, dgamma, dbeta, add)
+    _need_gpu(dy, x, gamma, dx, dgamma, dbeta, add, scaled, row_scale)
     ld_add = 0
     if add is not None:
         if add.shape != dx.shape or add.dtype != dx.dtype:
             raise _lib.CavpError("layernorm_bwd: `add` must have dx's shape and dtype")
         _, _, ld_add = _rows(add)
+    rpg = 0
+    if scaled is not None:
+        if row_scale is None or row_scale.dtype != torch.float32 or not row_scale.is_contiguous() or rows % row_scale.numel() \
+                or not scaled.is_contiguous() or scaled.numel() != rows * c or scaled.dtype != dx.dtype:
+            raise _lib.CavpError("layernorm_bwd: `scaled` needs a dense tensor of dx's size and dtype and an f32 factor per row group")
+        rpg = rows // row_scale.numel()
     _check(_lib.load().cavp_layernorm_bwd_add(dtype_code(dy.dtype), _ptr(dy), _ptr(x), _ptr(gamma), _ptr(add), ld_add, _ptr(dx),
-                                              _ptr(dgamma), _ptr(dbeta), rows, c, ld_dy, ld_x, ld_dx, C.c_float(eps), _s()),
+                                              _ptr(scaled), _ptr(row_scale if scaled is not None else None), rpg, _ptr(dgamma),
+                                              _ptr(dbeta), rows, c, ld_dy, ld_x, ld_dx, C.c_float(eps), _s()),
            "cavp_layernorm_bwd_add")
     return dx
 

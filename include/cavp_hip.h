@@ -284,10 +284,13 @@ int cavp_layernorm_bwd(int32_t dtype, const void* dy, const void* x, const float
                        float* dbeta, int32_t rows, int32_t C, int32_t ld_dy, int32_t ld_x, int32_t ld_dx, float eps,
                        void* stream);
 /* same, with the gradient the input already holds added in: dx = layernorm_bwd(dy) + dx_add (dx_add may be NULL, and may be dx
- * itself).  The residual stream of a transformer block (pvt.py:252-256, attn.py:194-197) reaches the norm's input twice. */
+ * itself).  The residual stream of a transformer block (pvt.py:252-256, attn.py:194-197) reaches the norm's input twice.
+ * dx_scaled (optional, dense [rows][C]): a second copy of dx with row r multiplied by row_scale[r / rows_per_group] - the
+ * gradient of a DropPath branch (timm drop_path: mask / keep per image) that hangs off the same residual stream. */
 int cavp_layernorm_bwd_add(int32_t dtype, const void* dy, const void* x, const float* gamma, const void* dx_add, int32_t ld_add,
-                           void* dx, float* dgamma, float* dbeta, int32_t rows, int32_t C, int32_t ld_dy, int32_t ld_x,
-                           int32_t ld_dx, float eps, void* stream);
+                           void* dx, void* dx_scaled, const float* row_scale, int32_t rows_per_group, float* dgamma,
+                           float* dbeta, int32_t rows, int32_t C, int32_t ld_dy, int32_t ld_x, int32_t ld_dx, float eps,
+                           void* stream);
 /* backward of cavp_attn_gate; dk, dv: f32 [B][heads*hd] accumulated with atomics (caller zeroes); dattn optional.
  * q: [q_batch][T][heads*hd] as in the forward; dq: [B][T][heads*hd] (the caller sums the q_batch-periodic parts). */
 int cavp_attn_gate_bwd(int32_t dtype, const void* dout, const void* q, const void* k, const void* v, const float* attn,

@@ -253,6 +253,14 @@ def test_layernorm_bwd(rows, C, dt):
                         add=out if inplace else pd)
         _check(out, x.grad + prior, dt, f"ln dx + prior (inplace={inplace})", 5e-5, 2e-2)
         _check(dg2, g.grad, dt, "ln dgamma (add)", 1e-4, 1e-2)
+    # second output: dx with the rows of group k (rows / groups consecutive rows) times a factor (DropPath branch gradient)
+    groups = 3 if rows % 3 == 0 else 1
+    fac = torch.tensor([0.0, 1.25, 1.0][:groups], device=DEV)
+    out, sc = torch.empty((rows, C), dtype=dt, device=DEV), torch.empty((rows, C), dtype=dt, device=DEV)
+    T.layernorm_bwd(dy.to(dt).to(DEV), x.detach().to(dt).to(DEV), g.detach().to(DEV), out, torch.zeros(C, device=DEV),
+                    torch.zeros(C, device=DEV), 1e-5, add=pd, scaled=sc, row_scale=fac)
+    want = (out.float().view(groups, -1, C) * fac.view(groups, 1, 1)).view(rows, C)
+    assert float((sc.float() - want).abs().max()) <= (1e-6 if dt == torch.float32 else 2e-2) * max(1.0, float(want.abs().max()))
 
 
 @pytest.mark.parametrize("H,hd", [(4, 76), (4, 28), (4, 128), (2, 64), (8, 32)], ids=["4x76", "4x28", "4x128", "2x64", "8x32"])
