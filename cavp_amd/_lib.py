@@ -57,6 +57,7 @@ PROTOTYPES = {
     "cavp_bilinear_nhwc": (_i32, [_i32, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "cavp_bilinear_nhwc_to_nchw": (_i32, [_i32, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "cavp_layernorm": (_i32, [_i32, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _vp]),
+    "cavp_layernorm_residual": (_i32, [_i32, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _vp]),
     "cavp_attn_gate": (_i32, [_i32, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _i32, _vp]),
     "cavp_bn_fold": (_i32, [_vp, _vp, _vp, _vp, _f32, _vp, _vp, _i32, _vp]),
     "cavp_pack_weight_ohwi": (_i32, [_i32, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),

@@ -21,10 +21,16 @@ __device__ __forceinline__ float group_sum(float v) {
   return v;
 }
 
+template <typename T> __device__ __forceinline__ float round_to(float v);
+template <> __device__ __forceinline__ float round_to<float>(float v) { return v; }
+template <> __device__ __forceinline__ float round_to<bf16_t>(float v) { return __uint_as_float(pack2bf(v, 0.f) << 16); }
+
 template <typename T, int G, int PLV>
 __global__ __launch_bounds__(256) void layernorm_vec_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, T* __restrict__ y, int rows,
-                                                            int C, int ldx, int ldy, float eps) {
+                                                            int C, int ldx, int ldy, float eps, const T* __restrict__ branch,
+                                                            const float* __restrict__ row_scale, int rows_per_group,
+                                                            T* __restrict__ sum_out) {
   constexpr int VE = VecT<T>::VE, RW = 64 / G;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int l = lane % G, g = lane / G;
@@ -50,6 +56,14 @@ __global__ __launch_bounds__(256) void layernorm_vec_kernel(const T* __restrict_
     for (int i = 0; i < PLV; ++i) {
       if (ok[i]) {
         VecT<T>::load(x + (size_t)row * ldx + (l + G * i) * VE, v[i]);
+        if (branch) {   // x + factor[row group] * branch first (residual + DropPath); the sum is stored, and normalised as stored
+          float b[VE];
+          VecT<T>::load(branch + (size_t)row * C + (l + G * i) * VE, b);
+          const float rs = row_scale[row / rows_per_group];
+#pragma unroll
+          for (int e = 0; e < VE; ++e) v[i][e] = round_to<T>(v[i][e] + rs * b[e]);
+          VecT<T>::store(sum_out + (size_t)row * C + (l + G * i) * VE, v[i]);
+        }
       } else {
 #pragma unroll
         for (int e = 0; e < VE; ++e) v[i][e] = 0.f;
@@ -252,11 +266,18 @@ inline bool ln_geometry(int C, int VE, int* G, int* PLV) {
 
 extern "C" int cavp_layernorm(int32_t dtype, const void* x, const float* gamma, const float* beta, void* y,
                               int32_t rows, int32_t C, int32_t ldx, int32_t ldy, float eps, void* stream) {
+  return cavp_layernorm_residual(dtype, x, nullptr, nullptr, 0, gamma, beta, nullptr, y, rows, C, ldx, ldy, eps, stream);
+}
+
+extern "C" int cavp_layernorm_residual(int32_t dtype, const void* x, const void* branch, const float* row_scale,
+                                       int32_t rows_per_group, const float* gamma, const float* beta, void* y_sum, void* y,
+                                       int32_t rows, int32_t C, int32_t ldx, int32_t ldy, float eps, void* stream) {
   if (!x || !gamma || !beta || !y || rows <= 0 || C <= 0 || ldx < C || ldy < C) return CAVP_ERR_BAD_ARG;
+  if (branch && (!row_scale || !y_sum || rows_per_group <= 0 || rows % rows_per_group)) return CAVP_ERR_BAD_ARG;
   if (!dt_ok(dtype)) return CAVP_ERR_UNSUPPORTED;
   const int VE = dtype == CAVP_F32 ? 4 : 8;
   if (C % VE || ldx % VE || ldy % VE) return CAVP_ERR_UNSUPPORTED;
-  if (!al16(x) || !al16(y) || !al16(gamma) || !al16(beta)) return CAVP_ERR_ALIGN;
+  if (!al16(x) || !al16(y) || !al16(gamma) || !al16(beta) || !al16(branch) || !al16(y_sum)) return CAVP_ERR_ALIGN;
   int G, PLV;
   if (!ln_geometry(C, VE, &G, &PLV)) return CAVP_ERR_UNSUPPORTED;
   const int rpb = 4 * (64 / G);
@@ -265,11 +286,11 @@ extern "C" int cavp_layernorm(int32_t dtype, const void* x, const float* gamma, 
   const int nb = (int)nbl;
   hipStream_t s = (hipStream_t)stream;
   if (dtype == CAVP_F32) {
-#define CALL(g, p) layernorm_vec_kernel<float, g, p><<<nb, 256, 0, s>>>((const float*)x, gamma, beta, (float*)y, rows, C, ldx, ldy, eps)
+#define CALL(g, p) layernorm_vec_kernel<float, g, p><<<nb, 256, 0, s>>>((const float*)x, gamma, beta, (float*)y, rows, C, ldx, ldy, eps, (const float*)branch, row_scale, rows_per_group, (float*)y_sum)
     LN_DISPATCH(CALL)
 #undef CALL
   } else {
-#define CALL(g, p) layernorm_vec_kernel<bf16_t, g, p><<<nb, 256, 0, s>>>((const bf16_t*)x, gamma, beta, (bf16_t*)y, rows, C, ldx, ldy, eps)
+#define CALL(g, p) layernorm_vec_kernel<bf16_t, g, p><<<nb, 256, 0, s>>>((const bf16_t*)x, gamma, beta, (bf16_t*)y, rows, C, ldx, ldy, eps, (const bf16_t*)branch, row_scale, rows_per_group, (bf16_t*)y_sum)
     LN_DISPATCH_BF16(CALL)
 #undef CALL
   }

@@ -273,6 +273,24 @@ def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, out: tor
     return out
 
 
+def layernorm_residual(x: torch.Tensor, branch: torch.Tensor, row_scale: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor,
+                       out_sum: torch.Tensor, out_norm: torch.Tensor, eps: float):
+    """out_sum = x + row_scale[group of the row] * branch, out_norm = LayerNorm(out_sum) in one pass; dense [groups * n, C]
+    tensors of one dtype, row_scale f32 [groups] (timm drop_path's mask / keep per image)."""
+    _need_gpu(x, branch, row_scale, gamma, beta, out_sum, out_norm)
+    c = x.shape[-1]
+    rows = x.numel() // c
+    ts = (x, branch, out_sum, out_norm)
+    if not all(t.is_contiguous() and t.shape == x.shape and t.dtype == x.dtype for t in ts) or row_scale.dtype != torch.float32 \
+            or not row_scale.is_contiguous() or rows % row_scale.numel() or gamma.dtype != torch.float32 or beta.dtype != torch.float32:
+        raise _lib.CavpError("layernorm_residual: dense tensors of one shape / dtype, f32 gamma / beta and an f32 factor per row group")
+    st = _lib.load().cavp_layernorm_residual(dtype_code(x.dtype), _ptr(x), _ptr(branch), _ptr(row_scale), rows // row_scale.numel(),
+                                             _ptr(gamma), _ptr(beta), _ptr(out_sum), _ptr(out_norm), rows, c, c, c, C.c_float(eps),
+                                             C.c_void_p(_stream()))
+    _lib.check(st, "cavp_layernorm_residual")
+    return out_sum, out_norm
+
+
 def attn_gate(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Tensor, attn: torch.Tensor, heads: int,
               scale: float) -> torch.Tensor:
     """q may hold fewer batch items than out / k / v (a divisor): batch item b then reads q[b % q_batch]."""

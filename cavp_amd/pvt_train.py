@@ -134,10 +134,17 @@ def _dwconv_gelu(tp: TrainPass, x: V, conv, w9c: torch.Tensor, B: int, H: int, W
     return y
 
 
-def _residual_drop_path(tp: TrainPass, x: V, branch: V, scale: torch.Tensor) -> V:
-    """x + DropPath(branch) with the per-sample factor `scale` = mask / keep_prob (f32 [B])."""
+def _residual_drop_path(tp: TrainPass, x: V, branch: V, scale: torch.Tensor, ln=None):
+    """x + DropPath(branch) with the per-sample factor `scale` = mask / keep_prob (f32 [B]).  With `ln` (the LayerNorm every
+    residual output of a PVT block feeds next - norm2, the next block's norm1 or the stage norm) the sum and its normalisation leave
+    ONE kernel (cavp_layernorm_residual) and (sum, normalised) are returned."""
     y = V(tp.empty(x.t.shape))
-    T.row_scale_add(x.t, branch.t, scale, y.t)
+    nrm = None
+    if ln is None:
+        T.row_scale_add(x.t, branch.t, scale, y.t)
+    else:
+        nrm = V(tp.empty(x.t.shape))
+        ops.layernorm_residual(x.t, branch.t, scale, ln.weight.detach(), ln.bias.detach(), y.t, nrm.t, ln.eps)
     y.dp_scale = scale
 
     def bwd():
@@ -150,7 +157,9 @@ def _residual_drop_path(tp: TrainPass, x: V, branch: V, scale: torch.Tensor) -> 
         tp.acc_add(branch, gb)
         tp.acc_add(x, y.g)
     tp.tape.append(bwd)
-    return y
+    if ln is None:
+        return y
+    return y, tp.layernorm(y, ln, _done=nrm)
 
 
 def draw_drop_path_scales(bb, B: int, device, _refresh_only: bool = False) -> List[Optional[torch.Tensor]]:
@@ -246,10 +255,20 @@ def pvt_train_forward(tp: TrainPass, bb, image: torch.Tensor, drop_scales: Optio
         _, H, W, C = t.t.shape
         N = H * W
         x = tp.layernorm(tp.reshape(t, (B, N, C)), pe.norm)
+        pend = None   # (x, branch, factor): the stream is x + DropPath(branch), materialised by the NEXT norm's kernel
+
+        def norm_of(ln):
+            nonlocal x, pend
+            if pend is None:
+                return tp.layernorm(x, ln)
+            x, nrm = _residual_drop_path(tp, pend[0], pend[1], pend[2], ln=ln)
+            pend = None
+            return nrm
+
         for j, blk in enumerate(getattr(bb, f"block{i + 1}")):
             k = f"pvt.b{i}.{j}."
             at = blk.attn
-            n1 = tp.layernorm(x, blk.norm1)
+            n1 = norm_of(blk.norm1)
             q = tp.conv(n1, k + "q")
             if at.sr_ratio > 1:
                 sr = at.sr_ratio
@@ -265,15 +284,15 @@ def pvt_train_forward(tp: TrainPass, bb, image: torch.Tensor, drop_scales: Optio
             if s_att is None:
                 x = tp.conv(o, k + "proj", residual=x)
             else:
-                x = _residual_drop_path(tp, x, tp.conv(o, k + "proj"), s_att)
-            n2 = tp.layernorm(x, blk.norm2)
+                pend = (x, tp.conv(o, k + "proj"), s_att)
+            n2 = norm_of(blk.norm2)
             h1 = tp.conv(n2, k + "fc1")
             h2 = _dwconv_gelu(tp, h1, blk.mlp.dwconv.dwconv, dw_packed[k], B, H, W)
             if s_mlp is None:
                 x = tp.conv(h2, k + "fc2", residual=x)
             else:
-                x = _residual_drop_path(tp, x, tp.conv(h2, k + "fc2"), s_mlp)
-        x = tp.layernorm(x, getattr(bb, f"norm{i + 1}"))
+                pend = (x, tp.conv(h2, k + "fc2"), s_mlp)
+        x = norm_of(getattr(bb, f"norm{i + 1}"))
         x4 = tp.reshape(x, (B, H, W, C))
         feats.append(x4)
     return feats

@@ -678,9 +678,11 @@ class TrainPass:
         self.tape.append(bwd)
         return out
 
-    def layernorm(self, x: V, ln) -> V:
-        y = V(self.empty(x.t.shape, x.t.dtype))
-        ops.layernorm(x.t, ln.weight.detach(), ln.bias.detach(), y.t, ln.eps)
+    def layernorm(self, x: V, ln, _done: Optional[V] = None) -> V:
+        """_done: the normalised tensor when a fused kernel already produced it (pvt_train: residual + DropPath + LayerNorm)."""
+        y = _done if _done is not None else V(self.empty(x.t.shape, x.t.dtype))
+        if _done is None:
+            ops.layernorm(x.t, ln.weight.detach(), ln.bias.detach(), y.t, ln.eps)
 
         def bwd():
             if y.g is None:

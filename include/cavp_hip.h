@@ -148,6 +148,12 @@ int cavp_bilinear_nhwc_to_nchw(int32_t dtype, const void* x, float* y_nchw, int3
 /* nn.LayerNorm(C, eps) over the last dim of [rows][C] (attn.py:130,136,229 -> :154-155,149,242). */
 int cavp_layernorm(int32_t dtype, const void* x, const float* gamma, const float* beta, void* y, int32_t rows,
                    int32_t C, int32_t ldx, int32_t ldy, float eps, void* stream);
+/* residual + DropPath + LayerNorm of a transformer block's stream in one pass (pvt.py:252-256 with timm's drop_path):
+ * y_sum = x + row_scale[row / rows_per_group] * branch (dense [rows][C], x's dtype), y = LayerNorm(y_sum).  branch = NULL: plain
+ * cavp_layernorm. */
+int cavp_layernorm_residual(int32_t dtype, const void* x, const void* branch, const float* row_scale, int32_t rows_per_group,
+                            const float* gamma, const float* beta, void* y_sum, void* y, int32_t rows, int32_t C, int32_t ldx,
+                            int32_t ldy, float eps, void* stream);
 
 /* Sigmoid-gated single-key attention (attn.py:73-106 with N_kv == 1):
  *   s[b,h,t] = sigmoid(scale * <q[b,t,h,:], k[b,h,:]>);  o[b,t,h,:] = s[b,h,t] * v[b,h,:];  attn[b,h,t] = s.

@@ -145,6 +145,12 @@ def test_space_to_depth_and_row_scale(dtype):
     assert _rel(out.float().cpu(), ref2) <= (1e-6 if dtype == torch.float32 else 4e-3)
     gb = T.row_scale_add(None, br, sc, torch.empty_like(br))
     assert float(gb[0].float().abs().max()) == 0.0 and _rel(gb[1].float().cpu(), 1.25 * br[1].float().cpu()) <= 4e-3
+    # residual + DropPath + LayerNorm in one kernel == the two kernels it replaces, bit for bit
+    from cavp_amd import ops
+    gam, bet = (torch.rand(C, device=DEV) + 0.5), torch.randn(C, device=DEV) * 0.1
+    two = ops.layernorm(out, gam, bet, torch.empty_like(out), 1e-6)
+    s1, n1 = ops.layernorm_residual(xx, br, sc, gam, bet, torch.empty_like(br), torch.empty_like(br), 1e-6)
+    assert torch.equal(s1, out) and torch.equal(n1, two)
 
 
 def _build_pvt(C, B, dtype=torch.float32):
