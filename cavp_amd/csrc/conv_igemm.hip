@@ -812,9 +812,10 @@ Plan make_plan(const cavp_conv_desc* d_in, bool allow_big = true) {
   // tiles than that the 2-stage tile at four workgroups per CU is faster.
   // (not for very long K loops: the ASPP 3x3 2048 -> 256 convs, 288 K tiles, are faster split over K on 128x128 tiles:
   // 76 vs 100 us)
-  // (Extending this to short K loops - 4 .. 15 K tiles: the PVTv2 kv / stage-4 linears at B = 8 - bought 0.15 ms per config-#4 step but
-  // two end-to-end parity tests moved past their bars with it (test_stage_methods_are_differentiable 1.6e-3 vs 2e-4 in f32) although
-  // the tile agrees bit for bit with the 2-stage one on single layers (tools/probes/ring_check*.py): not understood, not kept.)
+  // (Extending this to short K loops - 4 .. 15 K tiles: the PVTv2 kv / stage-4 linears at B = 8 - bought 0.15 ms per config-#4 step.
+  // Not kept: it changes the summation order of the token linears (no split-K), and two end-to-end parity tests sit on inputs
+  // where a 1e-6 change of a pre-activation flips ONE ReLU mask element under a large gradient (tools/probes/stage_grad_diff.py:
+  // 1.6e-3 of the gradient norm from that single element; the tile itself agrees bit for bit with the 2-stage one).)
   if (want_tile == 0 && d->splitk <= 0 && p.iters >= 16 && p.iters <= 96 && (long long)cdiv(p.Cout, 64) * cdiv(p.M, 64) <= 512) {
     for (int i = 0; i < kNumTiles; ++i)
       if (kTiles[i].id == 11) { best = i; best_sk = 1; }
