@@ -62,6 +62,10 @@ def parse():
     ap.add_argument("--no-side-stream", action="store_true", help="A/B: the audio encoder on the main stream instead of a second one")
     ap.add_argument("--no-group-wgrad", action="store_true", help="A/B: one weight-gradient launch (+ slab reduce) per layer instead of grouped launches")
     ap.add_argument("--no-tail-split", action="store_true", help="A/B: never split a 256x256-tile launch with a nearly empty last round")
+    ap.add_argument("--trainer-loop", action="store_true",
+                    help="the reference trainer's call sequence instead of the fused step: out = model(image, audio) -> torch "
+                         "cross-entropy on out[:B] + out[B:]*0 -> loss.backward() (trainer_cavp_vpo_mono.py:166-193); with the graph "
+                         "on (default) through CAVP.enable_graphed_autograd(), with --no-graph through the eager autograd node")
     ap.add_argument("--no-f32", action="store_true", help="skip the secondary f32 (parity path) training-step measurement")
     ap.add_argument("--cpu-sample-batch", type=int, default=8)
     return ap.parse_args()
@@ -225,14 +229,14 @@ class KernelTimer:
         return sum(max(fl / peak_flops, nb / peak_bytes) for name, _, _, fl, nb, _ in self.records if name in names) * 1e3
 
 
-def measure_roofline(model, run_step, image, dtype_name, reps=3, config="c1p", live_pmc=False):
+def measure_roofline(model, run_step, image, dtype_name, reps=3, config="c1p", live_pmc=False, trainer_loop=False):
     from cavp_amd import ops, train_ops
     import cavp_amd.train as _tr
     kt = KernelTimer().wrap(ops, train_ops)
     side_was = _tr._SIDE_STREAM
     _tr._SIDE_STREAM = False   # per-launch durations are taken with one stream: a co-running branch would inflate them
     try:
-        with torch.set_grad_enabled(config == "c5"):   # (c5 back-propagates through torch.autograd; the fused steps need none)
+        with torch.set_grad_enabled(config == "c5" or trainer_loop):   # (these back-propagate through torch.autograd; the fused steps need none)
             for _ in range(reps):
                 run_step()
         agg = kt.summary()
@@ -525,6 +529,21 @@ def main():
             loss.backward()
             return loss
         run_step_local = run_step
+    elif train and a.trainer_loop:
+        import torch.nn.functional as F
+        model.train()
+        a.trainer_graphed = not a.no_graph
+        if a.trainer_graphed:
+            model.enable_graphed_autograd()
+        a.no_graph = True          # (no capture_train_step below: the model replays its own graphs inside the autograd node)
+
+        def run_step():
+            model.zero_grad(set_to_none=True)
+            out, _, _ = model(image, audio, None, False)
+            loss = F.cross_entropy(out[:B] + out[B:] * 0.0, label, ignore_index=255)
+            loss.backward()
+            return loss
+        run_step_local = run_step
     elif train:
         model.train()
 
@@ -538,7 +557,7 @@ def main():
             return model(image, audio, eval_mode=True)
         run_step_local = run_step
 
-    with torch.set_grad_enabled(a.config == "c5"):
+    with torch.set_grad_enabled(a.config == "c5" or a.trainer_loop):
         run_step()      # eager warm-up: packs weights, sizes the workspace
         torch.cuda.synchronize()
         if train and not a.no_graph:
@@ -614,10 +633,17 @@ def main():
                        "global_batch": world * B, "per_gpu_batch": B, "parallelism": f"dp{world}",
                        "ranks": dist.get_world_size() if world > 1 else 1,
                        "collective_backend": (dist.get_backend() if world > 1 else None),
-                       "launch": "eager" if a.no_graph else "hipGraph replay", "deterministic": bool(a.deterministic)},
+                       "launch": ("trainer loop: autograd node over two hipGraph replays (enable_graphed_autograd) + torch loss" if getattr(a, "trainer_graphed", False)
+                                  else "trainer loop: eager autograd node + torch loss" if a.trainer_loop
+                                  else "eager" if a.no_graph else "hipGraph replay"), "deterministic": bool(a.deterministic)},
         }
+        if not a.no_roofline and getattr(a, "trainer_graphed", False):
+            print("[bench] --trainer-loop on graphs: no per-launch roofline (the launches are inside the replays); use --no-graph for it",
+                  file=sys.stderr)
+            a.no_roofline = True
         if not a.no_roofline:
-            roof = measure_roofline(model, run_step_local, image, a.dtype, config=a.config, live_pmc=a.pmc)
+            roof = measure_roofline(model, run_step_local, image, a.dtype, config=a.config, live_pmc=a.pmc,
+                                    trainer_loop=a.trainer_loop)
             step_gflop, meas_bytes = roof.pop("_step_gflop"), roof.pop("_measured_step_bytes")
             ms_step = elapsed / a.steps * 1e3
             if a.config in ("c1p", "c1") and a.dtype == "bf16":

@@ -729,9 +729,28 @@ class CAVP(nn.Module):
             raise CavpError("CAVP (MI355X path) needs inputs on a HIP device: there is no CPU fallback")
         from .train import CAVPTrainFunction
         params = [p for p in self.parameters() if p.requires_grad] if want_grad else []
+        graphed = getattr(self, "_graphed_autograd", None)
+        if graphed is not None and want_grad and bn_train and not audio_func and audio is not None:
+            # opt-in (enable_graphed_autograd): forward and backward as two hipGraph replays behind one autograd node
+            from .train import GraphedTrainFunction, GraphedTrainStep
+            step = next((g for g in graphed if g.matches(image, audio)), None)
+            if step is None and len(graphed) < 4:
+                step = GraphedTrainStep(self, image, audio)
+                graphed.append(step)
+            if step is not None:
+                out_pred, out_fusion, visual, audio_f, attn_v = GraphedTrainFunction.apply(step, image, audio, *params)
+                return out_pred, out_fusion, {"audio": audio_f, "visual": visual, "attn_v": attn_v}
         self._train_shuffle = shuffle
         out_pred, out_fusion, visual, audio_f, attn_v = CAVPTrainFunction.apply(self, image, audio, *params)
         return out_pred, out_fusion, {"audio": audio_f, "visual": visual, "attn_v": attn_v}
+
+    def enable_graphed_autograd(self, on: bool = True) -> None:
+        """Opt-in: `model(image, audio)` in training mode captures forward and backward as two hipGraphs per input shape (up to 4
+        shapes) and replays them behind one autograd node (cavp_amd/train.py::GraphedTrainStep) - the reference's trainer loop
+        (`out = model(...)`, torch loss, `loss.backward()`, torch optimisers) at graph speed.  The returned tensors are static
+        buffers, overwritten by the next forward.  Changing the compute dtype, the set of trainable parameters or train / eval
+        mode of the BatchNorm layers needs a fresh `enable_graphed_autograd()`."""
+        self.__dict__["_graphed_autograd"] = [] if on else None
 
     def params_without_grad(self):
         """Parameters the forward never touches (present in checkpoints only): torch leaves their .grad None."""

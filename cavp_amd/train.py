@@ -1232,3 +1232,121 @@ class CAVPStageFunction(torch.autograd.Function):
             grads.append(None if g is None else g.view(p.shape))
         ctx.tp = None
         return (None, None, None, None) + tuple(gin) + tuple(grads)
+
+
+class GraphedTrainStep:
+    """forward_train and its backward as two hipGraphs behind ONE autograd node: the reference's training call sequence
+    (`out, fus, pack = model(image, audio)`; a loss on `out` / `fus` built with torch; `loss.backward()`;
+    trainer_cavp_vpo_mono.py:166-193) at graph-replay speed instead of ~600 eager launches per direction.
+
+    Graph A = weight re-pack + forward on the tape + the f32 / NCHW output conversions, reading the static `image` / `audio`
+    buffers; graph B (same memory pool) = gradient layout conversion + the whole backward, reading static `d_pred` / `d_fusion`
+    buffers and leaving every parameter gradient in a flat arena.  torch.autograd runs whatever the caller computes in between.
+    The outputs are static buffers too: consume them (and call backward) before the next forward - the usual contract of graphed
+    callables.  Captured per (image shape, audio shape) by `CAVP.enable_graphed_autograd`; falls back to the eager node for any
+    other shape, for `audio_func=True` and without gradients."""
+
+    def __init__(self, model, image: torch.Tensor, audio: torch.Tensor):
+        from .cavp_model import _GRAD_OVERWRITE_MIN
+        self.m = model
+        self.key = (tuple(image.shape), tuple(audio.shape), model.compute_dtype)
+        self.image, self.audio = image.detach().clone().contiguous(), audio.detach().clone().contiguous()
+        dev = image.device
+        big = {id(mm.weight) for mm in model.modules() if isinstance(mm, (nn.Linear, nn.Conv2d))
+               and mm.weight.numel() >= _GRAD_OVERWRITE_MIN} if _GRAD_OVERWRITE_MIN > 0 else set()
+        self.arena = GradArena(list(model.parameters()), dev, late_ids=model._late_grad_ids(), no_zero_ids=big)
+        B2, C = audio.shape[0] if audio.shape[0] == 2 * image.shape[0] else 2 * image.shape[0], model.num_classes
+        self.d_pred = torch.zeros((B2, C) + tuple(image.shape[-2:]), dtype=torch.float32, device=dev)
+        self.d_fusion = None      # allocated by the first forward (needs the fusion map's size)
+        self._state = None
+        # the warm-up passes below run the real kernels: BatchNorm running statistics / counters are put back afterwards
+        saved = [(b, b.detach().clone()) for b in model.buffers()]
+        with torch.no_grad():
+            for _ in range(2):    # warm-up: workspaces, allocator, lazily configured kernels - on a side stream like torch's recipe
+                side = torch.cuda.Stream()
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    st = self._forward_body()
+                    if self.d_fusion is None:
+                        self.d_fusion = torch.zeros(st["out_fusion"].shape, dtype=torch.float32, device=dev).contiguous()
+                    self._backward_body(st)
+                torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            self.gA, self.gB = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+            cap = torch.cuda.Stream()
+            cap.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(cap):
+                self.gA.capture_begin(capture_error_mode="thread_local")
+                st = self._forward_body()
+                self.gA.capture_end()
+                self.gB.capture_begin(pool=self.gA.pool(), capture_error_mode="thread_local")
+                self._backward_body(st)
+                self.gB.capture_end()
+            torch.cuda.current_stream().wait_stream(cap)
+            for b, c in saved:
+                b.copy_(c)
+        self.outs = (st["out_pred"], st["out_fusion"], st["visual"], st["audio_f"], st["attn_v"])
+        self.touched = st["touched"]
+        model.params_changed()
+
+    def _forward_body(self):
+        m = self.m
+        self.arena.zero()
+        tp = TrainPass(m, m.compute_dtype, arena=self.arena)
+        lo, fusion, fea_v_proj, fea_a, attn = run_train_forward(m, self.image, self.audio, tp)
+        B2, C = lo.t.shape[0], m.num_classes
+        out_pred = torch.empty((B2, C) + tuple(self.image.shape[-2:]), dtype=torch.float32, device=self.image.device)
+        ops.bilinear_to_nchw(lo.t[..., :C], out_pred, align_corners=False)
+        f32 = m._as_f32
+        out_fusion = f32(fusion.t).permute(0, 3, 1, 2)
+        vis = f32(fea_v_proj.t).view((-1,) + tuple(fusion.t.shape[1:]))
+        visual = torch.cat((vis, vis), dim=0).permute(0, 3, 1, 2)
+        return dict(tp=tp, lo=lo, fusion=fusion, out_pred=out_pred, out_fusion=out_fusion, visual=visual,
+                    audio_f=f32(fea_a.t)[:, :, None, None], attn_v=attn.t.unsqueeze(-1), touched=None)
+
+    def _backward_body(self, st):
+        tp, lo, fusion = st["tp"], st["lo"], st["fusion"]
+        g = torch.zeros(lo.t.shape, dtype=lo.t.dtype, device=lo.t.device)
+        T.bilinear_bwd_from_nchw(self.d_pred, g[..., :self.d_pred.shape[1]], n_valid=lo.t.shape[0], align_corners=False)
+        lo.set_g(g)
+        gf = self.d_fusion.permute(0, 2, 3, 1).contiguous()
+        fusion.set_g(gf if fusion.t.dtype == torch.float32 else ops.cast(gf, tp.empty(gf.shape, fusion.t.dtype)))
+        tp.backward()
+        tp.finish_padded()
+        st["touched"] = set(tp.touched)
+
+    def matches(self, image, audio) -> bool:
+        return (tuple(image.shape), tuple(audio.shape), self.m.compute_dtype) == self.key and image.device == self.image.device
+
+
+class GraphedTrainFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, step: GraphedTrainStep, image, audio, *params):
+        m = step.m
+        step.image.copy_(image)
+        step.audio.copy_(audio)
+        if m.seg_model == "PVT" and getattr(m, "_pvt_drop_scales", None) is None:
+            from .pvt_train import refresh_drop_path
+            refresh_drop_path(m.backbone, image.shape[0], image.device)   # the graph reads the persistent mask buffer
+        step.gA.replay()
+        m.params_changed()      # the graph updated the running statistics through raw pointers
+        ctx.step, ctx.params = step, params
+        # fresh tensor objects over the static buffers every call (an output object must not carry the previous call's grad_fn)
+        out_pred, out_fusion, visual, audio_f, attn_v = (o.detach() for o in step.outs)
+        ctx.mark_non_differentiable(visual, audio_f, attn_v)
+        return out_pred, out_fusion, visual, audio_f, attn_v
+
+    @staticmethod
+    def backward(ctx, d_pred, d_fusion, *_unused):
+        step = ctx.step
+        if d_pred is not None:
+            step.d_pred.copy_(d_pred)
+        else:
+            step.d_pred.zero_()
+        if d_fusion is not None:
+            step.d_fusion.copy_(d_fusion)
+        else:
+            step.d_fusion.zero_()
+        step.gB.replay()
+        grads = tuple(step.arena.views[id(p)] if id(p) in step.touched else None for p in ctx.params)
+        return (None, None, None) + grads

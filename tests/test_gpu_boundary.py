@@ -110,6 +110,41 @@ def test_stage_methods_are_differentiable(deterministic):
     assert rel(f2, rf) <= 1e-4 and not f2.requires_grad
 
 
+def test_graphed_autograd_matches_the_eager_node(deterministic):
+    """enable_graphed_autograd(): `model(image, audio)` + torch loss + `loss.backward()` replays two hipGraphs behind one autograd
+    node; outputs, parameter gradients and running statistics equal the eager node's, for the captured batch and for new
+    inputs copied into the static buffers by the next call."""
+    B = CFG["B"]
+    crit = torch.nn.CrossEntropyLoss(ignore_index=255)
+    batches = [tuple(t.to(DEV) for t in synth_inputs(B, CFG["hw"], audio_batch=2 * B, num_classes=CFG["C"], seed=s)) for s in (21, 22, 23)]
+
+    def run(graphed):
+        m, _ = _model(train=True)
+        if graphed:
+            m.enable_graphed_autograd()
+        rec = []
+        for image, audio, label in batches:
+            m.zero_grad(set_to_none=True)
+            out, fus, pack = m(image, audio, None, False)
+            assert out.requires_grad and fus.requires_grad and not pack["attn_v"].requires_grad
+            loss = crit(out[:B] + out[B:] * 0.0, label) + 0.01 * fus.square().mean()
+            loss.backward()
+            rec.append((out.detach().clone(), fus.detach().clone(), {k: p.grad.detach().clone() for k, p in m.named_parameters() if p.grad is not None},
+                        m.backbone.backbone.bn1.running_mean.clone(), int(m.backbone.backbone.bn1.num_batches_tracked)))
+        return rec
+    eager, graph = run(False), run(True)
+    for (o1, f1, g1, rm1, n1), (o2, f2, g2, rm2, n2) in zip(eager, graph):
+        assert float((o1 - o2).abs().max()) <= 1e-5 * max(1.0, float(o1.abs().max()))
+        assert float((f1 - f2).abs().max()) <= 1e-5 * max(1.0, float(f1.abs().max()))
+        assert g1.keys() == g2.keys() and n1 == n2
+        assert float((rm1 - rm2).abs().max()) <= 1e-6
+        for k in g1:
+            a, b = g1[k].double().flatten(), g2[k].double().flatten()
+            if float(a.norm()) == 0.0:
+                continue
+            assert float((a - b).norm() / a.norm()) <= 1e-4, (k, float((a - b).norm() / a.norm()))
+
+
 def test_forward_audio_and_audio_func_path(deterministic):
     """forward_audio: [features | features[shuffle_idx]] + SoundBank update under ow_flag; forward_train(audio_func=True) on B
     clips == forward_train on the explicitly concatenated 2B clips (forward and every parameter gradient)."""
