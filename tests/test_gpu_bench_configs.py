@@ -45,3 +45,11 @@ def test_deterministic_line_and_cpu_thread_sweep():
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["value"] > 0 and str(cb["cores"]) in cb["thread_sweep_frames_per_s"]
     assert cb["value"] >= 0.5 * max(cb["thread_sweep_frames_per_s"].values())   # the reported figure is the sweep's best count, re-timed
+
+
+def test_trainer_loop_lines():
+    """--trainer-loop: the reference trainer's call sequence through the graphed autograd node and through the eager one."""
+    g = _bench("--trainer-loop", "--batch", "4", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-f32")
+    assert g["value"] > 0 and "hipGraph" in g["config"]["launch"] and "roofline" not in g or g.get("roofline") is None
+    e = _bench("--trainer-loop", "--no-graph", "--batch", "4", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-f32")
+    assert e["value"] > 0 and "eager autograd node" in e["config"]["launch"] and e["roofline"]["frac"] > 0
