@@ -735,8 +735,16 @@ class CAVP(nn.Module):
             from .train import GraphedTrainFunction, GraphedTrainStep
             step = next((g for g in graphed if g.matches(image, audio)), None)
             if step is None and len(graphed) < 4:
-                step = GraphedTrainStep(self, image, audio)
-                graphed.append(step)
+                try:
+                    step = GraphedTrainStep(self, image, audio)
+                    graphed.append(step)
+                except Exception as ex:  # noqa: BLE001 - a failed capture must not cost the training run: eager node from here on
+                    import warnings
+                    warnings.warn(f"enable_graphed_autograd: hipGraph capture failed ({type(ex).__name__}: {ex}); using the eager "
+                                  f"autograd node", RuntimeWarning)
+                    torch.cuda.synchronize()
+                    self.__dict__["_graphed_autograd"] = None
+                    step = None
             if step is not None:
                 out_pred, out_fusion, visual, audio_f, attn_v = GraphedTrainFunction.apply(step, image, audio, *params)
                 return out_pred, out_fusion, {"audio": audio_f, "visual": visual, "attn_v": attn_v}
