@@ -1268,7 +1268,9 @@ class GraphedTrainStep:
                 with torch.cuda.stream(side):
                     st = self._forward_body()
                     if self.d_fusion is None:
-                        self.d_fusion = torch.zeros(st["out_fusion"].shape, dtype=torch.float32, device=dev).contiguous()
+                        # NHWC memory behind an NCHW-shaped view, like out_fusion itself: the layout pass of the backward is then a no-op
+                        n_, c_, h_, w_ = st["out_fusion"].shape
+                        self.d_fusion = torch.zeros((n_, h_, w_, c_), dtype=torch.float32, device=dev).permute(0, 3, 1, 2)
                     self._backward_body(st)
                 torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
