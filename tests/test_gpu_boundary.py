@@ -143,6 +143,28 @@ def test_graphed_autograd_matches_the_eager_node(deterministic):
             if float(a.norm()) == 0.0:
                 continue
             assert float((a - b).norm() / a.norm()) <= 1e-4, (k, float((a - b).norm() / a.norm()))
+    # gradient accumulation over two backward passes without zero_grad: p.grad (adopted from the graph's arena) must not be
+    # overwritten by the second replay
+    m, _ = _model(train=True)
+    m.enable_graphed_autograd()
+    tot = {}
+    for image, audio, label in batches[:2]:
+        m.zero_grad(set_to_none=True)
+        out, fus, _ = m(image, audio, None, False)
+        crit(out[:B] + out[B:] * 0.0, label).backward()
+        for k, p in m.named_parameters():
+            if p.grad is not None:
+                tot[k] = tot.get(k, 0) + p.grad.detach().clone()
+    # (BatchNorm statistics moved with the two passes above: a fresh model replays the same two batches for the accumulated run)
+    m2, _ = _model(train=True)
+    m2.enable_graphed_autograd()
+    m2.zero_grad(set_to_none=True)
+    for image, audio, label in batches[:2]:
+        out, fus, _ = m2(image, audio, None, False)
+        crit(out[:B] + out[B:] * 0.0, label).backward()
+    for k, p in m2.named_parameters():
+        if p.grad is not None and float(tot[k].norm()) > 0:
+            assert float((p.grad - tot[k]).norm() / tot[k].norm()) <= 1e-4, k
 
 
 def test_forward_audio_and_audio_func_path(deterministic):
