@@ -1101,6 +1101,7 @@ class CAVPTrainFunction(torch.autograd.Function):
             visual = torch.cat((vis, vis), dim=0).permute(0, 3, 1, 2)   # cavp_model.py:181: the two halves are identical
             audio_f = f32(fea_a.t)[:, :, None, None]
             attn_v = attn.t.unsqueeze(-1)
+        ctx.set_materialize_grads(False)   # an unused output (out_fusion under a CE-only loss) arrives as None, not as 244 MB of zeros
         ctx.tp, ctx.lo, ctx.fusion, ctx.params, ctx.hw = tp, lo, fusion, params, tuple(image.shape[-2:])
         ctx.model_ref = model
         ctx.mark_non_differentiable(visual, audio_f, attn_v)
@@ -1181,6 +1182,7 @@ class CAVPStageFunction(torch.autograd.Function):
                 torch._foreach_add_(tp._nbt, 1)
                 tp._nbt = []
         model.params_changed()   # batch-statistics BatchNorm wrote running_mean / running_var through raw pointers
+        ctx.set_materialize_grads(False)
         ctx.tp, ctx.kind, ctx.params, ctx.n_in, ctx.in_meta = tp, kind, params, n_in, [(t.shape, t.dtype) for t in ins]
         return outs if len(outs) > 1 else outs[0]
 
@@ -1287,6 +1289,7 @@ class GraphedTrainStep:
             torch.cuda.current_stream().wait_stream(cap)
             for b, c in saved:
                 b.copy_(c)
+        self._zeroed = {"d_pred", "d_fusion"}    # static gradient buffers that currently hold zeros
         self.outs = (st["out_pred"], st["out_fusion"], st["visual"], st["audio_f"], st["attn_v"])
         self.touched = st["touched"]
         model.params_changed()
@@ -1342,6 +1345,7 @@ class GraphedTrainFunction(torch.autograd.Function):
         step.gA.replay()
         m.params_changed()      # the graph updated the running statistics through raw pointers
         ctx.step, ctx.params = step, params
+        ctx.set_materialize_grads(False)   # an output the loss does not use arrives as None in backward, not as a 244 MB zero tensor
         # fresh tensor objects over the static buffers every call (an output object must not carry the previous call's grad_fn)
         out_pred, out_fusion, visual, audio_f, attn_v = (o.detach() for o in step.outs)
         ctx.mark_non_differentiable(visual, audio_f, attn_v)
@@ -1350,14 +1354,16 @@ class GraphedTrainFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, d_pred, d_fusion, *_unused):
         step = ctx.step
-        if d_pred is not None:
-            step.d_pred.copy_(d_pred)
-        else:
-            step.d_pred.zero_()
-        if d_fusion is not None:
-            step.d_fusion.copy_(d_fusion)
-        else:
-            step.d_fusion.zero_()
+        # static gradient inputs of graph B; a buffer that is already zero is not cleared again (the trainers' CE-only loss never
+        # touches out_fusion: materialised zeros copied into the NHWC buffer were a 320 us strided copy per step)
+        for name, g in (("d_pred", d_pred), ("d_fusion", d_fusion)):
+            buf = getattr(step, name)
+            if g is not None:
+                buf.copy_(g)
+                step._zeroed.discard(name)
+            elif name not in step._zeroed:
+                buf.zero_()
+                step._zeroed.add(name)
         # The gradients are handed over as FRESH views of the arena: autograd's AccumulateGrad then adopts them as p.grad instead of
         # cloning ~230 tensors (0.8 ms of copy launches per step).  p.grad therefore aliases the arena until the caller drops it
         # (zero_grad(set_to_none=True), the default): a p.grad that still aliases it when the next
