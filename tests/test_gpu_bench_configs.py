@@ -34,7 +34,9 @@ def test_config_c1_train_line():
 def test_config_c5_clip_step_line():
     d = _bench("--config", "c5", "--batch", "10", "--steps", "2", "--warmup", "1", "--no-cpu-baseline")
     assert d["value"] > 0 and "ContrastLoss" in d["config"]["workload"] and "2 clips x 5 frames" in d["config"]["workload"]
-    assert d["config"]["launch"] == "eager"
+    assert "hipGraph" in d["config"]["launch"]          # the model's part on the graphed autograd node by default
+    e = _bench("--config", "c5", "--batch", "10", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-graph")
+    assert e["value"] > 0 and "eager autograd node" in e["config"]["launch"]
     with pytest.raises(AssertionError):
         _bench("--config", "c5", "--batch", "8", "--steps", "1", "--warmup", "0", "--no-cpu-baseline")   # not a multiple of 5 frames
 
