@@ -57,6 +57,9 @@ def parse():
                     help="force the two-graph replay of the data-parallel path (cut where the early gradients are final) on one GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--grad-allreduce", choices=["f32", "bf16"], default="f32",
+                    help="wire format of the data-parallel gradient all-reduce (--gpus > 1): f32 = the reference's DDP (479 MB per step), "
+                         "bf16 = cast / sum / cast back, 240 MB per step on the xGMI links (cavp_amd.train.set_grad_allreduce_dtype)")
     ap.add_argument("--deterministic", action="store_true", help="opt-in bit-reproducible reductions (cavp_set_deterministic)")
     ap.add_argument("--no-token-fusion", action="store_true", help="A/B: GELU as a separate pass, duplicated token tensors copied")
     ap.add_argument("--no-side-stream", action="store_true", help="A/B: the audio encoder on the main stream instead of a second one")
@@ -108,18 +111,47 @@ FUSED_MIN_MB_PER_FRAME_BF16 = {"train": 147.4 * (57.8 / 39.41) * 3.0, "eval": 14
 # C1 (OS8, 22 classes): 221.9 MB per frame; its train-mode forward adds the same 18.39 GFLOP of 2B work
 # (audio, projector, fusion, head) to 82.75 GFLOP
 FUSED_MIN_MB_PER_FRAME_BF16_C1 = {"train": 221.9 * ((82.75 + 57.8 - 39.41) / 82.75) * 3.0, "eval": 221.9}
+# C4 (PVTv2-B5, 512 x 512, 71 classes): derived in round 4 by tools/byte_model.py - forward hooks on the REFERENCE model with the
+# survey's rule (every conv / linear / pool reads its input once and writes its output once, one extra read per residual join,
+# both interpolates in + out, weights once per batch); the same hooks give 71.98 M elements per frame for C1' against the
+# survey's 70.07 M (+2.7 %).  Eval forward 612.50 M elements per frame, train-mode forward (fusion block and head on 2B) 706.64 M,
+# weights 160.34 M elements per batch.
+C4_ELEMS_PER_FRAME = {"eval": 612.50e6, "train_forward": 706.64e6, "weights": 160.34e6}
+
+
+def fused_min_mb_per_frame_c4(mode, batch):
+    if mode == "eval":
+        return (C4_ELEMS_PER_FRAME["eval"] + C4_ELEMS_PER_FRAME["weights"] / batch) * 2 / 1e6
+    return (C4_ELEMS_PER_FRAME["train_forward"] + C4_ELEMS_PER_FRAME["weights"] / batch) * 2 * 3.0 / 1e6
 
 
 class KernelTimer:
     """HIP-event timing of every libcavp_hip launch on the launching (current) stream."""
 
+    # wrappers whose Python side marshals a job table before the launch (16 cavp_wgrad_job structs: ~0.3 ms of host time)
+    HEAVY_HOST = ("conv2d_wgrad_group",)
+
     def __init__(self):
         self.records = []
-        # an event pair with nothing between its records still reads a few microseconds apart: calibrate that once and
-        # subtract it, so that the per-launch durations agree with the rocprofv3 kernel trace (profiles/)
+        # Round 3's timer recorded e0, ran the Python wrapper, recorded e1: on a drained stream e0 completes at once and the
+        # wrapper's HOST time (argument marshalling, the launch itself) was counted as kernel time - the grouped weight gradients
+        # read 8.3 ms per step against 3.5 ms in the rocprofv3 trace.  Now a filler kernel (torch.cuda._sleep) is queued in front
+        # of e0: the device is still busy with it while the host marshals and launches, so e0 .. e1 brackets device time only.
+        # The filler is sized from a calibration of _sleep on this box; an event pair behind a filler with nothing between its
+        # records still reads a few microseconds apart: that is calibrated too and subtracted.
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda._sleep(1000)
+        torch.cuda.synchronize()
+        e0.record()
+        torch.cuda._sleep(2_000_000)
+        e1.record()
+        torch.cuda.synchronize()
+        cyc_per_us = 2_000_000 / max(e0.elapsed_time(e1) * 1e3, 1e-3)
+        self.filler_cycles = {False: int(60 * cyc_per_us), True: int(1500 * cyc_per_us)}   # ~60 us / ~1.5 ms of device time
         pairs = []
         for _ in range(64):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda._sleep(self.filler_cycles[False])
             e0.record()
             e1.record()
             pairs.append((e0, e1))
@@ -154,6 +186,7 @@ class KernelTimer:
     def _timed(self, name, fn):
         def run(*a, **k):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda._sleep(self.filler_cycles[name in self.HEAVY_HOST])   # keeps the device busy while the host marshals + launches
             e0.record()
             r = fn(*a, **k)
             e1.record()
@@ -232,9 +265,18 @@ class KernelTimer:
 def measure_roofline(model, run_step, image, dtype_name, reps=3, config="c1p", live_pmc=False, trainer_loop=False):
     from cavp_amd import ops, train_ops
     import cavp_amd.train as _tr
-    kt = KernelTimer().wrap(ops, train_ops)
     side_was = _tr._SIDE_STREAM
     _tr._SIDE_STREAM = False   # per-launch durations are taken with one stream: a co-running branch would inflate them
+    # the same eager step without the timer: the sum of the per-kernel times must fit into it (see `host_bound` below)
+    with torch.set_grad_enabled(config == "c5" or trainer_loop):
+        run_step()
+        torch.cuda.synchronize()
+        t_e = time.perf_counter()
+        for _ in range(reps):
+            run_step()
+        torch.cuda.synchronize()
+        eager_ms = (time.perf_counter() - t_e) / reps * 1e3
+    kt = KernelTimer().wrap(ops, train_ops)
     try:
         with torch.set_grad_enabled(config == "c5" or trainer_loop):   # (these back-propagate through torch.autograd; the fused steps need none)
             for _ in range(reps):
@@ -315,9 +357,31 @@ def measure_roofline(model, run_step, image, dtype_name, reps=3, config="c1p", l
         roof["wgrad_kernel"] = {"launches_per_step": wl // reps, "ms_per_step": round(wms, 3),
                                 "achieved_tflops": round(wf / reps / (wms * 1e-3) / 1e12, 2),
                                 "frac_of_mfma_peak": round(wf / reps / (wms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS[dtype_name], 4)}
+    # consistency of the event timing: everything the timer saw, summed, against the untimed eager step.  A sum above the
+    # step means host time leaked into the "kernel" intervals (round 3's driver line: 20.9 ms of kernels in a 15.06 ms step).
+    roof["kernel_sum_ms"] = round(total_ms, 3)
+    roof["eager_step_ms"] = round(eager_ms, 3)
+    roof["host_bound"] = bool(total_ms > 1.1 * eager_ms)
+    rp = rocprof_igemm_ms(config, mode_name, dtype_name)
+    if rp is not None:
+        roof["igemm_ms_rocprof"] = rp   # the committed rocprofv3 kernel trace of the same command, beside the event figure
     roof["_step_gflop"] = step_flops / 1e9   # consumed by main(): the whole-step object needs ms_per_step of the timed region
     roof["_measured_step_bytes"] = traffic["all_kernels_hbm_bytes_per_step"] if traffic and "all_kernels_hbm_bytes_per_step" in traffic else None
     return roof
+
+
+def rocprof_igemm_ms(config, mode_name, dtype_name):
+    """igemm kernel time per step from the committed rocprofv3 --kernel-trace --stats summary of this command
+    (profiles/rNN_rocprof_igemm_<cfg><mode>_<dtype>.json, written by tools/summarize_rocprof.py --igemm-json), newest round first."""
+    cname = "" if config == "c1p" else config + "_"
+    for r in ("r04_", "r03_"):
+        q = os.path.join(REPO, "profiles", f"{r}rocprof_igemm_{cname}{mode_name}_{dtype_name}.json")
+        if os.path.exists(q):
+            with open(q) as f:
+                j = json.load(f)
+            j["source"] = "profiles/" + os.path.basename(q)
+            return j
+    return None
 
 
 def _host_cpu():
@@ -478,6 +542,9 @@ def main():
     if a.no_tail_split:
         from cavp_amd import _lib as _cl0
         _cl0.load().cavp_set_tail_split(0)
+    if a.grad_allreduce == "bf16":
+        import cavp_amd.train as _tr
+        _tr.set_grad_allreduce_dtype(torch.bfloat16)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -608,6 +675,34 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    collective = None
+    if world > 1 and train and getattr(model, "_grad_arena", None) is not None:
+        # the two gradient collectives of a step on their own (nothing else on the device), max over ranks: what the step would
+        # pay if nothing overlapped - the timed region above hides the early piece behind the backbone's backward
+        from cavp_amd.train import _allreduce_range, grad_allreduce_dtype
+        arena = model._grad_arena
+        n, split = arena.flat.numel(), arena.split
+        keep = arena.flat.clone()
+        ms = {}
+        for name_, lo, hi in (("early", split, n), ("late", 0, split)):
+            for _ in range(2):
+                _allreduce_range(arena, lo, hi, False)
+            torch.cuda.synchronize()
+            dist.barrier()
+            t_c = time.perf_counter()
+            for _ in range(5):
+                _allreduce_range(arena, lo, hi, False)
+            torch.cuda.synchronize()
+            tt = torch.tensor([(time.perf_counter() - t_c) / 5 * 1e3], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            ms[name_] = float(tt.item())
+        arena.flat.copy_(keep)
+        wire_b = 2 if grad_allreduce_dtype() == torch.bfloat16 else 4
+        collective = {"rccl_ranks": dist.get_world_size(), "backend": dist.get_backend(), "wire_dtype": a.grad_allreduce,
+                      "early_piece_mb": round((n - split) * wire_b / 1e6, 1), "late_piece_mb": round(split * wire_b / 1e6, 1),
+                      "early_piece_ms": round(ms["early"], 3), "late_piece_ms": round(ms["late"], 3),
+                      "note": "each piece timed alone after the run (max over ranks, incl. the bf16 casts when wire_dtype is bf16); "
+                              "inside the step the early piece overlaps the backbone's backward"}
 
     if rank == 0:
         value = world * B * a.steps / elapsed
@@ -640,6 +735,8 @@ def main():
                                   else "trainer loop: eager autograd node + torch loss" if (a.trainer_loop or a.config == "c5")
                                   else "eager" if a.no_graph else "hipGraph replay"), "deterministic": bool(a.deterministic)},
         }
+        if collective is not None:
+            line["collective"] = collective
         if not a.no_roofline and getattr(a, "trainer_graphed", False):
             print("[bench] --trainer-loop on graphs: no per-launch roofline (the launches are inside the replays); use --no-graph for it",
                   file=sys.stderr)
@@ -649,10 +746,13 @@ def main():
                                     trainer_loop=a.trainer_loop)
             step_gflop, meas_bytes = roof.pop("_step_gflop"), roof.pop("_measured_step_bytes")
             ms_step = elapsed / a.steps * 1e3
-            if a.config in ("c1p", "c1") and a.dtype == "bf16":
+            if a.config in ("c1p", "c1", "c4") and a.dtype == "bf16":
                 # the WHOLE step against both roofs (north_star: "fraction of the conv-bound HBM roofline"): algorithmic FLOPs of
                 # every conv / linear launch incl. weight gradients, and the perfectly-fused byte minimum
-                min_gb = (FUSED_MIN_MB_PER_FRAME_BF16 if a.config == "c1p" else FUSED_MIN_MB_PER_FRAME_BF16_C1)["train" if train else "eval"] * B / 1e3
+                if a.config == "c4":
+                    min_gb = fused_min_mb_per_frame_c4("train" if train else "eval", B) * B / 1e3
+                else:
+                    min_gb = (FUSED_MIN_MB_PER_FRAME_BF16 if a.config == "c1p" else FUSED_MIN_MB_PER_FRAME_BF16_C1)["train" if train else "eval"] * B / 1e3
                 roof["step"] = {
                     "bound": "hbm", "ms_per_step": round(ms_step, 3),
                     "algorithmic_gflop": round(step_gflop, 1), "fused_min_gb": round(min_gb, 2),

@@ -42,13 +42,23 @@ def build(force: bool = False, verbose: bool = True, profile: bool = False) -> s
     objs = []
     os.makedirs(os.path.join(HERE, "build"), exist_ok=True)
     procs = []
+    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + [os.path.join(HERE, "..", "include", "cavp_hip.h")]
+    tag = os.path.join(HERE, "build", ".profile" if profile else ".product")   # which flavour the objects in build/ are
+    same_flavour = os.path.exists(tag)
+    for f in (".profile", ".product"):
+        if os.path.exists(os.path.join(HERE, "build", f)) and not f == os.path.basename(tag):
+            os.remove(os.path.join(HERE, "build", f))
+    open(tag, "w").close()
     for src in SOURCES:
         obj = os.path.join(HERE, "build", src.replace(".hip", ".o"))
+        objs.append(obj)
+        deps = [os.path.join(CSRC, src), __file__] + headers
+        if not force and same_flavour and os.path.exists(obj) and all(os.path.getmtime(d) <= os.path.getmtime(obj) for d in deps):
+            continue   # incremental: this object is newer than its source and every header
         cmd = [hipcc, *flags, "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         procs.append((cmd, subprocess.Popen(cmd)))
-        objs.append(obj)
     for cmd, p in procs:
         if p.wait() != 0:
             raise RuntimeError("hipcc failed: " + " ".join(cmd))

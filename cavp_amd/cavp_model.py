@@ -646,7 +646,8 @@ class CAVP(nn.Module):
         from .train import CAVPStageFunction
         if not inputs[0].is_cuda:
             raise CavpError("CAVP (MI355X path) needs inputs on a HIP device: there is no CPU fallback")
-        params = [p for top in mods for p in top.parameters() if p.requires_grad] if torch.is_grad_enabled() else []
+        skip = {id(p) for p in self.params_without_grad()}
+        params = [p for top in mods for p in top.parameters() if p.requires_grad and id(p) not in skip] if torch.is_grad_enabled() else []
         return CAVPStageFunction.apply(self, kind, meta, len(inputs), *inputs, *params)
 
     @staticmethod
@@ -728,7 +729,13 @@ class CAVP(nn.Module):
         if not image.is_cuda:
             raise CavpError("CAVP (MI355X path) needs inputs on a HIP device: there is no CPU fallback")
         from .train import CAVPTrainFunction
-        params = [p for p in self.parameters() if p.requires_grad] if want_grad else []
+        # Parameters the forward never reads (position embeddings, VGGish's cls_head: checkpoint-only tensors) stay OUT of the
+        # autograd node, as they are out of the reference's graph: DistributedDataParallel(find_unused_parameters=True)
+        # (main_vpo_mono.py:131-135) marks them unused up front; as inputs of the node that get a None gradient they would look
+        # "used", their reducer hooks would never fire and the SECOND iteration would fail with "expected to have finished
+        # reduction in the prior iteration" (tests/test_gpu_wrappers.py).
+        skip = {id(p) for p in self.params_without_grad()}
+        params = [p for p in self.parameters() if p.requires_grad and id(p) not in skip] if want_grad else []
         graphed = getattr(self, "_graphed_autograd", None)
         if graphed is not None and want_grad and bn_train and not audio_func and audio is not None:
             # opt-in (enable_graphed_autograd): forward and backward as two hipGraph replays behind one autograd node

@@ -139,32 +139,84 @@ def collectives_on() -> bool:
     return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or FORCE_COLLECTIVES)
 
 
+# Wire format of the gradient all-reduce.  f32 (default) = the reference's DDP (main_vpo_mono.py:131-135: 479 MB per step).
+# bf16 (opt-in, `set_grad_allreduce_dtype(torch.bfloat16)`, `bench.py --grad-allreduce bf16`): each piece is cast into a bf16
+# staging buffer, summed over the ranks in bf16 and cast back - 240 MB on the xGMI links instead of 479 MB (SURVEY.md section 5:
+# a ring all-reduce is bound by ONE link's ~153 GB/s); the arena and the optimiser stay f32.  Every rank's contribution is
+# rounded to bf16 once and the partial sums are rounded on the way round the ring (relative error ~ 2^-8 per element).
+_GRAD_WIRE_DTYPE = torch.float32
+
+
+def set_grad_allreduce_dtype(dtype: torch.dtype) -> None:
+    global _GRAD_WIRE_DTYPE
+    if dtype not in (torch.float32, torch.bfloat16):
+        raise CavpError("gradient all-reduce wire format: torch.float32 or torch.bfloat16")
+    _GRAD_WIRE_DTYPE = dtype
+
+
+def grad_allreduce_dtype() -> torch.dtype:
+    return _GRAD_WIRE_DTYPE
+
+
+def _convert(src: torch.Tensor, dst: torch.Tensor) -> torch.Tensor:
+    """dtype conversion of a flat range: the HIP cast kernel on the device, a torch copy for the CPU arenas of the gloo tests."""
+    if src.is_cuda:
+        return ops.cast(src, dst)
+    return dst.copy_(src)
+
+
+class _WireWork:
+    """An in-flight piece of the compressed all-reduce: the collective's handle + the cast back into the f32 arena."""
+
+    def __init__(self, work, wire: torch.Tensor, dst: torch.Tensor):
+        self.work, self.wire, self.dst = work, wire, dst
+
+    def wait(self) -> None:
+        if self.work is not None:
+            self.work.wait()
+        _convert(self.wire, self.dst)
+
+
+def _allreduce_range(arena: "GradArena", lo: int, hi: int, async_op: bool):
+    """SUM over ranks of arena.flat[lo:hi] in the configured wire format; returns something with .wait() (or None)."""
+    import torch.distributed as dist
+    if hi <= lo:
+        return None
+    piece = arena.flat[lo:hi]
+    if _GRAD_WIRE_DTYPE == torch.float32:
+        return dist.all_reduce(piece, async_op=True) if async_op else dist.all_reduce(piece)
+    if getattr(arena, "wire", None) is None:
+        arena.wire = torch.empty(arena.flat.numel(), dtype=torch.bfloat16, device=arena.flat.device)
+    wire = _convert(piece, arena.wire[lo:hi])
+    if async_op:
+        return _WireWork(dist.all_reduce(wire, async_op=True), wire, piece)
+    dist.all_reduce(wire)
+    _convert(wire, piece)
+    return None
+
+
 def allreduce_arena(arena: GradArena) -> None:
     """The single gradient collective of a data-parallel step: SUM over ranks of the flat arena (RCCL over xGMI on
     MI355X; gloo in the CPU tests).  The loss gradient is pre-scaled by 1/world in train_step, so SUM == DDP's mean."""
-    import torch.distributed as dist
     if collectives_on():
-        dist.all_reduce(arena.flat)
+        _allreduce_range(arena, 0, arena.flat.numel(), False)
 
 
 def allreduce_arena_early(arena: GradArena):
     """Start the all-reduce of the early-final range `flat[split:]` without blocking the launching stream (the collective
     runs on RCCL's own stream behind everything queued so far); returns the work handle (None for a single process)."""
-    import torch.distributed as dist
     if collectives_on() and arena.split < arena.flat.numel():
-        return dist.all_reduce(arena.flat[arena.split:], async_op=True)
+        return _allreduce_range(arena, arena.split, arena.flat.numel(), True)
     return None
 
 
 def allreduce_arena_late(arena: GradArena, early_work) -> None:
     """All-reduce the late range `flat[:split]` and join the early collective: afterwards the whole arena is reduced."""
-    import torch.distributed as dist
     if collectives_on():
         if early_work is None:
-            dist.all_reduce(arena.flat)
+            _allreduce_range(arena, 0, arena.flat.numel(), False)
             return
-        if arena.split > 0:
-            dist.all_reduce(arena.flat[:arena.split])
+        _allreduce_range(arena, 0, arena.split, False)
         early_work.wait()
 
 
@@ -1081,6 +1133,13 @@ def run_train_forward(model, image: torch.Tensor, audio: torch.Tensor, tp: Train
     return lo, fusion, fea_v_proj, fea_a, attn
 
 
+def _private(g: torch.Tensor, src: torch.Tensor) -> torch.Tensor:
+    """`g` (a layout / dtype conversion of the foreign gradient `src`) as memory the tape may accumulate into IN PLACE
+    (TrainPass.acc): when the conversion was a no-op, `g` still is the caller's grad_output (autograd forbids mutating it) or a
+    static graph buffer (it would carry one replay's data gradient into the next), so it is copied."""
+    return g.clone() if g.untyped_storage().data_ptr() == src.untyped_storage().data_ptr() else g
+
+
 class CAVPTrainFunction(torch.autograd.Function):
     """One autograd node for the whole model: inputs (image, audio, *parameters) -> (out_pred, out_fusion, visual,
     audio_feat, attn_v).  Gradients flow from out_pred and out_fusion."""
@@ -1118,7 +1177,7 @@ class CAVPTrainFunction(torch.autograd.Function):
                 lo.set_g(g)
             if d_fusion is not None:
                 gf = d_fusion.permute(0, 2, 3, 1).contiguous().float()   # boundary layout conversion of a foreign tensor
-                gf = gf if fusion.t.dtype == torch.float32 else ops.cast(gf, tp.empty(gf.shape, fusion.t.dtype))
+                gf = _private(gf, d_fusion) if fusion.t.dtype == torch.float32 else ops.cast(gf, tp.empty(gf.shape, fusion.t.dtype))
                 fusion.set_g(gf)
             tp.backward()
             tp.finish_padded()
@@ -1193,9 +1252,9 @@ class CAVPStageFunction(torch.autograd.Function):
             raise CavpError("a stage's backward can run once (its tape is released afterwards)")
         dt = tp.dt
 
-        def to_nhwc(g):   # foreign NCHW-shaped gradient -> dense NHWC of the compute dtype
-            g = g.permute(0, 2, 3, 1).contiguous().float()
-            return g if dt == torch.float32 else ops.cast(g, tp.empty(g.shape, dt))
+        def to_nhwc(g0):   # foreign NCHW-shaped gradient -> dense NHWC of the compute dtype, in memory the tape owns
+            g = g0.permute(0, 2, 3, 1).contiguous().float()
+            return _private(g, g0) if dt == torch.float32 else ops.cast(g, tp.empty(g.shape, dt))
 
         with torch.no_grad():
             if kind == "cls":
@@ -1215,7 +1274,7 @@ class CAVPStageFunction(torch.autograd.Function):
                 fea = ctx.vout[0]
                 if douts[0] is not None:
                     g = douts[0].contiguous().float()
-                    fea.set_g(g if dt == torch.float32 else ops.cast(g, tp.empty(g.shape, dt)))
+                    fea.set_g(_private(g, douts[0]) if dt == torch.float32 else ops.cast(g, tp.empty(g.shape, dt)))
             tp.backward()
             tp.finish_padded()
             gin = []
@@ -1314,8 +1373,10 @@ class GraphedTrainStep:
         g = torch.zeros(lo.t.shape, dtype=lo.t.dtype, device=lo.t.device)
         T.bilinear_bwd_from_nchw(self.d_pred, g[..., :self.d_pred.shape[1]], n_valid=lo.t.shape[0], align_corners=False)
         lo.set_g(g)
+        # (d_fusion is NHWC memory, so this "conversion" is a view of the STATIC buffer: the head's data gradient is accumulated into
+        # fusion.g in place, and a replay must not leave it in the buffer the next replay starts from - f32 copies, bf16 casts)
         gf = self.d_fusion.permute(0, 2, 3, 1).contiguous()
-        fusion.set_g(gf if fusion.t.dtype == torch.float32 else ops.cast(gf, tp.empty(gf.shape, fusion.t.dtype)))
+        fusion.set_g(_private(gf, self.d_fusion) if fusion.t.dtype == torch.float32 else ops.cast(gf, tp.empty(gf.shape, fusion.t.dtype)))
         tp.backward()
         tp.finish_padded()
         st["touched"] = set(tp.touched)

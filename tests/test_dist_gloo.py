@@ -54,6 +54,35 @@ def _worker(rank, world, port, q):
             ar2.views[id(p)].fill_(float(rank + i))
         allreduce_arena_late(ar2, None)          # no early piece started: one collective over everything
         assert torch.allclose(ar2.views[id(params[2])], torch.full(params[2].shape, float(sum(r + 2 for r in range(world)))))
+        # 1c) opt-in bf16 wire format (240 MB instead of 479 MB per step over xGMI): each piece is cast to bf16, summed over the
+        #     ranks in bf16 and cast back into the f32 arena - one-piece and two-piece (asynchronous early range) forms
+        from cavp_amd.train import grad_allreduce_dtype, set_grad_allreduce_dtype
+        set_grad_allreduce_dtype(torch.bfloat16)
+        try:
+            assert grad_allreduce_dtype() == torch.bfloat16
+            gen = torch.Generator().manual_seed(100 + rank)
+            mine = {i: torch.randn(p.shape, generator=gen) / world for i, p in enumerate(params)}
+            for async_two_piece in (False, True):
+                for i, p in enumerate(params):
+                    ar2.views[id(p)].copy_(mine[i])
+                if async_two_piece:
+                    allreduce_arena_late(ar2, allreduce_arena_early(ar2))
+                else:
+                    allreduce_arena(ar2)
+                assert ar2.wire.dtype == torch.bfloat16 and ar2.flat.dtype == torch.float32
+                for i, p in enumerate(params):
+                    parts = []
+                    for r in range(world):   # every rank's contribution, regenerated from its seed
+                        gr = torch.Generator().manual_seed(100 + r)
+                        parts.append({j: torch.randn(q_.shape, generator=gr) / world for j, q_ in enumerate(params)}[i])
+                    exact = sum(parts)
+                    got = ar2.views[id(p)]
+                    # rounding: each contribution to bf16 (2^-9 relative), the sum once more
+                    tol = 2.0 ** -7 * sum(t.abs() for t in parts) + 1e-6
+                    assert bool(((got - exact).abs() <= tol).all()), (rank, i, async_two_piece, float((got - exact).abs().max()))
+                    assert not torch.equal(got, exact) or exact.numel() < 4   # it really went through bf16
+        finally:
+            set_grad_allreduce_dtype(torch.float32)
         # views alias the flat buffer (p.grad = view => the optimiser sees the reduced values with no copy)
         arena.zero()
         assert float(arena.views[id(params[0])].abs().sum()) == 0.0

@@ -167,6 +167,63 @@ def test_graphed_autograd_matches_the_eager_node(deterministic):
             assert float((p.grad - tot[k]).norm() / tot[k].norm()) <= 1e-4, k
 
 
+def test_graphed_autograd_ce_only_matches_eager_over_steps(deterministic):
+    """CE-only loss (the trainers' usual case: out_fusion unused, d_fusion arrives as None) on the graphed node against the
+    EAGER node over three steps in f32.  Round 3 shipped a replay that accumulated the head's data gradient into the static
+    d_fusion buffer (an NHWC view aliased the tape's gradient), so from the second step on every gradient upstream of the
+    fusion block was wrong; a graphed-vs-graphed comparison could not see it."""
+    B = CFG["B"]
+    crit = torch.nn.CrossEntropyLoss(ignore_index=255)
+    batches = [tuple(t.to(DEV) for t in synth_inputs(B, CFG["hw"], audio_batch=2 * B, num_classes=CFG["C"], seed=s)) for s in (31, 32, 33)]
+
+    def run(graphed):
+        m, _ = _model(train=True)
+        if graphed:
+            m.enable_graphed_autograd()
+        rec = []
+        for image, audio, label in batches:
+            m.zero_grad(set_to_none=True)
+            out, fus, _ = m(image, audio, None, False)
+            crit(out[:B] + out[B:] * 0.0, label).backward()
+            rec.append({k: p.grad.detach().clone() for k, p in m.named_parameters() if p.grad is not None})
+        return rec
+    eager, graph = run(False), run(True)
+    for step, (g1, g2) in enumerate(zip(eager, graph)):
+        assert g1.keys() == g2.keys()
+        for k in g1:
+            a, b = g1[k].double().flatten(), g2[k].double().flatten()
+            if float(a.norm()) == 0.0:
+                continue
+            assert float((a - b).norm() / a.norm()) <= 1e-4, (step, k, float((a - b).norm() / a.norm()))
+
+
+def test_backward_does_not_mutate_grad_outputs(deterministic):
+    """autograd contract: a node must not write into the gradients it is handed.  In f32 an NHWC-dense gradient needs no
+    conversion, and the tape accumulates data gradients in place - into a private copy, not into the caller's tensor."""
+    B = CFG["B"]
+    image, audio, label = (t.to(DEV) for t in synth_inputs(B, CFG["hw"], audio_batch=2 * B, num_classes=CFG["C"], seed=41))
+    m, _ = _model(train=True)
+    out, fus, _ = m(image, audio, None, False)
+    g_fus = torch.randn(fus.shape[0], fus.shape[2], fus.shape[3], fus.shape[1], device=DEV).permute(0, 3, 1, 2)   # NHWC-dense, like out_fusion
+    g_out = torch.randn_like(out)
+    keep_f, keep_o = g_fus.clone(), g_out.clone()
+    torch.autograd.backward([out, fus], [g_out, g_fus])
+    assert torch.equal(g_fus, keep_f) and torch.equal(g_out, keep_o)
+    # the stage node (forward_fusion): the gradient of the projected map is accumulated with the position-embedding path's
+    xv = torch.randn((2 * B, 304, 12, 12), device=DEV, requires_grad=True)
+    fa = torch.randn((2 * B, 304), device=DEV, requires_grad=True)
+    fus2, pack = m.forward_fusion(xv, fa)
+
+    def nhwc_dense(t):
+        return torch.randn(t.shape[0], t.shape[2], t.shape[3], t.shape[1], device=DEV).permute(0, 3, 1, 2)
+    gs = [nhwc_dense(fus2), nhwc_dense(pack["visual"])]
+    keeps = [g.clone() for g in gs]
+    torch.autograd.backward([fus2, pack["visual"]], gs)
+    assert xv.grad is not None and fa.grad is not None
+    for g, k in zip(gs, keeps):
+        assert torch.equal(g, k)
+
+
 def test_forward_audio_and_audio_func_path(deterministic):
     """forward_audio: [features | features[shuffle_idx]] + SoundBank update under ow_flag; forward_train(audio_func=True) on B
     clips == forward_train on the explicitly concatenated 2B clips (forward and every parameter gradient)."""

@@ -22,12 +22,12 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("mode,launcher", [("train", "torchrun"), ("eval", "torchrun"), ("train", "self")])
-def test_two_rank_bench_on_one_gpu(mode, launcher):
+@pytest.mark.parametrize("mode,launcher,wire", [("train", "torchrun", "f32"), ("eval", "torchrun", "f32"), ("train", "self", "bf16")])
+def test_two_rank_bench_on_one_gpu(mode, launcher, wire):
     env = dict(os.environ, CAVP_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
-    args = ["--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "4", "--mode", mode]
+    args = ["--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "4", "--mode", mode, "--grad-allreduce", wire]
     if launcher == "torchrun":   # as the driver runs N > 1; default flags: the roofline leg must stay rank-local
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                "--master-port", str(_free_port()), os.path.join(REPO, "bench.py")] + args
@@ -42,6 +42,12 @@ def test_two_rank_bench_on_one_gpu(mode, launcher):
     assert d["config"]["global_batch"] == 8 and d["config"]["parallelism"] == "dp2" and d["config"]["ranks"] == 2
     assert "capture failed" not in r.stderr
     assert d["roofline"]["frac"] > 0 and "cpu_baseline" not in d   # per-kernel timing on rank 0 only; CPU baseline is an N=1 leg
+    if mode == "train":   # the two gradient collectives, timed alone, in the line (rccl_ranks = ranks of the process group)
+        c = d["collective"]
+        assert c["rccl_ranks"] == 2 and c["wire_dtype"] == wire and c["early_piece_ms"] > 0 and c["late_piece_ms"] > 0
+        assert abs(c["early_piece_mb"] + c["late_piece_mb"] - (240 if wire == "bf16" else 479)) < 3
+    else:
+        assert "collective" not in d
 
 
 def test_gpus_flag_must_match_the_launcher():
