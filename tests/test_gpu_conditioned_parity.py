@@ -107,3 +107,25 @@ def test_bf16_step_vs_oracle_on_conditioned_weights(conditioned, oracle_step):
     assert abs(r["loss"] - r["ref_loss"]) <= 5e-3 * max(1.0, r["ref_loss"]), r
     assert r["whole_cos"] >= 0.96, r                              # measured 0.979
     assert r["cos_med"] >= 0.93 and r["cos_p05"] >= 0.80, r       # measured 0.958 / 0.891
+
+
+def test_bf16_forward_at_the_bench_shape_vs_oracle(conditioned):
+    """The benchmarked shape itself (B = 32 images + 64 audio clips, 224 x 224, bf16): train-mode forward logits and the CE loss of
+    the conditioned weights against the oracle's f32 forward (forward only on the CPU: the backward at this size is covered at
+    96 x 96 above and by the property tests of tests/test_gpu_fullsize.py)."""
+    from oracle import cavp_oracle as O
+    B, hw = 32, (224, 224)
+    sd = conditioned[0]
+    image, audio, label = learnable_inputs(B, hw, CFG["C"], seed=17)
+    with torch.no_grad():
+        ref, _, _ = O.cavp_forward(dict(sd), image, audio, CFG["lds"], eval_mode=False)
+        ref_loss = float(O.ce_loss_train(ref, label, B).item())
+    m = _build(sd, torch.bfloat16)
+    loss = m.train_step(image.to(DEV), audio.to(DEV), label.to(DEV), want_pred=True)
+    torch.cuda.synchronize()
+    pred = m._last_outputs[0].float().cpu()
+    rel = float((pred - ref).norm() / ref.norm())
+    print(f"bf16 @ B=32 224x224: logits rel L2 {rel:.3e} (std {float(ref.std()):.2f}), loss {float(loss.item()):.5f} vs oracle {ref_loss:.5f}")
+    assert float(ref.std()) > 1.0
+    assert rel <= 2e-2, rel
+    assert abs(float(loss.item()) - ref_loss) <= 5e-3 * max(1.0, ref_loss)

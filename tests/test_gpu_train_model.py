@@ -2,6 +2,8 @@
 golden vectors captured from the reference's own autograd (tests/golden/c1p_train.npz)."""
 import types
 
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -87,6 +89,79 @@ def test_train_step_matches_reference_f32(use_hip_ce, case):
         tol = (1.5e-1 if noisy else 2e-2) * max(1e-6, float(np.abs(ref).max()))  # 3x the measured floor; the tight bar is the B=8 test
         assert np.abs(smp - ref).max() <= tol, f"{k}: sampled grad err {np.abs(smp - ref).max():.3e} > {tol:.3e}"
     print("train step ok: loss", loss, "worst grad-norm rel err", worst)
+
+
+def test_train_step_b8_matches_reference_f32(deterministic):
+    """The operative element-wise gradient check on a well-conditioned batch (golden c1p_train_b8: 8 images + 16 audio clips,
+    no BatchNorm over 2 samples), against the REFERENCE's own autograd and against the exact value of the same graph.
+
+    Two f32 evaluations of this graph cannot agree arbitrarily well: the reference's own f32 gradients are 1.3e-2 .. 3.0e-2
+    (relative L2 over the sample) away from the float64 value on the backbone / ASPP tensors and ~2e-3 elsewhere, its gradient
+    norms up to 7e-3 (c1p_train_b8_f64.npz: the pinned oracle evaluated in float64, tools/make_golden.py::run_f64_arbiter).  So:
+      (1) HIP f32 vs the exact value is held to 1.5 x the REFERENCE's f32 error against that value (+ 1e-3) on every sampled
+          sentinel tensor, and the error distribution of all gradient norms to 1.5 x the reference's: this path is as accurate
+          as the reference's own arithmetic;
+      (2) HIP f32 vs reference f32 directly: 5e-3 / cosine 0.9995 where the reference itself is that close to the exact value
+          (attention, projector, audio encoder, head); on the noisy tensors the group's worst and mean error vs the exact value
+          stay within 1.25 x the reference's, each tensor within 4e-2 / cosine 0.999 of the reference.
+    Measured (round 4): HIP vs exact 0.6e-2 .. 2.7e-2 on the noisy tensors where the reference's f32 run is 1.3e-2 .. 3.0e-2."""
+    z, cfg = load_case("c1p_train_b8")
+    z64 = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "c1p_train_b8_f64.npz"), allow_pickle=True)
+    assert cfg["B"] == 8
+    m, _ = _build(cfg)
+    out, fus, pack, loss = _step(m, cfg, use_hip_ce=False)
+    assert abs(loss - float(z["loss"][0])) <= 2e-5 * max(1.0, abs(float(z["loss"][0]))), (loss, float(z["loss"][0]))
+    assert abs(loss - float(z64["loss"][0])) <= 5e-5   # (the reference's f32 loss is 7.5e-6 from the exact value, this path 3.3e-5)
+    for k, t in dict(out_pred=out, out_fusion=fus, pack_visual=pack["visual"], pack_audio=pack["audio"]).items():
+        scale = max(1.0, float(np.abs(z["sample/" + k]).max()))
+        check_tap(z, k, t.detach(), 1e-3 * scale, what="train b8:")
+    params = dict(m.named_parameters())
+    assert list(z["grad_norm_keys"]) == list(z64["grad_norm_keys"])
+    worst_n = (0.0, None)
+    en_hip, en_ref = [], []
+    for k, v, v64 in zip(list(z["grad_norm_keys"]), z["grad_norm_vals"], z64["grad_norm_vals"]):
+        g = params[k].grad
+        assert g is not None, k
+        n = float(g.double().norm().item())
+        if v64 < 1e-6:
+            continue
+        en_hip.append(abs(n - v64) / v64)
+        en_ref.append(abs(v - v64) / v64)
+        worst_n = max(worst_n, (en_hip[-1], k))
+        assert abs(n - v) / v <= 1e-2, f"{k}: |grad| {n:.6g} vs reference {v:.6g}"
+    # the per-tensor errors of the norms are quasi-random (either run may be lucky on a tensor): their distributions are compared
+    en_hip, en_ref = np.array(en_hip), np.array(en_ref)
+    print(f"b8 gradient norms vs exact: HIP median {np.median(en_hip):.2e} p90 {np.quantile(en_hip, 0.9):.2e} max {en_hip.max():.2e} | "
+          f"reference f32 median {np.median(en_ref):.2e} p90 {np.quantile(en_ref, 0.9):.2e} max {en_ref.max():.2e}")
+    assert np.median(en_hip) <= 1.5 * np.median(en_ref) + 2e-4 and np.quantile(en_hip, 0.9) <= 1.5 * np.quantile(en_ref, 0.9) + 2e-4
+    assert en_hip.max() <= 1.5 * en_ref.max()
+    rows = []
+    for s in [s for s in z.files if s.startswith("grad_sample/")]:
+        k = s[len("grad_sample/"):]
+        g = params[k].grad.detach().float().cpu().contiguous().flatten()
+        ref, exact = z[s].astype(np.float64), z64[s]
+        smp = g[:: max(1, g.numel() // 4096)][:4096].numpy().astype(np.float64)
+
+        def rel_cos(a, b):
+            return (float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30)),
+                    float(a @ b / max(np.linalg.norm(a) * np.linalg.norm(b), 1e-30)))
+        (e_hip, c_hip), (e_ref, c_ref), (e_dir, c_dir) = rel_cos(smp, exact), rel_cos(ref, exact), rel_cos(smp, ref)
+        rows.append((k, e_hip, e_ref, e_dir, c_dir))
+    print(f"b8 train step: loss {loss:.6f}; worst gradient norm vs exact {worst_n[0]:.2e} ({worst_n[1]})")
+    for k, e_hip, e_ref, e_dir, c_dir in rows:
+        print(f"  {k:48s} HIP vs exact {e_hip:.2e} | reference vs exact {e_ref:.2e} | HIP vs reference {e_dir:.2e} cos {c_dir:.6f}")
+    noisy = [r for r in rows if r[2] > 3.5e-3]      # backbone / ASPP / reduce: the reference's own f32 run is 0.6e-2 .. 3e-2 off
+    quiet = [r for r in rows if r[2] <= 3.5e-3]
+    assert len(noisy) >= 5 and len(quiet) >= 9
+    for k, e_hip, e_ref, e_dir, c_dir in quiet:
+        assert e_hip <= 1.5 * e_ref + 1e-3, f"{k}: vs exact {e_hip:.3e}, the reference's f32 run {e_ref:.3e}"
+        assert e_dir <= 5e-3 and c_dir >= 0.9995, f"{k}: vs reference rel L2 {e_dir:.3e} cosine {c_dir:.6f}"
+    # the noisy tensors' errors are rounding noise amplified by ~50 batch-statistics BatchNorm layers: quasi-random per tensor
+    # (either run is the closer one on some of them), so the group is compared: no worse than the reference's f32 run overall
+    assert max(r[1] for r in noisy) <= 1.25 * max(r[2] for r in noisy), [(r[0], r[1], r[2]) for r in noisy]
+    assert np.mean([r[1] for r in noisy]) <= 1.25 * np.mean([r[2] for r in noisy]), [(r[0], r[1], r[2]) for r in noisy]
+    for k, e_hip, e_ref, e_dir, c_dir in noisy:
+        assert e_hip <= 3.0 * e_ref and e_dir <= 4e-2 and c_dir >= 0.999, f"{k}: vs exact {e_hip:.3e} (reference {e_ref:.3e}), vs reference {e_dir:.3e} cosine {c_dir:.6f}"
 
 
 def test_running_stats_and_second_step():
