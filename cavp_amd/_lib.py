@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(HERE, "libcavp_hip.so")
 
 F32, BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_LEAKY, ACT_GELU = 0, 1, 2, 3
-ABI_VERSION = 7
+ABI_VERSION = 8
 WGRAD_GROUP_MAX = 16   # CAVP_WGRAD_GROUP_MAX
 
 
@@ -48,6 +48,13 @@ PROTOTYPES = {
     "cavp_conv2d_nhwc": (_i32, [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _vp]),
     "cavp_conv2d_nhwc_aux": (_i32, [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _vp]),
     "cavp_set_tail_split": (_i32, [_i32]),
+    "cavp_set_wgrad_variant": (_i32, [_i32]),
+    "cavp_attn1_supported": (_i32, [_i32, _i32]),
+    "cavp_attn1_prepare": (_i32, [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _f32, _vp]),
+    "cavp_attn1_fwd": (_i32, [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "cavp_attn1_bwd_workspace_bytes": (_sz, [_i32, _i32, _i32, _i32, _i32]),
+    "cavp_attn1_bwd": (_i32, [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "cavp_attn1_finish": (_i32, [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _f32, _vp]),
     "cavp_conv2d_tile_stats_layout": (_i32, [C.POINTER(ConvDesc), C.POINTER(_i32), C.POINTER(_i32)]),
     "cavp_bn_finalize_tiles": (_i32, [_vp, _i32, _i32, _i64, _vp, _vp, _f32, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp]),
     "cavp_bn_tiles_to_moments": (_i32, [_vp, _i32, _i32, _i64, _vp, _i32, _vp]),

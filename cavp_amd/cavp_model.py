@@ -543,13 +543,23 @@ class CAVP(nn.Module):
         n1w, n1b = blk.norm1.weight.detach(), blk.norm1.bias.detach()
         vn = ops.layernorm(v0, n1w, n1b, torch.empty_like(v0), blk.norm1.eps)
         an = ops.layernorm(a0, n1w, n1b, torch.empty_like(a0), blk.norm1.eps)
-        q = self._lin(vn, P["ca.q"])
         k = self._lin(an, P["ca.k"])
         vv = self._lin(an, P["ca.v"])
         heads = blk.attn.num_heads
         attn = torch.empty((B, heads, T), dtype=torch.float32, device=dev)
-        o = ops.attn_gate(q, k, vv, torch.empty((B, T, Cc), dtype=dt, device=dev), attn, heads, blk.attn.scale)
-        if B == Bv:
+        from . import train as _tr
+        if _tr._RANK1_ATTN and ops.attn1_supported(Cc, heads):
+            # one key per batch item: q GEMM + gate + proj GEMM + residual in one pass over the tokens (csrc/attn_rank1.hip)
+            u, pm = ops.attn1_prepare(blk.attn.q.weight.detach(), blk.attn.proj.weight.detach(), k, vv, heads, blk.attn.scale)
+            r1 = ops.attn1_fwd(vn, u, pm, blk.attn.proj.bias.detach() if blk.attn.proj.bias is not None else None,
+                               torch.empty((B, T, Cc), dtype=dt, device=dev), attn)
+            q = o = None
+        else:
+            q = self._lin(vn, P["ca.q"])
+            o = ops.attn_gate(q, k, vv, torch.empty((B, T, Cc), dtype=dt, device=dev), attn, heads, blk.attn.scale)
+        if q is None:
+            pass
+        elif B == Bv:
             r1 = self._lin(o, P["ca.proj"], residual=vn)
         elif (Bv * T) % 256 == 0:
             r1 = self._lin(o, P["ca.proj"], residual=vn, res_rows=Bv * T)
@@ -636,7 +646,9 @@ class CAVP(nn.Module):
     def _stage_on_tape(self, mods, *inputs) -> bool:
         """True when a stage entry point has to run on a training tape (CAVPStageFunction): one of its BatchNorm layers is in
         training mode (batch statistics, running-statistics update) or autograd wants gradients through it.  Otherwise the
-        forward-only eval kernels serve it."""
+        forward-only eval kernels serve it.  Note for validation loops: a freshly built model has requires_grad parameters, so
+        `model.eval()` alone still takes the tape (weight re-packs, saved activations, an autograd node - same results, more
+        time and memory); wrap inference in `torch.no_grad()`, as the reference's evaluation scripts do."""
         bn_train = any(m.training for top in mods for m in top.modules() if isinstance(m, nn.modules.batchnorm._BatchNorm))
         want = torch.is_grad_enabled() and (any(isinstance(t, torch.Tensor) and t.requires_grad for t in inputs)
                                             or any(p.requires_grad for top in mods for p in top.parameters()))

@@ -93,7 +93,7 @@ __device__ __forceinline__ void epilogue_store4(const IgemmParams& p, float v0, 
 // four single-stage ones 1667 TF/s; 64-byte LDS rows (BK = 32) lose 15 %: a DMA instruction then fetches 16 half cache lines).
 // Their epilogue is per WAVE (no workgroup barrier, accumulators released block by block, see below).
 template <typename T, int BC, int BP, int WC, int WP, bool UP, int NS>
-__global__ __launch_bounds__(64 * WC * WP, (WC * WP == 4 ? (NS == 1 ? 4 : 2) : 1)) void igemm_kernel(const IgemmParams p) {
+__global__ __launch_bounds__(64 * WC * WP, (WC * WP == 4 ? (NS == 1 ? 4 : 2) : (NS == 2 ? 4 : 1))) void igemm_kernel(const IgemmParams p) {
   constexpr int VE = Elem<T>::VE;
   constexpr int BK = 8 * VE;  // one 128-byte LDS row of K
   constexpr int TC = BC / WC, TP = BP / WP;
@@ -105,7 +105,7 @@ __global__ __launch_bounds__(64 * WC * WP, (WC * WP == 4 ? (NS == 1 ? 4 : 2) : 1
   constexpr int RSTEP = 8 * NW;  // LDS rows covered by one DMA instruction of the whole workgroup
   static_assert(NW == 4 || NW == 8, "4 or 8 waves per workgroup");
   static_assert(NS >= 1 && (NS < 2 || (NS - 2) * (LW + LX) < 64), "vmcnt is a 6-bit counter");
-  static_assert(NW == 4 || NS == 3, "the 8-wave tiles are written for three stages");
+  static_assert(NW == 4 || NS == 3 || NS == 2, "the 8-wave tiles: three stages (one workgroup per CU) or two (tile 19: two per CU)");
   static_assert(TC % 16 == 0 && TP % 16 == 0, "wave tile must be a multiple of the 16x16 MFMA block");
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -809,10 +809,11 @@ const TileCfg kTiles[] = {
     {10, 256, 256, 2.00f},                       // conv_igemm_big.hip: 8 waves in two ping-pong groups, one workgroup per CU
     {11, 64, 64, 0.70f}, {12, 64, 64, 0.70f}, {13, 128, 64, 0.80f}, {14, 64, 128, 0.80f},   // deep rings (4 / 8 / 4 / 4 stages) for under-filled launches
     {15, 128, 128, 1.25f}, {16, 64, 128, 1.00f}, {17, 128, 64, 1.00f}, {18, 64, 64, 0.85f},   // single stage, four workgroups per CU
+    {19, 128, 128, 1.10f}, {20, 128, 128, 1.10f},   // EIGHT waves (2 x 4 / 4 x 2), two stages, two 64 KiB workgroups per CU: 32 accumulator registers per wave
 };
-inline int tile_stages(int id) { return id >= 15 ? 1 : id == 12 ? 8 : id >= 11 ? 4 : id == 10 ? 2 : id >= 8 ? 3 : 2; }
+inline int tile_stages(int id) { return id >= 19 ? 2 : id >= 15 ? 1 : id == 12 ? 8 : id >= 11 ? 4 : id == 10 ? 2 : id >= 8 ? 3 : 2; }
 inline bool tile_is_big(int id) { return id == 10; }
-inline int tile_wp(int id) { return id == 5 ? 1 : (id == 6 || id == 7 || id == 9) ? 4 : 2; }   // waves along the pixel dimension (launch_tile)
+inline int tile_wp(int id) { return id == 5 ? 1 : (id == 6 || id == 7 || id == 9 || id == 19) ? 4 : 2; }   // waves along the pixel dimension (launch_tile)
 // A/B knob: CAVP_IGEMM_EFF="e1,e2,...,e9" overrides the efficiency column of kTiles (time-model sweeps without a rebuild)
 inline double tile_eff(const TileCfg& t) {
   static double ov[16];
@@ -886,6 +887,12 @@ hipError_t launch_tile(int id, const IgemmParams& p, int nblk, hipStream_t s) {
       return hipErrorInvalidValue;
     case 18:
       if constexpr (sizeof(T) == 2) return launch_cfg<T, 64, 64, 2, 2, UP, 1>(p, nblk, s);
+      return hipErrorInvalidValue;
+    case 19:
+      if constexpr (sizeof(T) == 2) return launch_cfg<T, 128, 128, 2, 4, UP, 2>(p, nblk, s);
+      return hipErrorInvalidValue;
+    case 20:
+      if constexpr (sizeof(T) == 2) return launch_cfg<T, 128, 128, 4, 2, UP, 2>(p, nblk, s);
       return hipErrorInvalidValue;
     default: return hipErrorInvalidValue;
   }

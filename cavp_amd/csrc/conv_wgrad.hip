@@ -60,7 +60,11 @@ static_assert(sizeof(WgradGroupArgs) <= 4096, "kernel-argument segment");
 typedef short s16x4_t __attribute__((ext_vector_type(4)));
 
 // One logical workgroup `bid` of one weight gradient (shared by the single and the grouped launch).
-template <typename T, int BK, bool BIAS>   // BK = pixel rows per stage; BIAS: also the bias gradient (column sums of dY) (64: two 64 KiB workgroups per CU; 32: four 32 KiB ones)
+// BK = pixel rows per stage; BIAS: also the bias gradient (column sums of dY); NSTG = LDS stages: 2 (BK = 32: four 32 KiB
+// workgroups per CU, BK = 64: two 64 KiB ones) or 1 (BK = 64: ONE 32 KiB stage, four workgroups per CU - load, wait, barrier,
+// multiply two k steps, barrier; nothing overlaps inside a workgroup, the co-resident ones fill the gaps.  In the K-loop
+// micro-benchmark tools/microbench/kloop.hip that shape beats two double-buffered workgroups by 26 %)
+template <typename T, int BK, bool BIAS, int NSTG = 2>
 __device__ __forceinline__ void wgrad_tile(const WgradParams& p, const int bid, char* smem) {
   constexpr int ES = (int)sizeof(T);
   constexpr int TCH = 256 / ES;      // channels per tile row (256 bytes)
@@ -240,7 +244,15 @@ __device__ __forceinline__ void wgrad_tile(const WgradParams& p, const int bid, 
     }
   };
 
-  if (r_begin < r_end) {
+  if constexpr (NSTG == 1) {
+    for (int r0 = r_begin; r0 < r_end; r0 += BK) {
+      if (r0 != r_begin) __builtin_amdgcn_s_barrier();   // everybody finished multiplying the previous stage
+      gdma(0);
+      __builtin_amdgcn_s_waitcnt(vmcnt_imm(0));
+      __builtin_amdgcn_s_barrier();
+      compute(0);
+    }
+  } else if (r_begin < r_end) {
     gdma(0);
     __syncthreads();
     int buf = 0;
@@ -295,6 +307,10 @@ __device__ __forceinline__ void wgrad_tile(const WgradParams& p, const int bid, 
             acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, af[a]),
                                                                 __builtin_bit_cast(bf16x8_t, bfv[b]), acc[a][b], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);   // (the scheduler otherwise hoists the wait + barrier above the MFMAs)
+        // the next stage's LDS-DMA must have LANDED before any wave crosses the barrier and reads it: hipcc (ROCm 7.2) emits this
+        // vmcnt(0) itself in front of the barrier, but nothing in the source required it - gfx950's workgroup release fence does
+        // not - so it is stated here (same instruction, no timing change; round-3 advisor note)
+        __builtin_amdgcn_s_waitcnt(vmcnt_imm(0));
         __syncthreads();
         buf ^= 1;
       }
@@ -354,22 +370,31 @@ __device__ __forceinline__ void wgrad_tile(const WgradParams& p, const int bid, 
   }
 }
 
-template <typename T, int BK, bool BIAS>
-__global__ __launch_bounds__(256, (BK == 32 ? 4 : 2)) void wgrad_kernel(const WgradParams p) {
+template <typename T, int BK, bool BIAS, int NSTG = 2>
+__global__ __launch_bounds__(256, (BK == 32 || NSTG == 1 ? 4 : 2)) void wgrad_kernel(const WgradParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  wgrad_tile<T, BK, BIAS>(p, xcd_remap(blockIdx.x, gridDim.x), smem);
+  wgrad_tile<T, BK, BIAS, NSTG>(p, xcd_remap(blockIdx.x, gridDim.x), smem);
 }
 
 // Grouped launch: the logical workgroups of up to 16 weight gradients in one grid.  The backward of a stage of small layers
 // (layer3: 19 convs on 6272 pixels) used to be 19 launches that each split their 98 pixel chunks ~8 ways to find 1024
 // workgroups - 19 x (slab write + slab read + reduce launch); together the same layers fill the chip with 2 splits.
-template <typename T, bool BIAS>
+template <typename T, bool BIAS, int BK = 32, int NSTG = 2>
 __global__ __launch_bounds__(256, 4) void wgrad_group_kernel(const WgradGroupArgs g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int bid = xcd_remap(blockIdx.x, gridDim.x);
   int j = 0;
   while (j + 1 < g.njobs && bid >= g.blk_end[j]) ++j;
-  wgrad_tile<T, 32, BIAS>(g.job[j], bid - (j ? g.blk_end[j - 1] : 0), smem);
+  wgrad_tile<T, BK, BIAS, NSTG>(g.job[j], bid - (j ? g.blk_end[j - 1] : 0), smem);
+}
+
+// A/B switch (bench / tests): 0 = two 32-row stages per workgroup, 1 = one 64-row stage (bf16).  Both keep four 32 KiB workgroups
+// per CU and give bit-identical results (same products, same summation order within a workgroup).
+static int g_wgrad_variant = 0;
+extern "C" int cavp_set_wgrad_variant(int v) {
+  if (v < 0 || v > 1) return CAVP_ERR_BAD_ARG;
+  g_wgrad_variant = v;
+  return CAVP_OK;
 }
 
 // dw += sum_z slabs[z] over the live taps only (dead-tap regions of the slabs are never written).
@@ -606,6 +631,9 @@ extern "C" int cavp_conv2d_wgrad_nhwc(const cavp_conv_desc* d, const void* x, co
   if (d->dtype == CAVP_F32) {
     if (bk == 32) { if (bi) WG_LAUNCH(float, 32, true); else WG_LAUNCH(float, 32, false); }
     else { if (bi) WG_LAUNCH(float, 64, true); else WG_LAUNCH(float, 64, false); }
+  } else if (g_wgrad_variant == 1 && bk == 32) {
+    if (bi) wgrad_kernel<bf16_t, 64, true, 1><<<pl.nblk, 256, lds, s>>>(p);
+    else wgrad_kernel<bf16_t, 64, false, 1><<<pl.nblk, 256, lds, s>>>(p);
   } else {
     if (bk == 32) { if (bi) WG_LAUNCH(bf16_t, 32, true); else WG_LAUNCH(bf16_t, 32, false); }
     else { if (bi) WG_LAUNCH(bf16_t, 64, true); else WG_LAUNCH(bf16_t, 64, false); }
@@ -762,6 +790,9 @@ extern "C" int cavp_conv2d_wgrad_group(const cavp_wgrad_job* jobs, int32_t njobs
   if (f32) {
     if (any_bias) wgrad_group_kernel<float, true><<<blocks, 256, lds, s>>>(g);
     else wgrad_group_kernel<float, false><<<blocks, 256, lds, s>>>(g);
+  } else if (g_wgrad_variant == 1) {
+    if (any_bias) wgrad_group_kernel<bf16_t, true, 64, 1><<<blocks, 256, lds, s>>>(g);
+    else wgrad_group_kernel<bf16_t, false, 64, 1><<<blocks, 256, lds, s>>>(g);
   } else {
     if (any_bias) wgrad_group_kernel<bf16_t, true><<<blocks, 256, lds, s>>>(g);
     else wgrad_group_kernel<bf16_t, false><<<blocks, 256, lds, s>>>(g);

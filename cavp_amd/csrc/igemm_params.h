@@ -63,8 +63,6 @@ __device__ __forceinline__ float row16_sum(float v) {
   return v;
 }
 
-// s_waitcnt immediate that only waits for vmcnt <= n (gfx9 encoding: vmcnt[3:0] | expcnt[6:4] | lgkmcnt[11:8] | vmcnt[15:14])
-constexpr int vmcnt_imm(int n) { return (n & 15) | ((n >> 4) << 14) | (7 << 4) | (15 << 8); }
 
 
 // conv_igemm_big.hip

@@ -312,6 +312,44 @@ def attn_gate(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Tens
     return out
 
 
+def attn1_supported(c: int, heads: int) -> bool:
+    """The one-key attention collapse (cavp_attn1_*) covers this shape (4 heads, C <= 512, C % 8 == 0)."""
+    return bool(_lib.load().cavp_attn1_supported(int(c), int(heads)))
+
+
+def attn1_prepare(wq: torch.Tensor, wp: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int, scale: float):
+    """u[b,h,:] = scale Wq[h-slice,:]^T k[b,h-slice], p[b,h,:] = Wp[:,h-slice] v[b,h-slice]: f32 [B, heads, C] each.
+    wq, wp: the f32 [C, C] nn.Linear weights of attn.q / attn.proj; k, v: [B, C] in the compute dtype."""
+    _need_gpu(wq, wp, k, v)
+    b, c = k.shape
+    if wq.dtype != torch.float32 or wp.dtype != torch.float32 or tuple(wq.shape) != (c, c) or tuple(wp.shape) != (c, c):
+        raise _lib.CavpError("attn1_prepare: wq / wp must be f32 [C, C]")
+    if k.dtype != v.dtype or v.shape != k.shape or not (wq.is_contiguous() and wp.is_contiguous() and k.is_contiguous() and v.is_contiguous()):
+        raise _lib.CavpError("attn1_prepare: k, v must be contiguous [B, C] of one dtype")
+    u = torch.empty((b, heads, c), dtype=torch.float32, device=k.device)
+    pm = torch.empty((b, heads, c), dtype=torch.float32, device=k.device)
+    st = _lib.load().cavp_attn1_prepare(dtype_code(k.dtype), _ptr(wq), _ptr(wp), _ptr(k), _ptr(v), _ptr(u), _ptr(pm), b, c, heads,
+                                        C.c_float(scale), C.c_void_p(_stream()))
+    _lib.check(st, "cavp_attn1_prepare")
+    return u, pm
+
+
+def attn1_fwd(x: torch.Tensor, u: torch.Tensor, pm: torch.Tensor, bp: Optional[torch.Tensor], out: torch.Tensor, attn: torch.Tensor):
+    """out[b,t,:] = x[b % xb, t, :] + bp + sum_h sigmoid(x . u[b,h]) pm[b,h];  attn[b,h,t] = the gate.  x: [xb, T, C], out: [B, T, C]."""
+    _need_gpu(x, u, pm, out, attn)
+    xb, t, c = x.shape
+    b, heads = u.shape[0], u.shape[1]
+    if tuple(out.shape) != (b, t, c) or b % xb or tuple(attn.shape) != (b, heads, t) or attn.dtype != torch.float32 or out.dtype != x.dtype:
+        raise _lib.CavpError("attn1_fwd: shape / dtype mismatch")
+    for ten in (x, u, pm, out, attn):
+        if not ten.is_contiguous():
+            raise _lib.CavpError("attn1_fwd: contiguous tensors required")
+    st = _lib.load().cavp_attn1_fwd(dtype_code(x.dtype), _ptr(x), _ptr(u), _ptr(pm), _ptr(bp) if bp is not None else None, _ptr(out),
+                                    _ptr(attn), b, xb, t, c, heads, C.c_void_p(_stream()))
+    _lib.check(st, "cavp_attn1_fwd")
+    return out
+
+
 def bn_fold(gamma, beta, mean, var, eps: float, scale: torch.Tensor, shift: torch.Tensor) -> None:
     _need_gpu(gamma, beta, mean, var, scale, shift)
     for t in (gamma, beta, mean, var, scale, shift):

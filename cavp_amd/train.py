@@ -238,6 +238,9 @@ def gather_bn_moments(local: torch.Tensor) -> torch.Tensor:
 
 # False (tests / A-B only): GELU as a separate pass with the pre-activation stored, and the duplicated token tensors copied
 _FUSE_TOKEN_PATH = True
+# False (tests / A-B only): the cross-modal attention as written in the reference - q GEMM, gate kernel, proj GEMM - instead of
+# the one-key collapse (csrc/attn_rank1.hip)
+_RANK1_ATTN = True
 _SIDE_STREAM = True      # False (tests / A-B only): the audio encoder on the main stream
 # Weight gradients are not consumed inside the backward: TrainPass collects them and issues up to 16 per launch
 # (cavp_conv2d_wgrad_group).  False (tests / A-B only): one launch (+ one slab reduce) per layer, where the layer's backward runs.
@@ -793,6 +796,35 @@ class TrainPass:
         self.tape.append(bwd)
         return o, attn
 
+    def attn_rank1(self, x: V, k: V, v: V, attn_mod) -> tuple:
+        """Attention with one key / value token per batch item + output projection + residual, collapsed to rank-H operations
+        (csrc/attn_rank1.hip; attn.py:73-106, 153-156): r1 = x + proj(sigmoid(scale q k^T) v) with q = attn.q(x).  x: [xb, T, C]
+        (xb divides the batch of k / v: forward_train's duplicated images are read, never copied); returns (r1 [B, T, C], attn).
+        The weights are read as f32 (no bf16 re-pack of attn.q / attn.proj); their gradients land in the flat arena."""
+        heads, scale = attn_mod.num_heads, attn_mod.scale
+        wq, wp, bp = attn_mod.q.weight.detach(), attn_mod.proj.weight.detach(), attn_mod.proj.bias
+        xb, t, c = x.t.shape
+        b = k.t.shape[0]
+        u, pm = ops.attn1_prepare(wq, wp, k.t, v.t, heads, scale)
+        attn = V(self.empty((b, heads, t), torch.float32))
+        r1 = V(self.empty((b, t, c), x.t.dtype))
+        ops.attn1_fwd(x.t, u, pm, bp.detach() if bp is not None else None, r1.t, attn.t)
+
+        def bwd():
+            if r1.g is None:
+                return
+            if attn.g is not None:
+                raise CavpError("attn_rank1: a gradient through the attention map is not supported (attn_v is an output only)")
+            dx = self.empty(x.t.shape, x.t.dtype)
+            du, dp = T.attn1_bwd(r1.g, x.t, u, pm, dx, self.grad_buffer(bp) if bp is not None else None)
+            dk, dv = T.attn1_finish(wq, wp, k.t, v.t, du, dp, self.grad_buffer(attn_mod.q.weight), self.grad_buffer(attn_mod.proj.weight),
+                                    heads, scale)
+            self.acc_add(x, dx)
+            self.acc_add(k, dk if k.t.dtype == torch.float32 else ops.cast(dk, self.empty(dk.shape, k.t.dtype)))
+            self.acc_add(v, dv if v.t.dtype == torch.float32 else ops.cast(dv, self.empty(dv.shape, v.t.dtype)))
+        self.tape.append(bwd)
+        return r1, attn
+
     def dup2(self, x: V) -> V:
         """torch.cat((x, x.clone()), 0) (cavp_model.py:181)."""
         n = x.t.shape[0]
@@ -930,7 +962,8 @@ def _pack_fusion(tp: TrainPass, m) -> None:
     ca, blk = m.cross_att, m.cross_att.blocks[0]
     tp.pack("ca.pe_v", ca.patch_embed_v.proj)
     tp.pack("ca.pe_a", ca.patch_embed_a.proj)
-    for nme in ("q", "k", "v", "proj"):
+    rank1 = _RANK1_ATTN and ops.attn1_supported(blk.attn.q.in_features, blk.attn.num_heads)
+    for nme in (("k", "v") if rank1 else ("q", "k", "v", "proj")):   # (the one-key collapse reads attn.q / attn.proj as f32)
         tp.pack("ca." + nme, getattr(blk.attn, nme))
     tp.pack("ca.fc1", blk.mlp.fc1)
     tp.pack("ca.fc2", blk.mlp.fc2)
@@ -973,15 +1006,21 @@ def _fusion_stage(tp: TrainPass, m, fea_v: V, fea_a: V, duplicate: bool):
     a0 = tp.conv(fea_a, "ca.pe_a")
     vnB = tp.layernorm(v0B, blk.norm1)
     an = tp.layernorm(a0, blk.norm1)
-    qB = tp.conv(vnB, "ca.q")
-    # the 2B rows of `vn` / `q` / pack["visual"] are never materialised: the gate reads q[b % B], ca.proj adds the residual row
-    # p % (B * T), and the output-only duplicate of fea_v_proj is made by whoever returns it (three 2 x 61 MB copies per step)
-    periodic = duplicate and (Bv * hh * ww) % 256 == 0 and _FUSE_TOKEN_PATH
-    vn, q = (vnB, qB) if (periodic or not duplicate) else (tp.dup2(vnB), tp.dup2(qB))
     k = tp.conv(an, "ca.k")
     vv = tp.conv(an, "ca.v")
-    o, attn = tp.attn_gate(q, k, vv, blk.attn.num_heads, blk.attn.scale)
-    r1 = tp.conv(o, "ca.proj", residual=vn, residual_periodic=periodic)
+    if _RANK1_ATTN and ops.attn1_supported(Cc, blk.attn.num_heads):
+        # one key per batch item: q-GEMM + gate + proj-GEMM + residual as ONE pass over the tokens (csrc/attn_rank1.hip); the 2B
+        # rows of `vn` are never materialised (batch item b reads vn[b % Bv])
+        r1, attn = tp.attn_rank1(vnB, k, vv, blk.attn)
+        vn = q = o = None
+    else:
+        qB = tp.conv(vnB, "ca.q")
+        # the 2B rows of `vn` / `q` / pack["visual"] are never materialised: the gate reads q[b % B], ca.proj adds the residual row
+        # p % (B * T), and the output-only duplicate of fea_v_proj is made by whoever returns it (three 2 x 61 MB copies per step)
+        periodic = duplicate and (Bv * hh * ww) % 256 == 0 and _FUSE_TOKEN_PATH
+        vn, q = (vnB, qB) if (periodic or not duplicate) else (tp.dup2(vnB), tp.dup2(qB))
+        o, attn = tp.attn_gate(q, k, vv, blk.attn.num_heads, blk.attn.scale)
+        r1 = tp.conv(o, "ca.proj", residual=vn, residual_periodic=periodic)
     l2 = tp.layernorm(r1, blk.norm2)
     hh2 = tp.conv(l2, "ca.fc1", act=ACT_GELU) if _FUSE_TOKEN_PATH else tp.gelu(tp.conv(l2, "ca.fc1"))
     r2 = tp.conv(hh2, "ca.fc2", residual=r1)
@@ -1012,11 +1051,16 @@ def run_train_forward(model, image: torch.Tensor, audio: torch.Tensor, tp: Train
     pvt = m.seg_model == "PVT"
     rn = None if pvt else m.backbone.backbone
     B = image.shape[0]
+    shape_key = (B, int(image.shape[-2]), int(image.shape[-1]))
     if (collectives_on() and tp.dev.type == "cuda" and not torch.cuda.is_current_stream_capturing()
+            and shape_key not in m.__dict__.setdefault("_syncbn_shapes_ok", set())
             and any(isinstance(mm, nn.SyncBatchNorm) for mm in m.modules())):
         # SyncBatchNorm combines the ranks' moments assuming every rank holds the same number of samples per layer (bn_act):
-        # one tiny exchange per eager step verifies it (torch's SyncBatchNorm gathers per-rank counts instead; uneven last
-        # batches need drop_last=True here)
+        # one tiny exchange verifies it (torch's SyncBatchNorm gathers per-rank counts instead; uneven last batches need
+        # drop_last=True here).  ONCE per (batch, height, width): the check costs a pageable upload, a blocking all-reduce and a
+        # device-to-host read, which round 3 paid on every eager step; captured steps replay the shape they were captured (and
+        # checked, in the eager warm-up pass) with.  A rank whose shape CHANGES alone still meets the others in this collective,
+        # because every rank sees a new shape key at the same step of a lock-step data-parallel loop.
         import torch.distributed as dist
         allv = torch.zeros((dist.get_world_size(), 3), dtype=torch.float32, device=tp.dev)
         allv[dist.get_rank()] = torch.tensor([B, image.shape[-2], image.shape[-1]], dtype=torch.float32)
@@ -1025,6 +1069,7 @@ def run_train_forward(model, image: torch.Tensor, audio: torch.Tensor, tp: Train
         if any(v != got[0] for v in got):
             raise CavpError("SyncBatchNorm on the MI355X path needs the same batch and image size on every rank "
                             f"(got {got}); use drop_last=True")
+        m.__dict__["_syncbn_shapes_ok"].add(shape_key)
     # ---- pack ----
     if not pvt:
         tp.pack("stem0", rn.conv1[0], raw=True)

@@ -398,6 +398,44 @@ def attn_gate_bwd(dout, q, k, v, attn, dattn, dq, dk, dv, heads: int, scale: flo
            "cavp_attn_gate_bwd")
 
 
+def attn1_bwd(dout, x, u, pm, dx, dbp):
+    """Backward of ops.attn1_fwd over the tokens: dx [xb, T, C] written; returns (dU, dP) f32 [B, heads, C]; dbp (f32 [C] or None)
+    accumulated."""
+    _need_gpu(dout, x, u, pm, dx)
+    b, t, c = dout.shape
+    xb, heads = x.shape[0], u.shape[1]
+    if b % xb or tuple(dx.shape) != tuple(x.shape) or dout.dtype != x.dtype or dx.dtype != x.dtype:
+        raise _lib.CavpError("attn1_bwd: shape / dtype mismatch")
+    for ten in (dout, x, u, pm, dx):
+        if not ten.is_contiguous():
+            raise _lib.CavpError("attn1_bwd: contiguous tensors required")
+    lib = _lib.load()
+    nbytes = lib.cavp_attn1_bwd_workspace_bytes(b, xb, t, c, heads)
+    ws = ops.workspace(nbytes, x.device)
+    du = torch.empty((b, heads, c), dtype=torch.float32, device=x.device)
+    dp = torch.empty((b, heads, c), dtype=torch.float32, device=x.device)
+    _check(lib.cavp_attn1_bwd(dtype_code(x.dtype), _ptr(dout), _ptr(x), _ptr(u), _ptr(pm), _ptr(dx), _ptr(du), _ptr(dp),
+                              _ptr(dbp) if dbp is not None else None, _ptr(ws), C.c_size_t(ws.numel()), b, xb, t, c, heads, _s()),
+           "cavp_attn1_bwd")
+    return du, dp
+
+
+def attn1_finish(wq, wp, k, v, du, dp, dwq, dwp, heads: int, scale: float):
+    """dwq / dwp (f32 [C, C]) accumulated; returns (dk, dv) f32 [B, C]."""
+    _need_gpu(wq, wp, k, v, du, dp, dwq, dwp)
+    b, c = k.shape
+    dk = torch.empty((b, c), dtype=torch.float32, device=k.device)
+    dv = torch.empty((b, c), dtype=torch.float32, device=k.device)
+    for ten in (wq, wp, k, v, du, dp, dwq, dwp):
+        if not ten.is_contiguous():
+            raise _lib.CavpError("attn1_finish: contiguous tensors required")
+    if dwq.dtype != torch.float32 or dwp.dtype != torch.float32 or dwq.numel() != c * c or dwp.numel() != c * c:
+        raise _lib.CavpError("attn1_finish: dwq / dwp must be f32 [C, C]")
+    _check(_lib.load().cavp_attn1_finish(dtype_code(k.dtype), _ptr(wq), _ptr(wp), _ptr(k), _ptr(v), _ptr(du), _ptr(dp), _ptr(dwq),
+                                         _ptr(dwp), _ptr(dk), _ptr(dv), b, c, heads, C.c_float(scale), _s()), "cavp_attn1_finish")
+    return dk, dv
+
+
 def maxpool_bwd(argmax, dy, dx, k: int, stride: int, pad: int) -> torch.Tensor:
     """argmax: uint8 [N][Ho][Wo][C] written by ops.maxpool; dy: same shape (dtype); dx: [N][H][W][C]."""
     n, h, w, c, _ = _nhwc(dx)

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define CAVP_ABI_VERSION 7
+#define CAVP_ABI_VERSION 8
 
 typedef enum { CAVP_F32 = 0, CAVP_BF16 = 1 } cavp_dtype_t;
 typedef enum { CAVP_ACT_NONE = 0, CAVP_ACT_RELU = 1, CAVP_ACT_LEAKY = 2, CAVP_ACT_GELU = 3 } cavp_act_t;
@@ -120,6 +120,10 @@ int cavp_conv2d_nhwc_aux(const cavp_conv_desc* d, const void* x, const void* w, 
  * + the remaining images on the small tiles.  Process-wide switch for A/B runs and tests (default on); results are identical
  * either way up to the summation order inside the tail images. */
 int cavp_set_tail_split(int32_t on);
+/* Weight-gradient kernel variant of the bf16 path (cavp_conv2d_wgrad_nhwc / cavp_conv2d_wgrad_group; the weight gradients
+ * torch.autograd computes for trainer_cavp_vpo_mono.py:190): 0 = two 32-row LDS stages per workgroup, 1 = one 64-row stage.
+ * Both keep four 32 KiB workgroups per CU and give bit-identical results.  Process-wide switch for A/B runs and tests. */
+int cavp_set_wgrad_variant(int32_t variant);
 
 /* Direct 3x3 conv for Cin in {1,2,3} reading an NCHW f32 tensor and writing NHWC (dtype) with scale/shift + act:
  * the ResNet deep-stem first conv (resnet.py:108-110, stride 2) and the first VGGish conv (vgg.py:26-36). */
@@ -297,6 +301,31 @@ int cavp_layernorm_bwd_add(int32_t dtype, const void* dy, const void* x, const f
                            void* dx, void* dx_scaled, const float* row_scale, int32_t rows_per_group, float* dgamma,
                            float* dbeta, int32_t rows, int32_t C, int32_t ld_dy, int32_t ld_x, int32_t ld_dx, float eps,
                            void* stream);
+/* ---- cross-modal attention with ONE key / value token per batch item, collapsed to rank-H operations (ABI 8) ------------------
+ * attn.py:73-106 as CAVP calls it (x_k = x_v = the audio token, cavp_model.py:145-149; 4 heads, q / k / v without bias, sigmoid):
+ *   q = x Wq^T, s[t,h] = scale q[t,h,:] . k[h,:], g = sigmoid(s), o[t,h,:] = g[t,h] v[h,:], out = x + o Wp^T + bp   (attn.py:153-156)
+ * equals, with u[b,h,:] = scale Wq[h-slice,:]^T k[b,h-slice] and p[b,h,:] = Wp[:,h-slice] v[b,h-slice] (H x C per batch item),
+ *   g[b,t,h] = sigmoid(x[t,:] . u[b,h,:]),   out[b,t,:] = x[t,:] + bp + sum_h g[b,t,h] p[b,h,:]
+ * so the two C x C token GEMMs (and their data / weight gradient GEMMs) become one pass over the tokens per direction.
+ * wq, wp: the f32 [C][C] weights of attn.q / attn.proj (nn.Linear layout); k, v: [B][C] in `dtype`; U, P: f32 [B][heads][C].
+ * x: [xb][T][C] with xb dividing B (forward_train duplicates the images, cavp_model.py:181: batch item b reads x[b % xb]).
+ * Supported: heads == 4, C <= 512, C % 8 == 0 (cavp_attn1_supported); callers keep cavp_attn_gate + two linears otherwise. */
+int cavp_attn1_supported(int32_t C, int32_t heads);
+int cavp_attn1_prepare(int32_t dtype, const float* wq, const float* wp, const void* k, const void* v, float* U, float* P, int32_t B,
+                       int32_t C, int32_t heads, float scale, void* stream);
+/* out: [B][T][C] in `dtype`; attn: f32 [B][heads][T] (the reference's attn_v, cavp_model.py:150); bp may be NULL. */
+int cavp_attn1_fwd(int32_t dtype, const void* x, const float* U, const float* P, const float* bp, void* out, float* attn, int32_t B,
+                   int32_t xb, int32_t T, int32_t C, int32_t heads, void* stream);
+/* Backward over the tokens: dx [xb][T][C] = sum over the batch items that share a row of (dout + sum_h ds[t,h] u[b,h,:]) is
+ * WRITTEN (not accumulated); dU / dP: f32 [B][heads][C] written; dbp (optional, f32 [C]) accumulated.  All sums in a fixed
+ * order (per-workgroup slabs in `workspace`, cavp_attn1_bwd_workspace_bytes). */
+size_t cavp_attn1_bwd_workspace_bytes(int32_t B, int32_t xb, int32_t T, int32_t C, int32_t heads);
+int cavp_attn1_bwd(int32_t dtype, const void* dout, const void* x, const float* U, const float* P, void* dx, float* dU, float* dP,
+                   float* dbp, void* workspace, size_t workspace_bytes, int32_t B, int32_t xb, int32_t T, int32_t C, int32_t heads,
+                   void* stream);
+/* dwq, dwp (f32 [C][C], nn.Linear layout) accumulated; dk, dv: f32 [B][C] written. */
+int cavp_attn1_finish(int32_t dtype, const float* wq, const float* wp, const void* k, const void* v, const float* dU, const float* dP,
+                      float* dwq, float* dwp, float* dk, float* dv, int32_t B, int32_t C, int32_t heads, float scale, void* stream);
 /* backward of cavp_attn_gate; dk, dv: f32 [B][heads*hd] accumulated with atomics (caller zeroes); dattn optional.
  * q: [q_batch][T][heads*hd] as in the forward; dq: [B][T][heads*hd] (the caller sums the q_batch-periodic parts). */
 int cavp_attn_gate_bwd(int32_t dtype, const void* dout, const void* q, const void* k, const void* v, const float* attn,

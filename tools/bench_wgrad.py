@@ -40,7 +40,10 @@ def main():
     ap.add_argument("--shapes", default="")
     ap.add_argument("--splitk", default="0")
     ap.add_argument("--reps", type=int, default=10)
+    ap.add_argument("--variant", type=int, default=0, help="cavp_set_wgrad_variant: 0 = two 32-row stages, 1 = one 64-row stage")
     a = ap.parse_args()
+    from cavp_amd import _lib
+    assert _lib.load().cavp_set_wgrad_variant(a.variant) == 0
     dt = torch.bfloat16 if a.dtype == "bf16" else torch.float32
     dev = "cuda:0"
     sks = [int(v) for v in a.splitk.split(",")]
