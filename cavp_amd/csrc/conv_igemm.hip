@@ -88,12 +88,8 @@ __device__ __forceinline__ void epilogue_store4(const IgemmParams& p, float v0, 
   }
 }
 
-// NS == 1 (tiles 15-18): ONE stage and <= 128 registers, so that FOUR workgroups share a CU and hide each other's load /
-// multiply phases (tools/microbench/kloop.hip on MI355X, K loop only, 128x128 tile: two 2-stage workgroups per CU 1322 TF/s,
-// four single-stage ones 1667 TF/s; 64-byte LDS rows (BK = 32) lose 15 %: a DMA instruction then fetches 16 half cache lines).
-// Their epilogue is per WAVE (no workgroup barrier, accumulators released block by block, see below).
 template <typename T, int BC, int BP, int WC, int WP, bool UP, int NS>
-__global__ __launch_bounds__(64 * WC * WP, (WC * WP == 4 ? (NS == 1 ? 4 : 2) : (NS == 2 ? 4 : 1))) void igemm_kernel(const IgemmParams p) {
+__global__ __launch_bounds__(64 * WC * WP, (WC * WP == 4 ? 2 : 1)) void igemm_kernel(const IgemmParams p) {
   constexpr int VE = Elem<T>::VE;
   constexpr int BK = 8 * VE;  // one 128-byte LDS row of K
   constexpr int TC = BC / WC, TP = BP / WP;
@@ -104,14 +100,14 @@ __global__ __launch_bounds__(64 * WC * WP, (WC * WP == 4 ? (NS == 1 ? 4 : 2) : (
   constexpr int TILE_BYTES = (BC + BP) * 128;
   constexpr int RSTEP = 8 * NW;  // LDS rows covered by one DMA instruction of the whole workgroup
   static_assert(NW == 4 || NW == 8, "4 or 8 waves per workgroup");
-  static_assert(NS >= 1 && (NS < 2 || (NS - 2) * (LW + LX) < 64), "vmcnt is a 6-bit counter");
-  static_assert(NW == 4 || NS == 3 || NS == 2, "the 8-wave tiles: three stages (one workgroup per CU) or two (tile 19: two per CU)");
+  static_assert(NS >= 2 && (NS - 2) * (LW + LX) < 64, "vmcnt is a 6-bit counter");
+  static_assert(NW == 4 || NS == 3, "the 8-wave tiles are written for three stages");
   static_assert(TC % 16 == 0 && TP % 16 == 0, "wave tile must be a multiple of the 16x16 MFMA block");
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   // (the wave index as a SCALAR: every LDS-DMA destination - M0 - then comes from SALU adds; as a vector value it cost one
-  // VGPR + one v_readfirstlane per DMA instruction, which is what pushed the single-stage tiles over 128 registers)
+  // VGPR + one v_readfirstlane per DMA instruction)
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   // persistent workgroups: gridDim.x (a multiple of 8, so a workgroup keeps its XCD) physical workgroups walk the
   // p.nblk logical ones: launch, kernel-argument load and teardown are paid once per physical workgroup
@@ -156,6 +152,23 @@ __global__ __launch_bounds__(64 * WC * WP, (WC * WP == 4 ? (NS == 1 ? 4 : 2) : (
   unsigned x_mask[LX];  // bit ti = live tap ti reads inside the image for this row
   int x_h0[LX], x_w0[LX], x_nb[LX];  // x_nb: UP only
   const int HoWo = p.Ho * p.Wo;
+  // pointwise layers (1x1, stride 1, no padding: two thirds of the conv / linear launches of a CAVP step): output pixel = input
+  // pixel, the one tap is always inside the image - no (n, ho, wo) split (two multiply-shift divisions per row) and no tap loop.
+  // Short-K layers pay this set-up once per tile next to a handful of K steps.
+  // (also a dilated 3x3 whose only live tap is the centre one: ASPP d = 18 on 14 x 14)
+  const bool pointwise = !UP && p.ntaps == 1 && p.stride == 1 && p.stride_w == 1 && p.tap_dh[0] == p.pad && p.tap_dw[0] == p.pad &&
+                         p.Ho == p.H && p.Wo == p.W;
+  if (pointwise) {
+#pragma unroll
+    for (int i = 0; i < LX; ++i) {
+      const int row = row0 + RSTEP * i;
+      const int pix = p_base + row;
+      const bool ok = (row < BP) && (pix < p.M);
+      x_h0[i] = 0; x_w0[i] = 0; x_nb[i] = 0;
+      x_mask[i] = ok ? 1u : 0u;
+      x_off[i] = (unsigned)pix * (unsigned)(p.ldx * (int)sizeof(T)) + (unsigned)kbyte - (unsigned)p.tap_xoff[0];   // (gdma adds tap_xoff back)
+    }
+  } else {
 #pragma unroll
   for (int i = 0; i < LX; ++i) {
     const int row = row0 + RSTEP * i;
@@ -182,6 +195,7 @@ __global__ __launch_bounds__(64 * WC * WP, (WC * WP == 4 ? (NS == 1 ? 4 : 2) : (
       for (int i = 0; i < LX; ++i)
         x_mask[i] |= ((unsigned)(x_h0[i] + dh) < (unsigned)p.H && (unsigned)(x_w0[i] + dw) < (unsigned)p.W) ? (1u << t) : 0u;
     }
+  }
   }
 
   // K-loop position (tap index, channel tile) kept incrementally: no division in the loop
@@ -267,22 +281,7 @@ __global__ __launch_bounds__(64 * WC * WP, (WC * WP == 4 ? (NS == 1 ? 4 : 2) : (
   };
 
   if (it_begin < it_end) {
-    if constexpr (NS == 1) {
-      // one stage, four workgroups per CU: load, wait, barrier, multiply, barrier - nothing overlaps inside the workgroup, the
-      // three co-resident ones fill the gaps
-      for (int it = it_begin; it < it_end; ++it) {
-        if (it != it_begin) __builtin_amdgcn_s_barrier();   // everybody finished multiplying the previous tile
-        gdma(0, true);
-        __builtin_amdgcn_s_waitcnt(vmcnt_imm(0));
-        __builtin_amdgcn_s_barrier();
-        u32x4_t af[MC], bfv[MP];
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          read_frag(af, bfv, 0, j);
-          mma_block(af, bfv);
-        }
-      }
-    } else if constexpr (NS == 2) {
+    if constexpr (NS == 2) {
       // two stages, two workgroups per CU.  Iteration `it`: wait for MY loads of tile `it`, barrier (=> everybody's
       // tile `it` landed and everybody finished multiplying tile it-1), issue tile it+1 into the stage tile it-1
       // vacated, multiply tile `it`.
@@ -360,190 +359,11 @@ __global__ __launch_bounds__(64 * WC * WP, (WC * WP == 4 ? (NS == 1 ? 4 : 2) : (
         buf = nb;
       }
     }
-    if (NS != 1 || !p.coalesced) __syncthreads();  // drains the (empty) tail DMAs and fences the K-loop LDS reads before the epilogue reuses LDS
+    __syncthreads();  // drains the (empty) tail DMAs and fences the K-loop LDS reads before the epilogue reuses LDS
   }
 
   // ---- epilogue ----
   if (CAVP_DBG(p, 16)) continue;
-  if constexpr (NS == 1) {
-    if (p.coalesced) {
-      // Per-WAVE epilogue of the single-stage tiles.  The f32 staging of the whole tile (BP x BC x 4 bytes) does not fit their
-      // 32 KiB, and at 128 registers the accumulators of a wave that waits for its turn in a workgroup-wide staging order would
-      // spill.  So every wave transposes its OWN TC x TP block through a private LDS scratch, HB 16-row blocks per round: the
-      // accumulators of a round are dead once they are staged, LDS operations of one wave execute in order (no barrier between
-      // the staging writes and the row reads), and a wave stores TC * sizeof(T) contiguous bytes per pixel row (128 B for the
-      // 128-wide bf16 tile).  One workgroup barrier remains: it fences the K loop's LDS reads and publishes the per-wave
-      // BatchNorm partials.
-      constexpr int CPR = TC / VE;                    // 16-byte output chunks per pixel row of the wave block
-      constexpr int RPP = 64 / CPR;                   // pixel rows per pass of the wave
-      constexpr int HB = (NW * 32 * TC * 4 <= TILE_BYTES && MP % 2 == 0) ? 2 : 1;   // 16-row blocks per round
-      constexpr int PASSES = HB * 16 / RPP;
-      static_assert(64 % CPR == 0 && (HB * 16) % RPP == 0 && NW * HB * 16 * TC * 4 <= TILE_BYTES, "per-wave epilogue geometry");
-      float* st = (float*)(smem + wave * (HB * 16 * TC * 4));
-      const int q = lane % CPR, r0 = lane / CPR;
-      const int ec = c_base + wc0 + q * VE;
-      const bool ec_ok = ec < p.Cout;
-      float sc[VE], sh[VE];
-#pragma unroll
-      for (int e = 0; e < VE; ++e) { sc[e] = 1.f; sh[e] = 0.f; }
-      if (ec_ok) {
-        if (p.scale) {
-#pragma unroll
-          for (int qq = 0; qq < VE / 4; ++qq) {
-            const float4 t = *(const float4*)(p.scale + ec + 4 * qq);
-            sc[4 * qq] = t.x; sc[4 * qq + 1] = t.y; sc[4 * qq + 2] = t.z; sc[4 * qq + 3] = t.w;
-          }
-        }
-        if (p.shift) {
-#pragma unroll
-          for (int qq = 0; qq < VE / 4; ++qq) {
-            const float4 t = *(const float4*)(p.shift + ec + 4 * qq);
-            sh[4 * qq] = t.x; sh[4 * qq + 1] = t.y; sh[4 * qq + 2] = t.z; sh[4 * qq + 3] = t.w;
-          }
-        }
-      }
-      float2* wstat = (float2*)(smem + NS * TILE_BYTES);   // [WP][BC] per-wave (mean, M2) partials
-      if (p.tile_stats) {   // (as in the multi-stage tiles below: sums about the wave's first row, DPP row reductions)
-        const int nvw = p.M - (p_base + wp0);
-#pragma unroll
-        for (int a = 0; a < MC; ++a) {
-          float s1[4], s2[4], x0[4];
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            x0[i] = __shfl(acc[a][0][i], lane & 48, 64);
-            s1[i] = 0.f; s2[i] = 0.f;
-          }
-#pragma unroll
-          for (int b = 0; b < MP; ++b) {
-            const bool ok = b * 16 + lrow < nvw;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-              const float d = ok ? acc[a][b][i] - x0[i] : 0.f;
-              s1[i] += d;
-              s2[i] = fmaf(d, d, s2[i]);
-            }
-          }
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            s1[i] = row16_sum(s1[i]);
-            s2[i] = row16_sum(s2[i]);
-          }
-          if (lrow == 0) {
-            const float n = (float)(nvw < TP ? (nvw > 0 ? nvw : 1) : TP);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-              const float m = s1[i] / n;
-              wstat[(wave / WC) * BC + wc0 + a * 16 + lgrp * 4 + i] = make_float2(x0[i] + m, fmaxf(s2[i] - s1[i] * m, 0.f));
-            }
-          }
-        }
-      }
-      __syncthreads();   // every wave is done with the K loop's LDS reads; the statistics partials are visible
-      if (p.tile_stats && tid < BC && c_base + tid < p.Cout) {
-        float n = 0.f, mean = 0.f, m2 = 0.f;
-#pragma unroll
-        for (int w = 0; w < WP; ++w) {
-          int nb = p.M - (p_base + w * TP);
-          nb = nb < TP ? nb : TP;
-          if (nb > 0) {
-            const float2 qq = wstat[w * BC + tid];
-            const float fb = (float)nb, nt = n + fb, dlt = qq.x - mean;
-            mean += dlt * (fb / nt);
-            m2 += qq.y + dlt * dlt * (n * fb / nt);
-            n = nt;
-          }
-        }
-        float* o = p.tile_stats + ((size_t)tp * p.Cout + c_base + tid) * 2;
-        o[0] = mean;
-        o[1] = m2;
-      }
-      auto key = [](int row) { return TC >= 64 ? (row & 7) : ((row >> 1) & 7); };   // conflict-free ds_write_b128 / ds_read_b128
-      const int rowg0 = p_base + wp0 + r0;            // first global pixel row of this lane
-      T* yp = (T*)p.y + (size_t)rowg0 * p.ldy + ec;
-      const T* rp = p.res ? (const T*)p.res + (size_t)((p.res_rows ? p_base % p.res_rows : p_base) + wp0 + r0) * p.ldr + ec : nullptr;
-      T* xp = p.aux_mode ? (T*)p.aux + (size_t)rowg0 * p.ld_aux + ec : nullptr;
-      const bool has_ss = p.scale != nullptr || p.shift != nullptr;
-      const int rows_left = p.M - rowg0;              // row offset d (from rowg0) is in range iff d < rows_left
-#pragma unroll
-      for (int h = 0; h < MP / HB; ++h) {
-#pragma unroll
-        for (int a = 0; a < MC; ++a)
-#pragma unroll
-          for (int bb = 0; bb < HB; ++bb) {
-            const int row = bb * 16 + lrow, slot = a * 4 + lgrp;
-            *(f32x4_t*)(st + row * TC + ((slot ^ key(row)) << 2)) = acc[a][h * HB + bb];
-          }
-        u32x4_t rr[PASSES];
-        if (rp) {
-#pragma unroll
-          for (int ps = 0; ps < PASSES; ++ps) {
-            const int d = h * HB * 16 + ps * RPP;
-            rr[ps] = (u32x4_t){0u, 0u, 0u, 0u};
-            if (ec_ok && d < rows_left) rr[ps] = *(const u32x4_t*)(rp + (size_t)d * p.ldr);
-          }
-        }
-#pragma unroll
-        for (int ps = 0; ps < PASSES; ++ps) {
-          const int row = r0 + ps * RPP, d = h * HB * 16 + ps * RPP;
-          float v[VE];
-          {
-            const f32x4_t t = *(const f32x4_t*)(st + row * TC + (((q * (VE / 4)) ^ key(row)) << 2));
-            v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3];
-          }
-          if constexpr (VE == 8) {
-            const f32x4_t t = *(const f32x4_t*)(st + row * TC + (((q * 2 + 1) ^ key(row)) << 2));
-            v[4] = t[0]; v[5] = t[1]; v[6] = t[2]; v[7] = t[3];
-          }
-          if (!(ec_ok && d < rows_left)) continue;
-          if (p.nbias) {
-            const float* nb = p.nbias + (size_t)fast_div(rowg0 + d, p.div_hw_m, p.div_hw_s) * p.Cout + ec;
-#pragma unroll
-            for (int e = 0; e < VE; ++e) v[e] += nb[e];
-          }
-          if (has_ss) {
-#pragma unroll
-            for (int e = 0; e < VE; ++e) v[e] = __fadd_rn(__fmul_rn(v[e], sc[e]), sh[e]);
-          }
-          if (p.aux_mode == 2) {
-            float m[VE];
-            VecT<T>::load(xp + (size_t)d * p.ld_aux, m);
-#pragma unroll
-            for (int e = 0; e < VE; ++e) v[e] *= m[e];
-          }
-          if (rp) {
-            if constexpr (sizeof(T) == 4) {
-#pragma unroll
-              for (int e = 0; e < 4; ++e) v[e] += __uint_as_float(rr[ps][e]);
-            } else {
-#pragma unroll
-              for (int e = 0; e < 4; ++e) {
-                v[2 * e] += __uint_as_float(rr[ps][e] << 16);
-                v[2 * e + 1] += __uint_as_float(rr[ps][e] & 0xffff0000u);
-              }
-            }
-          }
-          if (p.aux_mode == 1) {
-            float m[VE];
-#pragma unroll
-            for (int e = 0; e < VE; ++e) gelu_and_grad(v[e], v[e], m[e]);
-            VecT<T>::store(xp + (size_t)d * p.ld_aux, m);
-          } else {
-            apply_act_vec<VE>(v, p.act);
-          }
-          u32x4_t o;
-          if constexpr (sizeof(T) == 4) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = __float_as_uint(v[e]);
-          } else {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = pack2bf(v[2 * e], v[2 * e + 1]);
-          }
-          *(u32x4_t*)(yp + (size_t)d * p.ldy) = o;
-        }
-      }
-      continue;
-    }
-  }
   if (p.coalesced) {
     // Stage the f32 accumulators in LDS as [pixel][cout] (16-byte slots XOR-swizzled by pixel & 7), then let each
     // thread finish VE consecutive channels of one pixel: scale/shift/bias/residual are 16-byte vector loads and the
@@ -808,12 +628,10 @@ const TileCfg kTiles[] = {
     {8, 256, 128, 1.00f}, {9, 128, 256, 1.00f},  // 8 waves, 3 stages (eff set to 1.0 until measured: kBigEff below)
     {10, 256, 256, 2.00f},                       // conv_igemm_big.hip: 8 waves in two ping-pong groups, one workgroup per CU
     {11, 64, 64, 0.70f}, {12, 64, 64, 0.70f}, {13, 128, 64, 0.80f}, {14, 64, 128, 0.80f},   // deep rings (4 / 8 / 4 / 4 stages) for under-filled launches
-    {15, 128, 128, 1.25f}, {16, 64, 128, 1.00f}, {17, 128, 64, 1.00f}, {18, 64, 64, 0.85f},   // single stage, four workgroups per CU
-    {19, 128, 128, 1.10f}, {20, 128, 128, 1.10f},   // EIGHT waves (2 x 4 / 4 x 2), two stages, two 64 KiB workgroups per CU: 32 accumulator registers per wave
 };
-inline int tile_stages(int id) { return id >= 19 ? 2 : id >= 15 ? 1 : id == 12 ? 8 : id >= 11 ? 4 : id == 10 ? 2 : id >= 8 ? 3 : 2; }
+inline int tile_stages(int id) { return id == 12 ? 8 : id >= 11 ? 4 : id == 10 ? 2 : id >= 8 ? 3 : 2; }
 inline bool tile_is_big(int id) { return id == 10; }
-inline int tile_wp(int id) { return id == 5 ? 1 : (id == 6 || id == 7 || id == 9 || id == 19) ? 4 : 2; }   // waves along the pixel dimension (launch_tile)
+inline int tile_wp(int id) { return id == 5 ? 1 : (id == 6 || id == 7 || id == 9) ? 4 : 2; }   // waves along the pixel dimension (launch_tile)
 // A/B knob: CAVP_IGEMM_EFF="e1,e2,...,e9" overrides the efficiency column of kTiles (time-model sweeps without a rebuild)
 inline double tile_eff(const TileCfg& t) {
   static double ov[16];
@@ -836,7 +654,7 @@ constexpr int kNumTiles = sizeof(kTiles) / sizeof(kTiles[0]);
 template <typename T, int BC, int BP, int WC, int WP, bool UP, int NS = 2>
 hipError_t launch_cfg(const IgemmParams& p, int nblk, hipStream_t s) {
   constexpr int lds = NS * (BC + BP) * 128 + WP * BC * 8;   // + the per-wave BatchNorm-statistics partials
-  static_assert(NS == 1 || BP * BC * 4 <= NS * (BC + BP) * 128, "epilogue staging must fit in the K-loop LDS");
+  static_assert(BP * BC * 4 <= NS * (BC + BP) * 128, "epilogue staging must fit in the K-loop LDS");
   static_assert(BC <= 64 * WC * WP, "tile_stats: one thread per output channel of the tile");
   static bool attr_set = false;
   if (!attr_set) {
@@ -876,24 +694,6 @@ hipError_t launch_tile(int id, const IgemmParams& p, int nblk, hipStream_t s) {
     case 12: return launch_cfg<T, 64, 64, 2, 2, UP, 8>(p, nblk, s);
     case 13: return launch_cfg<T, 128, 64, 2, 2, UP, 4>(p, nblk, s);
     case 14: return launch_cfg<T, 64, 128, 2, 2, UP, 4>(p, nblk, s);
-    case 15:   // single-stage tiles: bf16 only (the f32 parity path is bound by its 16x slower MFMAs, not by the operand feed)
-      if constexpr (sizeof(T) == 2) return launch_cfg<T, 128, 128, 2, 2, UP, 1>(p, nblk, s);
-      return hipErrorInvalidValue;
-    case 16:
-      if constexpr (sizeof(T) == 2) return launch_cfg<T, 64, 128, 2, 2, UP, 1>(p, nblk, s);
-      return hipErrorInvalidValue;
-    case 17:
-      if constexpr (sizeof(T) == 2) return launch_cfg<T, 128, 64, 2, 2, UP, 1>(p, nblk, s);
-      return hipErrorInvalidValue;
-    case 18:
-      if constexpr (sizeof(T) == 2) return launch_cfg<T, 64, 64, 2, 2, UP, 1>(p, nblk, s);
-      return hipErrorInvalidValue;
-    case 19:
-      if constexpr (sizeof(T) == 2) return launch_cfg<T, 128, 128, 2, 4, UP, 2>(p, nblk, s);
-      return hipErrorInvalidValue;
-    case 20:
-      if constexpr (sizeof(T) == 2) return launch_cfg<T, 128, 128, 4, 2, UP, 2>(p, nblk, s);
-      return hipErrorInvalidValue;
     default: return hipErrorInvalidValue;
   }
 }

@@ -74,7 +74,7 @@ __device__ __forceinline__ void wgrad_tile(const WgradParams& p, const int bid, 
   constexpr int MB = WT / 16;        // 16x16 blocks per wave edge
   constexpr unsigned kOOB = 0x80000000u;
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (scalar: LDS-DMA bases via SALU)
 
   // (multiply + shift: integer division is a ~40-instruction VALU sequence even for wave-uniform values)
   const int b1 = fast_div(bid, p.dv_co[0], p.dv_co[1]), tco = bid - b1 * p.tiles_co;
@@ -174,6 +174,12 @@ __device__ __forceinline__ void wgrad_tile(const WgradParams& p, const int bid, 
   float bsum[MB];
 #pragma unroll
   for (int b = 0; b < MB; ++b) bsum[b] = 0.f;
+
+  // 16 x 16 blocks of this wave's 64 x 64 sub-tile that hold real channels: a 304-channel operand fills 2.375 tiles of 128, and the
+  // last tile's zero-filled blocks (5 of its 8 block rows) were multiplied like any other - 21 % of the MFMAs of a 304-wide
+  // dimension, 37 % of a 304 x 304 weight.  Dead blocks are skipped (wave-uniform), their accumulators stay zero.
+  const int na = __builtin_amdgcn_readfirstlane(min(MB, max(0, (p.Cin - ci_base - wci0 + 15) >> 4)));
+  const int nb = __builtin_amdgcn_readfirstlane(min(MB, max(0, (p.Cout - co_base - wco0 + 15) >> 4)));
 
   auto compute = [&](int buf) {
     const char* xb = smem + buf * STAGE;
@@ -301,11 +307,15 @@ __device__ __forceinline__ void wgrad_tile(const WgradParams& p, const int bid, 
               bsum[b] += __uint_as_float(bfv[b][e] << 16) + __uint_as_float(bfv[b][e] & 0xffff0000u);
         }
 #pragma unroll
-        for (int a = 0; a < MB; ++a)
+        for (int a = 0; a < MB; ++a) {
+          if (a >= na) break;   // (wave-uniform)
 #pragma unroll
-          for (int b = 0; b < MB; ++b)
+          for (int b = 0; b < MB; ++b) {
+            if (b >= nb) break;
             acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, af[a]),
                                                                 __builtin_bit_cast(bf16x8_t, bfv[b]), acc[a][b], 0, 0, 0);
+          }
+        }
         __builtin_amdgcn_sched_barrier(0);   // (the scheduler otherwise hoists the wait + barrier above the MFMAs)
         // the next stage's LDS-DMA must have LANDED before any wave crosses the barrier and reads it: hipcc (ROCm 7.2) emits this
         // vmcnt(0) itself in front of the barrier, but nothing in the source required it - gfx950's workgroup release fence does

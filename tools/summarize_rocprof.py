@@ -22,8 +22,12 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("dir")
     ap.add_argument("--out", default=None)
+    ap.add_argument("--igemm-json", default=None, help="write {steps, igemm_ms_per_step, ...} of the kernel trace (bench.py reads it as "
+                                                       "roofline.igemm_ms_rocprof); steps = calls of --step-kernel")
+    ap.add_argument("--step-kernel", default="head_fwd_kernel", help="a kernel that runs exactly once per step")
     a = ap.parse_args()
     lines = []
+    per_step = None
     traces = glob.glob(os.path.join(a.dir, "**", "*kernel_trace.csv"), recursive=True)
     for t in traces:
         agg = defaultdict(lambda: [0, 0.0, 1e30, 0.0])
@@ -37,6 +41,18 @@ def main():
         lines.append(f"{'calls':>7} {'total_us':>12} {'avg_us':>10} {'min_us':>9} {'max_us':>9} {'%':>6}  kernel")
         for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1]):
             lines.append(f"{v[0]:7d} {v[1]:12.1f} {v[1] / v[0]:10.2f} {v[2]:9.2f} {v[3]:9.2f} {100 * v[1] / tot:6.2f}  {k}")
+        steps = sum(v[0] for k, v in agg.items() if k.startswith(a.step_kernel))
+        if steps:
+            def grp(pred):
+                return sum(v[1] for k, v in agg.items() if pred(k)) / steps / 1e3, sum(v[0] for k, v in agg.items() if pred(k)) // steps
+            ig = grp(lambda k: k.startswith("igemm") or k.startswith("splitk_epilogue"))
+            wg = grp(lambda k: k.startswith("wgrad"))
+            per_step = {"traced_steps": steps, "igemm_ms_per_step": round(ig[0], 3), "igemm_launches_per_step": ig[1],
+                        "wgrad_ms_per_step": round(wg[0], 3), "wgrad_launches_per_step": wg[1],
+                        "all_kernels_ms_per_step": round(tot / steps / 1e3, 3),
+                        "kernels_per_step": sum(v[0] for v in agg.values()) // steps,
+                        "note": "rocprofv3 --kernel-trace; igemm = igemm_kernel* + igemm_big_kernel + splitk_epilogue_kernel; sums include "
+                                "kernels that overlap on the side stream"}
     for t in glob.glob(os.path.join(a.dir, "**", "*_results.db"), recursive=True):   # rocprofv3 default (rocpd sqlite)
         import sqlite3
         con = sqlite3.connect(t)
@@ -60,6 +76,10 @@ def main():
         for k, cs in sorted(agg.items(), key=lambda kv: -sum(v[1] for v in kv[1].values())):
             for c, v in sorted(cs.items()):
                 lines.append(f"{c:>22} {v[1]:18.1f} [{v[1] / v[0]:14.1f} x {v[0]:5d}]  {k}")
+    if a.igemm_json and per_step is not None:
+        import json
+        with open(a.igemm_json, "w") as f:
+            json.dump(per_step, f)
     text = "\n".join(lines) + "\n"
     if a.out:
         with open(a.out, "w") as f:
