@@ -112,6 +112,7 @@ PROTOTYPES = {
     "cavp_gather_l2norm": (_i32, [_vp, _i64, _i64, _i64, _vp, _vp, _i32, _i32, _f32, _vp, _vp, _vp]),
     "cavp_infonce_rows": (_i32, [_vp, _vp, _i32, _i32, _f32, _vp, _vp, _vp, _f32, _vp]),
     "cavp_symm_add": (_i32, [_vp, _vp, _i32, _f32, _vp]),
+    "cavp_symm_add_scaled": (_i32, [_vp, _vp, _i32, _f32, _vp, _vp]),
     "cavp_l2norm_bwd_scatter": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _i64, _i64, _i64, _vp]),
     # ---- PVTv2 ----
     "cavp_sra_attention": (_i32, [_i32, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _vp]),

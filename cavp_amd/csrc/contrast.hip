@@ -106,7 +106,8 @@ __global__ __launch_bounds__(256) void mean_neg_kernel(const float* rows, int N,
 }
 
 __global__ __launch_bounds__(256) void symm_add_kernel(const float* __restrict__ d, float* __restrict__ g, int n,
-                                                       float scale) {
+                                                       float scale, const float* __restrict__ scale_dev) {
+  if (scale_dev) scale *= *scale_dev;   // the upstream gradient of the loss, read on the device (no host round trip)
   const long long total = (long long)n * n;
   for (long long t = blockIdx.x * 256ll + threadIdx.x; t < total; t += (long long)gridDim.x * 256) {
     const int i = (int)(t / n), j = (int)(t - (long long)i * n);
@@ -180,7 +181,15 @@ extern "C" int cavp_symm_add(const float* d, float* g, int32_t n, float scale, v
   if (!d || !g || n <= 0) return CAVP_ERR_BAD_ARG;
   long long nb = ((long long)n * n + 255) / 256;
   if (nb > 8192) nb = 8192;
-  symm_add_kernel<<<(int)nb, 256, 0, (hipStream_t)stream>>>(d, g, n, scale);
+  symm_add_kernel<<<(int)nb, 256, 0, (hipStream_t)stream>>>(d, g, n, scale, nullptr);
+  CHECK_LAUNCH();
+}
+
+extern "C" int cavp_symm_add_scaled(const float* d, float* g, int32_t n, float scale, const float* scale_dev, void* stream) {
+  if (!d || !g || !scale_dev || n <= 0) return CAVP_ERR_BAD_ARG;
+  long long nb = ((long long)n * n + 255) / 256;
+  if (nb > 8192) nb = 8192;
+  symm_add_kernel<<<(int)nb, 256, 0, (hipStream_t)stream>>>(d, g, n, scale, scale_dev);
   CHECK_LAUNCH();
 }
 

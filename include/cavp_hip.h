@@ -411,6 +411,9 @@ int cavp_gather_l2norm(const float* x, int64_t stride_b, int64_t stride_c, int64
 int cavp_infonce_rows(const float* S, const int32_t* labels, int32_t N, int32_t ld, float eps, float* row_mlpp,
                       float* loss, float* dS, float grad_scale, void* stream);
 int cavp_symm_add(const float* d, float* g, int32_t n, float scale, void* stream); /* g = (d + d^T) * scale */
+/* g = (d + d^T) * scale * scale_dev[0]: the loss's upstream gradient (a device scalar in torch.autograd) stays on the device -
+ * reading it on the host stalled the launch queue behind the whole forward pass (config #5, trainer_cavp_vpo_mono.py:178-190) */
+int cavp_symm_add_scaled(const float* d, float* g, int32_t n, float scale, const float* scale_dev, void* stream);
 int cavp_l2norm_bwd_scatter(const float* dA, const float* A, const float* norms, const int32_t* idx_b,
                             const int32_t* idx_p, int32_t N, int32_t C, float* dx, int64_t stride_b, int64_t stride_c,
                             int64_t stride_p, void* stream);
