@@ -326,7 +326,7 @@ def measure_roofline(model, run_step, image, dtype_name, reps=3, config="c1p", l
     else:
         cname = "" if config == "c1p" else config + "_"
         tname = f"traffic_{cname}{dtype_name}.json" if mode_name == "eval" else f"traffic_{cname}train_{dtype_name}.json"
-        tpath = next((q for q in (os.path.join(REPO, "profiles", r + tname) for r in ("r03_", "r02_", "r01_")) if os.path.exists(q)), "")
+        tpath = next((q for q in (os.path.join(REPO, "profiles", r + tname) for r in ("r04_", "r03_", "r02_", "r01_")) if os.path.exists(q)), "")
         if tpath:
             with open(tpath) as f:
                 tj = json.load(f)

@@ -62,6 +62,7 @@ def main():
     ap.add_argument("--variants", default="0")
     ap.add_argument("--shapes", default="")
     ap.add_argument("--reps", type=int, default=20)
+    ap.add_argument("--aux", type=int, default=0, help="1: fc1-style epilogue (GELU + gelu' stored, no scale/shift); 2: fc2-dgrad style (result x aux)")
     ap.add_argument("--ldpad", type=int, default=0, help="round the channel stride of x / y / residual up to a multiple of this many elements")
     a = ap.parse_args()
     dt = torch.bfloat16 if a.dtype == "bf16" else torch.float32
@@ -86,8 +87,13 @@ def main():
         cells, ref = [], None
         for v in variants:
             try:
-                f = lambda: ops.conv2d(x, wt, y, kh=k, kw=k, stride=s, pad=p, dil=d, scale=sc, shift=sh, residual=r,
-                                       act=ops.ACT_RELU, tile=v)
+                if a.aux:
+                    auxt = torch.randn_like(y) if a.aux == 2 else torch.empty_like(y)
+                    f = lambda: ops.conv2d(x, wt, y, kh=k, kw=k, stride=s, pad=p, dil=d, shift=sh,
+                                           act=ops.ACT_GELU if a.aux == 1 else ops.ACT_NONE, tile=v, aux=auxt, aux_mode=a.aux)
+                else:
+                    f = lambda: ops.conv2d(x, wt, y, kh=k, kw=k, stride=s, pad=p, dil=d, scale=sc, shift=sh, residual=r,
+                                           act=ops.ACT_RELU, tile=v)
                 f(); f()
                 torch.cuda.synchronize()
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
