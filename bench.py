@@ -57,6 +57,8 @@ def parse():
                     help="force the two-graph replay of the data-parallel path (cut where the early gradients are final) on one GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--lib", default="", help="A/B and anatomy runs: load this build of libcavp_hip.so (e.g. cavp_amd/libcavp_hip_profile.so from "
+                                              "`python -m cavp_amd.build --profile`) instead of the product library")
     ap.add_argument("--grad-allreduce", choices=["f32", "bf16"], default="f32",
                     help="wire format of the data-parallel gradient all-reduce (--gpus > 1): f32 = the reference's DDP (479 MB per step), "
                          "bf16 = cast / sum / cast back, 240 MB per step on the xGMI links (cavp_amd.train.set_grad_allreduce_dtype)")
@@ -532,6 +534,9 @@ def main():
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(self_launch(a))
     cap_host_threads()
+    if a.lib:
+        from cavp_amd import _lib as _cl9
+        _cl9.LIB_PATH = os.path.abspath(a.lib)
     if a.no_token_fusion:
         import cavp_amd.train as _tr
         _tr._FUSE_TOKEN_PATH = False

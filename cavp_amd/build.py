@@ -35,22 +35,20 @@ def _stale() -> bool:
 def build(force: bool = False, verbose: bool = True, profile: bool = False) -> str:
     """profile=True adds -DCAVP_PROFILE: the kernels' compile-time anatomy variants (tools/bench_conv.py --variants);
     the product library carries none of them."""
-    if not force and not _stale():
+    if not force and not profile and not _stale():
         return LIB
     hipcc = _hipcc()
     flags = FLAGS + (["-DCAVP_PROFILE"] if profile else [])
     objs = []
-    os.makedirs(os.path.join(HERE, "build"), exist_ok=True)
+    # the profile flavour lives beside the product: build_profile/*.o -> libcavp_hip_profile.so (tools pick it with --lib)
+    objdir = os.path.join(HERE, "build_profile" if profile else "build")
+    lib = os.path.join(HERE, "libcavp_hip_profile.so") if profile else LIB
+    os.makedirs(objdir, exist_ok=True)
     procs = []
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + [os.path.join(HERE, "..", "include", "cavp_hip.h")]
-    tag = os.path.join(HERE, "build", ".profile" if profile else ".product")   # which flavour the objects in build/ are
-    same_flavour = os.path.exists(tag)
-    for f in (".profile", ".product"):
-        if os.path.exists(os.path.join(HERE, "build", f)) and not f == os.path.basename(tag):
-            os.remove(os.path.join(HERE, "build", f))
-    open(tag, "w").close()
+    same_flavour = True
     for src in SOURCES:
-        obj = os.path.join(HERE, "build", src.replace(".hip", ".o"))
+        obj = os.path.join(objdir, src.replace(".hip", ".o"))
         objs.append(obj)
         deps = [os.path.join(CSRC, src), __file__] + headers
         if not force and same_flavour and os.path.exists(obj) and all(os.path.getmtime(d) <= os.path.getmtime(obj) for d in deps):
@@ -62,12 +60,12 @@ def build(force: bool = False, verbose: bool = True, profile: bool = False) -> s
     for cmd, p in procs:
         if p.wait() != 0:
             raise RuntimeError("hipcc failed: " + " ".join(cmd))
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIB]
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", lib]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
-    return LIB
+    return lib
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv or "--profile" in sys.argv, profile="--profile" in sys.argv))
+    print(build(force="--force" in sys.argv, profile="--profile" in sys.argv))

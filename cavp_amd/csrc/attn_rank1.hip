@@ -395,19 +395,38 @@ __global__ __launch_bounds__(256) void attn1_finish_kernel(const float* __restri
     }
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int j = wave; j < d; j += 4) {
+    for (int j = wave; j < d; j += 8) {   // two rows per trip (independent load chains)
+      const int j2 = j + 4;
       const float* w = wq + (size_t)(h * d + j) * C;
-      float a = 0.f;
-      for (int i = lane; i < C; i += 64) a = fmaf(w[i], su[i], a);
+      const float* w2 = wq + (size_t)(h * d + (j2 < d ? j2 : j)) * C;
+      float a = 0.f, a2 = 0.f;
+      for (int i = lane; i < C; i += 64) {
+        a = fmaf(w[i], su[i], a);
+        a2 = fmaf(w2[i], su[i], a2);
+      }
       a = wave_total(a);
-      if (lane == 0) dk[(size_t)b * C + h * d + j] = scale * a;
+      a2 = wave_total(a2);
+      if (lane == 0) {
+        dk[(size_t)b * C + h * d + j] = scale * a;
+        if (j2 < d) dk[(size_t)b * C + h * d + j2] = scale * a2;
+      }
     }
     const int ng = 256 / d < 3 ? 256 / d : 3;   // (d <= 128)
     const int grp = threadIdx.x / d, j = threadIdx.x - grp * d;
     if (grp < ng) {
-      float c = 0.f;
-      for (int o = grp; o < C; o += ng) c = fmaf(wp[(size_t)o * C + h * d + j], sp[o], c);
-      part[grp * d + j] = c;
+      // (8 loads in flight per thread: a single fmaf chain over C / ng rows of Wp was ~100 dependent L2 round trips, 70 us)
+      float c[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      const float* w = wp + h * d + j;
+      int o = grp;
+      for (; o + 7 * ng < C; o += 8 * ng) {
+        float wv[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) wv[e] = w[(size_t)(o + e * ng) * C];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) c[e] = fmaf(wv[e], sp[o + e * ng], c[e]);
+      }
+      for (; o < C; o += ng) c[0] = fmaf(w[(size_t)o * C], sp[o], c[0]);
+      part[grp * d + j] = ((c[0] + c[1]) + (c[2] + c[3])) + ((c[4] + c[5]) + (c[6] + c[7]));
     }
     __syncthreads();
     if (threadIdx.x < d) {

@@ -788,6 +788,10 @@ Plan make_plan(const cavp_conv_desc* d_in, bool allow_big = true) {
   // d->tile = id + 1000 * (direct epilogue: testing) + profiling digits (hundreds, ten- and hundred-thousands: pieces of the
   // kernel switched off for the K-loop anatomy; honoured by -DCAVP_PROFILE builds only, the product kernels ignore p.dbg)
   p.dbg = (d->tile / 100) % 10 + ((d->tile / 10000) % 10) * 8 + ((d->tile / 100000) % 10) * 16;
+  {   // -DCAVP_PROFILE builds: CAVP_IGEMM_DBG=<bits> switches the same pieces off for EVERY launch (whole-step anatomy; results are garbage)
+    static const int all_dbg = cavp_knob_int("CAVP_IGEMM_DBG", 0);
+    p.dbg |= all_dbg;
+  }
   const int want_tile = d->tile % 100;
   const double peak = d->dtype == CAVP_F32 ? 100e12 : 600e12;
   static const double slab_bw = cavp_knob_double("CAVP_IGEMM_SLAB_TBS", 3.0) * 1e12;   // A/B knob
