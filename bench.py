@@ -67,6 +67,7 @@ def parse():
     ap.add_argument("--no-side-stream", action="store_true", help="A/B: the audio encoder on the main stream instead of a second one")
     ap.add_argument("--no-group-wgrad", action="store_true", help="A/B: one weight-gradient launch (+ slab reduce) per layer instead of grouped launches")
     ap.add_argument("--no-rank1-attn", action="store_true", help="A/B: the cross-modal attention as q GEMM + gate + proj GEMM (round 3) instead of the one-key collapse")
+    ap.add_argument("--igemm-epilogue", type=int, default=-1, help="A/B: cavp_set_igemm_epilogue (1 = register epilogue, 0 = LDS-staged)")
     ap.add_argument("--wgrad-variant", type=int, default=0, help="A/B: cavp_set_wgrad_variant (0 = two 32-row stages, 1 = one 64-row stage)")
     ap.add_argument("--no-tail-split", action="store_true", help="A/B: never split a 256x256-tile launch with a nearly empty last round")
     ap.add_argument("--trainer-loop", action="store_true",
@@ -552,6 +553,9 @@ def main():
     if a.no_rank1_attn:
         import cavp_amd.train as _tr
         _tr._RANK1_ATTN = False
+    if a.igemm_epilogue >= 0:
+        from cavp_amd import _lib as _cl2
+        _cl2.load().cavp_set_igemm_epilogue(a.igemm_epilogue)
     if a.wgrad_variant:
         from cavp_amd import _lib as _cl1
         _cl1.load().cavp_set_wgrad_variant(a.wgrad_variant)

@@ -35,6 +35,7 @@ struct IgemmParams {
   void* aux;                // aux_mode 1: gelu'(t) is stored here; 2: the result is multiplied by it
   int aux_mode, ld_aux;
   int res_rows;             // 0, or: output pixel p adds residual row p % res_rows (a multiple of 256)
+  int reg_epi;              // bf16, 4-wave tiles: epilogue straight from the accumulator registers (v_permlane16_swap), no LDS staging
 };
 
 template <typename T> struct Mma;

@@ -120,6 +120,10 @@ int cavp_conv2d_nhwc_aux(const cavp_conv_desc* d, const void* x, const void* w, 
  * + the remaining images on the small tiles.  Process-wide switch for A/B runs and tests (default on); results are identical
  * either way up to the summation order inside the tail images. */
 int cavp_set_tail_split(int32_t on);
+/* Epilogue of the bf16 conv / linear launches on the 4-wave tiles: 1 = straight from the MFMA accumulator registers
+ * (v_permlane16_swap pairs two 16-channel blocks into 16-byte vectors: no LDS staging, no workgroup barrier), 0 (default) = the
+ * LDS-staged epilogue of rounds 1-3 (the two tie: training step 14.81 vs 14.90 ms, inference 3.11 vs 3.08 ms).  Same values either way.  Process-wide switch for A/B runs and tests. */
+int cavp_set_igemm_epilogue(int32_t mode);
 /* Weight-gradient kernel variant of the bf16 path (cavp_conv2d_wgrad_nhwc / cavp_conv2d_wgrad_group; the weight gradients
  * torch.autograd computes for trainer_cavp_vpo_mono.py:190): 0 = two 32-row LDS stages per workgroup, 1 = one 64-row stage.
  * Both keep four 32 KiB workgroups per CU and give bit-identical results.  Process-wide switch for A/B runs and tests. */
