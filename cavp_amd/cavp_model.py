@@ -764,6 +764,11 @@ class CAVP(nn.Module):
                     torch.cuda.synchronize()
                     self.__dict__["_graphed_autograd"] = None
                     step = None
+            elif step is None and not self.__dict__.get("_graphed_cap_warned"):
+                import warnings
+                self.__dict__["_graphed_cap_warned"] = True
+                warnings.warn(f"enable_graphed_autograd: 4 input shapes are captured already; image {tuple(image.shape)} / audio "
+                              f"{tuple(audio.shape)} (and any further new shape) runs on the eager autograd node", RuntimeWarning)
             if step is not None:
                 out_pred, out_fusion, visual, audio_f, attn_v = GraphedTrainFunction.apply(step, image, audio, *params)
                 return out_pred, out_fusion, {"audio": audio_f, "visual": visual, "attn_v": attn_v}

@@ -44,6 +44,19 @@ SHAPES = {
     "T_aspp_1x1_2048_256@14": (32, 14, 14, 2048, 256, 1, 1, 0, 1, False),
     "T_cls_1x1_256_8@56": (64, 56, 56, 256, 8, 1, 1, 0, 1, False),
     "T_clsdg_1x1_8_256@56": (64, 56, 56, 8, 256, 1, 1, 0, 1, False),
+    # PVTv2-B5 (config #4, B = 8 -> 16 frames of 512 x 512): token linears of a stage-3 / stage-2 / stage-1 block
+    "P3_q_320_320": (16, 1, 1024, 320, 320, 1, 1, 0, 1, False),
+    "P3_fc1_320_1280": (16, 1, 1024, 320, 1280, 1, 1, 0, 1, False),
+    "P3_fc2_1280_320": (16, 1, 1024, 1280, 320, 1, 1, 0, 1, True),
+    "P3_kv_320_640": (16, 1, 256, 320, 640, 1, 1, 0, 1, False),
+    "P3_sr_1280_320": (16, 1, 256, 1280, 320, 1, 1, 0, 1, False),
+    "P2_q_128_128": (16, 1, 4096, 128, 128, 1, 1, 0, 1, False),
+    "P2_fc1_128_1024": (16, 1, 4096, 128, 1024, 1, 1, 0, 1, False),
+    "P2_fc2_1024_128": (16, 1, 4096, 1024, 128, 1, 1, 0, 1, True),
+    "P1_fc1_64_512": (16, 1, 16384, 64, 512, 1, 1, 0, 1, False),
+    "P1_fc2_512_64": (16, 1, 16384, 512, 64, 1, 1, 0, 1, True),
+    "P4_fc1_512_2048": (16, 1, 256, 512, 2048, 1, 1, 0, 1, False),
+    "P4_fc2_2048_512": (16, 1, 256, 2048, 512, 1, 1, 0, 1, True),
     # K sweep at a fixed output (anatomy of the per-tile fixed costs)
     "K_64_1216": (32, 1, 3136, 64, 1216, 1, 1, 0, 1, False),
     "K_128_1216": (32, 1, 3136, 128, 1216, 1, 1, 0, 1, False),
