@@ -56,7 +56,8 @@ def test_attn_rank1_forward_backward(dtype, xb, reps, t, c):
     torch.cuda.synchronize()
 
     def rel(a, r):
-        return float((a.double() - r.double()).norm() / max(float(r.double().norm()), 1e-30))
+        a, r = a.detach().double(), r.detach().double()
+        return float((a - r).norm() / max(float(r.norm()), 1e-30))
     tol_o = 2e-6 if dtype == torch.float32 else 6e-3      # outputs / dx are stored in the compute dtype
     tol_g = 2e-5 if dtype == torch.float32 else 2e-5      # parameter / key / value gradients are f32 sums of the same products
     assert rel(out.float(), ref_out) <= tol_o, rel(out.float(), ref_out)
