@@ -250,3 +250,14 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
   const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
   return base + idx;
 }
+
+// Spatial-reduction attention (pvt_ops.hip / pvt_train.hip): 64-query blocks per workgroup.  A workgroup stages the whole K / V of
+// its (image, head) - 64 KiB, two workgroups per CU - before its first query block; the smallest count (<= 8) that fits the launch
+// into ONE round of 512 workgroups amortises that staging (PVTv2-B5 at 512 x 512, 16 frames: stage 1 4096 -> 512 workgroups of 8
+// blocks, stage 2 2048 -> 512 of 4, stage 3 1280 -> 480 of 3, stage 4 unchanged).
+inline int cavp_sra_blocks_per_wg(int Nq, int bh) {
+  const int blocks = (Nq + 63) / 64;
+  int qpw = 1;
+  while (qpw < 8 && (long long)((blocks + qpw - 1) / qpw) * bh > 512) ++qpw;
+  return qpw;
+}

@@ -16,7 +16,7 @@ typedef short s16x4_t __attribute__((ext_vector_type(4)));
 // ------------------------------------------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void sra_attention_kernel(const T* __restrict__ q, const T* __restrict__ kv,
-                                                            T* __restrict__ o, int Nq, int Nk, int heads, float scale) {
+                                                            T* __restrict__ o, int Nq, int Nk, int heads, float scale, int qpw) {
   constexpr int ES = (int)sizeof(T), HD = 64, ROWB = HD * ES;  // bytes per K / V row in LDS
   constexpr int VE = 16 / ES;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -25,7 +25,6 @@ __global__ __launch_bounds__(256) void sra_attention_kernel(const T* __restrict_
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int bh = blockIdx.y, b = bh / heads, h = bh - b * heads;
   const int C = heads * HD;
-  const int q0 = blockIdx.x * 64 + wave * 16;
   // ---- stage K, V of this head: rows key, 64 channels; 16-byte slots XOR-swizzled by (key & 7) (bf16: 8 slots/row,
   //      f32: 16 slots/row -> swizzle the low 3 bits) ----
   const T* kvb = kv + (size_t)b * Nk * 2 * C + h * HD;
@@ -42,6 +41,11 @@ __global__ __launch_bounds__(256) void sra_attention_kernel(const T* __restrict_
   }
   __syncthreads();
   const int lrow = lane & 15, lgrp = lane >> 4;
+  // `qpw` blocks of 64 queries per workgroup, one after the other on the same staged K / V: the 64 KiB staging (a global ->
+  // LDS round trip of every thread) is paid once per workgroup, and the launch is sized to ONE round of two workgroups per CU
+  for (int qb = 0; qb < qpw; ++qb) {
+  const int q0 = ((int)blockIdx.x * qpw + qb) * 64 + wave * 16;
+  if (q0 >= Nq) break;   // (wave-uniform)
   const int qi = q0 + lrow;  // this lane's query (B operand column / C-D column)
   const bool qok = qi < Nq;
   const T* qp = q + ((size_t)b * Nq + (qok ? qi : 0)) * C + h * HD;
@@ -98,7 +102,7 @@ __global__ __launch_bounds__(256) void sra_attention_kernel(const T* __restrict_
   for (int kb = 0; kb < 16; ++kb)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const float e = expf(s[kb][r] - m);
+      const float e = __expf(s[kb][r] - m);   // (v_exp_f32 of x * log2 e: ~1e-6 relative, the precise expf is 4x the instructions)
       s[kb][r] = e;
       sum += e;
     }
@@ -161,6 +165,7 @@ __global__ __launch_bounds__(256) void sra_attention_kernel(const T* __restrict_
       }
     }
   }
+  }   // query blocks of this workgroup
 }
 
 // depth-wise 3x3, pad 1, + bias, optional exact GELU.  thread = (pixel, 16-byte channel vector); weights [9][C] f32
@@ -398,11 +403,12 @@ extern "C" int cavp_sra_attention(int32_t dtype, const void* q, const void* kv, 
     (void)hipFuncSetAttribute((const void*)sra_attention_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 256 * 64 * 2);
     attr = true;
   }
-  dim3 grid((Nq + 63) / 64, B * heads);
+  const int qpw = cavp_sra_blocks_per_wg(Nq, B * heads);
+  dim3 grid(((Nq + 63) / 64 + qpw - 1) / qpw, B * heads);
   if (dtype == CAVP_F32)
-    sra_attention_kernel<float><<<grid, 256, lds, s>>>((const float*)q, (const float*)kv, (float*)o, Nq, Nk, heads, scale);
+    sra_attention_kernel<float><<<grid, 256, lds, s>>>((const float*)q, (const float*)kv, (float*)o, Nq, Nk, heads, scale, qpw);
   else
-    sra_attention_kernel<bf16_t><<<grid, 256, lds, s>>>((const bf16_t*)q, (const bf16_t*)kv, (bf16_t*)o, Nq, Nk, heads, scale);
+    sra_attention_kernel<bf16_t><<<grid, 256, lds, s>>>((const bf16_t*)q, (const bf16_t*)kv, (bf16_t*)o, Nq, Nk, heads, scale, qpw);
   CHECK_LAUNCH();
 }
 

@@ -104,7 +104,7 @@ __global__ __launch_bounds__(256) void sra_bwd_q_kernel(const T* __restrict__ q,
   for (int kb = 0; kb < 16; ++kb)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const float e = expf(s[kb][r] - m);
+      const float e = __expf(s[kb][r] - m);   // (v_exp_f32 of x * log2 e: ~1e-6 relative, the precise expf is 4x the instructions)
       s[kb][r] = e;
       sum += e;
     }
@@ -214,7 +214,7 @@ __global__ __launch_bounds__(256) void sra_bwd_kv_kernel(const T* __restrict__ q
       for (int r = 0; r < 4; ++r) {
         const int ql = qb * 16 + lgrp * 4 + r;
         const bool ok = kok && ql < rows;
-        p[r] = ok ? expf(sa[r] * scale - lse_s[ql]) : 0.f;
+        p[r] = ok ? __expf(sa[r] * scale - lse_s[ql]) : 0.f;
         ds[r] = p[r] * (da[r] - del_s[ql]) * scale;
       }
 #pragma unroll
@@ -290,7 +290,8 @@ __device__ __forceinline__ void bstage(char* sw, char* lin, const bf16_t* src, s
 
 __global__ __launch_bounds__(256) void sra_bwd_q_bf16_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kv,
                                                              const bf16_t* __restrict__ dout, bf16_t* __restrict__ dq,
-                                                             float* __restrict__ stats, int Nq, int Nk, int heads, float scale) {
+                                                             float* __restrict__ stats, int Nq, int Nk, int heads, float scale,
+                                                             int qpw) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* ks = smem;                 // K, swizzled rows (A operand of S^T = K Q^T; transposed reads for dQ^T = K^T dS^T)
   char* vs = smem + 256 * 128;     // V, swizzled rows (A operand of dP^T = V dO^T)
@@ -303,7 +304,10 @@ __global__ __launch_bounds__(256) void sra_bwd_q_bf16_kernel(const bf16_t* __res
   bstage(vs, nullptr, kvb + C, (size_t)2 * C, Nk, 256, tid);
   __syncthreads();
   const int lrow = lane & 15, lgrp = lane >> 4;
-  const int qi = blockIdx.x * 64 + wave * 16 + lrow;
+  for (int qb = 0; qb < qpw; ++qb) {   // query blocks of this workgroup on the same staged K / V (cavp_sra_blocks_per_wg)
+  const int q0 = ((int)blockIdx.x * qpw + qb) * 64 + wave * 16;
+  if (q0 >= Nq) break;   // (wave-uniform)
+  const int qi = q0 + lrow;
   const bool qok = qi < Nq;
   const size_t qoff = ((size_t)b * Nq + (qok ? qi : 0)) * C + h * 64;
   u32x4_t qf[2], gf[2];
@@ -343,7 +347,7 @@ __global__ __launch_bounds__(256) void sra_bwd_q_bf16_kernel(const bf16_t* __res
   for (int kb = 0; kb < 16; ++kb)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const float e = expf(s[kb][r] - m);
+      const float e = __expf(s[kb][r] - m);   // (v_exp_f32 of x * log2 e: ~1e-6 relative, the precise expf is 4x the instructions)
       s[kb][r] = e;
       sum += e;
     }
@@ -382,6 +386,7 @@ __global__ __launch_bounds__(256) void sra_bwd_q_bf16_kernel(const bf16_t* __res
       stats[(size_t)gridDim.y * Nq + (size_t)bh * Nq + qi] = delta;
     }
   }
+  }   // query blocks of this workgroup
 }
 
 __global__ __launch_bounds__(256) void sra_bwd_kv_bf16_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kv,
@@ -458,7 +463,7 @@ __global__ __launch_bounds__(256) void sra_bwd_kv_bf16_kernel(const bf16_t* __re
       for (int r = 0; r < 4; ++r) {
         const int qlr = qb * 16 + lgrp * 4 + r;
         const bool ok = kok && qlr < rows;
-        p[qb][r] = ok ? expf(sa[r] * scale - lse_s[qlr]) : 0.f;
+        p[qb][r] = ok ? __expf(sa[r] * scale - lse_s[qlr]) : 0.f;
         ds[qb][r] = p[qb][r] * (da[r] - del_s[qlr]) * scale;
       }
     }
@@ -743,8 +748,10 @@ extern "C" int cavp_sra_attention_bwd_to(int32_t dtype, const void* q, const voi
     sra_bwd_kv_kernel<float><<<gb, 256, 0, s>>>((const float*)q, (const float*)kv, (const float*)dout, stats, kv_out, Nq, Nk, heads,
                                                 scale, slab);
   } else {
-    sra_bwd_q_bf16_kernel<<<ga, 256, 2 * 256 * 128, s>>>((const bf16_t*)q, (const bf16_t*)kv, (const bf16_t*)dout, (bf16_t*)dq, stats,
-                                                        Nq, Nk, heads, scale);
+    const int qpw = cavp_sra_blocks_per_wg(Nq, B * heads);
+    const dim3 gq((chunks + qpw - 1) / qpw, B * heads);
+    sra_bwd_q_bf16_kernel<<<gq, 256, 2 * 256 * 128, s>>>((const bf16_t*)q, (const bf16_t*)kv, (const bf16_t*)dout, (bf16_t*)dq, stats,
+                                                        Nq, Nk, heads, scale, qpw);
     sra_bwd_kv_bf16_kernel<<<gb, 256, 0, s>>>((const bf16_t*)q, (const bf16_t*)kv, (const bf16_t*)dout, stats, kv_out, Nq, Nk, heads,
                                               scale, slab);
   }
