@@ -50,6 +50,11 @@ SHAPES = {
     "P3_fc2_1280_320": (16, 1, 1024, 1280, 320, 1, 1, 0, 1, True),
     "P3_kv_320_640": (16, 1, 256, 320, 640, 1, 1, 0, 1, False),
     "P3_sr_1280_320": (16, 1, 256, 1280, 320, 1, 1, 0, 1, False),
+    "P3_srconv_k2s2_320": (16, 32, 32, 320, 320, 2, 2, 0, 1, False),
+    "P2_srconv_k4s4_128": (16, 64, 64, 128, 128, 4, 4, 0, 1, False),
+    "P1_srconv_k8s8_64": (16, 128, 128, 64, 64, 8, 8, 0, 1, False),
+    "P2_sr_2048_128": (16, 1, 256, 2048, 128, 1, 1, 0, 1, False),
+    "P1_sr_4096_64": (16, 1, 256, 4096, 64, 1, 1, 0, 1, False),
     "P2_q_128_128": (16, 1, 4096, 128, 128, 1, 1, 0, 1, False),
     "P2_fc1_128_1024": (16, 1, 4096, 128, 1024, 1, 1, 0, 1, False),
     "P2_fc2_1024_128": (16, 1, 4096, 1024, 128, 1, 1, 0, 1, True),
