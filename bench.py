@@ -667,7 +667,8 @@ def main():
             with torch.cuda.stream(side):
                 model(image, audio, eval_mode=True)
             torch.cuda.current_stream().wait_stream(side)
-            with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+            from cavp_amd.train import _no_gc_during_capture
+            with _no_gc_during_capture(), torch.cuda.graph(graph, capture_error_mode="thread_local"):
                 outs = model(image, audio, eval_mode=True)
 
             def step():

@@ -861,7 +861,7 @@ class CAVP(nn.Module):
         Single process: ONE graph.  Data parallel (or `split=True`): TWO graphs cut where the early gradient range is
         final; replay() = graph 1 -> asynchronous RCCL all-reduce of that range -> graph 2 (rest of the backward, runs
         concurrently with the collective) -> all-reduce of the late range -> join."""
-        from .train import allreduce_arena_early, allreduce_arena_late, collectives_on, dist_world
+        from .train import _no_gc_during_capture, allreduce_arena_early, allreduce_arena_late, collectives_on, dist_world
         world = dist_world()
         if split is None:
             split = collectives_on()
@@ -876,7 +876,7 @@ class CAVP(nn.Module):
             if not split:
                 graph = torch.cuda.CUDAGraph()
                 # thread_local: other threads (RCCL's watchdog polls its events) must not invalidate the capture
-                with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+                with _no_gc_during_capture(), torch.cuda.graph(graph, capture_error_mode="thread_local"):
                     loss = self.train_step(image, audio, label, ignore_index, loss_scale / world, all_reduce=False)
                 graphs = (graph,)
             else:
@@ -884,7 +884,7 @@ class CAVP(nn.Module):
                 torch.cuda.synchronize()
                 cap = torch.cuda.Stream()
                 cap.wait_stream(torch.cuda.current_stream())
-                with torch.cuda.stream(cap):
+                with _no_gc_during_capture(), torch.cuda.stream(cap):
                     g1.capture_begin(capture_error_mode="thread_local")
 
                     def cut():

@@ -1178,6 +1178,26 @@ def run_train_forward(model, image: torch.Tensor, audio: torch.Tensor, tp: Train
     return lo, fusion, fea_v_proj, fea_a, attn
 
 
+class _no_gc_during_capture:
+    """Python's cyclic collector can run at any allocation - also in the middle of a stream capture - and whatever it finalises then
+    (an old hipGraph / graph-exec of an earlier GraphedTrainStep, a stream, a pinned buffer) issues HIP calls that are illegal
+    while capturing: the error surfaces in a C++ destructor and aborts the process (seen once in the GPU suite, in a capture that
+    followed several captured models).  Collect BEFORE the capture starts, keep the collector off until it has ended."""
+
+    def __enter__(self):
+        import gc
+        self._was = gc.isenabled()
+        gc.collect()
+        gc.disable()
+        return self
+
+    def __exit__(self, *exc):
+        import gc
+        if self._was:
+            gc.enable()
+        return False
+
+
 def _private(g: torch.Tensor, src: torch.Tensor) -> torch.Tensor:
     """`g` (a layout / dtype conversion of the foreign gradient `src`) as memory the tape may accumulate into IN PLACE
     (TrainPass.acc): when the conversion was a no-op, `g` still is the caller's grad_output (autograd forbids mutating it) or a
@@ -1383,7 +1403,7 @@ class GraphedTrainStep:
             self.gA, self.gB = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
             cap = torch.cuda.Stream()
             cap.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(cap):
+            with _no_gc_during_capture(), torch.cuda.stream(cap):
                 self.gA.capture_begin(capture_error_mode="thread_local")
                 st = self._forward_body()
                 self.gA.capture_end()
