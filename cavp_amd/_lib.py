@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(HERE, "libcavp_hip.so")
 
 F32, BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_LEAKY, ACT_GELU = 0, 1, 2, 3
-ABI_VERSION = 8
+ABI_VERSION = 9
 WGRAD_GROUP_MAX = 16   # CAVP_WGRAD_GROUP_MAX
 
 
@@ -50,6 +50,7 @@ PROTOTYPES = {
     "cavp_set_tail_split": (_i32, [_i32]),
     "cavp_set_igemm_epilogue": (_i32, [_i32]),
     "cavp_set_wgrad_variant": (_i32, [_i32]),
+    "cavp_set_wgrad_big": (_i32, [_i32, _i32]),
     "cavp_attn1_supported": (_i32, [_i32, _i32]),
     "cavp_attn1_prepare": (_i32, [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _f32, _vp]),
     "cavp_attn1_fwd": (_i32, [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),

@@ -12,7 +12,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libcavp_hip.so")
-SOURCES = ["conv_igemm.hip", "conv_igemm_big.hip", "pointwise.hip", "train_pointwise.hip", "conv_wgrad.hip", "contrast.hip", "pvt_ops.hip", "pvt_train.hip", "layernorm.hip", "attn_gate.hip", "attn_rank1.hip", "mel_frontend.hip", "optimizer.hip"]
+SOURCES = ["conv_igemm.hip", "conv_igemm_big.hip", "pointwise.hip", "train_pointwise.hip", "conv_wgrad.hip", "conv_wgrad_big.hip", "contrast.hip", "pvt_ops.hip", "pvt_train.hip", "layernorm.hip", "attn_gate.hip", "attn_rank1.hip", "mel_frontend.hip", "optimizer.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
          "-munsafe-fp-atomics", "-ffp-contract=on"]
 

@@ -21,43 +21,7 @@
 //   consecutive ci of one co = 16 contiguous bytes of dW.
 #include <stdlib.h>
 
-#include "common.h"
-
-struct WgradParams {
-  const void* x;
-  const void* dy;
-  float* dw;
-  int N, H, W, Cin, ldx, Cout, ldy, KW, stride, pad, dil;
-  int Ho, Wo, M;
-  int ntaps, ntaps_all;
-  unsigned long long taps;
-  int tiles_co, tiles_ci, ksplit;
-  int rows_per_split;  // multiple of 64
-  unsigned dv_co[2], dv_ci[2], dv_nt[2], dv_kw[2], dv_hw[2], dv_w[2], dv_cq[2];  // fast_div (multiplier, shift) of tiles_co, tiles_ci, ntaps, KW, Ho*Wo, Wo
-  int x_bytes, dy_bytes;
-  int overwrite;       // 1: dw = gradient (beta = 0, dw is not read); 0: dw += gradient
-  int oihw;            // dw layout: 0 = [Cout][taps][Cin] (OHWI), 1 = [Cout][Cin][taps] (torch .grad layout)
-  int dbg;             // -DCAVP_PROFILE builds only (CAVP_WGRAD_DBG): 1 = loads out of range, 2 = no MFMAs, 4 = no DMA, 8 = no epilogue
-  float* dbias;        // optional: dbias[co] += sum_pix dY[pix][co] (bias gradient), taken from the dY tiles streamed anyway
-  float* bias_slabs;   // ksplit > 1: [ksplit][Cout] partial column sums
-  float* slabs;        // ksplit > 1: per-split partial gradients [ksplit][Cout][taps][Cin] (plain stores, then reduced)
-  int red_zg;          // grouped launches: split groups per workgroup of this job's slab reduce (1, 2, 4, 8, 16)
-  int pad_;
-};
-
-// Kernel-argument block of a grouped launch (cavp_conv2d_wgrad_group): up to CAVP_WGRAD_GROUP_MAX independent weight gradients
-// walked by ONE grid.  Logical workgroup b belongs to job j with blk_end[j-1] <= b < blk_end[j]; the slab reduces of the jobs
-// that split their pixel range form a second grouped launch (red_end).  The whole block travels as kernel arguments (< 4 KiB),
-// so a grouped launch is hipGraph-capturable like any other and needs no device-side table.
-struct WgradGroupArgs {
-  int njobs;
-  int blk_end[CAVP_WGRAD_GROUP_MAX];
-  int red_end[CAVP_WGRAD_GROUP_MAX];
-  WgradParams job[CAVP_WGRAD_GROUP_MAX];
-};
-static_assert(sizeof(WgradGroupArgs) <= 4096, "kernel-argument segment");
-
-typedef short s16x4_t __attribute__((ext_vector_type(4)));
+#include "wgrad_params.h"
 
 // One logical workgroup `bid` of one weight gradient (shared by the single and the grouped launch).
 // BK = pixel rows per stage; BIAS: also the bias gradient (column sums of dY); NSTG = LDS stages: 2 (BK = 32: four 32 KiB
@@ -407,6 +371,19 @@ extern "C" int cavp_set_wgrad_variant(int v) {
   return CAVP_OK;
 }
 
+// The 256 x 256 tile of conv_wgrad_big.hip (bf16).  mode 0 (default): the jobs big enough for it (wgrad_big_eligible), 1: never
+// (the 128 x 128 tile everywhere: A/B baseline), 2: every bf16 job (tests: tiny shapes through the big tile).  stagger: its
+// ping-pong schedule (conv_wgrad_big.hip).  The choice depends on the job alone, never on the group it travels in, so a grouped
+// and a single launch of one job with the same split count stay bit-identical.
+static int g_wgrad_big_mode = 0;
+static int g_wgrad_big_stagger = 1;
+extern "C" int cavp_set_wgrad_big(int mode, int stagger) {
+  if (mode < 0 || mode > 2 || stagger < 0 || stagger > 1) return CAVP_ERR_BAD_ARG;
+  g_wgrad_big_mode = mode;
+  g_wgrad_big_stagger = stagger;
+  return CAVP_OK;
+}
+
 // dw += sum_z slabs[z] over the live taps only (dead-tap regions of the slabs are never written).
 // 256 threads = QPB output quads x ZG split groups: group zg sums the splits zg, zg + ZG, ... and the groups are
 // combined through LDS in a fixed order (deterministic).  Small dW (16 K elements from 392 splits) needs the split
@@ -511,10 +488,28 @@ __global__ __launch_bounds__(256) void wgrad_reduce_group_kernel(const WgradGrou
 }
 
 namespace {
+// time model of the 256 x 256 tile (conv_wgrad_big.hip): seconds per 128-row ring trip of one workgroup and per workgroup
+// (ring fill + 256 KiB accumulator store)
+static const double kBigUnitSec = cavp_knob_double("CAVP_WGRAD_BIG_UNIT_US", 2.0) * 1e-6;
+static const double kBigFixSec = cavp_knob_double("CAVP_WGRAD_BIG_FIX_US", 4.0) * 1e-6;
 struct WgradPlan { WgradParams p; int nblk; size_t ws_bytes; int status; int base, chunks; };
 
-// force_ks > 0: the group planner's split count (cavp_conv_desc.splitk still wins)
-WgradPlan make_wgrad_plan(const cavp_conv_desc* d, int force_ks = 0) {
+// Jobs that go to the 256 x 256 tile: bf16, both channel counts fill most of a 256-wide tile edge and the pixel range is long
+// enough for >= 256 workgroups of a few ring trips each (the head / token / projector layers at 2B x 56 x 56 pixels; the 14 x 14
+// and 28 x 28 layers of the backbone stay on the 128 x 128 tile: four co-resident workgroups per CU fill the chip with fewer
+// pixel splits there).
+bool wgrad_big_eligible(const cavp_conv_desc* d) {
+  if (!d || d->dtype != CAVP_BF16 || g_wgrad_big_mode == 1 || g_wgrad_variant != 0) return false;
+  if (g_wgrad_big_mode == 2) return true;
+  const long long Ho = (d->H + 2 * d->pad - d->dil * (d->KH - 1) - 1) / d->stride + 1;
+  const long long Wo = (d->W + 2 * d->pad - d->dil * (d->KW - 1) - 1) / d->stride + 1;
+  static const int min_rows = cavp_knob_int("CAVP_WGRAD_BIG_MIN_ROWS", 16384), min_ch = cavp_knob_int("CAVP_WGRAD_BIG_MIN_CH", 192);
+  return (long long)d->N * Ho * Wo >= min_rows && d->Cin >= min_ch && d->Cout >= min_ch;
+}
+
+// force_ks > 0: the group planner's split count (cavp_conv_desc.splitk still wins).  big: plan for the 256 x 256 tile (256-channel
+// tiles, pixel slices in units of 128 rows = one trip of its 4-stage ring, 256 resident workgroups)
+WgradPlan make_wgrad_plan(const cavp_conv_desc* d, int force_ks = 0, bool big = false) {
   WgradPlan pl{};
   pl.status = CAVP_OK;
   if (!d || d->N <= 0 || d->H <= 0 || d->W <= 0 || d->Cin <= 0 || d->Cout <= 0 || d->KH <= 0 || d->KW <= 0 || d->stride <= 0 ||
@@ -546,7 +541,8 @@ WgradPlan make_wgrad_plan(const cavp_conv_desc* d, int force_ks = 0) {
     }
   }
   if (p.ntaps == 0) { pl.nblk = 0; return pl; }
-  const int TCH = 256 / es;
+  const int TCH = big ? 256 : 256 / es;
+  const int unit = big ? 128 : 64;   // pixel rows per planning chunk
   p.tiles_co = (d->Cout + TCH - 1) / TCH;
   p.tiles_ci = (d->Cin + TCH - 1) / TCH;
   const int base = p.tiles_co * p.tiles_ci * p.ntaps;
@@ -557,7 +553,7 @@ WgradPlan make_wgrad_plan(const cavp_conv_desc* d, int force_ks = 0) {
   fast_div_prepare(p.Cin >> 2, &p.dv_cq[0], &p.dv_cq[1]);
   fast_div_prepare(p.Ho * p.Wo, &p.dv_hw[0], &p.dv_hw[1]);
   fast_div_prepare(p.Wo, &p.dv_w[0], &p.dv_w[1]);
-  const int chunks = (p.M + 63) / 64;
+  const int chunks = (p.M + unit - 1) / unit;
   pl.base = base; pl.chunks = chunks;
   // Split count from a small time model fitted to tools/bench_wgrad.py on MI355X (profiles/r01_notes.md):
   //   t(ks) = rounds * steps * 1.08 us  +  ks * |dW| * 8 B / 5 TB/s (the slabs mostly live in the 256 MB MALL)  (+ reduce launch)
@@ -578,8 +574,9 @@ WgradPlan make_wgrad_plan(const cavp_conv_desc* d, int force_ks = 0) {
     for (int k = 1; k <= ks_max && k <= 512; ++k) {
       const int steps = (chunks + k - 1) / k;
       const int kk = (chunks + steps - 1) / steps;   // effective split count for this step count
-      const long long rounds = ((long long)base * kk + 1023) / 1024;
-      double t = (double)rounds * (2 * steps) * 1.08e-6 + (kk > 1 ? kk * dw_bytes * 2.0 / slab_bw + 6e-6 : 0.0);
+      const long long rounds = big ? ((long long)base * kk + 255) / 256 : ((long long)base * kk + 1023) / 1024;
+      double t = (big ? (double)rounds * (steps * kBigUnitSec + kBigFixSec) : (double)rounds * (2 * steps) * 1.08e-6) +
+                 (kk > 1 ? kk * dw_bytes * 2.0 / slab_bw + 6e-6 : 0.0);
       if (t < best) { best = t; ks = kk; }
     }
   }
@@ -588,7 +585,7 @@ WgradPlan make_wgrad_plan(const cavp_conv_desc* d, int force_ks = 0) {
   const int cps = (chunks + ks - 1) / ks;
   ks = (chunks + cps - 1) / cps;
   p.ksplit = ks;
-  p.rows_per_split = cps * 64;
+  p.rows_per_split = cps * unit;
   pl.nblk = base * ks;
   pl.ws_bytes = ks > 1 ? ((size_t)ks * d->Cout * p.ntaps_all * d->Cin + (size_t)ks * d->Cout) * sizeof(float) : 0;   // dW slabs + bias slabs
   return pl;
@@ -596,6 +593,11 @@ WgradPlan make_wgrad_plan(const cavp_conv_desc* d, int force_ks = 0) {
 }  // namespace
 
 extern "C" size_t cavp_conv2d_wgrad_workspace_bytes(const cavp_conv_desc* d) {
+  if (wgrad_big_eligible(d)) {   // the 256 x 256 tile has one launch path: a group of one
+    cavp_wgrad_job jb{};
+    jb.desc = *d;
+    return cavp_conv2d_wgrad_group_workspace_bytes(&jb, 1);
+  }
   WgradPlan pl = make_wgrad_plan(d);
   return pl.status == CAVP_OK ? pl.ws_bytes : 0;
 }
@@ -603,6 +605,11 @@ extern "C" size_t cavp_conv2d_wgrad_workspace_bytes(const cavp_conv_desc* d) {
 extern "C" int cavp_conv2d_wgrad_nhwc(const cavp_conv_desc* d, const void* x, const void* dy, float* dw, float* dbias,
                                       void* workspace, size_t workspace_bytes, void* stream) {
   if (!d || !x || !dy || !dw) return CAVP_ERR_BAD_ARG;
+  if (wgrad_big_eligible(d)) {
+    cavp_wgrad_job jb{};
+    jb.desc = *d; jb.x = x; jb.dy = dy; jb.dw = dw; jb.dbias = dbias;
+    return cavp_conv2d_wgrad_group(&jb, 1, workspace, workspace_bytes, stream);
+  }
   WgradPlan pl = make_wgrad_plan(d);
   if (pl.status != CAVP_OK) return pl.status;
   const size_t dw_bytes = (size_t)d->Cout * d->KH * d->KW * d->Cin * sizeof(float);
@@ -675,61 +682,99 @@ extern "C" int cavp_conv2d_wgrad_nhwc(const cavp_conv_desc* d, const void* x, co
 namespace {
 struct GroupPlan {
   WgradPlan pl[CAVP_WGRAD_GROUP_MAX];
+  bool big[CAVP_WGRAD_GROUP_MAX];          // job runs on the 256 x 256 tile (conv_wgrad_big.hip)
   size_t slab_off[CAVP_WGRAD_GROUP_MAX];   // byte offsets into the workspace
   size_t ws_bytes;
   int status;
 };
 
-// One pixel-range length L (in 64-row chunks) for the whole group: job j splits its chunks_j into ks_j = ceil(chunks_j / L)
-// slices, so every workgroup of the launch runs about L chunk steps.  L minimises the single-launch model of make_wgrad_plan
-// applied to the sum:  rounds(L) * steps(L) * 2.16 us  +  slab traffic  (+ the reduce launch).
-GroupPlan make_group_plan(const cavp_wgrad_job* jobs, int njobs) {
-  GroupPlan gp{};
-  gp.status = CAVP_OK;
-  if (!jobs || njobs <= 0 || njobs > CAVP_WGRAD_GROUP_MAX) { gp.status = CAVP_ERR_BAD_ARG; return gp; }
+// average relative cost of a job's 256 x 256 tiles: a tile with few live 32-channel blocks (304 = 256 + 48) skips the dead
+// MFMAs and fetches zero-filled rows without memory traffic, but still walks its stages
+double big_tile_weight(const WgradParams& p) {
+  double w = 0.0;
+  for (int tc = 0; tc < p.tiles_ci; ++tc)
+    for (int to = 0; to < p.tiles_co; ++to) {
+      const int lci = (p.Cin - tc * 256 > 256 ? 256 : p.Cin - tc * 256 + 31) / 32, lco = (p.Cout - to * 256 > 256 ? 256 : p.Cout - to * 256 + 31) / 32;
+      w += 0.3 + 0.7 * (double)(lci * lco) / 64.0;
+    }
+  return w / (p.tiles_ci * p.tiles_co);
+}
+
+// One pixel-range length L (in planning chunks: 64 rows, 128 for the 256 x 256 tile) for all the jobs of one tile kind: job j
+// splits its chunks_j into ks_j = ceil(chunks_j / L) slices, so every workgroup of the launch runs about L chunk steps.  L
+// minimises the single-launch model of make_wgrad_plan applied to the sum:  rounds(L) * steps(L) * t_step  +  slab traffic
+// (+ the reduce launch).
+void plan_subset(GroupPlan& gp, const cavp_wgrad_job* jobs, int njobs, bool big) {
   int max_chunks = 1;
-  for (int j = 0; j < njobs; ++j) {
-    if (jobs[j].desc.dtype != jobs[0].desc.dtype) { gp.status = CAVP_ERR_BAD_ARG; return gp; }
-    gp.pl[j] = make_wgrad_plan(&jobs[j].desc, 1);
-    if (gp.pl[j].status != CAVP_OK) { gp.status = gp.pl[j].status; return gp; }
-    if (gp.pl[j].nblk > 0 && gp.pl[j].chunks > max_chunks) max_chunks = gp.pl[j].chunks;
-  }
+  bool any = false;
+  for (int j = 0; j < njobs; ++j)
+    if (gp.big[j] == big && gp.pl[j].nblk > 0) {
+      any = true;
+      if (gp.pl[j].chunks > max_chunks) max_chunks = gp.pl[j].chunks;
+    }
+  if (!any) return;
   static const double slab_bw = cavp_knob_double("CAVP_WGRAD_SLAB_TBS", 5.0) * 1e12;
   double best = 1e30;
   int bestL = max_chunks;
   for (int L = 1; L <= max_chunks; ++L) {
     long long wgs = 0;
+    double wwgs = 0.0;
     int steps = 0;
     double slab = 0.0;
     bool split = false;
     for (int j = 0; j < njobs; ++j) {
       const WgradPlan& q = gp.pl[j];
-      if (q.nblk == 0) continue;
+      if (gp.big[j] != big || q.nblk == 0) continue;
       int ks = jobs[j].desc.splitk > 0 ? jobs[j].desc.splitk : (q.chunks + L - 1) / L;
       if (ks > 512) ks = 512;
       if (ks > q.chunks) ks = q.chunks;
       const int st = (q.chunks + ks - 1) / ks;
       ks = (q.chunks + st - 1) / st;
       wgs += (long long)q.base * ks;
+      if (big) wwgs += (double)q.base * ks * big_tile_weight(q.p);
       if (st > steps) steps = st;
       if (ks > 1) {
         split = true;
         slab += (double)ks * q.p.Cout * q.p.ntaps * q.p.Cin * 4.0 * 2.0;
       }
     }
-    const long long rounds = (wgs + 1023) / 1024;
-    const double t = (double)rounds * (2 * steps) * 1.08e-6 + slab / slab_bw + (split ? 6e-6 : 0.0);
+    double t;
+    if (big) {   // 256 resident workgroups; the dispatcher balances tiles of different cost over the rounds
+      const long long rounds = wgs <= 256 ? 1 : (long long)(wwgs / 256.0 + 0.999);
+      t = (double)(rounds < 1 ? 1 : rounds) * (steps * kBigUnitSec + kBigFixSec);
+    } else {
+      const long long rounds = (wgs + 1023) / 1024;
+      t = (double)rounds * (2 * steps) * 1.08e-6;
+    }
+    t += slab / slab_bw + (split ? 6e-6 : 0.0);
     if (t < best) { best = t; bestL = L; }
   }
-  size_t off = 0;
   for (int j = 0; j < njobs; ++j) {
     WgradPlan& q = gp.pl[j];
-    if (q.nblk == 0) continue;
+    if (gp.big[j] != big || q.nblk == 0) continue;
     int ks = (q.chunks + bestL - 1) / bestL;
     if (ks > 512) ks = 512;
-    q = make_wgrad_plan(&jobs[j].desc, ks);
+    q = make_wgrad_plan(&jobs[j].desc, ks, big);
+  }
+}
+
+GroupPlan make_group_plan(const cavp_wgrad_job* jobs, int njobs) {
+  GroupPlan gp{};
+  gp.status = CAVP_OK;
+  if (!jobs || njobs <= 0 || njobs > CAVP_WGRAD_GROUP_MAX) { gp.status = CAVP_ERR_BAD_ARG; return gp; }
+  for (int j = 0; j < njobs; ++j) {
+    if (jobs[j].desc.dtype != jobs[0].desc.dtype) { gp.status = CAVP_ERR_BAD_ARG; return gp; }
+    gp.big[j] = wgrad_big_eligible(&jobs[j].desc);
+    gp.pl[j] = make_wgrad_plan(&jobs[j].desc, 1, gp.big[j]);
+    if (gp.pl[j].status != CAVP_OK) { gp.status = gp.pl[j].status; return gp; }
+  }
+  plan_subset(gp, jobs, njobs, false);
+  plan_subset(gp, jobs, njobs, true);
+  size_t off = 0;
+  for (int j = 0; j < njobs; ++j) {
+    if (gp.pl[j].nblk == 0) continue;
     gp.slab_off[j] = off;
-    off += (q.ws_bytes + 255) & ~(size_t)255;
+    off += (gp.pl[j].ws_bytes + 255) & ~(size_t)255;
   }
   gp.ws_bytes = off;
   return gp;
@@ -747,9 +792,11 @@ extern "C" int cavp_conv2d_wgrad_group(const cavp_wgrad_job* jobs, int32_t njobs
   if (gp.status != CAVP_OK) return gp.status;
   if (gp.ws_bytes > 0 && (!workspace || workspace_bytes < gp.ws_bytes || ((uintptr_t)workspace & 15))) return CAVP_ERR_WORKSPACE;
   hipStream_t s = (hipStream_t)stream;
-  WgradGroupArgs g{};
-  int nj = 0, blocks = 0, rblocks = 0;
-  bool any_bias = false, any_split = false;
+  // three kernel-argument blocks: the jobs of the 128 x 128 tile, the jobs of the 256 x 256 tile, and ALL jobs that split their
+  // pixel range for the one grouped slab reduce (only its red_end / red_zg / job fields are read there)
+  WgradGroupArgs gs{}, gb{}, gr{};
+  int ns = 0, nb = 0, nr = 0, sblocks = 0, bblocks = 0, rblocks = 0;
+  bool sbias = false, bbias = false;
   for (int j = 0; j < njobs; ++j) {
     const cavp_wgrad_job& jb = jobs[j];
     const cavp_conv_desc* d = &jb.desc;
@@ -775,41 +822,54 @@ extern "C" int cavp_conv2d_wgrad_group(const cavp_wgrad_job* jobs, int32_t njobs
     p.bias_slabs = p.slabs ? p.slabs + (size_t)p.ksplit * d->Cout * p.ntaps_all * d->Cin : nullptr;
     p.dbg = 0;
     p.red_zg = 1;
-    blocks += pl.nblk;
     if (p.ksplit > 1) {
       const long long quads = (long long)p.Cout * p.ntaps * (p.Cin / 4);
       if (quads > 0x7fffffffll) return CAVP_ERR_UNSUPPORTED;
       int zgrp = 1;
       while (zgrp < 16 && zgrp * 2 <= p.ksplit && quads * zgrp < 131072) zgrp *= 2;
-      long long nb = (quads + (256 / zgrp) - 1) / (256 / zgrp);
-      if (nb > 2048) nb = 2048;
+      long long nbk = (quads + (256 / zgrp) - 1) / (256 / zgrp);
+      if (nbk > 2048) nbk = 2048;
       p.red_zg = zgrp;
-      rblocks += (int)nb;
-      any_split = true;
+      rblocks += (int)nbk;
+      gr.job[nr] = p;
+      gr.red_end[nr] = rblocks;
+      ++nr;
     }
-    any_bias = any_bias || jb.dbias != nullptr;
-    g.job[nj] = p;
-    g.blk_end[nj] = blocks;
-    g.red_end[nj] = rblocks;
-    ++nj;
+    if (gp.big[j]) {
+      bblocks += pl.nblk;
+      bbias = bbias || jb.dbias != nullptr;
+      gb.job[nb] = p;
+      gb.blk_end[nb] = bblocks;
+      ++nb;
+    } else {
+      sblocks += pl.nblk;
+      sbias = sbias || jb.dbias != nullptr;
+      gs.job[ns] = p;
+      gs.blk_end[ns] = sblocks;
+      ++ns;
+    }
   }
-  if (nj == 0) return CAVP_OK;
-  g.njobs = nj;
-  const int lds = 2 * 2 * 32 * 256;
-  const bool f32 = jobs[0].desc.dtype == CAVP_F32;
-  if (f32) {
-    if (any_bias) wgrad_group_kernel<float, true><<<blocks, 256, lds, s>>>(g);
-    else wgrad_group_kernel<float, false><<<blocks, 256, lds, s>>>(g);
-  } else if (g_wgrad_variant == 1) {
-    if (any_bias) wgrad_group_kernel<bf16_t, true, 64, 1><<<blocks, 256, lds, s>>>(g);
-    else wgrad_group_kernel<bf16_t, false, 64, 1><<<blocks, 256, lds, s>>>(g);
-  } else {
-    if (any_bias) wgrad_group_kernel<bf16_t, true><<<blocks, 256, lds, s>>>(g);
-    else wgrad_group_kernel<bf16_t, false><<<blocks, 256, lds, s>>>(g);
+  gs.njobs = ns; gb.njobs = nb; gr.njobs = nr;
+  if (nb > 0) {   // the long-running workgroups first
+    if (cavp_launch_wgrad_big_group(gb, bblocks, bbias, g_wgrad_big_stagger != 0, s) != hipSuccess) return CAVP_ERR_LAUNCH;
   }
-  if (hipGetLastError() != hipSuccess) return CAVP_ERR_LAUNCH;
-  if (any_split) {
-    wgrad_reduce_group_kernel<<<rblocks, 256, 0, s>>>(g);
+  if (ns > 0) {
+    const int lds = 2 * 2 * 32 * 256;
+    const bool f32 = jobs[0].desc.dtype == CAVP_F32;
+    if (f32) {
+      if (sbias) wgrad_group_kernel<float, true><<<sblocks, 256, lds, s>>>(gs);
+      else wgrad_group_kernel<float, false><<<sblocks, 256, lds, s>>>(gs);
+    } else if (g_wgrad_variant == 1) {
+      if (sbias) wgrad_group_kernel<bf16_t, true, 64, 1><<<sblocks, 256, lds, s>>>(gs);
+      else wgrad_group_kernel<bf16_t, false, 64, 1><<<sblocks, 256, lds, s>>>(gs);
+    } else {
+      if (sbias) wgrad_group_kernel<bf16_t, true><<<sblocks, 256, lds, s>>>(gs);
+      else wgrad_group_kernel<bf16_t, false><<<sblocks, 256, lds, s>>>(gs);
+    }
+    if (hipGetLastError() != hipSuccess) return CAVP_ERR_LAUNCH;
+  }
+  if (nr > 0) {
+    wgrad_reduce_group_kernel<<<rblocks, 256, 0, s>>>(gr);
     if (hipGetLastError() != hipSuccess) return CAVP_ERR_LAUNCH;
   }
   return CAVP_OK;

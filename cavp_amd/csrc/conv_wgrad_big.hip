@@ -1,0 +1,375 @@
+// 256 x 256 weight-gradient tile for the large CAVP layers (bf16, gfx950): one 8-wave workgroup per CU, four-stage LDS-DMA ring.
+//
+//   dW[co][tap][ci] += sum_pix dY[pix][co] * X[pix @ tap][ci]      (encoder_decoder.py:62-75, attn.py:136-143, cavp_model.py:123-128)
+//
+// Why a second kernel: the 4-wave 128 x 128 tile of conv_wgrad.hip moves 64 flop per operand byte through the LDS-DMA path and
+// lives off four co-resident workgroups hiding each other's single stage in flight; with 22 .. 27 % of the operand requests
+// missing the XCD's L2 (the tensors of the head / token layers are 100 .. 500 MB) it is bound by the feed: 450 .. 600 TF/s
+// (profiles/r04_wgrad_l2_prefetch_ab.txt, r04_feed_rate_microbench.txt).  This tile needs half the operand bytes per flop and keeps
+// 96 KiB of loads in flight per CU instead of 64:
+//
+//  * 8 waves = 4 (ci) x 2 (co); wave tile 64 ci x 128 co = 2 x 4 blocks of v_mfma_f32_32x32x16_bf16 (128 accumulator
+//    registers; the 32 x 32 form issues at 32 cycles per SIMD = the full matrix-pipe rate, the 16 x 16 x 32 form tops out at
+//    ~0.75 .. 0.8 of it).
+//  * a stage = 32 pixel rows of both operands exactly as they lie in memory (512-byte LDS rows = 256 channels), 32 KiB; the
+//    ring holds 4 stages (128 KiB): while stage s is multiplied, s+1 .. s+3 are in flight or landed behind a counted
+//    s_waitcnt vmcnt(8) - never 0 inside the loop.
+//  * a stage is two phases of 8 MFMAs per wave (co half 0 / 1).  Phase A issues the X pieces of stage s+3 and reads the A
+//    fragments (kept for both phases) + the B fragments of co half 0; phase B issues the dY pieces of s+3, reads the B
+//    fragments of co half 1 and retires stage s+1.  Fragments are gathered with the LDS transpose read ds_read_b64_tr_b16
+//    (inline asm: hipcc puts an s_waitcnt vmcnt(0) in front of the builtin whenever an LDS-DMA is pending, which would drain
+//    the ring in every phase, profiles/r03_notes.md).
+//  * optional ping-pong (STAGGER): the two co halves of the workgroup (waves 0-3 / 4-7, one wave of each per SIMD) run one
+//    barrier apart, so that one wave of a SIMD issues MFMAs while the other issues its LDS reads and LDS-DMA; two raw
+//    s_barrier per phase.  Without it: one barrier per phase, the two waves of a SIMD run in step.
+//  * swizzle: the 32-byte chunk index (16 channels) of a row is XORed with ((row & 3) << 1) | ((row >> 3) & 1) on the DMA
+//    SOURCE side; a 32-lane half of a transpose read touches rows r .. r+3 of two neighbouring chunks -> 8 different bank
+//    groups (conflict-free for this 32 x 32 fragment shape and for the 16 x 16 x 32 one).
+//  * rows outside the image (padding taps), beyond the pixel range or beyond Cin / Cout are zero-filled by the buffer
+//    descriptor's bounds check; 32-channel blocks without a real channel are not multiplied (wave-uniform).
+#include <type_traits>
+
+#include "wgrad_params.h"
+
+namespace {
+
+constexpr int TC = 256;              // channels per tile edge (ci and co)
+constexpr int BK = 32;               // pixel rows per stage
+constexpr int NS = 4;                // ring stages
+constexpr int NT = 512;
+constexpr int ROWB = TC * 2;         // bytes per LDS row
+constexpr int OPB = BK * ROWB;       // one operand of one stage: 16 KiB
+constexpr int STAGE = 2 * OPB;       // X rows, then dY rows
+constexpr int LDS_BYTES = NS * STAGE;
+constexpr unsigned kOOB = 0x80000000u;
+static_assert(LDS_BYTES == 128 * 1024, "ring");
+
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+typedef __attribute__((ext_vector_type(2))) unsigned u32x2_t;
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+// (asm volatile: ordered against the barriers / waits around it; the compiler does not track the LDS counter for it - every
+// use is behind an explicit s_waitcnt lgkmcnt(0) + sched_barrier, cdna_hip_programming.md rule 18)
+template <int OFF>
+__device__ __forceinline__ u32x2_t lds_tr16(unsigned addr) {
+  static_assert(OFF >= 0 && OFF < 65536, "ds offset field");
+  u32x2_t v;
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+  return v;
+}
+
+__device__ __forceinline__ int swz_key(int row) { return ((row & 3) << 1) | ((row >> 3) & 1); }
+
+__device__ __forceinline__ float bf16x2_sum(unsigned u) { return __uint_as_float(u << 16) + __uint_as_float(u & 0xffff0000u); }
+
+}  // namespace
+
+// One logical workgroup `bid` of one weight gradient on the 256 x 256 tile.
+template <bool BIAS, bool STAGGER>
+__device__ __forceinline__ void wgrad_big_tile(const WgradParams& p, const int bid, char* smem) {
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wc = wave & 3, wp = wave >> 2;   // ci quarter, co half (= ping-pong group)
+
+  const int b1 = fast_div(bid, p.dv_co[0], p.dv_co[1]), tco = bid - b1 * p.tiles_co;
+  const int b2 = fast_div(b1, p.dv_ci[0], p.dv_ci[1]), tci = b1 - b2 * p.tiles_ci;
+  const int z = fast_div(b2, p.dv_nt[0], p.dv_nt[1]), ti = b2 - z * p.ntaps;
+  const int tap = (int)((p.taps >> (4 * ti)) & 15ull);
+  const int kh = fast_div(tap, p.dv_kw[0], p.dv_kw[1]), kw = tap - kh * p.KW;
+  const int co_base = tco * TC, ci_base = tci * TC;
+  const int r_begin = z * p.rows_per_split;
+  int r_end = r_begin + p.rows_per_split;
+  if (r_end > p.M) r_end = p.M;
+  // stages of this slice, rounded up to whole trips of the 4-stage ring (rows past r_end are zero-filled)
+  const int nst = __builtin_amdgcn_readfirstlane(r_end > r_begin ? ((r_end - r_begin + 4 * BK - 1) / (4 * BK)) * 4 : 0);
+
+  const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.dy, 0, p.dy_bytes, 0x00020000);
+
+  // ---------------------------------------------------------------------------------------------------------------------
+  // issue side.  A wave DMA instruction fills 1 KiB = 2 LDS rows; instruction g = wave + 8 i (i < 2) of an operand fills rows
+  // 2 g, 2 g + 1: lane l lands in row 2 g + (l >> 5), 16-byte slot l & 31.  The swizzle key of row drow0 + 16 i does not depend
+  // on i, so the lane's channel offset is fixed; pixel coordinates advance incrementally (conv_wgrad.hip).
+  // ---------------------------------------------------------------------------------------------------------------------
+  const int drow0 = 2 * wave + (lane >> 5);
+  const int cel = ((((lane & 31) >> 1) ^ swz_key(drow0)) << 4) + ((lane & 1) << 3);   // logical channel of this lane's 16 bytes
+  const bool ci_ok = ci_base + cel < p.Cin, co_ok = co_base + cel < p.Cout;
+  const unsigned xcb = (unsigned)((ci_base + cel) * 2), ycb = (unsigned)((co_base + cel) * 2);
+  const bool pointwise = (p.ntaps_all == 1) && p.stride == 1 && p.pad == 0;
+  const int dh = kh * p.dil - p.pad, dw = kw * p.dil - p.pad;
+  const int gH = __builtin_amdgcn_readfirstlane(p.H), gW = __builtin_amdgcn_readfirstlane(p.W);
+  const int gWo = __builtin_amdgcn_readfirstlane(p.Wo), gHo = __builtin_amdgcn_readfirstlane(p.Ho);
+  const int gStride = __builtin_amdgcn_readfirstlane(p.stride);
+  const unsigned gLdx = (unsigned)__builtin_amdgcn_readfirstlane(p.ldx * 2), gLdy = (unsigned)__builtin_amdgcn_readfirstlane(p.ldy * 2);
+  const int gWoS = gWo * gStride, gHoS = gHo * gStride;
+  const unsigned stepY = (unsigned)BK * gLdy;
+  const unsigned stepX = (unsigned)(BK * (pointwise ? 1 : gStride)) * gLdx;
+  const unsigned stepRow = (unsigned)((gW - gWo) * gStride) * gLdx;
+  const unsigned stepImg = (unsigned)((gH - gHoS) * gW) * gLdx;
+  int hin[2], win[2];
+  unsigned xo[2], yo[2];   // (the X pieces of a stage are issued before its dY pieces: yo is also the X issue's pixel-range test)
+  const unsigned yEnd = (unsigned)r_end * gLdy + ycb;
+  const int hWrap = gHoS + dh, wWrap = gWoS + dw;
+  const int HoWo = p.Ho * p.Wo;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int pix = r_begin + drow0 + 16 * i;
+    yo[i] = (unsigned)pix * gLdy + ycb;
+    const int pp = pix < p.M ? pix : 0;
+    const int n = fast_div(pp, p.dv_hw[0], p.dv_hw[1]);
+    const int rr = pp - n * HoWo;
+    const int ho = fast_div(rr, p.dv_w[0], p.dv_w[1]);
+    hin[i] = ho * gStride + dh;
+    win[i] = (rr - ho * p.Wo) * gStride + dw;
+    xo[i] = pointwise ? (unsigned)pix * gLdx + xcb : (unsigned)((n * gH + hin[i]) * gW + win[i]) * gLdx + xcb;
+  }
+  auto issue_x = [&](auto bufc) {
+    constexpr int B = decltype(bufc)::value;
+    char* base = smem + B * STAGE + wave * 1024;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      bool xok = yo[i] < yEnd && ci_ok;
+      if (!pointwise) xok = xok && ((unsigned)hin[i] < (unsigned)gH) && ((unsigned)win[i] < (unsigned)gW);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (lds_ptr_t)(base + i * 8192), 16, (int)(xok ? xo[i] : kOOB), 0, 0, 0);
+      xo[i] += stepX;
+      if (!pointwise) {
+        win[i] += BK * gStride;
+        while (win[i] >= wWrap) { win[i] -= gWoS; xo[i] += stepRow; hin[i] += gStride; }
+        while (hin[i] >= hWrap) { hin[i] -= gHoS; xo[i] += stepImg; }
+      }
+    }
+  };
+  auto issue_y = [&](auto bufc) {
+    constexpr int B = decltype(bufc)::value;
+    char* base = smem + B * STAGE + OPB + wave * 1024;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const bool yok = yo[i] < yEnd && co_ok;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(yrsrc, (lds_ptr_t)(base + i * 8192), 16, (int)(yok ? yo[i] : kOOB), 0, 0, 0);
+      yo[i] += stepY;
+    }
+  };
+
+  // ---------------------------------------------------------------------------------------------------------------------
+  // compute side.  v_mfma_f32_32x32x16_bf16: lane l holds A[m = l & 31][k = 8 (l >> 5) .. +7] and B[k = ..][n = l & 31].  The 16-lane
+  // group q = l >> 4 gathers channels 16 (q & 1) .. +15 of a 32-channel block at pixel rows 8 (q >> 1) .. +7 (+16 for the second
+  // k step of the stage) with two transpose reads: lane s of the group passes the address of row r0 + (s >> 2), channels
+  // c0 + 4 (s & 3) .. +3 and receives channel c0 + s of rows r0 .. r0+3 (probe: profiles/r01_ds_read_b64_tr_b16_probe.txt).
+  // One address register per block; k step, second read and ring buffer are immediate offsets (the ring's upper half: a
+  // second register, + 64 KiB).
+  // ---------------------------------------------------------------------------------------------------------------------
+  const int q = lane >> 4, sl = lane & 15;
+  const int row0 = 8 * (q >> 1) + (sl >> 2);
+  const int fkey = swz_key(row0);
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+  const unsigned rbase = lds0 + (unsigned)(row0 * ROWB + (sl & 3) * 8);
+  unsigned aaddr[2][2], baddr[2][4];   // [ring half][block]
+#pragma unroll
+  for (int a = 0; a < 2; ++a) {
+    aaddr[0][a] = rbase + (unsigned)(((4 * wc + 2 * a + (q & 1)) ^ fkey) << 5);
+    aaddr[1][a] = aaddr[0][a] + 2 * STAGE;
+  }
+#pragma unroll
+  for (int b = 0; b < 4; ++b) {
+    baddr[0][b] = rbase + OPB + (unsigned)(((8 * wp + 2 * b + (q & 1)) ^ fkey) << 5);
+    baddr[1][b] = baddr[0][b] + 2 * STAGE;
+  }
+
+  f32x16_t acc[2][4];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+  u32x4_t fa[2][2], fb[2][2];   // [block][k step]
+
+  // 32-channel blocks of this wave that hold real channels (304 = 256 + 48: the second tile's waves 1 .. 3 multiply nothing)
+  const int na = __builtin_amdgcn_readfirstlane(min(2, max(0, (p.Cin - ci_base - wc * 64 + 31) >> 5)));
+  const int nb = __builtin_amdgcn_readfirstlane(min(4, max(0, (p.Cout - co_base - wp * 128 + 31) >> 5)));
+  const bool do_bias = BIAS && p.dbias != nullptr && tci == 0 && ti == 0 && wc == 0;
+  float bsum[4] = {0.f, 0.f, 0.f, 0.f};
+
+  auto read_a = [&](auto bufc) {
+    constexpr int B = decltype(bufc)::value;
+    constexpr int O = (B & 1) * STAGE;
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      const unsigned ad = aaddr[B >> 1][a];
+      const u32x2_t l0 = lds_tr16<O>(ad), h0 = lds_tr16<O + 4 * ROWB>(ad);
+      const u32x2_t l1 = lds_tr16<O + 16 * ROWB>(ad), h1 = lds_tr16<O + 20 * ROWB>(ad);
+      fa[a][0] = (u32x4_t){l0.x, l0.y, h0.x, h0.y};
+      fa[a][1] = (u32x4_t){l1.x, l1.y, h1.x, h1.y};
+    }
+  };
+  auto read_b = [&](auto bufc, auto halfc) {
+    constexpr int B = decltype(bufc)::value, H = decltype(halfc)::value;
+    constexpr int O = (B & 1) * STAGE;
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const unsigned ad = baddr[B >> 1][2 * H + b];
+      const u32x2_t l0 = lds_tr16<O>(ad), h0 = lds_tr16<O + 4 * ROWB>(ad);
+      const u32x2_t l1 = lds_tr16<O + 16 * ROWB>(ad), h1 = lds_tr16<O + 20 * ROWB>(ad);
+      fb[b][0] = (u32x4_t){l0.x, l0.y, h0.x, h0.y};
+      fb[b][1] = (u32x4_t){l1.x, l1.y, h1.x, h1.y};
+    }
+  };
+  // FULL: every block of this wave is live (straight-line cluster); otherwise wave-uniform guards
+  auto mma = [&](auto halfc, auto fullc) {
+    constexpr int H = decltype(halfc)::value;
+    constexpr bool FULL = decltype(fullc)::value;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+          if (FULL || (a < na && 2 * H + b < nb))
+            acc[a][2 * H + b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, fa[a][ks]),
+                                                                       __builtin_bit_cast(bf16x8_t, fb[b][ks]), acc[a][2 * H + b], 0, 0, 0);
+        }
+  };
+  auto bias_add = [&](auto halfc) {
+    constexpr int H = decltype(halfc)::value;
+    if (BIAS && do_bias) {
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) bsum[2 * H + b] += bf16x2_sum(fb[b][ks][e]);
+    }
+  };
+
+  // one stage = two phases; B = ring buffer of the stage that is multiplied, (B + 3) & 3 the one that is fetched
+  auto stage = [&](auto bufc, auto fullc) {
+    constexpr int B = decltype(bufc)::value;
+    using NXT = std::integral_constant<int, (B + 3) & 3>;
+    using H0 = std::integral_constant<int, 0>;
+    using H1 = std::integral_constant<int, 1>;
+    // ---- phase A: X pieces of stage s+3; A fragments + B fragments of co half 0
+    issue_x(NXT{});
+    __builtin_amdgcn_sched_barrier(0);
+    read_a(bufc);
+    read_b(bufc, H0{});
+    __builtin_amdgcn_s_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    bias_add(H0{});
+    __builtin_amdgcn_s_setprio(1);
+    mma(H0{}, fullc);
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (STAGGER) __builtin_amdgcn_s_barrier();
+    // ---- phase B: dY pieces of stage s+3; B fragments of co half 1; retire stage s+1 (read from the next phase on)
+    issue_y(NXT{});
+    __builtin_amdgcn_sched_barrier(0);
+    read_b(bufc, H1{});
+    __builtin_amdgcn_s_waitcnt(vmcnt_imm(8));
+    __builtin_amdgcn_s_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    bias_add(H1{});
+    __builtin_amdgcn_s_setprio(1);
+    mma(H1{}, fullc);
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (STAGGER) __builtin_amdgcn_s_barrier();
+  };
+
+  if (nst > 0) {
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>;
+    using I3 = std::integral_constant<int, 3>;
+    issue_x(I0{}); issue_y(I0{});
+    issue_x(I1{}); issue_y(I1{});
+    issue_x(I2{}); issue_y(I2{});
+    __builtin_amdgcn_s_waitcnt(vmcnt_imm(8));   // stage 0 landed (this thread's pieces)
+    __builtin_amdgcn_s_barrier();
+    if (STAGGER && wp == 1) __builtin_amdgcn_s_barrier();   // group 1 runs one barrier behind
+    if (na == 2 && nb == 4) {
+      for (int s0 = 0; s0 < nst; s0 += 4) {
+        stage(I0{}, std::true_type{}); stage(I1{}, std::true_type{}); stage(I2{}, std::true_type{}); stage(I3{}, std::true_type{});
+      }
+    } else {
+      for (int s0 = 0; s0 < nst; s0 += 4) {
+        stage(I0{}, std::false_type{}); stage(I1{}, std::false_type{}); stage(I2{}, std::false_type{}); stage(I3{}, std::false_type{});
+      }
+    }
+    if (STAGGER && wp == 0) __builtin_amdgcn_s_barrier();
+  }
+
+  // ---------------------------------------------------------------------------------------------------------------------
+  // D[m = ci][n = co]: register r of a 32 x 32 block is row (r & 3) + 8 (r >> 2) + 4 (lane >> 5), column lane & 31: four
+  // consecutive ci of one co = 16 contiguous bytes of dW (OHWI).  ksplit == 1: this workgroup owns the tile; otherwise plain
+  // stores into this split's slab (reduced afterwards in split order: deterministic, no atomics).
+  // ---------------------------------------------------------------------------------------------------------------------
+  if (BIAS && do_bias) {   // lanes l and l + 32 hold the two k halves of column co
+    float* bo = p.ksplit > 1 ? p.bias_slabs + (size_t)z * p.Cout : p.dbias;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      float v = bsum[b];
+      v += __shfl_xor(v, 32, 64);
+      const int co = co_base + wp * 128 + b * 32 + (lane & 31);
+      if (lane < 32 && co < p.Cout) bo[co] = p.ksplit > 1 ? v : bo[co] + v;   // one writer per (split, co)
+    }
+  }
+  float* out = p.ksplit > 1 ? p.slabs + (size_t)z * p.Cout * p.ntaps_all * p.Cin : p.dw;
+#pragma unroll
+  for (int a = 0; a < 2; ++a) {
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const int co = co_base + wp * 128 + b * 32 + (lane & 31);
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        const int ci = ci_base + wc * 64 + a * 32 + 8 * g4 + 4 * (lane >> 5);
+        if (co < p.Cout && ci < p.Cin) {   // Cin % 8 == 0: a quad is in range as a whole
+          if (p.ksplit == 1 && p.oihw) {   // straight into the torch-layout gradient: 4 strided read-modify-writes
+            float* dst = out + ((size_t)co * p.Cin + ci) * p.ntaps_all + tap;
+            if (p.overwrite) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) dst[(size_t)e * p.ntaps_all] = acc[a][b][4 * g4 + e];
+            } else {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) dst[(size_t)e * p.ntaps_all] += acc[a][b][4 * g4 + e];
+            }
+          } else {
+            float4* dst = (float4*)(out + ((size_t)co * p.ntaps_all + tap) * p.Cin + ci);
+            float4 v = make_float4(acc[a][b][4 * g4], acc[a][b][4 * g4 + 1], acc[a][b][4 * g4 + 2], acc[a][b][4 * g4 + 3]);
+            if (p.ksplit == 1 && !p.overwrite) {
+              const float4 o = *dst;
+              v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+            }
+            *dst = v;
+          }
+        }
+      }
+    }
+  }
+}
+
+template <bool BIAS, bool STAGGER>
+__global__ __launch_bounds__(NT, 2) void wgrad_big_group_kernel(const WgradGroupArgs g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int bid = xcd_remap(blockIdx.x, gridDim.x);
+  int j = 0;
+  while (j + 1 < g.njobs && bid >= g.blk_end[j]) ++j;
+  wgrad_big_tile<BIAS, STAGGER>(g.job[j], bid - (j ? g.blk_end[j - 1] : 0), smem);
+}
+
+template <bool BIAS, bool STAGGER>
+static hipError_t launch_big(const WgradGroupArgs& g, int blocks, hipStream_t s) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)wgrad_big_group_kernel<BIAS, STAGGER>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    attr_set = true;
+  }
+  wgrad_big_group_kernel<BIAS, STAGGER><<<dim3(blocks), dim3(NT), LDS_BYTES, s>>>(g);
+  return hipGetLastError();
+}
+
+hipError_t cavp_launch_wgrad_big_group(const WgradGroupArgs& g, int blocks, bool bias, bool stagger, hipStream_t s) {
+  if (stagger) return bias ? launch_big<true, true>(g, blocks, s) : launch_big<false, true>(g, blocks, s);
+  return bias ? launch_big<true, false>(g, blocks, s) : launch_big<false, false>(g, blocks, s);
+}

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define CAVP_ABI_VERSION 8
+#define CAVP_ABI_VERSION 9
 
 typedef enum { CAVP_F32 = 0, CAVP_BF16 = 1 } cavp_dtype_t;
 typedef enum { CAVP_ACT_NONE = 0, CAVP_ACT_RELU = 1, CAVP_ACT_LEAKY = 2, CAVP_ACT_GELU = 3 } cavp_act_t;
@@ -128,6 +128,13 @@ int cavp_set_igemm_epilogue(int32_t mode);
  * torch.autograd computes for trainer_cavp_vpo_mono.py:190): 0 = two 32-row LDS stages per workgroup, 1 = one 64-row stage.
  * Both keep four 32 KiB workgroups per CU and give bit-identical results.  Process-wide switch for A/B runs and tests. */
 int cavp_set_wgrad_variant(int32_t variant);
+/* ABI 9: the 256 x 256 weight-gradient tile (csrc/conv_wgrad_big.hip; bf16: one 8-wave workgroup per CU, four-stage LDS-DMA
+ * ring, v_mfma_f32_32x32x16_bf16) for the weight gradients of encoder_decoder.py:62-75 (decoder head), models/attn.py:136-143 and
+ * cavp_model.py:123-128 (token / projector Mlp) - the jobs with >= 16384 pixel rows and >= 192 input and output channels.
+ * mode: 0 (default) = those jobs, 1 = never (the 128 x 128 tile everywhere), 2 = every bf16 job (tests).  stagger: 1 (default) =
+ * the two halves of a workgroup run one barrier apart (ping-pong), 0 = in step.  The choice depends on the job alone, so grouped
+ * and single launches of a job with one split count stay bit-identical.  Process-wide switch for A/B runs and tests. */
+int cavp_set_wgrad_big(int32_t mode, int32_t stagger);
 
 /* Direct 3x3 conv for Cin in {1,2,3} reading an NCHW f32 tensor and writing NHWC (dtype) with scale/shift + act:
  * the ResNet deep-stem first conv (resnet.py:108-110, stride 2) and the first VGGish conv (vgg.py:26-36). */
