@@ -372,15 +372,15 @@ extern "C" int cavp_set_wgrad_variant(int v) {
 }
 
 // The 256 x 256 tile of conv_wgrad_big.hip (bf16).  mode 0 (default): the jobs big enough for it (wgrad_big_eligible), 1: never
-// (the 128 x 128 tile everywhere: A/B baseline), 2: every bf16 job (tests: tiny shapes through the big tile).  stagger: its
-// ping-pong schedule (conv_wgrad_big.hip).  The choice depends on the job alone, never on the group it travels in, so a grouped
+// (the 128 x 128 tile everywhere: A/B baseline), 2: every bf16 job (tests: tiny shapes through the big tile).  pipelined: its
+// software-pipelined schedule (conv_wgrad_big.hip; 0 = read, barrier, multiply).  The choice depends on the job alone, never on the group it travels in, so a grouped
 // and a single launch of one job with the same split count stay bit-identical.
 static int g_wgrad_big_mode = 0;
-static int g_wgrad_big_stagger = 1;
-extern "C" int cavp_set_wgrad_big(int mode, int stagger) {
-  if (mode < 0 || mode > 2 || stagger < 0 || stagger > 1) return CAVP_ERR_BAD_ARG;
+static int g_wgrad_big_pipe = 1;
+extern "C" int cavp_set_wgrad_big(int mode, int pipelined) {
+  if (mode < 0 || mode > 2 || pipelined < 0 || pipelined > 1) return CAVP_ERR_BAD_ARG;
   g_wgrad_big_mode = mode;
-  g_wgrad_big_stagger = stagger;
+  g_wgrad_big_pipe = pipelined;
   return CAVP_OK;
 }
 
@@ -820,7 +820,10 @@ extern "C" int cavp_conv2d_wgrad_group(const cavp_wgrad_job* jobs, int32_t njobs
       p.overwrite = 0;
     }
     p.bias_slabs = p.slabs ? p.slabs + (size_t)p.ksplit * d->Cout * p.ntaps_all * d->Cin : nullptr;
-    p.dbg = 0;
+    {
+      static const int dbg = cavp_knob_int("CAVP_WGRAD_DBG", 0);   // (profile builds; the 256 x 256 tile reads bits 1 and 2)
+      p.dbg = dbg;
+    }
     p.red_zg = 1;
     if (p.ksplit > 1) {
       const long long quads = (long long)p.Cout * p.ntaps * (p.Cin / 4);
@@ -851,7 +854,7 @@ extern "C" int cavp_conv2d_wgrad_group(const cavp_wgrad_job* jobs, int32_t njobs
   }
   gs.njobs = ns; gb.njobs = nb; gr.njobs = nr;
   if (nb > 0) {   // the long-running workgroups first
-    if (cavp_launch_wgrad_big_group(gb, bblocks, bbias, g_wgrad_big_stagger != 0, s) != hipSuccess) return CAVP_ERR_LAUNCH;
+    if (cavp_launch_wgrad_big_group(gb, bblocks, bbias, g_wgrad_big_pipe != 0, s) != hipSuccess) return CAVP_ERR_LAUNCH;
   }
   if (ns > 0) {
     const int lds = 2 * 2 * 32 * 256;

@@ -14,14 +14,16 @@
 //  * a stage = 32 pixel rows of both operands exactly as they lie in memory (512-byte LDS rows = 256 channels), 32 KiB; the
 //    ring holds 4 stages (128 KiB): while stage s is multiplied, s+1 .. s+3 are in flight or landed behind a counted
 //    s_waitcnt vmcnt(8) - never 0 inside the loop.
-//  * a stage is two phases of 8 MFMAs per wave (co half 0 / 1).  Phase A issues the X pieces of stage s+3 and reads the A
-//    fragments (kept for both phases) + the B fragments of co half 0; phase B issues the dY pieces of s+3, reads the B
-//    fragments of co half 1 and retires stage s+1.  Fragments are gathered with the LDS transpose read ds_read_b64_tr_b16
-//    (inline asm: hipcc puts an s_waitcnt vmcnt(0) in front of the builtin whenever an LDS-DMA is pending, which would drain
-//    the ring in every phase, profiles/r03_notes.md).
-//  * optional ping-pong (STAGGER): the two co halves of the workgroup (waves 0-3 / 4-7, one wave of each per SIMD) run one
-//    barrier apart, so that one wave of a SIMD issues MFMAs while the other issues its LDS reads and LDS-DMA; two raw
-//    s_barrier per phase.  Without it: one barrier per phase, the two waves of a SIMD run in step.
+//  * a stage is two clusters of 8 MFMAs per wave (co half 0 / 1) and ONE raw s_barrier.  The fragments of a cluster are
+//    read while the previous cluster is multiplied (two B fragment sets, two A sets): a wave never waits for the LDS with the
+//    matrix pipe idle, and the two waves of a SIMD do not depend on each other for overlap.  Phase A: issue the X pieces of
+//    stage s+3, issue the reads of the B fragments of co half 1, multiply co half 0.  Phase B: issue the dY pieces of s+3,
+//    retire stage s+1 (counted vmcnt + barrier), issue the reads of the A fragments + co half 0 of stage s+1, multiply co
+//    half 1.  Fragments are gathered with the LDS transpose read ds_read_b64_tr_b16 (inline asm: hipcc puts an
+//    s_waitcnt vmcnt(0) in front of the builtin whenever an LDS-DMA is pending, which would drain the ring in every phase,
+//    profiles/r03_notes.md).  PIPE = false is the plain schedule (read, barrier, multiply; one barrier per cluster) kept for
+//    A/B runs.  (A ping-pong of the two co halves one barrier apart - the structure of conv_igemm_big.hip - was measured on
+//    the first version of this kernel: 4 .. 8 % slower than running in step, profiles/r05_notes.md.)
 //  * swizzle: the 32-byte chunk index (16 channels) of a row is XORed with ((row & 3) << 1) | ((row >> 3) & 1) on the DMA
 //    SOURCE side; a 32-lane half of a transpose read touches rows r .. r+3 of two neighbouring chunks -> 8 different bank
 //    groups (conflict-free for this 32 x 32 fragment shape and for the 16 x 16 x 32 one).
@@ -65,11 +67,10 @@ __device__ __forceinline__ float bf16x2_sum(unsigned u) { return __uint_as_float
 }  // namespace
 
 // One logical workgroup `bid` of one weight gradient on the 256 x 256 tile.
-template <bool BIAS, bool STAGGER>
+template <bool BIAS, bool PIPE>
 __device__ __forceinline__ void wgrad_big_tile(const WgradParams& p, const int bid, char* smem) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wc = wave & 3, wp = wave >> 2;   // ci quarter, co half (= ping-pong group)
 
   const int b1 = fast_div(bid, p.dv_co[0], p.dv_co[1]), tco = bid - b1 * p.tiles_co;
   const int b2 = fast_div(b1, p.dv_ci[0], p.dv_ci[1]), tci = b1 - b2 * p.tiles_ci;
@@ -93,7 +94,7 @@ __device__ __forceinline__ void wgrad_big_tile(const WgradParams& p, const int b
   // ---------------------------------------------------------------------------------------------------------------------
   const int drow0 = 2 * wave + (lane >> 5);
   const int cel = ((((lane & 31) >> 1) ^ swz_key(drow0)) << 4) + ((lane & 1) << 3);   // logical channel of this lane's 16 bytes
-  const bool ci_ok = ci_base + cel < p.Cin, co_ok = co_base + cel < p.Cout;
+  const bool ci_ok = ci_base + cel < p.Cin && !CAVP_DBG(p, 1), co_ok = co_base + cel < p.Cout && !CAVP_DBG(p, 1);   // (dbg 1: no memory traffic)
   const unsigned xcb = (unsigned)((ci_base + cel) * 2), ycb = (unsigned)((co_base + cel) * 2);
   const bool pointwise = (p.ntaps_all == 1) && p.stride == 1 && p.pad == 0;
   const int dh = kh * p.dil - p.pad, dw = kw * p.dil - p.pad;
@@ -123,8 +124,10 @@ __device__ __forceinline__ void wgrad_big_tile(const WgradParams& p, const int b
     win[i] = (rr - ho * p.Wo) * gStride + dw;
     xo[i] = pointwise ? (unsigned)pix * gLdx + xcb : (unsigned)((n * gH + hin[i]) * gW + win[i]) * gLdx + xcb;
   }
+  const bool dbg_nodma = CAVP_DBG(p, 4), dbg_noread = CAVP_DBG(p, 8);   // (profile builds: pieces of the loop switched off)
   auto issue_x = [&](auto bufc) {
     constexpr int B = decltype(bufc)::value;
+    if (dbg_nodma) return;
     char* base = smem + B * STAGE + wave * 1024;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -141,6 +144,7 @@ __device__ __forceinline__ void wgrad_big_tile(const WgradParams& p, const int b
   };
   auto issue_y = [&](auto bufc) {
     constexpr int B = decltype(bufc)::value;
+    if (dbg_nodma) return;
     char* base = smem + B * STAGE + OPB + wave * 1024;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -151,13 +155,28 @@ __device__ __forceinline__ void wgrad_big_tile(const WgradParams& p, const int b
   };
 
   // ---------------------------------------------------------------------------------------------------------------------
-  // compute side.  v_mfma_f32_32x32x16_bf16: lane l holds A[m = l & 31][k = 8 (l >> 5) .. +7] and B[k = ..][n = l & 31].  The 16-lane
-  // group q = l >> 4 gathers channels 16 (q & 1) .. +15 of a 32-channel block at pixel rows 8 (q >> 1) .. +7 (+16 for the second
-  // k step of the stage) with two transpose reads: lane s of the group passes the address of row r0 + (s >> 2), channels
-  // c0 + 4 (s & 3) .. +3 and receives channel c0 + s of rows r0 .. r0+3 (probe: profiles/r01_ds_read_b64_tr_b16_probe.txt).
-  // One address register per block; k step, second read and ring buffer are immediate offsets (the ring's upper half: a
-  // second register, + 64 KiB).
+  // compute side.  Sub-tile of this wave, by the live extent of the workgroup's tile (wave-uniform):
+  //   full tile      : 8 waves = 4 (ci) x 2 (co), wave tile 64 ci x 128 co = 2 x 4 blocks of 32 x 32 (waves 2 w, 2 w + 1 share
+  //                    a ci quarter: consecutive waves sit on different SIMD pairs, so the live waves of a partly filled
+  //                    tile do not pile up on one SIMD)
+  //   <= 64 live ci   : (the 48-channel rest of 304 = 256 + 48) every wave takes the 64 ci x 32 co block column `wave`: the
+  //                    rest tile costs its operand stream, not a full tile's MFMA time on two waves
+  //   <= 64 live co   : every wave takes the 32 ci x 64 co block row `wave`
+  // A wave whose sub-tile holds no real channel only issues its DMA pieces and meets the barriers.
   // ---------------------------------------------------------------------------------------------------------------------
+  const int live_ci = min(TC, p.Cin - ci_base), live_co = min(TC, p.Cout - co_base);
+  const int mode = __builtin_amdgcn_readfirstlane(live_ci <= 64 ? 1 : (live_co <= 64 ? 2 : 0));
+  const int ci0 = mode == 0 ? (wave >> 1) * 64 : (mode == 1 ? 0 : wave * 32);
+  const int co0 = mode == 0 ? (wave & 1) * 128 : (mode == 1 ? wave * 32 : 0);
+  const int NAw = mode == 2 ? 1 : 2, NBw = mode == 0 ? 4 : (mode == 1 ? 1 : 2);   // 32-blocks of the wave's sub-tile
+  const bool active = __builtin_amdgcn_readfirstlane((ci0 < live_ci && co0 < live_co) ? 1 : 0) != 0;
+
+  // v_mfma_f32_32x32x16_bf16: lane l holds A[m = l & 31][k = 8 (l >> 5) .. +7] and B[k = ..][n = l & 31].  The 16-lane group
+  // q = l >> 4 gathers channels 16 (q & 1) .. +15 of a 32-channel block at pixel rows 8 (q >> 1) .. +7 (+16 for the second k step
+  // of the stage) with two transpose reads: lane s of the group passes the address of row r0 + (s >> 2), channels
+  // c0 + 4 (s & 3) .. +3 and receives channel c0 + s of rows r0 .. r0+3 (probe: profiles/r01_ds_read_b64_tr_b16_probe.txt).
+  // One address register per block; k step, second read and ring buffer are immediate offsets (the ring's upper half: + 64 KiB
+  // in a second register).
   const int q = lane >> 4, sl = lane & 15;
   const int row0 = 8 * (q >> 1) + (sl >> 2);
   const int fkey = swz_key(row0);
@@ -166,12 +185,12 @@ __device__ __forceinline__ void wgrad_big_tile(const WgradParams& p, const int b
   unsigned aaddr[2][2], baddr[2][4];   // [ring half][block]
 #pragma unroll
   for (int a = 0; a < 2; ++a) {
-    aaddr[0][a] = rbase + (unsigned)(((4 * wc + 2 * a + (q & 1)) ^ fkey) << 5);
+    aaddr[0][a] = rbase + (unsigned)((((ci0 >> 4) + 2 * a + (q & 1)) ^ fkey) << 5);
     aaddr[1][a] = aaddr[0][a] + 2 * STAGE;
   }
 #pragma unroll
   for (int b = 0; b < 4; ++b) {
-    baddr[0][b] = rbase + OPB + (unsigned)(((8 * wp + 2 * b + (q & 1)) ^ fkey) << 5);
+    baddr[0][b] = rbase + OPB + (unsigned)((((co0 >> 4) + 2 * b + (q & 1)) ^ fkey) << 5);
     baddr[1][b] = baddr[0][b] + 2 * STAGE;
   }
 
@@ -182,123 +201,201 @@ __device__ __forceinline__ void wgrad_big_tile(const WgradParams& p, const int b
     for (int b = 0; b < 4; ++b)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
-  u32x4_t fa[2][2], fb[2][2];   // [block][k step]
+  u32x4_t fa[2][2][2], fb[2][2][2];   // [set][block][k step]: full tile: A sets alternate by stage, B sets by co half
 
-  // 32-channel blocks of this wave that hold real channels (304 = 256 + 48: the second tile's waves 1 .. 3 multiply nothing)
-  const int na = __builtin_amdgcn_readfirstlane(min(2, max(0, (p.Cin - ci_base - wc * 64 + 31) >> 5)));
-  const int nb = __builtin_amdgcn_readfirstlane(min(4, max(0, (p.Cout - co_base - wp * 128 + 31) >> 5)));
-  const bool do_bias = BIAS && p.dbias != nullptr && tci == 0 && ti == 0 && wc == 0;
+  // bias gradient: the workgroups of the first ci tile and first live tap see every dY element exactly once; there the waves whose
+  // B fragments cover a co range first (full tile: the ci quarter 0 = waves 0, 1; <= 64 live ci: every wave owns a co block;
+  // <= 64 live co: wave 0) add them up.
+  const bool do_bias = BIAS && p.dbias != nullptr && tci == 0 && ti == 0 && active && (mode == 0 ? wave < 2 : (mode == 1 || wave == 0));
   float bsum[4] = {0.f, 0.f, 0.f, 0.f};
+  const bool dbg_nomma = CAVP_DBG(p, 2);
 
-  auto read_a = [&](auto bufc) {
-    constexpr int B = decltype(bufc)::value;
-    constexpr int O = (B & 1) * STAGE;
-#pragma unroll
-    for (int a = 0; a < 2; ++a) {
-      const unsigned ad = aaddr[B >> 1][a];
-      const u32x2_t l0 = lds_tr16<O>(ad), h0 = lds_tr16<O + 4 * ROWB>(ad);
-      const u32x2_t l1 = lds_tr16<O + 16 * ROWB>(ad), h1 = lds_tr16<O + 20 * ROWB>(ad);
-      fa[a][0] = (u32x4_t){l0.x, l0.y, h0.x, h0.y};
-      fa[a][1] = (u32x4_t){l1.x, l1.y, h1.x, h1.y};
-    }
+  using C0 = std::integral_constant<int, 0>;
+  using C1 = std::integral_constant<int, 1>;
+  using C2 = std::integral_constant<int, 2>;
+  using C3 = std::integral_constant<int, 3>;
+  // one fragment = 8 pixel rows x 32 channels per lane group = two transpose reads
+  auto rf_a = [&](auto bufc, auto setc, auto blkc, auto ksc) {   // block BLK of the wave's A blocks, k step KS -> set S
+    constexpr int B = decltype(bufc)::value & 3, S = decltype(setc)::value, A = decltype(blkc)::value, KS = decltype(ksc)::value;
+    constexpr int O = (B & 1) * STAGE + KS * 16 * ROWB;
+    if (dbg_noread) return;
+    const unsigned ad = aaddr[B >> 1][A];
+    const u32x2_t l = lds_tr16<O>(ad), h = lds_tr16<O + 4 * ROWB>(ad);
+    fa[S][A][KS] = (u32x4_t){l.x, l.y, h.x, h.y};
   };
-  auto read_b = [&](auto bufc, auto halfc) {
-    constexpr int B = decltype(bufc)::value, H = decltype(halfc)::value;
-    constexpr int O = (B & 1) * STAGE;
-#pragma unroll
-    for (int b = 0; b < 2; ++b) {
-      const unsigned ad = baddr[B >> 1][2 * H + b];
-      const u32x2_t l0 = lds_tr16<O>(ad), h0 = lds_tr16<O + 4 * ROWB>(ad);
-      const u32x2_t l1 = lds_tr16<O + 16 * ROWB>(ad), h1 = lds_tr16<O + 20 * ROWB>(ad);
-      fb[b][0] = (u32x4_t){l0.x, l0.y, h0.x, h0.y};
-      fb[b][1] = (u32x4_t){l1.x, l1.y, h1.x, h1.y};
-    }
+  auto rf_b = [&](auto bufc, auto setc, auto blkc, auto slotc, auto ksc) {   // block BLK of the wave's B blocks -> set S, slot SLOT
+    constexpr int B = decltype(bufc)::value & 3, S = decltype(setc)::value, BB = decltype(blkc)::value, SL = decltype(slotc)::value;
+    constexpr int KS = decltype(ksc)::value;
+    constexpr int O = (B & 1) * STAGE + KS * 16 * ROWB;
+    if (dbg_noread) return;
+    const unsigned ad = baddr[B >> 1][BB];
+    const u32x2_t l = lds_tr16<O>(ad), h = lds_tr16<O + 4 * ROWB>(ad);
+    fb[S][SL][KS] = (u32x4_t){l.x, l.y, h.x, h.y};
   };
-  // FULL: every block of this wave is live (straight-line cluster); otherwise wave-uniform guards
-  auto mma = [&](auto halfc, auto fullc) {
-    constexpr int H = decltype(halfc)::value;
-    constexpr bool FULL = decltype(fullc)::value;
+  auto read_a = [&](auto bufc, auto setc, auto blkc) { rf_a(bufc, setc, blkc, C0{}); rf_a(bufc, setc, blkc, C1{}); };
+  auto read_b = [&](auto bufc, auto setc, auto blkc, auto slotc) { rf_b(bufc, setc, blkc, slotc, C0{}); rf_b(bufc, setc, blkc, slotc, C1{}); };
+  // acc[a][B0 + b] += A set SA block a x B set SB slot b, a < NA, b < NB, both k steps
+  auto mma = [&](auto sac, auto sbc, auto nac, auto nbc, auto b0c) {
+    constexpr int SA = decltype(sac)::value, SB = decltype(sbc)::value, NA = decltype(nac)::value, NB = decltype(nbc)::value;
+    constexpr int B0 = decltype(b0c)::value;
+    if (dbg_nomma) return;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-      for (int a = 0; a < 2; ++a)
+      for (int a = 0; a < NA; ++a)
 #pragma unroll
-        for (int b = 0; b < 2; ++b) {
-          if (FULL || (a < na && 2 * H + b < nb))
-            acc[a][2 * H + b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, fa[a][ks]),
-                                                                       __builtin_bit_cast(bf16x8_t, fb[b][ks]), acc[a][2 * H + b], 0, 0, 0);
-        }
+        for (int b = 0; b < NB; ++b)
+          acc[a][B0 + b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, fa[SA][a][ks]),
+                                                                  __builtin_bit_cast(bf16x8_t, fb[SB][b][ks]), acc[a][B0 + b], 0, 0, 0);
   };
-  auto bias_add = [&](auto halfc) {
-    constexpr int H = decltype(halfc)::value;
+  // one MFMA: acc[A][BO + SL] += A set SA block A x B set SB slot SL, k step KS
+  auto mm1 = [&](auto sac, auto sbc, auto ac, auto slc, auto ksc, auto boc) {
+    constexpr int SA = decltype(sac)::value, SB = decltype(sbc)::value, A = decltype(ac)::value, SL = decltype(slc)::value;
+    constexpr int KS = decltype(ksc)::value, BO = decltype(boc)::value;
+    if (dbg_nomma) return;
+    acc[A][BO + SL] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, fa[SA][A][KS]),
+                                                             __builtin_bit_cast(bf16x8_t, fb[SB][SL][KS]), acc[A][BO + SL], 0, 0, 0);
+  };
+  auto bias_add = [&](auto sbc, auto nbc, auto b0c) {
+    constexpr int SB = decltype(sbc)::value, NB = decltype(nbc)::value, B0 = decltype(b0c)::value;
     if (BIAS && do_bias) {
 #pragma unroll
-      for (int b = 0; b < 2; ++b)
+      for (int b = 0; b < NB; ++b)
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-          for (int e = 0; e < 4; ++e) bsum[2 * H + b] += bf16x2_sum(fb[b][ks][e]);
+          for (int e = 0; e < 4; ++e) bsum[B0 + b] += bf16x2_sum(fb[SB][b][ks][e]);
     }
   };
 
-  // one stage = two phases; B = ring buffer of the stage that is multiplied, (B + 3) & 3 the one that is fetched
-  auto stage = [&](auto bufc, auto fullc) {
+  // ---- every schedule: stage s lives in ring buffer B = s & 3; once every wave has its last fragment of stage s in registers
+  // and stage s+1 has landed (counted vmcnt + the stage's one barrier), the pieces of stage s+4 are issued into buffer B: three
+  // stages are in flight at any time.
+#define CAVP_SB __builtin_amdgcn_sched_barrier(0)
+  // ---- full tile, PIPE: 16 MFMAs per wave and stage with every LDS read and DMA issue placed in the gaps between them (a wave
+  // sits in the issue of its next MFMA until the matrix pipe takes it - anything queued behind a cluster of 8 waits 256 cycles,
+  // and the two waves of a SIMD run in step, so reads issued in front of a cluster do not overlap with anybody's MFMAs:
+  // profiles/r05_notes.md, 246 us -> see there).  Cluster 0 (co half 0: A set + B set 0, read during the previous cluster 1)
+  // carries the reads of co half 1; cluster 1 carries the reads of the next stage's A set and co half 0 and the DMA issue.
+  auto stage_full = [&](auto bufc) {
     constexpr int B = decltype(bufc)::value;
-    using NXT = std::integral_constant<int, (B + 3) & 3>;
-    using H0 = std::integral_constant<int, 0>;
-    using H1 = std::integral_constant<int, 1>;
-    // ---- phase A: X pieces of stage s+3; A fragments + B fragments of co half 0
-    issue_x(NXT{});
-    __builtin_amdgcn_sched_barrier(0);
-    read_a(bufc);
-    read_b(bufc, H0{});
-    __builtin_amdgcn_s_barrier();
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
-    bias_add(H0{});
-    __builtin_amdgcn_s_setprio(1);
-    mma(H0{}, fullc);
-    __builtin_amdgcn_s_setprio(0);
-    __builtin_amdgcn_sched_barrier(0);
-    if constexpr (STAGGER) __builtin_amdgcn_s_barrier();
-    // ---- phase B: dY pieces of stage s+3; B fragments of co half 1; retire stage s+1 (read from the next phase on)
-    issue_y(NXT{});
-    __builtin_amdgcn_sched_barrier(0);
-    read_b(bufc, H1{});
+    using SET = std::integral_constant<int, B & 1>;
+    using NB1 = std::integral_constant<int, B + 1>;
+    using NSET = std::integral_constant<int, (B + 1) & 1>;
+    if constexpr (PIPE) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // A set + co half 0 landed
+      CAVP_SB;
+      bias_add(C0{}, C2{}, C0{});
+      mm1(SET{}, C0{}, C0{}, C0{}, C0{}, C0{}); rf_b(bufc, C1{}, C2{}, C0{}, C0{}); CAVP_SB;
+      mm1(SET{}, C0{}, C0{}, C1{}, C0{}, C0{}); rf_b(bufc, C1{}, C3{}, C1{}, C0{}); CAVP_SB;
+      mm1(SET{}, C0{}, C1{}, C0{}, C0{}, C0{}); rf_b(bufc, C1{}, C2{}, C0{}, C1{}); CAVP_SB;
+      mm1(SET{}, C0{}, C1{}, C1{}, C0{}, C0{}); rf_b(bufc, C1{}, C3{}, C1{}, C1{}); CAVP_SB;
+      mm1(SET{}, C0{}, C0{}, C0{}, C1{}, C0{});
+      mm1(SET{}, C0{}, C0{}, C1{}, C1{}, C0{});
+      mm1(SET{}, C0{}, C1{}, C0{}, C1{}, C0{});
+      mm1(SET{}, C0{}, C1{}, C1{}, C1{}, C0{});
+      CAVP_SB;
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // co half 1 landed = this wave's last read of buffer B is complete
+      __builtin_amdgcn_s_waitcnt(vmcnt_imm(8));            // this thread's pieces of stage s+1 landed
+      __builtin_amdgcn_s_barrier();
+      CAVP_SB;
+      bias_add(C1{}, C2{}, C2{});
+      mm1(SET{}, C1{}, C0{}, C0{}, C0{}, C2{}); rf_a(NB1{}, NSET{}, C0{}, C0{}); rf_b(NB1{}, C0{}, C0{}, C0{}, C0{}); CAVP_SB;
+      mm1(SET{}, C1{}, C0{}, C1{}, C0{}, C2{}); rf_a(NB1{}, NSET{}, C1{}, C0{}); rf_b(NB1{}, C0{}, C1{}, C1{}, C0{}); CAVP_SB;
+      mm1(SET{}, C1{}, C1{}, C0{}, C0{}, C2{}); rf_a(NB1{}, NSET{}, C0{}, C1{}); rf_b(NB1{}, C0{}, C0{}, C0{}, C1{}); CAVP_SB;
+      mm1(SET{}, C1{}, C1{}, C1{}, C0{}, C2{}); rf_a(NB1{}, NSET{}, C1{}, C1{}); rf_b(NB1{}, C0{}, C1{}, C1{}, C1{}); CAVP_SB;
+      mm1(SET{}, C1{}, C0{}, C0{}, C1{}, C2{}); issue_x(bufc); CAVP_SB;
+      mm1(SET{}, C1{}, C0{}, C1{}, C1{}, C2{}); issue_y(bufc); CAVP_SB;
+      mm1(SET{}, C1{}, C1{}, C0{}, C1{}, C2{});
+      mm1(SET{}, C1{}, C1{}, C1{}, C1{}, C2{});
+      CAVP_SB;
+    } else {   // plain: read, multiply, retire, fetch
+      read_a(bufc, SET{}, C0{});
+      read_a(bufc, SET{}, C1{});
+      read_b(bufc, C0{}, C0{}, C0{});
+      read_b(bufc, C0{}, C1{}, C1{});
+      read_b(bufc, C1{}, C2{}, C0{});
+      read_b(bufc, C1{}, C3{}, C1{});
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      CAVP_SB;
+      bias_add(C0{}, C2{}, C0{});
+      bias_add(C1{}, C2{}, C2{});
+      mma(SET{}, C0{}, C2{}, C2{}, C0{});
+      mma(SET{}, C1{}, C2{}, C2{}, C2{});
+      CAVP_SB;
+      __builtin_amdgcn_s_waitcnt(vmcnt_imm(8));
+      __builtin_amdgcn_s_barrier();
+      issue_x(bufc);
+      issue_y(bufc);
+      CAVP_SB;
+    }
+  };
+  // ---- rest tiles (NA x NB = 2 x 1 or 1 x 2 blocks per wave, 4 MFMAs per stage): the fragments of stage s+1 are read behind the
+  // barrier that retires it (fragment sets alternate by stage)
+  auto read_rest = [&](auto bufc, auto setc, auto nac) {
+    constexpr int NA = decltype(nac)::value;
+    read_a(bufc, setc, C0{});
+    if constexpr (NA == 2) {
+      read_a(bufc, setc, C1{});
+      read_b(bufc, setc, C0{}, C0{});
+    } else {
+      read_b(bufc, setc, C0{}, C0{});
+      read_b(bufc, setc, C1{}, C1{});
+    }
+  };
+  auto stage_rest = [&](auto bufc, auto nac) {
+    constexpr int B = decltype(bufc)::value, NA = decltype(nac)::value;
+    using SET = std::integral_constant<int, B & 1>;
+    using NBc = std::integral_constant<int, 3 - NA>;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the fragments of stage s (read one stage ago) landed
+    CAVP_SB;
+    bias_add(SET{}, NBc{}, C0{});
+    mma(SET{}, SET{}, nac, NBc{}, C0{});
+    CAVP_SB;
     __builtin_amdgcn_s_waitcnt(vmcnt_imm(8));
     __builtin_amdgcn_s_barrier();
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
-    bias_add(H1{});
-    __builtin_amdgcn_s_setprio(1);
-    mma(H1{}, fullc);
-    __builtin_amdgcn_s_setprio(0);
-    __builtin_amdgcn_sched_barrier(0);
-    if constexpr (STAGGER) __builtin_amdgcn_s_barrier();
+    read_rest(std::integral_constant<int, B + 1>{}, std::integral_constant<int, (B + 1) & 1>{}, nac);
+    issue_x(bufc);
+    issue_y(bufc);
+    CAVP_SB;
+  };
+  auto stage_idle = [&](auto bufc) {
+    __builtin_amdgcn_s_waitcnt(vmcnt_imm(8));
+    __builtin_amdgcn_s_barrier();
+    issue_x(bufc);
+    issue_y(bufc);
   };
 
   if (nst > 0) {
-    using I0 = std::integral_constant<int, 0>;
-    using I1 = std::integral_constant<int, 1>;
-    using I2 = std::integral_constant<int, 2>;
-    using I3 = std::integral_constant<int, 3>;
-    issue_x(I0{}); issue_y(I0{});
-    issue_x(I1{}); issue_y(I1{});
-    issue_x(I2{}); issue_y(I2{});
-    __builtin_amdgcn_s_waitcnt(vmcnt_imm(8));   // stage 0 landed (this thread's pieces)
+    issue_x(C0{}); issue_y(C0{});
+    issue_x(C1{}); issue_y(C1{});
+    issue_x(C2{}); issue_y(C2{});
+    issue_x(C3{}); issue_y(C3{});
+    __builtin_amdgcn_s_waitcnt(vmcnt_imm(12));   // stage 0 landed (this thread's pieces)
     __builtin_amdgcn_s_barrier();
-    if (STAGGER && wp == 1) __builtin_amdgcn_s_barrier();   // group 1 runs one barrier behind
-    if (na == 2 && nb == 4) {
-      for (int s0 = 0; s0 < nst; s0 += 4) {
-        stage(I0{}, std::true_type{}); stage(I1{}, std::true_type{}); stage(I2{}, std::true_type{}); stage(I3{}, std::true_type{});
+    if (!active) {   // (all branches here are workgroup- or wave-uniform; every wave meets the same barriers and issues the same DMA pieces)
+      for (int s0 = 0; s0 < nst; s0 += 4) { stage_idle(C0{}); stage_idle(C1{}); stage_idle(C2{}); stage_idle(C3{}); }
+    } else if (mode == 0) {
+      if constexpr (PIPE) {
+        read_a(C0{}, C0{}, C0{});
+        read_a(C0{}, C0{}, C1{});
+        read_b(C0{}, C0{}, C0{}, C0{});
+        read_b(C0{}, C0{}, C1{}, C1{});
       }
+      for (int s0 = 0; s0 < nst; s0 += 4) { stage_full(C0{}); stage_full(C1{}); stage_full(C2{}); stage_full(C3{}); }
+      if constexpr (PIPE) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the last stage's look-ahead reads (unused)
+    } else if (mode == 1) {
+      read_rest(C0{}, C0{}, C2{});
+      for (int s0 = 0; s0 < nst; s0 += 4) { stage_rest(C0{}, C2{}); stage_rest(C1{}, C2{}); stage_rest(C2{}, C2{}); stage_rest(C3{}, C2{}); }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     } else {
-      for (int s0 = 0; s0 < nst; s0 += 4) {
-        stage(I0{}, std::false_type{}); stage(I1{}, std::false_type{}); stage(I2{}, std::false_type{}); stage(I3{}, std::false_type{});
-      }
+      read_rest(C0{}, C0{}, C1{});
+      for (int s0 = 0; s0 < nst; s0 += 4) { stage_rest(C0{}, C1{}); stage_rest(C1{}, C1{}); stage_rest(C2{}, C1{}); stage_rest(C3{}, C1{}); }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
-    if (STAGGER && wp == 0) __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_s_waitcnt(vmcnt_imm(0));   // (the zero-fill pieces issued past the last stage: nothing may land in LDS after this workgroup ends)
   }
+#undef CAVP_SB
 
   // ---------------------------------------------------------------------------------------------------------------------
   // D[m = ci][n = co]: register r of a 32 x 32 block is row (r & 3) + 8 (r >> 2) + 4 (lane >> 5), column lane & 31: four
@@ -311,19 +408,21 @@ __device__ __forceinline__ void wgrad_big_tile(const WgradParams& p, const int b
     for (int b = 0; b < 4; ++b) {
       float v = bsum[b];
       v += __shfl_xor(v, 32, 64);
-      const int co = co_base + wp * 128 + b * 32 + (lane & 31);
-      if (lane < 32 && co < p.Cout) bo[co] = p.ksplit > 1 ? v : bo[co] + v;   // one writer per (split, co)
+      const int co = co_base + co0 + b * 32 + (lane & 31);
+      if (b < NBw && lane < 32 && co < p.Cout) bo[co] = p.ksplit > 1 ? v : bo[co] + v;   // one writer per (split, co)
     }
   }
+  if (!active) return;
   float* out = p.ksplit > 1 ? p.slabs + (size_t)z * p.Cout * p.ntaps_all * p.Cin : p.dw;
 #pragma unroll
   for (int a = 0; a < 2; ++a) {
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
-      const int co = co_base + wp * 128 + b * 32 + (lane & 31);
+      if (a >= NAw || b >= NBw) continue;   // (wave-uniform)
+      const int co = co_base + co0 + b * 32 + (lane & 31);
 #pragma unroll
       for (int g4 = 0; g4 < 4; ++g4) {
-        const int ci = ci_base + wc * 64 + a * 32 + 8 * g4 + 4 * (lane >> 5);
+        const int ci = ci_base + ci0 + a * 32 + 8 * g4 + 4 * (lane >> 5);
         if (co < p.Cout && ci < p.Cin) {   // Cin % 8 == 0: a quad is in range as a whole
           if (p.ksplit == 1 && p.oihw) {   // straight into the torch-layout gradient: 4 strided read-modify-writes
             float* dst = out + ((size_t)co * p.Cin + ci) * p.ntaps_all + tap;
@@ -349,27 +448,27 @@ __device__ __forceinline__ void wgrad_big_tile(const WgradParams& p, const int b
   }
 }
 
-template <bool BIAS, bool STAGGER>
+template <bool BIAS, bool PIPE>
 __global__ __launch_bounds__(NT, 2) void wgrad_big_group_kernel(const WgradGroupArgs g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int bid = xcd_remap(blockIdx.x, gridDim.x);
   int j = 0;
   while (j + 1 < g.njobs && bid >= g.blk_end[j]) ++j;
-  wgrad_big_tile<BIAS, STAGGER>(g.job[j], bid - (j ? g.blk_end[j - 1] : 0), smem);
+  wgrad_big_tile<BIAS, PIPE>(g.job[j], bid - (j ? g.blk_end[j - 1] : 0), smem);
 }
 
-template <bool BIAS, bool STAGGER>
+template <bool BIAS, bool PIPE>
 static hipError_t launch_big(const WgradGroupArgs& g, int blocks, hipStream_t s) {
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)wgrad_big_group_kernel<BIAS, STAGGER>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    (void)hipFuncSetAttribute((const void*)wgrad_big_group_kernel<BIAS, PIPE>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     attr_set = true;
   }
-  wgrad_big_group_kernel<BIAS, STAGGER><<<dim3(blocks), dim3(NT), LDS_BYTES, s>>>(g);
+  wgrad_big_group_kernel<BIAS, PIPE><<<dim3(blocks), dim3(NT), LDS_BYTES, s>>>(g);
   return hipGetLastError();
 }
 
-hipError_t cavp_launch_wgrad_big_group(const WgradGroupArgs& g, int blocks, bool bias, bool stagger, hipStream_t s) {
-  if (stagger) return bias ? launch_big<true, true>(g, blocks, s) : launch_big<false, true>(g, blocks, s);
+hipError_t cavp_launch_wgrad_big_group(const WgradGroupArgs& g, int blocks, bool bias, bool pipelined, hipStream_t s) {
+  if (pipelined) return bias ? launch_big<true, true>(g, blocks, s) : launch_big<false, true>(g, blocks, s);
   return bias ? launch_big<true, false>(g, blocks, s) : launch_big<false, false>(g, blocks, s);
 }

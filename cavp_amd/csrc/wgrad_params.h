@@ -41,5 +41,5 @@ typedef short s16x4_t __attribute__((ext_vector_type(4)));
 
 // conv_wgrad_big.hip: the grouped launch of the 256 x 256 tile (one 512-thread workgroup per CU, 128 KiB of LDS).  The job fields
 // that depend on the tile (tiles_co / tiles_ci and their divisors, rows_per_split: a multiple of 128) are planned for that tile.
-// stagger: the two co halves of a workgroup run one barrier apart (ping-pong), two barriers per phase.
-hipError_t cavp_launch_wgrad_big_group(const WgradGroupArgs& g, int blocks, bool bias, bool stagger, hipStream_t s);
+// pipelined: fragment reads of the next MFMA cluster under the current one, one barrier per stage (false: read, barrier, multiply).
+hipError_t cavp_launch_wgrad_big_group(const WgradGroupArgs& g, int blocks, bool bias, bool pipelined, hipStream_t s);

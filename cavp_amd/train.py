@@ -220,6 +220,36 @@ def allreduce_arena_late(arena: GradArena, early_work) -> None:
         early_work.wait()
 
 
+def _syncbn_shape_exchange(m, dev, shape_key):
+    """SyncBatchNorm combines the ranks' moments assuming every rank holds the same number of samples per layer (bn_act; torch's
+    SyncBatchNorm gathers per-rank counts instead, uneven last batches need drop_last=True here).  The check is collective-
+    SYMMETRIC and never blocks the host: EVERY eager forward of EVERY rank gathers (B, H, W) with one tiny collective at the same
+    point of the step (a rank that decided from its own shape history whether to take part - round 4 - could leave the others
+    alone in the collective); the comparison stays on the device, a mismatch (a) turns the step's logits into NaN (a ReLU would
+    swallow a NaN planted earlier), so its loss and gradients are visibly invalid, and (b) sets a sticky flag that travels to pinned host memory
+    asynchronously: the next eager forward that finds the copy complete raises CavpError.  Captured steps replay the shape their
+    eager warm-up pass was checked with.  Returns the 0-dim poison tensor (0.0 or NaN)."""
+    st = m.__dict__.setdefault("_syncbn_check", {})
+    if "event" in st and st["event"].query():
+        if float(st["host"][0]) != 0.0:
+            raise CavpError("SyncBatchNorm on the MI355X path needs the same batch and image size on every rank (a step with "
+                            f"unequal shapes ran: its results are NaN; this rank last ran {st.get('last')}); use drop_last=True")
+    tags = st.setdefault("tags", {})
+    if shape_key not in tags:   # one small upload per NEW shape
+        tags[shape_key] = torch.tensor([float(v) for v in shape_key], dtype=torch.float32, device=dev).reshape(3, 1)
+    if "bad" not in st:
+        st["bad"] = torch.zeros((1,), dtype=torch.float32, device=dev)
+        st["host"] = torch.zeros((1,), dtype=torch.float32).pin_memory()
+    got = gather_bn_moments(tags[shape_key])                      # [world, 3, 1]
+    mism = (got != got[0:1]).any().to(torch.float32).reshape(1)   # device-side compare, no host read
+    torch.maximum(st["bad"], mism, out=st["bad"])
+    st["host"].copy_(st["bad"], non_blocking=True)
+    st["event"] = torch.cuda.Event()
+    st["event"].record(torch.cuda.current_stream())
+    st["last"] = shape_key
+    return torch.where(mism > 0, torch.full_like(mism, float("nan")), torch.zeros_like(mism)).reshape(())
+
+
 def gather_bn_moments(local: torch.Tensor) -> torch.Tensor:
     """SyncBatchNorm forward exchange: every rank's per-channel (mean, M2) [C, 2] -> [world, C, 2] on every rank, ONE
     collective per layer.  RCCL: all-gather.  Other backends (gloo in the tests, which has no device all-gather): the same
@@ -262,6 +292,7 @@ class TrainPass:
         self.on_early_final: Optional[Callable[[], None]] = None   # called in backward once head / attention / audio grads are final
         self.dev = next(model.parameters()).device
         self.named: Dict[str, V] = {}   # debug taps (activations + their gradients after backward)
+        self.syncbn_poison: Optional[torch.Tensor] = None   # 0-dim 0.0 / NaN from _syncbn_shape_exchange, added to the logits
         # side section (the audio encoder): tape range run on a second stream, concurrently with the visual backbone
         self.side_range: Optional[tuple] = None
         self._side_done = None
@@ -1051,25 +1082,9 @@ def run_train_forward(model, image: torch.Tensor, audio: torch.Tensor, tp: Train
     pvt = m.seg_model == "PVT"
     rn = None if pvt else m.backbone.backbone
     B = image.shape[0]
-    shape_key = (B, int(image.shape[-2]), int(image.shape[-1]))
     if (collectives_on() and tp.dev.type == "cuda" and not torch.cuda.is_current_stream_capturing()
-            and shape_key not in m.__dict__.setdefault("_syncbn_shapes_ok", set())
             and any(isinstance(mm, nn.SyncBatchNorm) for mm in m.modules())):
-        # SyncBatchNorm combines the ranks' moments assuming every rank holds the same number of samples per layer (bn_act):
-        # one tiny exchange verifies it (torch's SyncBatchNorm gathers per-rank counts instead; uneven last batches need
-        # drop_last=True here).  ONCE per (batch, height, width): the check costs a pageable upload, a blocking all-reduce and a
-        # device-to-host read, which round 3 paid on every eager step; captured steps replay the shape they were captured (and
-        # checked, in the eager warm-up pass) with.  A rank whose shape CHANGES alone still meets the others in this collective,
-        # because every rank sees a new shape key at the same step of a lock-step data-parallel loop.
-        import torch.distributed as dist
-        allv = torch.zeros((dist.get_world_size(), 3), dtype=torch.float32, device=tp.dev)
-        allv[dist.get_rank()] = torch.tensor([B, image.shape[-2], image.shape[-1]], dtype=torch.float32)
-        dist.all_reduce(allv)   # (an all-gather every backend has, see gather_bn_moments)
-        got = allv.tolist()
-        if any(v != got[0] for v in got):
-            raise CavpError("SyncBatchNorm on the MI355X path needs the same batch and image size on every rank "
-                            f"(got {got}); use drop_last=True")
-        m.__dict__["_syncbn_shapes_ok"].add(shape_key)
+        tp.syncbn_poison = _syncbn_shape_exchange(m, tp.dev, (B, int(image.shape[-2]), int(image.shape[-1])))
     # ---- pack ----
     if not pvt:
         tp.pack("stem0", rn.conv1[0], raw=True)
@@ -1175,6 +1190,9 @@ def run_train_forward(model, image: torch.Tensor, audio: torch.Tensor, tp: Train
     if tp._nbt:
         torch._foreach_add_(tp._nbt, 1)   # 61 counters, one launch
         tp._nbt = []
+    if tp.syncbn_poison is not None:   # ranks with unequal shapes in this step (_syncbn_shape_exchange): NaN logits -> NaN loss and gradients
+        lo.t.add_(tp.syncbn_poison.to(lo.t.dtype))
+        tp.syncbn_poison = None
     return lo, fusion, fea_v_proj, fea_a, attn
 
 

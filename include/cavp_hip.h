@@ -131,10 +131,11 @@ int cavp_set_wgrad_variant(int32_t variant);
 /* ABI 9: the 256 x 256 weight-gradient tile (csrc/conv_wgrad_big.hip; bf16: one 8-wave workgroup per CU, four-stage LDS-DMA
  * ring, v_mfma_f32_32x32x16_bf16) for the weight gradients of encoder_decoder.py:62-75 (decoder head), models/attn.py:136-143 and
  * cavp_model.py:123-128 (token / projector Mlp) - the jobs with >= 16384 pixel rows and >= 192 input and output channels.
- * mode: 0 (default) = those jobs, 1 = never (the 128 x 128 tile everywhere), 2 = every bf16 job (tests).  stagger: 1 (default) =
- * the two halves of a workgroup run one barrier apart (ping-pong), 0 = in step.  The choice depends on the job alone, so grouped
- * and single launches of a job with one split count stay bit-identical.  Process-wide switch for A/B runs and tests. */
-int cavp_set_wgrad_big(int32_t mode, int32_t stagger);
+ * mode: 0 (default) = those jobs, 1 = never (the 128 x 128 tile everywhere), 2 = every bf16 job (tests).  pipelined: 1 (default) =
+ * the fragment reads of the next MFMA cluster are issued under the current one (one barrier per 32-row stage), 0 = read, barrier,
+ * multiply.  Same products, same summation order either way.  The choice of tile depends on the job alone, so grouped and single
+ * launches of a job with one split count stay bit-identical.  Process-wide switch for A/B runs and tests. */
+int cavp_set_wgrad_big(int32_t mode, int32_t pipelined);
 
 /* Direct 3x3 conv for Cin in {1,2,3} reading an NCHW f32 tensor and writing NHWC (dtype) with scale/shift + act:
  * the ResNet deep-stem first conv (resnet.py:108-110, stride 2) and the first VGGish conv (vgg.py:26-36). */

@@ -92,6 +92,24 @@ def main():
     assert e_run <= 2e-3, e_run
     assert e_ctl >= 10 * max(e_run, 1e-3), (e_ctl, e_run)
     assert max(e_grad.values()) <= 0.05 and min(cos.values()) >= 0.99, (max(e_grad.values()), min(cos.values()))
+    # unequal shards (a last batch without drop_last): every rank still meets every collective of the step - no hang -, the step's
+    # loss is NaN on every rank and the NEXT eager step raises (round-4 advisor finding: the shape check must be collective-symmetric)
+    from cavp_amd._lib import CavpError
+    m = build(True)
+    nb = Bl if rank == 0 else Bl // 2
+    img, lab = image[:nb].contiguous(), label[:nb].contiguous()
+    aud = torch.cat((audio[:nb], audio[B:B + nb]), 0).contiguous()
+    loss = m.train_step(img, aud, lab)
+    torch.cuda.synchronize()
+    assert not bool(torch.isfinite(loss).all()), float(loss)
+    try:
+        m.train_step(img, aud, lab)
+        raised = False
+    except CavpError as e:
+        raised = "same batch and image size" in str(e)
+    assert raised
+    if rank == 0:
+        print("SYNCBN_MISMATCH_OK")
     dist.barrier()
     dist.destroy_process_group()
 

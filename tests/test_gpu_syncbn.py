@@ -24,4 +24,5 @@ def test_syncbn_two_ranks_equal_full_batch():
     key = [ln for ln in (r.stdout + r.stderr).splitlines() if "SYNCBN_OK" in ln or "AssertionError" in ln]
     assert r.returncode == 0, (key, r.stderr[-3000:])
     assert "SYNCBN_OK" in r.stdout, r.stdout[-1500:]
+    assert "SYNCBN_MISMATCH_OK" in r.stdout, r.stdout[-1500:]
     print([ln for ln in r.stdout.splitlines() if "SYNCBN_OK" in ln][-1])

@@ -35,7 +35,7 @@ def _case(name, n, h, w, cin, cout, k, s, p, d, seed=0):
     return _nhwc(x.detach(), BF), _nhwc(dy, BF), wt.grad, dy.sum(dim=(0, 2, 3))
 
 
-@pytest.mark.parametrize("stagger", [1, 0], ids=["pingpong", "instep"])
+@pytest.mark.parametrize("stagger", [1, 0], ids=["pipelined", "plain"])
 @pytest.mark.parametrize("case", CONV, ids=[c[0] for c in CONV])
 def test_big_tile_forced_on_small_shapes(case, stagger, big):
     """every layer shape of the op tests (strides, dilations with dead taps, 304 / 48 channels: tiles with dead 32-channel blocks,
