@@ -42,9 +42,12 @@ constexpr int NT = 512;
 constexpr int ROWB = TC * 2;         // bytes per LDS row
 constexpr int OPB = BK * ROWB;       // one operand of one stage: 16 KiB
 constexpr int STAGE = 2 * OPB;       // X rows, then dY rows
-constexpr int LDS_BYTES = NS * STAGE;
+constexpr int RING_BYTES = NS * STAGE;
+constexpr int NTAB = 8;              // row-offset tables in flight (one per stage, 32 rows x {X offset, dY offset})
+constexpr int TAB_BYTES = BK * 8;
+constexpr int LDS_BYTES = RING_BYTES + NTAB * TAB_BYTES;
 constexpr unsigned kOOB = 0x80000000u;
-static_assert(LDS_BYTES == 128 * 1024, "ring");
+static_assert(RING_BYTES == 128 * 1024, "ring");
 
 typedef __attribute__((ext_vector_type(16))) float f32x16_t;
 typedef __attribute__((ext_vector_type(2))) unsigned u32x2_t;
@@ -62,15 +65,30 @@ __device__ __forceinline__ u32x2_t lds_tr16(unsigned addr) {
 
 __device__ __forceinline__ int swz_key(int row) { return ((row & 3) << 1) | ((row >> 3) & 1); }
 
+#ifdef CAVP_PROFILE
+// Timeline of ONE wave (profile builds, CAVP_WGRAD_DBG bit 16): s_memtime stamps of workgroup 0 / wave 0, summed per segment over
+// the stages (the stamps are taken where the schedule drains the LDS counter anyway and used one stage later, so they add no
+// wait of their own): [0] stages, [1] kernel entry -> first stage, [2] stage loop, [3] loop end -> last store issued,
+// [4] wait for A set + co half 0, [5] cluster 0, [6] wait for co half 1 + stage s+1, [7] barrier, [8] cluster 1 (reads + DMA issue).
+__device__ unsigned long long g_wgrad_tl[16];
+#define CAVP_TL_NOW() __builtin_readcyclecounter()
+#else
+#define CAVP_TL_NOW() 0ull   // (never instantiated with TL = true)
+#endif
+
 __device__ __forceinline__ float bf16x2_sum(unsigned u) { return __uint_as_float(u << 16) + __uint_as_float(u & 0xffff0000u); }
 
 }  // namespace
 
 // One logical workgroup `bid` of one weight gradient on the 256 x 256 tile.
-template <bool BIAS, bool PIPE>
+template <bool BIAS, bool PIPE, bool TL = false>
 __device__ __forceinline__ void wgrad_big_tile(const WgradParams& p, const int bid, char* smem) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#ifdef CAVP_PROFILE
+  unsigned long long tl_entry = 0, tl_loop0 = 0, tl_loop1 = 0;
+  if constexpr (TL) tl_entry = CAVP_TL_NOW();
+#endif
 
   const int b1 = fast_div(bid, p.dv_co[0], p.dv_co[1]), tco = bid - b1 * p.tiles_co;
   const int b2 = fast_div(b1, p.dv_ci[0], p.dv_ci[1]), tci = b1 - b2 * p.tiles_ci;
@@ -90,68 +108,65 @@ __device__ __forceinline__ void wgrad_big_tile(const WgradParams& p, const int b
   // ---------------------------------------------------------------------------------------------------------------------
   // issue side.  A wave DMA instruction fills 1 KiB = 2 LDS rows; instruction g = wave + 8 i (i < 2) of an operand fills rows
   // 2 g, 2 g + 1: lane l lands in row 2 g + (l >> 5), 16-byte slot l & 31.  The swizzle key of row drow0 + 16 i does not depend
-  // on i, so the lane's channel offset is fixed; pixel coordinates advance incrementally (conv_wgrad.hip).
+  // on i, so the lane's channel offset is fixed.
+  // Row offsets come from a TABLE in LDS, not from per-thread pixel arithmetic: the byte offsets of the 32 pixel rows of a stage
+  // (X at this workgroup's tap, dY; 0x80000000 = outside the image / beyond the pixel range -> zero fill) are computed ONCE per
+  // stage by one wave (lane = row; two multiply-shift divisions, eight stages ahead, the waves take turns) and every wave reads
+  // its four rows back with two ds_read_b64.  A piece then costs add + or + s_mov m0 + the DMA instruction.  (Per-thread
+  // incremental coordinates with wrap tests - conv_wgrad.hip's form - were ~45 instructions of compare / select / exec-mask
+  // chains per X piece, ~350 cycles of the issuing wave's time in front of its next MFMA: profiles/r05_notes.md.)
   // ---------------------------------------------------------------------------------------------------------------------
   const int drow0 = 2 * wave + (lane >> 5);
   const int cel = ((((lane & 31) >> 1) ^ swz_key(drow0)) << 4) + ((lane & 1) << 3);   // logical channel of this lane's 16 bytes
   const bool ci_ok = ci_base + cel < p.Cin && !CAVP_DBG(p, 1), co_ok = co_base + cel < p.Cout && !CAVP_DBG(p, 1);   // (dbg 1: no memory traffic)
   const unsigned xcb = (unsigned)((ci_base + cel) * 2), ycb = (unsigned)((co_base + cel) * 2);
+  const unsigned xoob = ci_ok ? 0u : kOOB, yoob = co_ok ? 0u : kOOB;
   const bool pointwise = (p.ntaps_all == 1) && p.stride == 1 && p.pad == 0;
   const int dh = kh * p.dil - p.pad, dw = kw * p.dil - p.pad;
-  const int gH = __builtin_amdgcn_readfirstlane(p.H), gW = __builtin_amdgcn_readfirstlane(p.W);
-  const int gWo = __builtin_amdgcn_readfirstlane(p.Wo), gHo = __builtin_amdgcn_readfirstlane(p.Ho);
-  const int gStride = __builtin_amdgcn_readfirstlane(p.stride);
-  const unsigned gLdx = (unsigned)__builtin_amdgcn_readfirstlane(p.ldx * 2), gLdy = (unsigned)__builtin_amdgcn_readfirstlane(p.ldy * 2);
-  const int gWoS = gWo * gStride, gHoS = gHo * gStride;
-  const unsigned stepY = (unsigned)BK * gLdy;
-  const unsigned stepX = (unsigned)(BK * (pointwise ? 1 : gStride)) * gLdx;
-  const unsigned stepRow = (unsigned)((gW - gWo) * gStride) * gLdx;
-  const unsigned stepImg = (unsigned)((gH - gHoS) * gW) * gLdx;
-  int hin[2], win[2];
-  unsigned xo[2], yo[2];   // (the X pieces of a stage are issued before its dY pieces: yo is also the X issue's pixel-range test)
-  const unsigned yEnd = (unsigned)r_end * gLdy + ycb;
-  const int hWrap = gHoS + dh, wWrap = gWoS + dw;
-  const int HoWo = p.Ho * p.Wo;
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int pix = r_begin + drow0 + 16 * i;
-    yo[i] = (unsigned)pix * gLdy + ycb;
-    const int pp = pix < p.M ? pix : 0;
-    const int n = fast_div(pp, p.dv_hw[0], p.dv_hw[1]);
-    const int rr = pp - n * HoWo;
-    const int ho = fast_div(rr, p.dv_w[0], p.dv_w[1]);
-    hin[i] = ho * gStride + dh;
-    win[i] = (rr - ho * p.Wo) * gStride + dw;
-    xo[i] = pointwise ? (unsigned)pix * gLdx + xcb : (unsigned)((n * gH + hin[i]) * gW + win[i]) * gLdx + xcb;
-  }
   const bool dbg_nodma = CAVP_DBG(p, 4), dbg_noread = CAVP_DBG(p, 8);   // (profile builds: pieces of the loop switched off)
-  auto issue_x = [&](auto bufc) {
-    constexpr int B = decltype(bufc)::value;
-    if (dbg_nodma) return;
-    char* base = smem + B * STAGE + wave * 1024;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      bool xok = yo[i] < yEnd && ci_ok;
-      if (!pointwise) xok = xok && ((unsigned)hin[i] < (unsigned)gH) && ((unsigned)win[i] < (unsigned)gW);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (lds_ptr_t)(base + i * 8192), 16, (int)(xok ? xo[i] : kOOB), 0, 0, 0);
-      xo[i] += stepX;
-      if (!pointwise) {
-        win[i] += BK * gStride;
-        while (win[i] >= wWrap) { win[i] -= gWoS; xo[i] += stepRow; hin[i] += gStride; }
-        while (hin[i] >= hWrap) { hin[i] -= gHoS; xo[i] += stepImg; }
-      }
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+  // table of stage t: slot t & 7, row r at + 8 r: {X byte offset, dY byte offset} of pixel r_begin + 32 t + r
+  auto tab_compute = [&](int t) {
+    const int r = lane & 31;   // (both halves of the wave compute and store the same 32 entries)
+    const int pix = r_begin + BK * t + r;
+    const bool inr = pix < r_end;
+    const int pp = inr ? pix : 0;
+    unsigned xoff, yoff = inr ? (unsigned)pp * (unsigned)(p.ldy * 2) : kOOB;
+    if (pointwise) {
+      xoff = inr ? (unsigned)pp * (unsigned)(p.ldx * 2) : kOOB;
+    } else {
+      const int n = fast_div(pp, p.dv_hw[0], p.dv_hw[1]);
+      const int rr = pp - n * (p.Ho * p.Wo);
+      const int ho = fast_div(rr, p.dv_w[0], p.dv_w[1]);
+      const int hin = ho * p.stride + dh, win = (rr - ho * p.Wo) * p.stride + dw;
+      const bool ok = inr && (unsigned)hin < (unsigned)p.H && (unsigned)win < (unsigned)p.W;
+      xoff = ok ? (unsigned)((n * p.H + hin) * p.W + win) * (unsigned)(p.ldx * 2) : kOOB;
     }
+    const unsigned ad = lds0 + RING_BYTES + (unsigned)((t & (NTAB - 1)) * TAB_BYTES + r * 8);
+    asm volatile("ds_write_b64 %0, %1" ::"v"(ad), "v"((u32x2_t){xoff, yoff}) : "memory");
   };
-  auto issue_y = [&](auto bufc) {
-    constexpr int B = decltype(bufc)::value;
-    if (dbg_nodma) return;
-    char* base = smem + B * STAGE + OPB + wave * 1024;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const bool yok = yo[i] < yEnd && co_ok;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(yrsrc, (lds_ptr_t)(base + i * 8192), 16, (int)(yok ? yo[i] : kOOB), 0, 0, 0);
-      yo[i] += stepY;
-    }
+  // this wave's four rows of stage t: tv[i] = {X, dY} offsets of row drow0 + 16 i (landed behind the next s_waitcnt lgkmcnt(0))
+  u32x2_t tv[2];
+  const unsigned tabrd = lds0 + RING_BYTES + (unsigned)(drow0 * 8);
+  auto tab_read = [&](int t) {
+    const unsigned ad = tabrd + (unsigned)((t & (NTAB - 1)) * TAB_BYTES);
+    asm volatile("ds_read_b64 %0, %1" : "=v"(tv[0]) : "v"(ad));
+    asm volatile("ds_read_b64 %0, %1 offset:128" : "=v"(tv[1]) : "v"(ad));
+  };
+  // one DMA piece (1 KiB): rows drow0 + 16 I of the stage whose offsets are in tv, into ring buffer B
+  auto issue_x1 = [&](auto bufc, auto ic) {
+    constexpr int B = decltype(bufc)::value & 3, I = decltype(ic)::value;
+    if (dbg_nodma || CAVP_DBG(p, 64)) return;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (lds_ptr_t)(smem + B * STAGE + wave * 1024 + I * 8192), 16, (int)((tv[I].x + xcb) | xoob), 0, 0, 0);
+  };
+  auto issue_y1 = [&](auto bufc, auto ic) {
+    constexpr int B = decltype(bufc)::value & 3, I = decltype(ic)::value;
+    if (dbg_nodma || CAVP_DBG(p, 128)) return;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(yrsrc, (lds_ptr_t)(smem + B * STAGE + OPB + wave * 1024 + I * 8192), 16, (int)((tv[I].y + ycb) | yoob), 0, 0, 0);
+  };
+  auto issue_stage = [&](auto bufc) {
+    issue_x1(bufc, std::integral_constant<int, 0>{}); issue_x1(bufc, std::integral_constant<int, 1>{});
+    issue_y1(bufc, std::integral_constant<int, 0>{}); issue_y1(bufc, std::integral_constant<int, 1>{});
   };
 
   // ---------------------------------------------------------------------------------------------------------------------
@@ -180,7 +195,6 @@ __device__ __forceinline__ void wgrad_big_tile(const WgradParams& p, const int b
   const int q = lane >> 4, sl = lane & 15;
   const int row0 = 8 * (q >> 1) + (sl >> 2);
   const int fkey = swz_key(row0);
-  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
   const unsigned rbase = lds0 + (unsigned)(row0 * ROWB + (sl & 3) * 8);
   unsigned aaddr[2][2], baddr[2][4];   // [ring half][block]
 #pragma unroll
@@ -269,46 +283,69 @@ __device__ __forceinline__ void wgrad_big_tile(const WgradParams& p, const int b
   };
 
   // ---- every schedule: stage s lives in ring buffer B = s & 3; once every wave has its last fragment of stage s in registers
-  // and stage s+1 has landed (counted vmcnt + the stage's one barrier), the pieces of stage s+4 are issued into buffer B: three
-  // stages are in flight at any time.
+  // and stage s+1 has landed (counted vmcnt + the stage's one barrier) buffer B is free for the pieces of stage s+4: three
+  // stages are in flight at any time.  In stage s, wave s & 7 also computes the row-offset table of stage s+8.
 #define CAVP_SB __builtin_amdgcn_sched_barrier(0)
+  auto tab_turn = [&](int st) {   // (wave-uniform)
+    if (((st ^ wave) & (NTAB - 1)) == 0) tab_compute(st + NTAB);
+  };
   // ---- full tile, PIPE: 16 MFMAs per wave and stage with every LDS read and DMA issue placed in the gaps between them (a wave
   // sits in the issue of its next MFMA until the matrix pipe takes it - anything queued behind a cluster of 8 waits 256 cycles,
   // and the two waves of a SIMD run in step, so reads issued in front of a cluster do not overlap with anybody's MFMAs:
-  // profiles/r05_notes.md, 246 us -> see there).  Cluster 0 (co half 0: A set + B set 0, read during the previous cluster 1)
-  // carries the reads of co half 1; cluster 1 carries the reads of the next stage's A set and co half 0 and the DMA issue.
-  auto stage_full = [&](auto bufc) {
+  // profiles/r05_notes.md).  Cluster 0 (co half 0: A set + B set 0, read during the previous cluster 1) carries the reads of co
+  // half 1 and the four DMA pieces of stage s+3; cluster 1 carries the reads of the next stage's A set and co half 0, the
+  // lookup of stage s+4's rows and (wave s & 7) the table of stage s+8; the four DMA pieces of stage s+3 - into buffer B - 1, free
+  // since the previous stage's barrier - sit behind the last four MFMAs of cluster 0, where this wave has no LDS read left to issue.
+  // (timeline, profile builds) tl[0..4]: this stage's stamps; tls[]: per-segment sums; a stage's stamps are summed at the top of the next
+  unsigned long long tl[5] = {0, 0, 0, 0, 0}, tls[5] = {0, 0, 0, 0, 0};
+  bool tl_have = false;
+  auto tl_top = [&]() {
+#ifdef CAVP_PROFILE
+    const unsigned long long now = CAVP_TL_NOW();
+    if (tl_have) {
+      tls[0] += tl[1] - tl[0]; tls[1] += tl[2] - tl[1]; tls[2] += tl[3] - tl[2]; tls[3] += tl[4] - tl[3]; tls[4] += now - tl[4];
+    }
+    tl[0] = now;
+    tl_have = true;
+#endif
+  };
+  auto stage_full = [&](auto bufc, int st) {
     constexpr int B = decltype(bufc)::value;
     using SET = std::integral_constant<int, B & 1>;
     using NB1 = std::integral_constant<int, B + 1>;
     using NSET = std::integral_constant<int, (B + 1) & 1>;
+    using PRV = std::integral_constant<int, (B + 3) & 3>;
     if constexpr (PIPE) {
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // A set + co half 0 landed
+      if constexpr (TL) tl_top();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // A set + co half 0 (+ the rows of stage s+3) landed
       CAVP_SB;
+      if constexpr (TL) { tl[1] = CAVP_TL_NOW(); CAVP_SB; }
       bias_add(C0{}, C2{}, C0{});
+      // (buffer B - 1 = the buffer of stage s+3, free since the previous stage's barrier)
       mm1(SET{}, C0{}, C0{}, C0{}, C0{}, C0{}); rf_b(bufc, C1{}, C2{}, C0{}, C0{}); CAVP_SB;
       mm1(SET{}, C0{}, C0{}, C1{}, C0{}, C0{}); rf_b(bufc, C1{}, C3{}, C1{}, C0{}); CAVP_SB;
       mm1(SET{}, C0{}, C1{}, C0{}, C0{}, C0{}); rf_b(bufc, C1{}, C2{}, C0{}, C1{}); CAVP_SB;
       mm1(SET{}, C0{}, C1{}, C1{}, C0{}, C0{}); rf_b(bufc, C1{}, C3{}, C1{}, C1{}); CAVP_SB;
-      mm1(SET{}, C0{}, C0{}, C0{}, C1{}, C0{});
-      mm1(SET{}, C0{}, C0{}, C1{}, C1{}, C0{});
-      mm1(SET{}, C0{}, C1{}, C0{}, C1{}, C0{});
-      mm1(SET{}, C0{}, C1{}, C1{}, C1{}, C0{});
-      CAVP_SB;
+      mm1(SET{}, C0{}, C0{}, C0{}, C1{}, C0{}); issue_x1(PRV{}, C0{}); CAVP_SB;
+      mm1(SET{}, C0{}, C0{}, C1{}, C1{}, C0{}); issue_x1(PRV{}, C1{}); CAVP_SB;
+      mm1(SET{}, C0{}, C1{}, C0{}, C1{}, C0{}); issue_y1(PRV{}, C0{}); CAVP_SB;
+      mm1(SET{}, C0{}, C1{}, C1{}, C1{}, C0{}); issue_y1(PRV{}, C1{}); CAVP_SB;
+      if constexpr (TL) { tl[2] = CAVP_TL_NOW(); CAVP_SB; }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // co half 1 landed = this wave's last read of buffer B is complete
-      __builtin_amdgcn_s_waitcnt(vmcnt_imm(8));            // this thread's pieces of stage s+1 landed
+      __builtin_amdgcn_s_waitcnt(vmcnt_imm(8));            // this thread's pieces of stage s+1 landed (s+2, s+3 in flight)
+      if constexpr (TL) { CAVP_SB; tl[3] = CAVP_TL_NOW(); CAVP_SB; }
       __builtin_amdgcn_s_barrier();
       CAVP_SB;
+      if constexpr (TL) { tl[4] = CAVP_TL_NOW(); CAVP_SB; }
       bias_add(C1{}, C2{}, C2{});
       mm1(SET{}, C1{}, C0{}, C0{}, C0{}, C2{}); rf_a(NB1{}, NSET{}, C0{}, C0{}); rf_b(NB1{}, C0{}, C0{}, C0{}, C0{}); CAVP_SB;
       mm1(SET{}, C1{}, C0{}, C1{}, C0{}, C2{}); rf_a(NB1{}, NSET{}, C1{}, C0{}); rf_b(NB1{}, C0{}, C1{}, C1{}, C0{}); CAVP_SB;
       mm1(SET{}, C1{}, C1{}, C0{}, C0{}, C2{}); rf_a(NB1{}, NSET{}, C0{}, C1{}); rf_b(NB1{}, C0{}, C0{}, C0{}, C1{}); CAVP_SB;
       mm1(SET{}, C1{}, C1{}, C1{}, C0{}, C2{}); rf_a(NB1{}, NSET{}, C1{}, C1{}); rf_b(NB1{}, C0{}, C1{}, C1{}, C1{}); CAVP_SB;
-      mm1(SET{}, C1{}, C0{}, C0{}, C1{}, C2{}); issue_x(bufc); CAVP_SB;
-      mm1(SET{}, C1{}, C0{}, C1{}, C1{}, C2{}); issue_y(bufc); CAVP_SB;
-      mm1(SET{}, C1{}, C1{}, C0{}, C1{}, C2{});
-      mm1(SET{}, C1{}, C1{}, C1{}, C1{}, C2{});
-      CAVP_SB;
+      mm1(SET{}, C1{}, C0{}, C0{}, C1{}, C2{}); tab_read(st + 4); CAVP_SB;   // the rows of stage s+4 (issued in the next stage's cluster 0)
+      mm1(SET{}, C1{}, C0{}, C1{}, C1{}, C2{}); CAVP_SB;
+      mm1(SET{}, C1{}, C1{}, C0{}, C1{}, C2{}); tab_turn(st); CAVP_SB;
+      mm1(SET{}, C1{}, C1{}, C1{}, C1{}, C2{}); CAVP_SB;
     } else {   // plain: read, multiply, retire, fetch
       read_a(bufc, SET{}, C0{});
       read_a(bufc, SET{}, C1{});
@@ -316,7 +353,7 @@ __device__ __forceinline__ void wgrad_big_tile(const WgradParams& p, const int b
       read_b(bufc, C0{}, C1{}, C1{});
       read_b(bufc, C1{}, C2{}, C0{});
       read_b(bufc, C1{}, C3{}, C1{});
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (also the rows of stage s+4, looked up one stage ago)
       CAVP_SB;
       bias_add(C0{}, C2{}, C0{});
       bias_add(C1{}, C2{}, C2{});
@@ -325,8 +362,10 @@ __device__ __forceinline__ void wgrad_big_tile(const WgradParams& p, const int b
       CAVP_SB;
       __builtin_amdgcn_s_waitcnt(vmcnt_imm(8));
       __builtin_amdgcn_s_barrier();
-      issue_x(bufc);
-      issue_y(bufc);
+      CAVP_SB;
+      issue_stage(bufc);
+      tab_read(st + 5);
+      tab_turn(st);
       CAVP_SB;
     }
   };
@@ -343,38 +382,57 @@ __device__ __forceinline__ void wgrad_big_tile(const WgradParams& p, const int b
       read_b(bufc, setc, C1{}, C1{});
     }
   };
-  auto stage_rest = [&](auto bufc, auto nac) {
+  auto stage_rest = [&](auto bufc, auto nac, int st) {
     constexpr int B = decltype(bufc)::value, NA = decltype(nac)::value;
     using SET = std::integral_constant<int, B & 1>;
     using NBc = std::integral_constant<int, 3 - NA>;
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the fragments of stage s (read one stage ago) landed
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the fragments of stage s and the rows of stage s+4 (read one stage ago) landed
     CAVP_SB;
     bias_add(SET{}, NBc{}, C0{});
     mma(SET{}, SET{}, nac, NBc{}, C0{});
     CAVP_SB;
     __builtin_amdgcn_s_waitcnt(vmcnt_imm(8));
     __builtin_amdgcn_s_barrier();
+    CAVP_SB;
     read_rest(std::integral_constant<int, B + 1>{}, std::integral_constant<int, (B + 1) & 1>{}, nac);
-    issue_x(bufc);
-    issue_y(bufc);
+    issue_stage(bufc);
+    tab_read(st + 5);
+    tab_turn(st);
     CAVP_SB;
   };
-  auto stage_idle = [&](auto bufc) {
+  auto stage_idle = [&](auto bufc, int st) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the rows of stage s+4; this wave's table store, if it had the turn
     __builtin_amdgcn_s_waitcnt(vmcnt_imm(8));
     __builtin_amdgcn_s_barrier();
-    issue_x(bufc);
-    issue_y(bufc);
+    CAVP_SB;   // (nothing that reads tv may move above the wait: the compiler takes an asm result as available at once)
+    issue_stage(bufc);
+    tab_read(st + 5);
+    tab_turn(st);
+    CAVP_SB;
   };
 
   if (nst > 0) {
-    issue_x(C0{}); issue_y(C0{});
-    issue_x(C1{}); issue_y(C1{});
-    issue_x(C2{}); issue_y(C2{});
-    issue_x(C3{}); issue_y(C3{});
-    __builtin_amdgcn_s_waitcnt(vmcnt_imm(12));   // stage 0 landed (this thread's pieces)
+    const bool pipe_full = PIPE && active && mode == 0;   // (wave-uniform; the interleaved schedule issues the pieces of stage s+3 inside stage s)
+    tab_compute(wave);   // the tables of stages 0 .. 7, one per wave
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      if (t == 3 && pipe_full) break;
+      tab_read(t);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      CAVP_SB;
+      if (t == 0) issue_stage(C0{});
+      if (t == 1) issue_stage(C1{});
+      if (t == 2) issue_stage(C2{});
+      if (t == 3) issue_stage(C3{});
+    }
+    tab_read(pipe_full ? 3 : 4);   // the rows of the first stage that the loop issues
+    if (pipe_full) __builtin_amdgcn_s_waitcnt(vmcnt_imm(8));   // stage 0 landed (this thread's pieces)
+    else __builtin_amdgcn_s_waitcnt(vmcnt_imm(12));
     __builtin_amdgcn_s_barrier();
     if (!active) {   // (all branches here are workgroup- or wave-uniform; every wave meets the same barriers and issues the same DMA pieces)
-      for (int s0 = 0; s0 < nst; s0 += 4) { stage_idle(C0{}); stage_idle(C1{}); stage_idle(C2{}); stage_idle(C3{}); }
+      for (int s0 = 0; s0 < nst; s0 += 4) { stage_idle(C0{}, s0); stage_idle(C1{}, s0 + 1); stage_idle(C2{}, s0 + 2); stage_idle(C3{}, s0 + 3); }
     } else if (mode == 0) {
       if constexpr (PIPE) {
         read_a(C0{}, C0{}, C0{});
@@ -382,17 +440,22 @@ __device__ __forceinline__ void wgrad_big_tile(const WgradParams& p, const int b
         read_b(C0{}, C0{}, C0{}, C0{});
         read_b(C0{}, C0{}, C1{}, C1{});
       }
-      for (int s0 = 0; s0 < nst; s0 += 4) { stage_full(C0{}); stage_full(C1{}); stage_full(C2{}); stage_full(C3{}); }
+#ifdef CAVP_PROFILE
+      if constexpr (TL) tl_loop0 = CAVP_TL_NOW();
+#endif
+      for (int s0 = 0; s0 < nst; s0 += 4) { stage_full(C0{}, s0); stage_full(C1{}, s0 + 1); stage_full(C2{}, s0 + 2); stage_full(C3{}, s0 + 3); }
       if constexpr (PIPE) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the last stage's look-ahead reads (unused)
+#ifdef CAVP_PROFILE
+      if constexpr (TL) { tl_top(); tl_loop1 = tl[0]; }
+#endif
     } else if (mode == 1) {
       read_rest(C0{}, C0{}, C2{});
-      for (int s0 = 0; s0 < nst; s0 += 4) { stage_rest(C0{}, C2{}); stage_rest(C1{}, C2{}); stage_rest(C2{}, C2{}); stage_rest(C3{}, C2{}); }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      for (int s0 = 0; s0 < nst; s0 += 4) { stage_rest(C0{}, C2{}, s0); stage_rest(C1{}, C2{}, s0 + 1); stage_rest(C2{}, C2{}, s0 + 2); stage_rest(C3{}, C2{}, s0 + 3); }
     } else {
       read_rest(C0{}, C0{}, C1{});
-      for (int s0 = 0; s0 < nst; s0 += 4) { stage_rest(C0{}, C1{}); stage_rest(C1{}, C1{}); stage_rest(C2{}, C1{}); stage_rest(C3{}, C1{}); }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      for (int s0 = 0; s0 < nst; s0 += 4) { stage_rest(C0{}, C1{}, s0); stage_rest(C1{}, C1{}, s0 + 1); stage_rest(C2{}, C1{}, s0 + 2); stage_rest(C3{}, C1{}, s0 + 3); }
     }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_waitcnt(vmcnt_imm(0));   // (the zero-fill pieces issued past the last stage: nothing may land in LDS after this workgroup ends)
   }
 #undef CAVP_SB
@@ -446,15 +509,27 @@ __device__ __forceinline__ void wgrad_big_tile(const WgradParams& p, const int b
       }
     }
   }
+#ifdef CAVP_PROFILE
+  if constexpr (TL) {
+    if (bid == 0 && wave == 0 && lane == 0) {
+      const unsigned long long tend = CAVP_TL_NOW();
+      g_wgrad_tl[0] = (unsigned long long)nst;
+      g_wgrad_tl[1] = tl_loop0 - tl_entry;
+      g_wgrad_tl[2] = tl_loop1 - tl_loop0;
+      g_wgrad_tl[3] = tend - tl_loop1;
+      for (int i = 0; i < 5; ++i) g_wgrad_tl[4 + i] = tls[i];
+    }
+  }
+#endif
 }
 
-template <bool BIAS, bool PIPE>
+template <bool BIAS, bool PIPE, bool TL = false>
 __global__ __launch_bounds__(NT, 2) void wgrad_big_group_kernel(const WgradGroupArgs g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int bid = xcd_remap(blockIdx.x, gridDim.x);
   int j = 0;
   while (j + 1 < g.njobs && bid >= g.blk_end[j]) ++j;
-  wgrad_big_tile<BIAS, PIPE>(g.job[j], bid - (j ? g.blk_end[j - 1] : 0), smem);
+  wgrad_big_tile<BIAS, PIPE, TL>(g.job[j], bid - (j ? g.blk_end[j - 1] : 0), smem);
 }
 
 template <bool BIAS, bool PIPE>
@@ -468,7 +543,25 @@ static hipError_t launch_big(const WgradGroupArgs& g, int blocks, hipStream_t s)
   return hipGetLastError();
 }
 
+#ifdef CAVP_PROFILE
+// profile builds: the timeline of the last CAVP_WGRAD_DBG=16 launch (not part of the product ABI)
+extern "C" int cavp_prof_wgrad_timeline(unsigned long long* out16) {
+  return hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_wgrad_tl), sizeof(unsigned long long) * 16) == hipSuccess ? 0 : -1;
+}
+#endif
+
 hipError_t cavp_launch_wgrad_big_group(const WgradGroupArgs& g, int blocks, bool bias, bool pipelined, hipStream_t s) {
+#ifdef CAVP_PROFILE
+  if (pipelined && g.njobs > 0 && (g.job[0].dbg & 16)) {
+    static bool attr_set = false;
+    if (!attr_set) {
+      (void)hipFuncSetAttribute((const void*)wgrad_big_group_kernel<false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+      attr_set = true;
+    }
+    wgrad_big_group_kernel<false, true, true><<<dim3(blocks), dim3(NT), LDS_BYTES, s>>>(g);
+    return hipGetLastError();
+  }
+#endif
   if (pipelined) return bias ? launch_big<true, true>(g, blocks, s) : launch_big<false, true>(g, blocks, s);
   return bias ? launch_big<true, false>(g, blocks, s) : launch_big<false, false>(g, blocks, s);
 }

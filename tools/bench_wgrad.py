@@ -77,6 +77,17 @@ def main():
             tot[j] += us
             cells.append(f"{us:8.1f}us {flops / us / 1e6:7.1f}TF")
         print(f"{name:28s} " + " ".join(f"{c:>24s}" for c in cells), flush=True)
+        if int(os.environ.get("CAVP_WGRAD_DBG", "0")) & 16:   # profile build: s_memtime timeline of workgroup 0 / wave 0 (conv_wgrad_big.hip)
+            import ctypes
+            buf = (ctypes.c_ulonglong * 16)()
+            lib = _lib.load()
+            if lib.cavp_prof_wgrad_timeline(buf) == 0 and buf[0]:
+                n = buf[0]
+                lab = ["wait A + co half 0", "cluster 0 (8 MFMA + 8 reads)", "wait co half 1 + stage s+1", "barrier", "cluster 1 (8 MFMA + 16 reads + DMA issue)"]
+                print(f"    timeline (s_memtime ticks = 100 MHz? see notes; workgroup 0 / wave 0): stages {n}, entry->loop {buf[1]}, loop {buf[2]} "
+                      f"({buf[2] / n:.1f} per stage), loop end->last store issued {buf[3]}")
+                for i, l in enumerate(lab):
+                    print(f"      {l:44s} {buf[4 + i] / max(n - 1, 1):9.1f} per stage  ({100.0 * buf[4 + i] / max(buf[2], 1):5.1f} % of the loop)")
     print(f"{'sum':28s} " + " ".join(f"{t:8.1f}us{'':>14s}" for t in tot))
 
 
