@@ -376,9 +376,9 @@ extern "C" int cavp_set_wgrad_variant(int v) {
 // software-pipelined schedule (conv_wgrad_big.hip; 0 = read, barrier, multiply).  The choice depends on the job alone, never on the group it travels in, so a grouped
 // and a single launch of one job with the same split count stay bit-identical.
 static int g_wgrad_big_mode = 0;
-static int g_wgrad_big_pipe = 1;
+static int g_wgrad_big_pipe = 2;
 extern "C" int cavp_set_wgrad_big(int mode, int pipelined) {
-  if (mode < 0 || mode > 2 || pipelined < 0 || pipelined > 1) return CAVP_ERR_BAD_ARG;
+  if (mode < 0 || mode > 2 || pipelined < 0 || pipelined > 2) return CAVP_ERR_BAD_ARG;
   g_wgrad_big_mode = mode;
   g_wgrad_big_pipe = pipelined;
   return CAVP_OK;
@@ -854,7 +854,7 @@ extern "C" int cavp_conv2d_wgrad_group(const cavp_wgrad_job* jobs, int32_t njobs
   }
   gs.njobs = ns; gb.njobs = nb; gr.njobs = nr;
   if (nb > 0) {   // the long-running workgroups first
-    if (cavp_launch_wgrad_big_group(gb, bblocks, bbias, g_wgrad_big_pipe != 0, s) != hipSuccess) return CAVP_ERR_LAUNCH;
+    if (cavp_launch_wgrad_big_group(gb, bblocks, bbias, g_wgrad_big_pipe, s) != hipSuccess) return CAVP_ERR_LAUNCH;
   }
   if (ns > 0) {
     const int lds = 2 * 2 * 32 * 256;

@@ -523,6 +523,284 @@ __device__ __forceinline__ void wgrad_big_tile(const WgradParams& p, const int b
 #endif
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// The same 256 x 256 tile on SIXTEEN waves (1024 threads, four per SIMD, <= 128 registers): wave tile 64 ci x 64 co = 2 x 2
+// blocks of 32 x 32.  Why: with two waves per SIMD a wave's own non-MFMA issue time per stage (4 DMA pieces at ~90 .. 170 cycles
+// each under contention, 24 LDS reads, waits) exceeds the 512 cycles its partner's MFMAs can cover, so the matrix pipe idles
+// half of every stage whatever the order of the instructions (s_memtime timeline, profiles/r05_notes.md).  With four waves per
+// SIMD a wave issues 8 MFMAs, 2 DMA pieces and 16 LDS reads per stage, and three other waves are there to fill the pipe - the
+// regime the 128 x 128 kernel lives in with its four co-resident workgroups, at half its operand traffic and a four-stage ring.
+// Fragments are double-buffered by K STEP (the 16 rows of k step 1 are read under the MFMAs of k step 0, the next stage's k
+// step 0 under k step 1): 32 fragment registers, never an LDS wait with the pipe idle inside a wave.
+// ---------------------------------------------------------------------------------------------------------------------------
+constexpr int NT16 = 1024;
+
+template <bool BIAS>
+__device__ __forceinline__ void wgrad_big16_tile(const WgradParams& p, const int bid, char* smem) {
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // 0 .. 15
+
+  const int b1 = fast_div(bid, p.dv_co[0], p.dv_co[1]), tco = bid - b1 * p.tiles_co;
+  const int b2 = fast_div(b1, p.dv_ci[0], p.dv_ci[1]), tci = b1 - b2 * p.tiles_ci;
+  const int z = fast_div(b2, p.dv_nt[0], p.dv_nt[1]), ti = b2 - z * p.ntaps;
+  const int tap = (int)((p.taps >> (4 * ti)) & 15ull);
+  const int kh = fast_div(tap, p.dv_kw[0], p.dv_kw[1]), kw = tap - kh * p.KW;
+  const int co_base = tco * TC, ci_base = tci * TC;
+  const int r_begin = z * p.rows_per_split;
+  int r_end = r_begin + p.rows_per_split;
+  if (r_end > p.M) r_end = p.M;
+  const int nst = __builtin_amdgcn_readfirstlane(r_end > r_begin ? ((r_end - r_begin + 4 * BK - 1) / (4 * BK)) * 4 : 0);
+
+  const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.dy, 0, p.dy_bytes, 0x00020000);
+
+  // ---- issue side: wave w owns LDS rows 2 w, 2 w + 1 of both operands (ONE 1 KiB piece each per stage); row offsets from the
+  // table in LDS (see wgrad_big_tile)
+  const int drow0 = 2 * wave + (lane >> 5);
+  const int cel = ((((lane & 31) >> 1) ^ swz_key(drow0)) << 4) + ((lane & 1) << 3);
+  const bool ci_ok = ci_base + cel < p.Cin && !CAVP_DBG(p, 1), co_ok = co_base + cel < p.Cout && !CAVP_DBG(p, 1);
+  const unsigned xcb = (unsigned)((ci_base + cel) * 2), ycb = (unsigned)((co_base + cel) * 2);
+  const unsigned xoob = ci_ok ? 0u : kOOB, yoob = co_ok ? 0u : kOOB;
+  const bool pointwise = (p.ntaps_all == 1) && p.stride == 1 && p.pad == 0;
+  const int dh = kh * p.dil - p.pad, dw = kw * p.dil - p.pad;
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+  auto tab_compute = [&](int t) {
+    const int r = lane & 31;
+    const int pix = r_begin + BK * t + r;
+    const bool inr = pix < r_end;
+    const int pp = inr ? pix : 0;
+    unsigned xoff, yoff = inr ? (unsigned)pp * (unsigned)(p.ldy * 2) : kOOB;
+    if (pointwise) {
+      xoff = inr ? (unsigned)pp * (unsigned)(p.ldx * 2) : kOOB;
+    } else {
+      const int n = fast_div(pp, p.dv_hw[0], p.dv_hw[1]);
+      const int rr = pp - n * (p.Ho * p.Wo);
+      const int ho = fast_div(rr, p.dv_w[0], p.dv_w[1]);
+      const int hin = ho * p.stride + dh, win = (rr - ho * p.Wo) * p.stride + dw;
+      const bool ok = inr && (unsigned)hin < (unsigned)p.H && (unsigned)win < (unsigned)p.W;
+      xoff = ok ? (unsigned)((n * p.H + hin) * p.W + win) * (unsigned)(p.ldx * 2) : kOOB;
+    }
+    const unsigned ad = lds0 + RING_BYTES + (unsigned)((t & (NTAB - 1)) * TAB_BYTES + r * 8);
+    asm volatile("ds_write_b64 %0, %1" ::"v"(ad), "v"((u32x2_t){xoff, yoff}) : "memory");
+  };
+  u32x2_t tv;   // {X, dY} offsets of this lane's row of the stage that is issued next
+  const unsigned tabrd = lds0 + RING_BYTES + (unsigned)(drow0 * 8);
+  auto tab_read = [&](int t) {
+    const unsigned ad = tabrd + (unsigned)((t & (NTAB - 1)) * TAB_BYTES);
+    asm volatile("ds_read_b64 %0, %1" : "=v"(tv) : "v"(ad));
+  };
+  auto issue_x = [&](auto bufc) {
+    constexpr int B = decltype(bufc)::value & 3;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (lds_ptr_t)(smem + B * STAGE + wave * 1024), 16, (int)((tv.x + xcb) | xoob), 0, 0, 0);
+  };
+  auto issue_y = [&](auto bufc) {
+    constexpr int B = decltype(bufc)::value & 3;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(yrsrc, (lds_ptr_t)(smem + B * STAGE + OPB + wave * 1024), 16, (int)((tv.y + ycb) | yoob), 0, 0, 0);
+  };
+  auto tab_turn = [&](int st) {   // (wave-uniform) waves 0 .. 7 take turns: the table of stage s+8
+    if (wave == (st & (NTAB - 1))) tab_compute(st + NTAB);
+  };
+
+  // ---- compute side: full tile 4 (ci) x 4 (co) waves; <= 64 live ci / co: waves 0 .. 7 take a 64 x 32 / 32 x 64 block strip each
+  const int live_ci = min(TC, p.Cin - ci_base), live_co = min(TC, p.Cout - co_base);
+  const int mode = __builtin_amdgcn_readfirstlane(live_ci <= 64 ? 1 : (live_co <= 64 ? 2 : 0));
+  const int ci0 = mode == 0 ? (wave >> 2) * 64 : (mode == 1 ? 0 : (wave & 7) * 32);
+  const int co0 = mode == 0 ? (wave & 3) * 64 : (mode == 1 ? (wave & 7) * 32 : 0);
+  const int NAw = mode == 2 ? 1 : 2, NBw = mode == 1 ? 1 : 2;
+  const bool active = __builtin_amdgcn_readfirstlane(((mode == 0 || wave < 8) && ci0 < live_ci && co0 < live_co) ? 1 : 0) != 0;
+
+  const int q = lane >> 4, sl = lane & 15;
+  const int row0 = 8 * (q >> 1) + (sl >> 2);
+  const int fkey = swz_key(row0);
+  const unsigned rbase = lds0 + (unsigned)(row0 * ROWB + (sl & 3) * 8);
+  unsigned aaddr[2][2], baddr[2][2];   // [ring half][block]
+#pragma unroll
+  for (int a = 0; a < 2; ++a) {
+    aaddr[0][a] = rbase + (unsigned)((((ci0 >> 4) + 2 * a + (q & 1)) ^ fkey) << 5);
+    aaddr[1][a] = aaddr[0][a] + 2 * STAGE;
+    baddr[0][a] = rbase + OPB + (unsigned)((((co0 >> 4) + 2 * a + (q & 1)) ^ fkey) << 5);
+    baddr[1][a] = baddr[0][a] + 2 * STAGE;
+  }
+  f32x16_t acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+  u32x4_t fa[2][2], fb[2][2];   // [block][k step]
+  // bias gradient: first ci tile, first live tap; full tile: the ci quarter 0 (waves 0 .. 3 cover the four co quarters), <= 64 live ci:
+  // every active wave owns a co block, <= 64 live co: wave 0
+  const bool do_bias = BIAS && p.dbias != nullptr && tci == 0 && ti == 0 && active && (mode == 0 ? wave < 4 : (mode == 1 || wave == 0));
+  float bsum[2] = {0.f, 0.f};
+  const bool dbg_nomma = CAVP_DBG(p, 2);
+
+  using C0 = std::integral_constant<int, 0>;
+  using C1 = std::integral_constant<int, 1>;
+  using C2 = std::integral_constant<int, 2>;
+  using C3 = std::integral_constant<int, 3>;
+  auto rf_a = [&](auto bufc, auto blkc, auto ksc) {
+    constexpr int B = decltype(bufc)::value & 3, A = decltype(blkc)::value, KS = decltype(ksc)::value;
+    constexpr int O = (B & 1) * STAGE + KS * 16 * ROWB;
+    const unsigned ad = aaddr[B >> 1][A];
+    const u32x2_t l = lds_tr16<O>(ad), h = lds_tr16<O + 4 * ROWB>(ad);
+    fa[A][KS] = (u32x4_t){l.x, l.y, h.x, h.y};
+  };
+  auto rf_b = [&](auto bufc, auto blkc, auto ksc) {
+    constexpr int B = decltype(bufc)::value & 3, BB = decltype(blkc)::value, KS = decltype(ksc)::value;
+    constexpr int O = (B & 1) * STAGE + KS * 16 * ROWB;
+    const unsigned ad = baddr[B >> 1][BB];
+    const u32x2_t l = lds_tr16<O>(ad), h = lds_tr16<O + 4 * ROWB>(ad);
+    fb[BB][KS] = (u32x4_t){l.x, l.y, h.x, h.y};
+  };
+  auto mm1 = [&](auto ac, auto bc, auto ksc) {
+    constexpr int A = decltype(ac)::value, BB = decltype(bc)::value, KS = decltype(ksc)::value;
+    if (dbg_nomma) return;
+    acc[A][BB] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, fa[A][KS]), __builtin_bit_cast(bf16x8_t, fb[BB][KS]),
+                                                         acc[A][BB], 0, 0, 0);
+  };
+  auto bias_add = [&](auto ksc, auto nbc) {
+    constexpr int KS = decltype(ksc)::value, NB = decltype(nbc)::value;
+    if (BIAS && do_bias) {
+#pragma unroll
+      for (int b = 0; b < NB; ++b)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) bsum[b] += bf16x2_sum(fb[b][KS][e]);
+    }
+  };
+#define CAVP_SB __builtin_amdgcn_sched_barrier(0)
+  // one stage (ring buffer B = s & 3).  NA x NB = the wave's blocks: 2 x 2 (full tile), 2 x 1, 1 x 2 (rest tiles), 0 (idle).  Every
+  // variant issues the X piece of stage s+3 in the first half, waits for its own pieces of stage s+1, meets the stage's one
+  // barrier, and issues the dY piece of stage s+3 and the lookup of stage s+4's row in the second half.
+  auto stage = [&](auto bufc, auto nac, auto nbc, int st) {
+    constexpr int B = decltype(bufc)::value, NA = decltype(nac)::value, NB = decltype(nbc)::value;
+    using NB1 = std::integral_constant<int, B + 1>;
+    using PRV = std::integral_constant<int, (B + 3) & 3>;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // k step 0 of stage s and the row of stage s+3 landed
+    CAVP_SB;
+    if constexpr (NA == 0) {
+      issue_x(PRV{});
+    } else {
+      bias_add(C0{}, nbc);
+      // k step 0, with the reads of k step 1 and the X piece in its gaps
+      mm1(C0{}, C0{}, C0{}); rf_a(bufc, C0{}, C1{}); if constexpr (NA == 2) rf_a(bufc, C1{}, C1{}); CAVP_SB;
+      if constexpr (NB == 2) { mm1(C0{}, C1{}, C0{}); }
+      rf_b(bufc, C0{}, C1{}); if constexpr (NB == 2) rf_b(bufc, C1{}, C1{}); CAVP_SB;
+      if constexpr (NA == 2) { mm1(C1{}, C0{}, C0{}); }
+      issue_x(PRV{}); CAVP_SB;
+      if constexpr (NA == 2 && NB == 2) { mm1(C1{}, C1{}, C0{}); CAVP_SB; }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // k step 1 landed = this wave's last read of buffer B is complete
+    __builtin_amdgcn_s_waitcnt(vmcnt_imm(3));            // this thread's pieces of stage s+1 landed (s+2 and the X piece of s+3 in flight)
+    __builtin_amdgcn_s_barrier();
+    CAVP_SB;
+    if constexpr (NA == 0) {
+      issue_y(PRV{});
+      tab_read(st + 4);
+      tab_turn(st);
+    } else {
+      bias_add(C1{}, nbc);
+      // k step 1, with the reads of the next stage's k step 0, the dY piece and the row lookup in its gaps
+      mm1(C0{}, C0{}, C1{}); rf_a(NB1{}, C0{}, C0{}); if constexpr (NA == 2) rf_a(NB1{}, C1{}, C0{}); CAVP_SB;
+      if constexpr (NB == 2) { mm1(C0{}, C1{}, C1{}); }
+      rf_b(NB1{}, C0{}, C0{}); if constexpr (NB == 2) rf_b(NB1{}, C1{}, C0{}); CAVP_SB;
+      if constexpr (NA == 2) { mm1(C1{}, C0{}, C1{}); }
+      issue_y(PRV{}); tab_read(st + 4); CAVP_SB;
+      if constexpr (NA == 2 && NB == 2) { mm1(C1{}, C1{}, C1{}); }
+      tab_turn(st);
+      CAVP_SB;
+    }
+  };
+
+  if (nst > 0) {
+    if (wave < NTAB) tab_compute(wave);   // the tables of stages 0 .. 7
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+      tab_read(t);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      CAVP_SB;
+      if (t == 0) { issue_x(C0{}); issue_y(C0{}); }
+      if (t == 1) { issue_x(C1{}); issue_y(C1{}); }
+      if (t == 2) { issue_x(C2{}); issue_y(C2{}); }
+    }
+    tab_read(3);
+    __builtin_amdgcn_s_waitcnt(vmcnt_imm(4));   // stage 0 landed (this thread's pieces)
+    __builtin_amdgcn_s_barrier();
+    CAVP_SB;
+    if (!active) {   // (workgroup- / wave-uniform branches: every wave meets the same barriers and issues the same pieces)
+      for (int s0 = 0; s0 < nst; s0 += 4) { stage(C0{}, C0{}, C0{}, s0); stage(C1{}, C0{}, C0{}, s0 + 1); stage(C2{}, C0{}, C0{}, s0 + 2); stage(C3{}, C0{}, C0{}, s0 + 3); }
+    } else if (mode == 0) {
+      rf_a(C0{}, C0{}, C0{}); rf_a(C0{}, C1{}, C0{}); rf_b(C0{}, C0{}, C0{}); rf_b(C0{}, C1{}, C0{});
+      for (int s0 = 0; s0 < nst; s0 += 4) { stage(C0{}, C2{}, C2{}, s0); stage(C1{}, C2{}, C2{}, s0 + 1); stage(C2{}, C2{}, C2{}, s0 + 2); stage(C3{}, C2{}, C2{}, s0 + 3); }
+    } else if (mode == 1) {
+      rf_a(C0{}, C0{}, C0{}); rf_a(C0{}, C1{}, C0{}); rf_b(C0{}, C0{}, C0{});
+      for (int s0 = 0; s0 < nst; s0 += 4) { stage(C0{}, C2{}, C1{}, s0); stage(C1{}, C2{}, C1{}, s0 + 1); stage(C2{}, C2{}, C1{}, s0 + 2); stage(C3{}, C2{}, C1{}, s0 + 3); }
+    } else {
+      rf_a(C0{}, C0{}, C0{}); rf_b(C0{}, C0{}, C0{}); rf_b(C0{}, C1{}, C0{});
+      for (int s0 = 0; s0 < nst; s0 += 4) { stage(C0{}, C1{}, C2{}, s0); stage(C1{}, C1{}, C2{}, s0 + 1); stage(C2{}, C1{}, C2{}, s0 + 2); stage(C3{}, C1{}, C2{}, s0 + 3); }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_waitcnt(vmcnt_imm(0));   // (zero-fill pieces issued past the last stage must not land after the workgroup ends)
+  }
+#undef CAVP_SB
+
+  if (BIAS && do_bias) {   // lanes l and l + 32 hold the two k halves of column co
+    float* bo = p.ksplit > 1 ? p.bias_slabs + (size_t)z * p.Cout : p.dbias;
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      float v = bsum[b];
+      v += __shfl_xor(v, 32, 64);
+      const int co = co_base + co0 + b * 32 + (lane & 31);
+      if (b < NBw && lane < 32 && co < p.Cout) bo[co] = p.ksplit > 1 ? v : bo[co] + v;
+    }
+  }
+  if (!active) return;
+  float* out = p.ksplit > 1 ? p.slabs + (size_t)z * p.Cout * p.ntaps_all * p.Cin : p.dw;
+#pragma unroll
+  for (int a = 0; a < 2; ++a) {
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      if (a >= NAw || b >= NBw) continue;   // (wave-uniform)
+      const int co = co_base + co0 + b * 32 + (lane & 31);
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        const int ci = ci_base + ci0 + a * 32 + 8 * g4 + 4 * (lane >> 5);
+        if (co < p.Cout && ci < p.Cin) {
+          if (p.ksplit == 1 && p.oihw) {
+            float* dst = out + ((size_t)co * p.Cin + ci) * p.ntaps_all + tap;
+            if (p.overwrite) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) dst[(size_t)e * p.ntaps_all] = acc[a][b][4 * g4 + e];
+            } else {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) dst[(size_t)e * p.ntaps_all] += acc[a][b][4 * g4 + e];
+            }
+          } else {
+            float4* dst = (float4*)(out + ((size_t)co * p.ntaps_all + tap) * p.Cin + ci);
+            float4 v = make_float4(acc[a][b][4 * g4], acc[a][b][4 * g4 + 1], acc[a][b][4 * g4 + 2], acc[a][b][4 * g4 + 3]);
+            if (p.ksplit == 1 && !p.overwrite) {
+              const float4 o = *dst;
+              v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+            }
+            *dst = v;
+          }
+        }
+      }
+    }
+  }
+}
+
+template <bool BIAS>
+__global__ __launch_bounds__(NT16, 4) void wgrad_big16_group_kernel(const WgradGroupArgs g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int bid = xcd_remap(blockIdx.x, gridDim.x);
+  int j = 0;
+  while (j + 1 < g.njobs && bid >= g.blk_end[j]) ++j;
+  wgrad_big16_tile<BIAS>(g.job[j], bid - (j ? g.blk_end[j - 1] : 0), smem);
+}
+
 template <bool BIAS, bool PIPE, bool TL = false>
 __global__ __launch_bounds__(NT, 2) void wgrad_big_group_kernel(const WgradGroupArgs g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -550,7 +828,20 @@ extern "C" int cavp_prof_wgrad_timeline(unsigned long long* out16) {
 }
 #endif
 
-hipError_t cavp_launch_wgrad_big_group(const WgradGroupArgs& g, int blocks, bool bias, bool pipelined, hipStream_t s) {
+template <bool BIAS>
+static hipError_t launch_big16(const WgradGroupArgs& g, int blocks, hipStream_t s) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)wgrad_big16_group_kernel<BIAS>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    attr_set = true;
+  }
+  wgrad_big16_group_kernel<BIAS><<<dim3(blocks), dim3(NT16), LDS_BYTES, s>>>(g);
+  return hipGetLastError();
+}
+
+hipError_t cavp_launch_wgrad_big_group(const WgradGroupArgs& g, int blocks, bool bias, int schedule, hipStream_t s) {
+  if (schedule == 2) return bias ? launch_big16<true>(g, blocks, s) : launch_big16<false>(g, blocks, s);
+  const bool pipelined = schedule != 0;
 #ifdef CAVP_PROFILE
   if (pipelined && g.njobs > 0 && (g.job[0].dbg & 16)) {
     static bool attr_set = false;

@@ -41,5 +41,6 @@ typedef short s16x4_t __attribute__((ext_vector_type(4)));
 
 // conv_wgrad_big.hip: the grouped launch of the 256 x 256 tile (one 512-thread workgroup per CU, 128 KiB of LDS).  The job fields
 // that depend on the tile (tiles_co / tiles_ci and their divisors, rows_per_split: a multiple of 128) are planned for that tile.
-// pipelined: fragment reads of the next MFMA cluster under the current one, one barrier per stage (false: read, barrier, multiply).
-hipError_t cavp_launch_wgrad_big_group(const WgradGroupArgs& g, int blocks, bool bias, bool pipelined, hipStream_t s);
+// schedule: 2 = sixteen waves (64 x 64 wave tiles, four waves per SIMD), 1 = eight waves with every LDS read and DMA issue in the
+// gaps between the MFMAs, 0 = eight waves: read, multiply, retire, fetch.
+hipError_t cavp_launch_wgrad_big_group(const WgradGroupArgs& g, int blocks, bool bias, int schedule, hipStream_t s);

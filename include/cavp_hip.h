@@ -128,14 +128,15 @@ int cavp_set_igemm_epilogue(int32_t mode);
  * torch.autograd computes for trainer_cavp_vpo_mono.py:190): 0 = two 32-row LDS stages per workgroup, 1 = one 64-row stage.
  * Both keep four 32 KiB workgroups per CU and give bit-identical results.  Process-wide switch for A/B runs and tests. */
 int cavp_set_wgrad_variant(int32_t variant);
-/* ABI 9: the 256 x 256 weight-gradient tile (csrc/conv_wgrad_big.hip; bf16: one 8-wave workgroup per CU, four-stage LDS-DMA
+/* ABI 9: the 256 x 256 weight-gradient tile (csrc/conv_wgrad_big.hip; bf16: one workgroup per CU, four-stage LDS-DMA
  * ring, v_mfma_f32_32x32x16_bf16) for the weight gradients of encoder_decoder.py:62-75 (decoder head), models/attn.py:136-143 and
  * cavp_model.py:123-128 (token / projector Mlp) - the jobs with >= 16384 pixel rows and >= 192 input and output channels.
- * mode: 0 (default) = those jobs, 1 = never (the 128 x 128 tile everywhere), 2 = every bf16 job (tests).  pipelined: 1 (default) =
- * the fragment reads of the next MFMA cluster are issued under the current one (one barrier per 32-row stage), 0 = read, barrier,
- * multiply.  Same products, same summation order either way.  The choice of tile depends on the job alone, so grouped and single
+ * mode: 0 (default) = those jobs, 1 = never (the 128 x 128 tile everywhere), 2 = every bf16 job (tests).  schedule: 2 (default) =
+ * sixteen waves per workgroup (64 x 64 wave tiles, four waves per SIMD, fragments double-buffered by k step), 1 = eight waves
+ * (64 x 128 wave tiles) with every LDS read and DMA issue in the gaps between the MFMAs, 0 = eight waves: read, multiply, retire,
+ * fetch.  Same products, same summation order in all three.  The choice of tile depends on the job alone, so grouped and single
  * launches of a job with one split count stay bit-identical.  Process-wide switch for A/B runs and tests. */
-int cavp_set_wgrad_big(int32_t mode, int32_t pipelined);
+int cavp_set_wgrad_big(int32_t mode, int32_t schedule);
 
 /* Direct 3x3 conv for Cin in {1,2,3} reading an NCHW f32 tensor and writing NHWC (dtype) with scale/shift + act:
  * the ResNet deep-stem first conv (resnet.py:108-110, stride 2) and the first VGGish conv (vgg.py:26-36). */

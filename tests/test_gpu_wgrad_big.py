@@ -20,10 +20,10 @@ def big():
     """set(mode, stagger) -> None; the process-wide switch is restored afterwards"""
     lib, _ = _mods()
 
-    def set_(mode, stagger=1):
+    def set_(mode, stagger=2):
         assert lib.cavp_set_wgrad_big(mode, stagger) == 0
     yield set_
-    assert lib.cavp_set_wgrad_big(0, 1) == 0
+    assert lib.cavp_set_wgrad_big(0, 2) == 0
 
 
 def _case(name, n, h, w, cin, cout, k, s, p, d, seed=0):
@@ -35,7 +35,7 @@ def _case(name, n, h, w, cin, cout, k, s, p, d, seed=0):
     return _nhwc(x.detach(), BF), _nhwc(dy, BF), wt.grad, dy.sum(dim=(0, 2, 3))
 
 
-@pytest.mark.parametrize("stagger", [1, 0], ids=["pipelined", "plain"])
+@pytest.mark.parametrize("stagger", [2, 1, 0], ids=["16waves", "8waves_interleaved", "8waves_plain"])
 @pytest.mark.parametrize("case", CONV, ids=[c[0] for c in CONV])
 def test_big_tile_forced_on_small_shapes(case, stagger, big):
     """every layer shape of the op tests (strides, dilations with dead taps, 304 / 48 channels: tiles with dead 32-channel blocks,
@@ -76,7 +76,7 @@ def test_big_tile_auto_vs_torch_and_small_tile(case, big):
     name, n, h, w, cin, cout, k, s, p, d = case
     xv, dyv, gw, gb = _case(*case, seed=40)
     outs = {}
-    for mode, stagger in ((0, 1), (0, 0), (1, 1)):
+    for mode, stagger in ((0, 2), (0, 1), (0, 0), (1, 1)):
         big(mode, stagger)
         dw = torch.zeros((cout, k, k, cin), dtype=torch.float32, device=DEV)
         db = torch.zeros((cout,), dtype=torch.float32, device=DEV)
@@ -85,9 +85,10 @@ def test_big_tile_auto_vs_torch_and_small_tile(case, big):
         _check(db, gb, BF, f"{name}.mode{mode}.dbias", bf16_tol=1e-2)
         outs[(mode, stagger)] = (dw, db)
     # the schedule does not change a single product or the order they are added in
-    assert torch.equal(outs[(0, 1)][0], outs[(0, 0)][0]) and torch.equal(outs[(0, 1)][1], outs[(0, 0)][1])
+    for other in ((0, 1), (0, 0)):
+        assert torch.equal(outs[(0, 2)][0], outs[other][0]) and torch.equal(outs[(0, 2)][1], outs[other][1])
     # the two tiles compute the same f32 sums in a different association: equal to f32 rounding
-    a, b = outs[(0, 1)][0], outs[(1, 1)][0]
+    a, b = outs[(0, 2)][0], outs[(1, 1)][0]
     assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max())
 
 
@@ -103,7 +104,7 @@ def test_big_tile_group_matches_single_launch_bitwise(big):
         db = torch.full((cout,), 0.5, dtype=torch.float32, device=DEV) if i % 2 == 0 else None
         jobs.append(dict(x=xv, dy=dyv, dw=dw, kh=k, kw=k, stride=s, pad=p, dil=d, dbias=db, dw_oihw=oihw, overwrite=over,
                          splitk=(5, 1, 7, 3, 2)[i], _ref=(name, gw, gb)))
-    big(0, 1)
+    big(0, 2)
     T.conv2d_wgrad_group([{k: v for k, v in j.items() if k != "_ref"} for j in jobs])
     for j in jobs:
         name, gw, gb = j["_ref"]
@@ -121,7 +122,7 @@ def test_big_tile_is_deterministic(big):
     lib, T = _mods()
     name, n, h, w, cin, cout, k, s, p, d = BIG[0]
     xv, dyv, gw, gb = _case(*BIG[0], seed=90)
-    big(0, 1)
+    big(0, 2)
     outs = []
     for _ in range(3):
         dw = torch.empty((cout, k, k, cin), dtype=torch.float32, device=DEV)
