@@ -69,6 +69,8 @@ def parse():
     ap.add_argument("--no-rank1-attn", action="store_true", help="A/B: the cross-modal attention as q GEMM + gate + proj GEMM (round 3) instead of the one-key collapse")
     ap.add_argument("--igemm-epilogue", type=int, default=-1, help="A/B: cavp_set_igemm_epilogue (1 = register epilogue, 0 = LDS-staged)")
     ap.add_argument("--wgrad-variant", type=int, default=0, help="A/B: cavp_set_wgrad_variant (0 = two 32-row stages, 1 = one 64-row stage)")
+    ap.add_argument("--wgrad-big", default="", help="A/B: cavp_set_wgrad_big MODE:SCHEDULE (mode 0 = the 256x256 weight-gradient tile where it qualifies, "
+                                                     "1 = never; schedule 2 = 16 waves, 1 / 0 = 8 waves)")
     ap.add_argument("--no-tail-split", action="store_true", help="A/B: never split a 256x256-tile launch with a nearly empty last round")
     ap.add_argument("--trainer-loop", action="store_true",
                     help="the reference trainer's call sequence instead of the fused step: out = model(image, audio) -> torch "
@@ -556,6 +558,9 @@ def main():
     if a.igemm_epilogue >= 0:
         from cavp_amd import _lib as _cl2
         _cl2.load().cavp_set_igemm_epilogue(a.igemm_epilogue)
+    if a.wgrad_big:
+        from cavp_amd import _lib as _cl1b
+        assert _cl1b.load().cavp_set_wgrad_big(*(int(v) for v in a.wgrad_big.split(":"))) == 0
     if a.wgrad_variant:
         from cavp_amd import _lib as _cl1
         _cl1.load().cavp_set_wgrad_variant(a.wgrad_variant)

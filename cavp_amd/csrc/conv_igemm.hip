@@ -88,6 +88,19 @@ __device__ __forceinline__ void epilogue_store4(const IgemmParams& p, float v0, 
   }
 }
 
+#ifdef CAVP_PROFILE
+// Timeline of physical workgroup 0 / wave 0 (profile builds, CAVP_IGEMM_DBG bit 256): s_memtime sums over the tiles it walks.
+// [0] tiles, [1] K iterations, [2] kernel entry -> first tile, [3] tile set-up (tile ids, per-row descriptors, tap masks),
+// [4] first DMA issue -> first stage landed for everybody, [5] rest of the K loop, [6] epilogue, [7] whole kernel.
+__device__ unsigned long long g_igemm_tl[8];
+extern "C" int cavp_prof_igemm_timeline(unsigned long long* out8) {
+  return hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_igemm_tl), sizeof(unsigned long long) * 8) == hipSuccess ? 0 : -1;
+}
+#define CAVP_TLI(stmt) do { if (tl_on) { stmt; } } while (0)
+#else
+#define CAVP_TLI(stmt) do { } while (0)
+#endif
+
 template <typename T, int BC, int BP, int WC, int WP, bool UP, int NS>
 __global__ __launch_bounds__(64 * WC * WP, (WC * WP == 4 ? 2 : 1)) void igemm_kernel(const IgemmParams p) {
   constexpr int VE = Elem<T>::VE;
@@ -109,10 +122,23 @@ __global__ __launch_bounds__(64 * WC * WP, (WC * WP == 4 ? 2 : 1)) void igemm_ke
   // (the wave index as a SCALAR: every LDS-DMA destination - M0 - then comes from SALU adds; as a vector value it cost one
   // VGPR + one v_readfirstlane per DMA instruction)
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#ifdef CAVP_PROFILE
+  const bool tl_on = (p.dbg & 256) != 0 && blockIdx.x == 0 && wave == 0;   // (wave-uniform)
+  unsigned long long tl_entry = 0, tl_t0 = 0, tl_t1 = 0, tl_t2 = 0, tl_t3 = 0, tl_s[4] = {0, 0, 0, 0}, tl_tiles = 0, tl_iters = 0, tl_first = 0;
+  CAVP_TLI(tl_entry = __builtin_readcyclecounter());
+#endif
   // persistent workgroups: gridDim.x (a multiple of 8, so a workgroup keeps its XCD) physical workgroups walk the
   // p.nblk logical ones: launch, kernel-argument load and teardown are paid once per physical workgroup
   for (int vb = blockIdx.x; vb < p.nblk; vb += gridDim.x) {
   if (vb != (int)blockIdx.x) __syncthreads();   // the previous tile's epilogue is done with the LDS
+#ifdef CAVP_PROFILE
+  CAVP_TLI({
+    const unsigned long long now = __builtin_readcyclecounter();
+    if (tl_tiles) { tl_s[0] += tl_t1 - tl_t0; tl_s[1] += tl_t2 - tl_t1; tl_s[2] += tl_t3 - tl_t2; tl_s[3] += now - tl_t3; } else { tl_first = now - tl_entry; }
+    tl_t0 = now; tl_t2 = 0;
+    ++tl_tiles;
+  });
+#endif
   const int sid = xcd_remap(vb, p.nblk);
   const int tiles = p.tiles_c * p.tiles_p;
   // (wave-uniform, but integer division has no scalar instruction: each `/` below used to be a ~40-instruction VALU
@@ -280,6 +306,7 @@ __global__ __launch_bounds__(64 * WC * WP, (WC * WP == 4 ? 2 : 1)) void igemm_ke
       for (int b = 0; b < MP; ++b) Mma<T>::run(acc[a][b], af[a], bfv[b]);
   };
 
+  CAVP_TLI({ tl_t1 = __builtin_readcyclecounter(); tl_iters += (unsigned long long)(it_end - it_begin); });
   if (it_begin < it_end) {
     if constexpr (NS == 2) {
       // two stages, two workgroups per CU.  Iteration `it`: wait for MY loads of tile `it`, barrier (=> everybody's
@@ -290,6 +317,7 @@ __global__ __launch_bounds__(64 * WC * WP, (WC * WP == 4 ? 2 : 1)) void igemm_ke
       for (int it = it_begin; it < it_end; ++it) {
         __builtin_amdgcn_s_waitcnt(vmcnt_imm(0));
         __builtin_amdgcn_s_barrier();
+        CAVP_TLI(if (tl_t2 == 0) tl_t2 = __builtin_readcyclecounter());
         if (!CAVP_DBG(p, 8)) gdma(buf ^ 1, it + 1 < it_end && !CAVP_DBG(p, 1));
         if (!CAVP_DBG(p, 2)) {
           u32x4_t af[MC], bfv[MP];
@@ -314,6 +342,7 @@ __global__ __launch_bounds__(64 * WC * WP, (WC * WP == 4 ? 2 : 1)) void igemm_ke
       for (int it = 0; it < n; ++it) {
         __builtin_amdgcn_s_waitcnt(vmcnt_imm((NS - 2) * LD));
         __builtin_amdgcn_s_barrier();
+        CAVP_TLI(if (tl_t2 == 0) tl_t2 = __builtin_readcyclecounter());
         gdma(fill, it + NS - 1 < n);
         u32x4_t af[MC], bfv[MP];
 #pragma unroll
@@ -341,6 +370,7 @@ __global__ __launch_bounds__(64 * WC * WP, (WC * WP == 4 ? 2 : 1)) void igemm_ke
       u32x4_t a0[MC] = {}, b0[MP] = {}, a1[MC] = {}, b1[MP] = {};
       __builtin_amdgcn_s_waitcnt(vmcnt_imm(2 * LD));
       __builtin_amdgcn_s_barrier();
+      CAVP_TLI(tl_t2 = __builtin_readcyclecounter());
       read_frag(a0, b0, 0, 0);
       int buf = 0;
       for (int it = 0; it < n; ++it) {
@@ -361,6 +391,7 @@ __global__ __launch_bounds__(64 * WC * WP, (WC * WP == 4 ? 2 : 1)) void igemm_ke
     }
     __syncthreads();  // drains the (empty) tail DMAs and fences the K-loop LDS reads before the epilogue reuses LDS
   }
+  CAVP_TLI({ tl_t3 = __builtin_readcyclecounter(); if (tl_t2 == 0) tl_t2 = tl_t3; });
 
   // ---- epilogue ----
   if (CAVP_DBG(p, 16)) continue;
@@ -727,6 +758,16 @@ __global__ __launch_bounds__(64 * WC * WP, (WC * WP == 4 ? 2 : 1)) void igemm_ke
     }
   }
   }  // persistent loop
+#ifdef CAVP_PROFILE
+  CAVP_TLI({
+    const unsigned long long now = __builtin_readcyclecounter();
+    if (tl_tiles) { tl_s[0] += tl_t1 - tl_t0; tl_s[1] += tl_t2 - tl_t1; tl_s[2] += tl_t3 - tl_t2; tl_s[3] += now - tl_t3; }
+    if (lane == 0) {
+      g_igemm_tl[0] = tl_tiles; g_igemm_tl[1] = tl_iters; g_igemm_tl[2] = tl_first;
+      g_igemm_tl[3] = tl_s[0]; g_igemm_tl[4] = tl_s[1]; g_igemm_tl[5] = tl_s[2]; g_igemm_tl[6] = tl_s[3]; g_igemm_tl[7] = now - tl_entry;
+    }
+  });
+#endif
 }
 
 // Reduce split-K slabs (deterministic order) and apply the epilogue.  One thread per 4 consecutive channels.

@@ -4,7 +4,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from test_gpu_train_ops import CONV, DEV, _check, _nhwc, _q, _rand
+from tests.test_gpu_train_ops import CONV, DEV, _check, _nhwc, _q, _rand
 
 pytestmark = pytest.mark.gpu
 BF = torch.bfloat16

@@ -83,8 +83,12 @@ def main():
     ap.add_argument("--aux", type=int, default=0, help="1: fc1-style epilogue (GELU + gelu' stored, no scale/shift); 2: fc2-dgrad style (result x aux)")
     ap.add_argument("--epi", type=int, default=0, help="cavp_set_igemm_epilogue: 1 = register epilogue, 0 = LDS-staged (default)")
     ap.add_argument("--ldpad", type=int, default=0, help="round the channel stride of x / y / residual up to a multiple of this many elements")
+    ap.add_argument("--lib", default="", help="load this build of the library (cavp_amd/libcavp_hip_profile.so: CAVP_IGEMM_* knobs; "
+                                              "CAVP_IGEMM_DBG=256 prints the s_memtime timeline of workgroup 0 / wave 0 and the plan)")
     a = ap.parse_args()
     from cavp_amd import _lib
+    if a.lib:
+        _lib.LIB_PATH = os.path.abspath(a.lib)
     assert _lib.load().cavp_set_igemm_epilogue(a.epi) == 0
     dt = torch.bfloat16 if a.dtype == "bf16" else torch.float32
     dev = "cuda:0"
@@ -135,6 +139,15 @@ def main():
             except Exception as ex:  # noqa: BLE001
                 cells.append(f"{'fail: ' + str(ex)[:14]:>22s}")
         print(f"{name:28s} " + " ".join(f"{c:>22s}" for c in cells), flush=True)
+        if int(os.environ.get("CAVP_IGEMM_DBG", "0")) & 256:
+            import ctypes
+            buf = (ctypes.c_ulonglong * 8)()
+            lib = _lib.load()
+            if lib.cavp_prof_igemm_timeline(buf) == 0 and buf[0]:
+                t, it = buf[0], max(buf[1], 1)
+                print(f"    timeline (shader cycles, physical workgroup 0 / wave 0, last launch): {t} tile(s), {buf[1]} K iterations, kernel {buf[7]}; "
+                      f"entry->first tile {buf[2]}; per tile: set-up {buf[3] / t:.0f}, first stage landed {buf[4] / t:.0f}, "
+                      f"K loop after that {buf[5] / t:.0f} ({buf[5] / it:.0f} per K iteration), epilogue {buf[6] / t:.0f}")
 
 
 if __name__ == "__main__":

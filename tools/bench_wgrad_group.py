@@ -32,7 +32,10 @@ def main():
     ap.add_argument("--reps", type=int, default=10)
     ap.add_argument("--modes", default="1:1,0:2,0:1")
     ap.add_argument("--single", action="store_true", help="also time every job as its own launch")
+    ap.add_argument("--lib", default="", help="load this build of the library (cavp_amd/libcavp_hip_profile.so: CAVP_WGRAD_* knobs)")
     a = ap.parse_args()
+    if a.lib:
+        _lib.LIB_PATH = os.path.abspath(a.lib)
     lib = _lib.load()
     dev = "cuda:0"
     jobs, flops = [], 0.0
