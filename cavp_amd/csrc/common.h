@@ -192,6 +192,30 @@ static inline hipError_t cavp_det_finish(const float* part, int nparts, int n, f
   return hipGetLastError();
 }
 
+// Touch every 64-byte line of the kernel-argument segment at kernel entry.  hipcc loads kernel arguments lazily, field by field
+// where they are first used, and a fresh launch's argument block is in nobody's cache: the s_memtime timeline of an igemm
+// workgroup (profiles/r05_igemm_tile_timeline.txt) shows 3000 .. 4000 cycles between kernel entry and the first tile - three or
+// four DEPENDENT scalar-cache misses in a row.  Issued together up front they overlap into one.
+template <int BYTES>
+__device__ __forceinline__ void cavp_prefetch_kernargs() {
+  const __attribute__((address_space(4))) unsigned* ka = (const __attribute__((address_space(4))) unsigned*)__builtin_amdgcn_kernarg_segment_ptr();
+  unsigned any = 0;
+#pragma unroll
+  for (int o = 0; o < BYTES; o += 64) any |= ka[o / 4];
+  asm volatile("" ::"s"(any));
+}
+
+// the same for BYTES at a run-time (wave-uniform) byte offset into the segment: one job of a grouped launch's table
+template <int BYTES>
+__device__ __forceinline__ void cavp_prefetch_kernargs_at(int byte_off) {
+  const __attribute__((address_space(4))) unsigned* ka =
+      (const __attribute__((address_space(4))) unsigned*)((const __attribute__((address_space(4))) char*)__builtin_amdgcn_kernarg_segment_ptr() + (byte_off & ~63));
+  unsigned any = 0;
+#pragma unroll
+  for (int o = 0; o < BYTES + 64; o += 64) any |= ka[o / 4];
+  asm volatile("" ::"s"(any));
+}
+
 // s_waitcnt immediate that only waits for vmcnt <= n (gfx9 encoding: vmcnt[3:0] | expcnt[6:4] | lgkmcnt[11:8] | vmcnt[15:14])
 constexpr int vmcnt_imm(int n) { return (n & 15) | ((n >> 4) << 14) | (7 << 4) | (15 << 8); }
 

@@ -118,6 +118,7 @@ __global__ __launch_bounds__(64 * WC * WP, (WC * WP == 4 ? 2 : 1)) void igemm_ke
   static_assert(TC % 16 == 0 && TP % 16 == 0, "wave tile must be a multiple of the 16x16 MFMA block");
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  cavp_prefetch_kernargs<(int)sizeof(IgemmParams)>();
 
   // (the wave index as a SCALAR: every LDS-DMA destination - M0 - then comes from SALU adds; as a vector value it cost one
   // VGPR + one v_readfirstlane per DMA instruction)

@@ -56,6 +56,7 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 template <int DBG>
 __global__ __launch_bounds__(512, 2) void igemm_big_kernel(const IgemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  cavp_prefetch_kernargs<(int)sizeof(IgemmParams)>();
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wc = wave & 3, wp = wave >> 2;   // wp = wave group

@@ -356,9 +356,11 @@ __global__ __launch_bounds__(256, (BK == 32 || NSTG == 1 ? 4 : 2)) void wgrad_ke
 template <typename T, bool BIAS, int BK = 32, int NSTG = 2>
 __global__ __launch_bounds__(256, 4) void wgrad_group_kernel(const WgradGroupArgs g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  cavp_prefetch_kernargs<(int)offsetof(WgradGroupArgs, job)>();
   const int bid = xcd_remap(blockIdx.x, gridDim.x);
   int j = 0;
   while (j + 1 < g.njobs && bid >= g.blk_end[j]) ++j;
+  cavp_prefetch_kernargs_at<(int)sizeof(WgradParams)>((int)offsetof(WgradGroupArgs, job) + j * (int)sizeof(WgradParams));
   wgrad_tile<T, BK, BIAS, NSTG>(g.job[j], bid - (j ? g.blk_end[j - 1] : 0), smem);
 }
 

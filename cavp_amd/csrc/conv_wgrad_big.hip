@@ -795,18 +795,22 @@ __device__ __forceinline__ void wgrad_big16_tile(const WgradParams& p, const int
 template <bool BIAS>
 __global__ __launch_bounds__(NT16, 4) void wgrad_big16_group_kernel(const WgradGroupArgs g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  cavp_prefetch_kernargs<(int)offsetof(WgradGroupArgs, job)>();
   const int bid = xcd_remap(blockIdx.x, gridDim.x);
   int j = 0;
   while (j + 1 < g.njobs && bid >= g.blk_end[j]) ++j;
+  cavp_prefetch_kernargs_at<(int)sizeof(WgradParams)>((int)offsetof(WgradGroupArgs, job) + j * (int)sizeof(WgradParams));
   wgrad_big16_tile<BIAS>(g.job[j], bid - (j ? g.blk_end[j - 1] : 0), smem);
 }
 
 template <bool BIAS, bool PIPE, bool TL = false>
 __global__ __launch_bounds__(NT, 2) void wgrad_big_group_kernel(const WgradGroupArgs g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  cavp_prefetch_kernargs<(int)offsetof(WgradGroupArgs, job)>();
   const int bid = xcd_remap(blockIdx.x, gridDim.x);
   int j = 0;
   while (j + 1 < g.njobs && bid >= g.blk_end[j]) ++j;
+  cavp_prefetch_kernargs_at<(int)sizeof(WgradParams)>((int)offsetof(WgradGroupArgs, job) + j * (int)sizeof(WgradParams));
   wgrad_big_tile<BIAS, PIPE, TL>(g.job[j], bid - (j ? g.blk_end[j - 1] : 0), smem);
 }
 
