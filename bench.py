@@ -71,12 +71,15 @@ def parse():
     ap.add_argument("--wgrad-variant", type=int, default=0, help="A/B: cavp_set_wgrad_variant (0 = two 32-row stages, 1 = one 64-row stage)")
     ap.add_argument("--wgrad-big", default="", help="A/B: cavp_set_wgrad_big MODE:SCHEDULE (mode 0 = the 256x256 weight-gradient tile where it qualifies, "
                                                      "1 = never; schedule 2 = 16 waves, 1 / 0 = 8 waves)")
+    ap.add_argument("--no-wgrad-stream", action="store_true", help="A/B: grouped weight gradients on the main stream instead of their own (round 3)")
+    ap.add_argument("--no-bn-apply-fusion", action="store_true", help="A/B: BatchNorm forward as finalize launch + apply launch for every layer (round 4)")
     ap.add_argument("--no-tail-split", action="store_true", help="A/B: never split a 256x256-tile launch with a nearly empty last round")
     ap.add_argument("--trainer-loop", action="store_true",
                     help="the reference trainer's call sequence instead of the fused step: out = model(image, audio) -> torch "
                          "cross-entropy on out[:B] + out[B:]*0 -> loss.backward() (trainer_cavp_vpo_mono.py:166-193); with the graph "
                          "on (default) through CAVP.enable_graphed_autograd(), with --no-graph through the eager autograd node")
     ap.add_argument("--no-f32", action="store_true", help="skip the secondary f32 (parity path) training-step measurement")
+    ap.add_argument("--no-eval-leg", action="store_true", help="skip the secondary eval-forward measurement (`eval_forward` object of the default line)")
     ap.add_argument("--cpu-sample-batch", type=int, default=8)
     return ap.parse_args()
 
@@ -331,7 +334,7 @@ def measure_roofline(model, run_step, image, dtype_name, reps=3, config="c1p", l
     else:
         cname = "" if config == "c1p" else config + "_"
         tname = f"traffic_{cname}{dtype_name}.json" if mode_name == "eval" else f"traffic_{cname}train_{dtype_name}.json"
-        tpath = next((q for q in (os.path.join(REPO, "profiles", r + tname) for r in ("r04_", "r03_", "r02_", "r01_")) if os.path.exists(q)), "")
+        tpath = next((q for q in (os.path.join(REPO, "profiles", r + tname) for r in ("r05_", "r04_", "r03_", "r02_", "r01_")) if os.path.exists(q)), "")
         if tpath:
             with open(tpath) as f:
                 tj = json.load(f)
@@ -372,6 +375,21 @@ def measure_roofline(model, run_step, image, dtype_name, reps=3, config="c1p", l
     rp = rocprof_igemm_ms(config, mode_name, dtype_name)
     if rp is not None:
         roof["igemm_ms_rocprof"] = rp   # the committed rocprofv3 kernel trace of the same command, beside the event figure
+        # Two clocks on the same launches: HIP events around each launch (live, above) and the committed rocprofv3 trace of the
+        # graph replays (igemm_kernel* + igemm_big_kernel + the split-K epilogues).  `frac` is the SMALLER of the two fractions.
+        rp_ms = rp.get("igemm_ms_per_step")
+        if rp_ms and image.shape[0] == rp.get("batch", 32) and config == "c1p":
+            roof["frac_event_timing"] = roof["frac"]
+            t_r, g_r = flops / (rp_ms * 1e-3) / 1e12, nbytes / (rp_ms * 1e-3) / 1e9
+            frac_r = t_r / MFMA_PEAK_TFLOPS[dtype_name] if roof["bound"] == "mfma" else g_r / HBM_PEAK_GBS
+            roof["frac_rocprof_timing"] = round(frac_r, 4)
+            roof["timing_sources_agree_within"] = round(abs(rp_ms - ms) / ms, 3)
+            if frac_r < roof["frac"]:
+                roof["frac"] = round(frac_r, 4)
+                roof["achieved"] = round(t_r, 2) if roof["bound"] == "mfma" else round(g_r, 1)
+                roof["frac_source"] = "committed rocprofv3 trace (graph replays only; smaller than the live HIP-event figure)"
+            else:
+                roof["frac_source"] = "live HIP events (smaller than the committed rocprofv3 figure)"
     roof["_step_gflop"] = step_flops / 1e9   # consumed by main(): the whole-step object needs ms_per_step of the timed region
     roof["_measured_step_bytes"] = traffic["all_kernels_hbm_bytes_per_step"] if traffic and "all_kernels_hbm_bytes_per_step" in traffic else None
     return roof
@@ -381,7 +399,7 @@ def rocprof_igemm_ms(config, mode_name, dtype_name):
     """igemm kernel time per step from the committed rocprofv3 --kernel-trace --stats summary of this command
     (profiles/rNN_rocprof_igemm_<cfg><mode>_<dtype>.json, written by tools/summarize_rocprof.py --igemm-json), newest round first."""
     cname = "" if config == "c1p" else config + "_"
-    for r in ("r04_", "r03_"):
+    for r in ("r05_", "r04_", "r03_"):
         q = os.path.join(REPO, "profiles", f"{r}rocprof_igemm_{cname}{mode_name}_{dtype_name}.json")
         if os.path.exists(q):
             with open(q) as f:
@@ -389,6 +407,69 @@ def rocprof_igemm_ms(config, mode_name, dtype_name):
             j["source"] = "profiles/" + os.path.basename(q)
             return j
     return None
+
+
+def eval_forward_leg(model, image, audio, B, dtype_name, steps=30, warmup=5):
+    """Inference forward of the same model (eval-mode BN folded into the conv epilogues) on one hipGraph: frames/s, ms and the
+    fraction of the HBM roof north_star's target is stated on (fused byte minimum of SURVEY.md section 8d / 8 TB/s)."""
+    was_training = model.training
+    model.eval()
+    try:
+        with torch.no_grad():
+            model(image, audio, eval_mode=True)
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                model(image, audio, eval_mode=True)
+            torch.cuda.current_stream().wait_stream(side)
+            from cavp_amd.train import _no_gc_during_capture
+            with _no_gc_during_capture(), torch.cuda.graph(graph, capture_error_mode="thread_local"):
+                model(image, audio, eval_mode=True)
+            for _ in range(warmup):
+                graph.replay()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                graph.replay()
+            torch.cuda.synchronize()
+            ms = (time.perf_counter() - t0) / steps * 1e3
+    finally:
+        model.train(was_training)
+    min_gb = FUSED_MIN_MB_PER_FRAME_BF16["eval"] * B / 1e3
+    out = {"value": round(B / ms * 1e3, 1), "unit": "frames/s", "ms_per_step": round(ms, 3), "steps": steps, "warmup": warmup, "dtype": dtype_name,
+           "launch": "hipGraph replay", "bound": "hbm", "fused_min_gb": round(min_gb, 3), "achieved_gbs": round(min_gb / ms * 1e3, 1),
+           "frac_of_hbm_peak": round(min_gb / ms * 1e3 / HBM_PEAK_GBS, 4), "target": {"frames_per_s": 400, "frac_of_hbm_peak": 0.60}}
+    tpath = next((q for q in (os.path.join(REPO, "profiles", f"{r}traffic_{dtype_name}.json") for r in ("r05_", "r04_", "r03_")) if os.path.exists(q)), "")
+    if tpath:
+        with open(tpath) as f:
+            tj = json.load(f)
+        if tj.get("batch") == B and tj.get("all_kernels_hbm_bytes_per_step"):
+            out["measured_hbm_gb"] = round(tj["all_kernels_hbm_bytes_per_step"] / 1e9, 2)
+            out["measured_vs_fused_min"] = round(tj["all_kernels_hbm_bytes_per_step"] / 1e9 / min_gb, 2)
+            out["traffic_source"] = "profiles/" + os.path.basename(tpath) + " (committed PMC measurement of `bench.py --mode eval`, not taken in this run)"
+    return out
+
+
+def graphed_step_roofline(model, image, audio, label, ms_step, config, B, dtype_name):
+    """Whole-step roofline object for the lines whose launches sit inside graph replays (--trainer-loop, c5): algorithmic FLOPs =
+    the conv / linear / weight-gradient launches of ONE eager fused step of the same model on the same batch, counted by the
+    launch wrappers (durations unused); bytes = the perfectly-fused minimum of the C1' model (the ContrastLoss of c5 adds < 1 %)."""
+    from cavp_amd import ops, train_ops
+    kt = KernelTimer().wrap(ops, train_ops)
+    try:
+        with torch.no_grad():
+            model.train_step(image, audio, label, all_reduce=False)
+        agg = kt.summary()
+    finally:
+        kt.unwrap(ops)
+    gflop = sum(v[2] for k, v in agg.items() if k in ("conv2d", "conv2d_dgrad", "conv2d_wgrad", "conv2d_wgrad_group")) / 1e9
+    min_gb = FUSED_MIN_MB_PER_FRAME_BF16["train"] * B / 1e3
+    return {"bound": "hbm", "ms_per_step": round(ms_step, 3), "algorithmic_gflop": round(gflop, 1), "fused_min_gb": round(min_gb, 2),
+            "achieved_tflops": round(gflop / ms_step, 2), "frac_of_mfma_peak": round(gflop / ms_step / MFMA_PEAK_TFLOPS[dtype_name], 4),
+            "achieved_gbs": round(min_gb / ms_step * 1e3, 1), "frac_of_hbm_peak": round(min_gb / ms_step * 1e3 / HBM_PEAK_GBS, 4),
+            "note": "FLOPs counted on one eager fused step of the same model and batch; the timed region is the trainer loop"}
 
 
 def _host_cpu():
@@ -549,6 +630,12 @@ def main():
     if a.no_group_wgrad:
         import cavp_amd.train as _tr
         _tr._GROUP_WGRAD = False
+    if a.no_wgrad_stream:
+        import cavp_amd.train as _tr
+        _tr._WGRAD_STREAM = False
+    if a.no_bn_apply_fusion:
+        import cavp_amd.train as _tr
+        _tr._FUSE_BN_APPLY = False
     if a.no_tail_split:
         from cavp_amd import _lib as _cl0
         _cl0.load().cavp_set_tail_split(0)
@@ -769,13 +856,13 @@ def main():
                                     trainer_loop=a.trainer_loop)
             step_gflop, meas_bytes = roof.pop("_step_gflop"), roof.pop("_measured_step_bytes")
             ms_step = elapsed / a.steps * 1e3
-            if a.config in ("c1p", "c1", "c4") and a.dtype == "bf16":
+            if a.config in ("c1p", "c1", "c4", "c5") and a.dtype == "bf16":
                 # the WHOLE step against both roofs (north_star: "fraction of the conv-bound HBM roofline"): algorithmic FLOPs of
                 # every conv / linear launch incl. weight gradients, and the perfectly-fused byte minimum
                 if a.config == "c4":
                     min_gb = fused_min_mb_per_frame_c4("train" if train else "eval", B) * B / 1e3
                 else:
-                    min_gb = (FUSED_MIN_MB_PER_FRAME_BF16 if a.config == "c1p" else FUSED_MIN_MB_PER_FRAME_BF16_C1)["train" if train else "eval"] * B / 1e3
+                    min_gb = (FUSED_MIN_MB_PER_FRAME_BF16 if a.config in ("c1p", "c5") else FUSED_MIN_MB_PER_FRAME_BF16_C1)["train" if train else "eval"] * B / 1e3
                 roof["step"] = {
                     "bound": "hbm", "ms_per_step": round(ms_step, 3),
                     "algorithmic_gflop": round(step_gflop, 1), "fused_min_gb": round(min_gb, 2),
@@ -785,6 +872,20 @@ def main():
                     "measured_vs_fused_min": round(meas_bytes / 1e9 / min_gb, 2) if meas_bytes else None,
                 }
             line["roofline"] = roof
+        if getattr(a, "trainer_graphed", False) and a.dtype == "bf16":
+            # (--trainer-loop / c5 on graph replays: no per-launch view, but the whole step against both roofs: the algorithmic
+            # FLOPs of the same model's fused eager step, counted once through the launch wrappers, and the fused byte minimum)
+            try:
+                line["roofline"] = {"step": graphed_step_roofline(model, image, audio, label, elapsed / a.steps * 1e3, a.config, B, a.dtype)}
+            except Exception as ex:  # noqa: BLE001
+                print(f"[bench] step roofline of the graphed trainer loop failed: {type(ex).__name__}: {ex}", file=sys.stderr)
+        if train and a.dtype == "bf16" and a.config == "c1p" and world == 1 and not a.no_eval_leg:
+            # north_star states its target on the inference forward (">= 400 frames/s at >= 60 % of the conv-bound HBM roofline"):
+            # the same model, eval forward on one hipGraph, beside the training headline
+            try:
+                line["eval_forward"] = eval_forward_leg(model, image, audio[:B], B, a.dtype)
+            except Exception as ex:  # noqa: BLE001
+                print(f"[bench] eval_forward leg failed: {type(ex).__name__}: {ex}", file=sys.stderr)
         if train and a.dtype == "bf16" and a.config in ("c1p", "c1") and world == 1 and not a.no_f32:
             # the same step on the f32 parity path (every kernel within 1e-3 of the reference, tests/): a throughput at the
             # north-star tolerance next to the bf16 headline

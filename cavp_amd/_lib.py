@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(HERE, "libcavp_hip.so")
 
 F32, BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_LEAKY, ACT_GELU = 0, 1, 2, 3
-ABI_VERSION = 9
+ABI_VERSION = 10
 WGRAD_GROUP_MAX = 16   # CAVP_WGRAD_GROUP_MAX
 
 
@@ -88,6 +88,9 @@ PROTOTYPES = {
     "cavp_colstats": (_i32, [_i32, _vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp]),
     "cavp_scale_f32": (_i32, [_vp, _f32, _vp, _i32, _vp]),
     "cavp_bn_finalize": (_i32, [_vp, _vp, _vp, _i64, _vp, _vp, _f32, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp]),
+    "cavp_bn_apply_tiles_supported": (_i32, [_i32]),
+    "cavp_bn_apply_tiles": (_i32, [_i32, _vp, _i32, _i32, _i64, _vp, _vp, _f32, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64,
+                                   _i32, _i32, _i32, _i32, _i32, _vp]),
     "cavp_scale_shift_act": (_i32, [_i32, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _vp]),
     "cavp_bn_act_bwd_reduce": (_i32, [_i32, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp,
                                       _vp]),

@@ -40,8 +40,16 @@ def nearest_indices(n_in: int, n_out: int) -> np.ndarray:
 #     forward): the reduction + download run there, behind nothing, and the loss call finds the copy here;
 #   * a label tensor OBJECT that was already downloaded and has not been written since (same object, same version counter) is
 #     not downloaded again (validation-style loops over fixed batches, bench.py's synthetic step).
+#     CONTRACT: the hit test is identity + torch's version counter, so it sees torch writes only.  A label buffer refilled behind
+#     torch's back (a raw-pointer kernel, .data, a DLPack / numpy alias) must be followed by
+#     invalidate_label_cache() before the next loss call (the returned arrays are read-only: callers never write into a cached copy).
 _LABEL_CACHE: dict = {}
 _LABEL_CACHE_MAX = 8
+
+
+def invalidate_label_cache() -> None:
+    """Forget every cached label download (see the contract above)."""
+    _LABEL_CACHE.clear()
 
 
 def _label_key(gt: torch.Tensor, size):
@@ -59,6 +67,7 @@ def downsample_labels(gt: torch.Tensor, size: Tuple[int, int]) -> np.ndarray:
         if hit is not None and hit[0]() is gt and hit[1] == gt._version:
             return hit[2]
         out = _downsample_labels_device(gt, size)
+        out.setflags(write=False)   # the cached array is handed out by reference: a caller that wrote into it would poison later hits
         for k in [k for k, v in _LABEL_CACHE.items() if v[0]() is None]:
             del _LABEL_CACHE[k]
         if len(_LABEL_CACHE) >= _LABEL_CACHE_MAX:
@@ -89,9 +98,13 @@ def _upload_i32(arrs, dev):
     is a blocking copy each); returns the device views.  One staging buffer per call slot (two rotate) so that a copy still in
     flight is not overwritten by the next step's indices."""
     n = sum(int(a.size) for a in arrs)
-    slot = _PINNED.get("slot", 0)
-    _PINNED["slot"] = slot ^ 1
-    buf, ev = _PINNED.get(slot, (None, None))
+    # staging slots per (device, thread): nn.DataParallel replica threads and loss calls on different devices must not share one
+    # (the event is recorded after the host writes, so a second user of the slot could overwrite a buffer whose copy is pending)
+    import threading
+    own = _PINNED.setdefault((torch.device(dev).index or 0, threading.get_ident()), {})
+    slot = own.get("slot", 0)
+    own["slot"] = slot ^ 1
+    buf, ev = own.get(slot, (None, None))
     if ev is not None:
         ev.synchronize()       # the copy that last used this staging buffer has run (two steps ago: normally long done)
     if buf is None or buf.numel() < n:
@@ -104,7 +117,7 @@ def _upload_i32(arrs, dev):
     d = buf[:n].to(dev, non_blocking=True)
     ev = torch.cuda.Event()
     ev.record()
-    _PINNED[slot] = (buf, ev)
+    own[slot] = (buf, ev)
     o = 0
     for a in arrs:
         views.append(d[o:o + a.size])

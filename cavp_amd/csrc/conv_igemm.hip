@@ -580,6 +580,22 @@ __global__ __launch_bounds__(64 * WC * WP, (WC * WP == 4 ? 2 : 1)) void igemm_ke
         }
       }
     }
+    // The residual of the thread's first G chunks is requested HERE, before the statistics and the staging round trip: issued
+    // behind the staging barrier (rounds 1-4) every tile waited out one full memory latency (~2000 cycles of the ~14000-cycle
+    // epilogue of a 128 x 128 bottleneck-output tile, profiles/r05_igemm_tile_timeline.txt) with nothing else to do.
+    constexpr int G = ITER < 8 ? ITER : 8;  // chunks finished per batch: all residual loads of a batch fly together
+    static_assert(ITER % G == 0, "chunk batches");
+    const T* rp = p.res ? (const T*)p.res + (size_t)((p.res_rows ? p_base % p.res_rows : p_base) + eprow0) * p.ldr + ec : nullptr;
+    const size_t rstep = (size_t)RSTR * p.ldr;
+    const int rows_left = p.M - (p_base + eprow0);   // chunk k is in range iff k * RSTR < rows_left
+    u32x4_t rr0[G];
+    if (rp) {
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        rr0[g] = (u32x4_t){0u, 0u, 0u, 0u};
+        if (ec_ok && g * RSTR < rows_left) rr0[g] = *(const u32x4_t*)(rp + (size_t)g * rstep);
+      }
+    }
     float2* wstat = (float2*)(smem + NS * TILE_BYTES);   // [WP][BC] per-wave (mean, M2) partials (launch_cfg adds the bytes)
     if (p.tile_stats) {
       // BatchNorm batch statistics for free, straight from the f32 accumulators IN REGISTERS: a lane holds 4 channels x MP
@@ -649,8 +665,6 @@ __global__ __launch_bounds__(64 * WC * WP, (WC * WP == 4 ? 2 : 1)) void igemm_ke
       o[0] = mean;
       o[1] = m2;
     }
-    constexpr int G = ITER < 8 ? ITER : 8;  // chunks finished per batch: all residual loads of a batch fly together
-    static_assert(ITER % G == 0, "chunk batches");
     static_assert(RSTR % 8 == 0, "the LDS swizzle key (row & 7) is the same for all chunks of a thread");
     // per-thread invariants: everything that does not depend on the chunk index is computed once, the chunk loop only
     // adds constants (this loop was VALU-bound: 64-bit multiplies and the swizzle per chunk, activation dispatch and an
@@ -660,17 +674,16 @@ __global__ __launch_bounds__(64 * WC * WP, (WC * WP == 4 ? 2 : 1)) void igemm_ke
     const float* lds1 = VE == 8 ? st + (size_t)eprow0 * BC + (((ecc / 4 + 1) ^ key) << 2) : lds0;  // second (bf16 only)
     T* yp = (T*)p.y + (size_t)(p_base + eprow0) * p.ldy + ec;
     // (res_rows: a multiple of every tile height, so a tile never straddles the wrap)
-    const T* rp = p.res ? (const T*)p.res + (size_t)((p.res_rows ? p_base % p.res_rows : p_base) + eprow0) * p.ldr + ec : nullptr;
     T* xp = p.aux_mode ? (T*)p.aux + (size_t)(p_base + eprow0) * p.ld_aux + ec : nullptr;
     const size_t xstep = (size_t)RSTR * p.ld_aux;
-    const size_t ystep = (size_t)RSTR * p.ldy, rstep = (size_t)RSTR * p.ldr;
+    const size_t ystep = (size_t)RSTR * p.ldy;
     const bool has_ss = p.scale != nullptr || p.shift != nullptr;
-    const int rows_left = p.M - (p_base + eprow0);   // chunk k is in range iff k * RSTR < rows_left
     for (int i0 = 0; i0 < ITER; i0 += G) {
       u32x4_t rr[G];
       if (rp) {
 #pragma unroll
         for (int g = 0; g < G; ++g) {
+          if (i0 == 0) { rr[g] = rr0[g]; continue; }
           rr[g] = (u32x4_t){0u, 0u, 0u, 0u};
           if (ec_ok && (i0 + g) * RSTR < rows_left) rr[g] = *(const u32x4_t*)(rp + (size_t)(i0 + g) * rstep);
         }

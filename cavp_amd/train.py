@@ -275,6 +275,8 @@ _SIDE_STREAM = True      # False (tests / A-B only): the audio encoder on the ma
 # Weight gradients are not consumed inside the backward: TrainPass collects them and issues up to 16 per launch
 # (cavp_conv2d_wgrad_group).  False (tests / A-B only): one launch (+ one slab reduce) per layer, where the layer's backward runs.
 _GROUP_WGRAD = True
+_WGRAD_STREAM = False    # False (tests / A-B only): grouped weight gradients on the main stream, between the data gradients (round 3)
+_FUSE_BN_APPLY = True    # False (tests / A-B only): BatchNorm forward always as finalize launch + apply launch (round 4)
 _BN_BWD_READ_Y = False   # True (tests / A-B only): the BatchNorm backward always re-reads y instead of re-deriving the mask from z
 
 
@@ -302,6 +304,11 @@ class TrainPass:
         self._wg_dst: set = set()
         self._wg_src: set = set()      # storages of their dy operands (see _pinned)
         self._wg_after: list = []      # callbacks run right behind the next grouped launch (defer_wgrad)
+        # grouped launches in flight on the weight-gradient stream (wgrad_stream()): storages they still read, references that keep
+        # their operands from being recycled, the event behind the last of them
+        self._wg_src_async: set = set()
+        self._wg_keep: list = []
+        self._wg_done = None
 
     # ---- parameter helpers -----------------------------------------------------------------------------------
     def pack(self, key: str, mod, need_dgrad: bool = True, raw: bool = False, pad_cout_to: int = 0) -> _P:
@@ -456,7 +463,10 @@ class TrainPass:
         """True while a deferred weight gradient reads t's storage: a conv with a fused residual hands its output gradient to
         the residual branch WITHOUT a copy (acc_add: x.g = g), so a later in-place accumulation into that branch's gradient
         would change the dy of the pending job.  The accumulation then goes into a fresh tensor (same traffic, no extra pass)."""
-        return bool(self._wg_src) and t.untyped_storage().data_ptr() in self._wg_src
+        if not self._wg_src and not self._wg_src_async:
+            return False
+        q = t.untyped_storage().data_ptr()
+        return q in self._wg_src or q in self._wg_src_async
 
     def _dense_copy(self, g: torch.Tensor) -> torch.Tensor:
         out = self.empty(g.shape, g.dtype)
@@ -568,24 +578,72 @@ class TrainPass:
         # a second contribution to a destination that is already pending would race inside the launch: flush first
         dst = {dw.data_ptr()} | ({db.data_ptr()} if db is not None else set())
         if dst & self._wg_dst:
-            self.flush_wgrads()
+            self.flush_wgrads(join=False)
         self._wg_jobs.append(job)
         self._wg_dst |= dst
         self._wg_src.add(g4.untyped_storage().data_ptr())
         if after is not None:
             self._wg_after.append(after)
         if len(self._wg_jobs) >= 16:
-            self.flush_wgrads()
+            self.flush_wgrads(join=False)
 
-    def flush_wgrads(self) -> None:
-        """Issue the pending weight gradients (before anything reads a parameter gradient: finish_padded, the early / late
-        gradient collectives, the end of the backward)."""
+    def wgrad_stream(self):
+        """Third stream: the grouped weight gradients.  Nothing in the backward CHAIN reads a weight gradient, and the chain is a
+        sequence of small, latency-bound launches (14 x 14 / 28 x 28 data gradients and BatchNorm passes on <= 1.5 workgroups per
+        CU) that leaves most of the chip idle, while a grouped weight-gradient launch is pure throughput: run on a stream of their
+        own, the groups fill the CUs the chain leaves free instead of standing in its way.  None: CPU tensors, deterministic mode
+        (process-wide scratch), A/B switch."""
+        if self.dev.type != "cuda" or not _WGRAD_STREAM or _lib_load().cavp_get_deterministic():
+            return None
+        s = getattr(self.m, "_wgrad_stream", None)
+        if s is None or s.device != self.dev:
+            s = torch.cuda.Stream(device=self.dev)
+            self.m.__dict__["_wgrad_stream"] = s
+        return s
+
+    def flush_wgrads(self, join: bool = True) -> None:
+        """Issue the pending weight gradients.  join=True (before anything reads a parameter gradient or overwrites an operand:
+        finish_padded, the early / late gradient collectives, the end of the backward) also waits for the weight-gradient stream;
+        join=False (a full group, a second contribution to a pending destination) only queues the launch there - launches on that
+        stream are ordered among themselves."""
         if self._wg_jobs:
-            jobs, self._wg_jobs, self._wg_dst, self._wg_src = self._wg_jobs, [], set(), set()
+            jobs, self._wg_jobs, self._wg_dst = self._wg_jobs, [], set()
             after, self._wg_after = self._wg_after, []
-            T.conv2d_wgrad_group(jobs)
-            for fn in after:
-                fn()
+            ws = self.wgrad_stream() if self._slot == 0 else None
+            if ws is None:
+                self._wg_src = set()
+                T.conv2d_wgrad_group(jobs)
+                for fn in after:
+                    fn()
+            else:
+                # operands stay pinned (no in-place accumulation into a dy the launch still reads) and referenced (their memory
+                # is not handed to a later allocation of the main stream) until join_wgrads()
+                self._wg_src_async |= self._wg_src
+                self._wg_src = set()
+                self._wg_keep.append(jobs)
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream())
+                ws.wait_event(ev)
+                with torch.cuda.stream(ws), ops.workspace_slot(2):
+                    self._slot = 2
+                    try:
+                        T.conv2d_wgrad_group(jobs)
+                        for fn in after:
+                            fn()
+                    finally:
+                        self._slot = 0
+                    self._wg_done = torch.cuda.Event()
+                    self._wg_done.record(ws)
+        if join:
+            self.join_wgrads()
+
+    def join_wgrads(self) -> None:
+        """The current stream waits for every grouped weight gradient issued so far (their destinations are final after this)."""
+        if self._wg_done is not None:
+            torch.cuda.current_stream().wait_event(self._wg_done)
+            self._wg_done = None
+        self._wg_src_async = set()
+        self._wg_keep = []
 
     def conv_smallcin(self, x_nchw: torch.Tensor, key: str, stride: int, act: int) -> V:
         """First stem conv (raw, BN follows) / first VGG conv (bias + ReLU fused).  Input needs no gradient."""
@@ -618,6 +676,7 @@ class TrainPass:
         mom = bn.momentum if bn.momentum is not None else 0.1
         sync = isinstance(bn, nn.SyncBatchNorm) and collectives_on()   # (a forced single-rank group runs the collectives too)
         frozen = (not bn.training) and bn.running_mean is not None   # torch: eval-mode BatchNorm normalises with the running statistics
+        fused_apply = False
         if frozen:
             # fine-tuning with frozen statistics: y = gamma (z - running_mean) rstd + beta, no update of the running buffers;
             # backward dz = gamma rstd g, dgamma = sum g zhat, dbeta = sum g (no batch-mean terms)
@@ -633,9 +692,17 @@ class TrainPass:
             # ASPP pooled branch
             ts, tiles, rpt = z.tile_stats if z.tile_stats is not None else T.col_tile_stats(z.t)
             count = rows
-            T.bn_finalize_tiles(ts, tiles, rpt, rows, bn.weight.detach(), bn.bias.detach(), bn.eps, mom,
-                                bn.running_mean if track else None, bn.running_var if track else None, scale, shift,
-                                mean, rstd)
+            if _FUSE_BN_APPLY and T.bn_apply_tiles_supported(tiles):
+                # few tiles (the 14 x 14 layers): combine + apply in ONE launch, every workgroup redoes the combine of its channels
+                fused_apply = True
+                y = out if out is not None else V(self.empty(z.t.shape, z.t.dtype))
+                T.bn_apply_tiles(ts, tiles, rpt, rows, bn.weight.detach(), bn.bias.detach(), bn.eps, mom,
+                                 bn.running_mean if track else None, bn.running_var if track else None, scale, shift, mean, rstd,
+                                 z.t, y.t, act, residual=residual.t if residual is not None else None)
+            else:
+                T.bn_finalize_tiles(ts, tiles, rpt, rows, bn.weight.detach(), bn.bias.detach(), bn.eps, mom,
+                                    bn.running_mean if track else None, bn.running_var if track else None, scale, shift,
+                                    mean, rstd)
         else:
             # SyncBatchNorm (main_vpo_mono.py:130): this rank's (mean, M2) -> ONE all-gather -> Chan combine over the ranks (the
             # same kernel that combines tiles; every rank holds `rows` samples).  Round 1 issued three all-reduces per layer.
@@ -650,8 +717,9 @@ class TrainPass:
                                 mean, rstd)
         if track and bn.num_batches_tracked is not None:
             self._nbt.append(bn.num_batches_tracked)
-        y = out if out is not None else V(self.empty(z.t.shape, z.t.dtype))
-        T.scale_shift_act(z.t, scale, shift, y.t, act, residual=residual.t if residual is not None else None)
+        if not fused_apply:
+            y = out if out is not None else V(self.empty(z.t.shape, z.t.dtype))
+            T.scale_shift_act(z.t, scale, shift, y.t, act, residual=residual.t if residual is not None else None)
 
         def bwd():
             dy = y.g

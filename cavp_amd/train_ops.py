@@ -271,6 +271,28 @@ def bn_finalize_tiles(tile_stats, tiles: int, rows_per_tile: int, count: int, ga
            "cavp_bn_finalize_tiles")
 
 
+def bn_apply_tiles_supported(tiles: int) -> bool:
+    return bool(_lib.load().cavp_bn_apply_tiles_supported(int(tiles)))
+
+
+def bn_apply_tiles(tile_stats, tiles: int, rows_per_tile: int, count: int, gamma, beta, eps: float, momentum: float, running_mean,
+                   running_var, scale, shift, mean, rstd, x, y, act: int, residual=None) -> torch.Tensor:
+    """bn_finalize_tiles + scale_shift_act in one launch (tensors with <= 128 statistics tiles)."""
+    rows, c, ldx = _rows(x)
+    r2, c2, ldy = _rows(y)
+    ldr = 0
+    if residual is not None:
+        _, _, ldr = _rows(residual)
+    _need_gpu(tile_stats, gamma, beta, scale, shift, mean, rstd, x, y, residual)
+    if (rows, c) != (r2, c2) or y.dtype != x.dtype or gamma.numel() != c:
+        raise _lib.CavpError("bn_apply_tiles: shape mismatch")
+    _check(_lib.load().cavp_bn_apply_tiles(dtype_code(x.dtype), _ptr(tile_stats), tiles, rows_per_tile, count, _ptr(gamma), _ptr(beta),
+                                           C.c_float(eps), C.c_float(momentum), _ptr(running_mean), _ptr(running_var), _ptr(scale),
+                                           _ptr(shift), _ptr(mean), _ptr(rstd), _ptr(x), _ptr(residual), _ptr(y), rows, c, ldx, ldr, ldy,
+                                           act, _s()), "cavp_bn_apply_tiles")
+    return y
+
+
 def scale_shift_act(x, scale, shift, y, act: int, residual=None) -> torch.Tensor:
     rows, c, ldx = _rows(x)
     r2, c2, ldy = _rows(y)

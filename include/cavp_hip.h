@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define CAVP_ABI_VERSION 9
+#define CAVP_ABI_VERSION 10
 
 typedef enum { CAVP_F32 = 0, CAVP_BF16 = 1 } cavp_dtype_t;
 typedef enum { CAVP_ACT_NONE = 0, CAVP_ACT_RELU = 1, CAVP_ACT_LEAKY = 2, CAVP_ACT_GELU = 3 } cavp_act_t;
@@ -279,6 +279,17 @@ int cavp_bn_tiles_to_moments(const float* tile_stats, int32_t tiles, int32_t row
 int cavp_scale_shift_act(int32_t dtype, const void* x, const float* scale, const float* shift, const void* residual,
                          void* y, int64_t rows, int32_t C, int32_t ldx, int32_t ldr, int32_t ldy, int32_t act,
                          void* stream);
+/* ABI 10: train-mode BatchNorm forward in one launch - cavp_bn_finalize_tiles + cavp_scale_shift_act (same arguments, same outputs:
+ * scale / shift / mean / rstd are published for the backward, the running statistics updated once) for tensors with at most 128
+ * statistics tiles (cavp_bn_apply_tiles_supported): the 14 x 14 layers of the ResNet at B = 32, where the separate finalize launch
+ * cost twice the apply pass.  Replaces nn.BatchNorm2d.forward (training) + ReLU (+ the bottleneck's residual add) of
+ * /root/reference/models/visual/backbones/resnet.py:75-98. */
+int cavp_bn_apply_tiles_supported(int32_t tiles);
+int cavp_bn_apply_tiles(int32_t dtype, const float* tile_stats, int32_t tiles, int32_t rows_per_tile, int64_t count,
+                        const float* gamma, const float* beta, float eps, float momentum, float* running_mean,
+                        float* running_var, float* scale, float* shift, float* mean, float* rstd, const void* x,
+                        const void* residual, void* y, int64_t rows, int32_t C, int32_t ldx, int32_t ldr, int32_t ldy,
+                        int32_t act, void* stream);
 /* y may be NULL for a BN + activation WITHOUT residual: the activation mask is then re-derived from z with the forward's
  * folded fwd_scale / fwd_shift (y = act(z*scale + shift) > 0 <=> z*scale + shift > 0), which saves reading y in both passes */
 int cavp_bn_act_bwd_reduce(int32_t dtype, const void* dy, const void* y, const void* z, const float* mean,

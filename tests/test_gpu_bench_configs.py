@@ -35,6 +35,7 @@ def test_config_c5_clip_step_line():
     d = _bench("--config", "c5", "--batch", "10", "--steps", "2", "--warmup", "1", "--no-cpu-baseline")
     assert d["value"] > 0 and "ContrastLoss" in d["config"]["workload"] and "2 clips x 5 frames" in d["config"]["workload"]
     assert "hipGraph" in d["config"]["launch"]          # the model's part on the graphed autograd node by default
+    assert d["roofline"]["step"]["algorithmic_gflop"] > 0 and 0 < d["roofline"]["step"]["frac_of_hbm_peak"] < 1
     e = _bench("--config", "c5", "--batch", "10", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-graph")
     assert e["value"] > 0 and "eager autograd node" in e["config"]["launch"]
     with pytest.raises(AssertionError):
@@ -52,6 +53,9 @@ def test_deterministic_line_and_cpu_thread_sweep():
 def test_trainer_loop_lines():
     """--trainer-loop: the reference trainer's call sequence through the graphed autograd node and through the eager one."""
     g = _bench("--trainer-loop", "--batch", "4", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-f32")
-    assert g["value"] > 0 and "hipGraph" in g["config"]["launch"] and "roofline" not in g or g.get("roofline") is None
+    # launches inside graph replays: no per-launch view, but the whole step against both roofs (round 5)
+    assert g["value"] > 0 and "hipGraph" in g["config"]["launch"] and set(g["roofline"]) == {"step"}
+    st = g["roofline"]["step"]
+    assert st["algorithmic_gflop"] > 0 and st["fused_min_gb"] > 0 and 0 < st["frac_of_hbm_peak"] < 1 and 0 < st["frac_of_mfma_peak"] < 1
     e = _bench("--trainer-loop", "--no-graph", "--batch", "4", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-f32")
     assert e["value"] > 0 and "eager autograd node" in e["config"]["launch"] and e["roofline"]["frac"] > 0

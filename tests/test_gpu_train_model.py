@@ -597,3 +597,47 @@ def test_second_stream_equals_single_stream():
         assert torch.equal(a, b)
     finally:
         TR._SIDE_STREAM = old
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+def test_wgrad_stream_equals_main_stream(dtype):
+    """The grouped weight gradients run on a stream of their own, concurrently with the backward chain (round 5).  Same set-up as
+    the second-stream test (frozen BatchNorm: no chaotic amplifier): gradients with the weight-gradient stream == gradients with the
+    groups issued on the main stream, eagerly, over repeated steps (operands must stay pinned and referenced until the join) and as
+    graph replays.  A missing dependency, a recycled operand or a shared scratch buffer would show."""
+    import cavp_amd.train as TR
+    cfg = dict(C=3, B=4, hw=(96, 96), lds=[False, False, False])
+    image, audio, label = [t.to(DEV) for t in synth_inputs(cfg["B"], cfg["hw"], audio_batch=2 * cfg["B"], num_classes=cfg["C"], seed=9)]
+
+    def build():
+        m, _ = _build(cfg)
+        m.set_compute_dtype(dtype)
+        for mod in m.modules():
+            if isinstance(mod, torch.nn.modules.batchnorm._BatchNorm):
+                mod.eval()
+        return m
+
+    tol = 1e-5 if dtype == torch.float32 else 2e-3
+    old = TR._WGRAD_STREAM
+    try:
+        TR._WGRAD_STREAM = False
+        m0 = build()
+        l0 = float(m0.train_step(image, audio, label, all_reduce=False).item())
+        ref = m0._grad_arena.flat.clone()
+        assert getattr(m0, "_wgrad_stream", None) is None
+        TR._WGRAD_STREAM = True
+        m1 = build()
+        for _ in range(3):
+            l1 = float(m1.train_step(image, audio, label, all_reduce=False).item())
+            torch.cuda.synchronize()
+            assert m1._wgrad_stream is not None
+            err = float((m1._grad_arena.flat - ref).norm() / ref.norm())
+            assert abs(l1 - l0) <= 1e-6 * max(1.0, abs(l0)) and err <= tol, (l1, l0, err)
+        step = m1.capture_train_step(image, audio, label)
+        for _ in range(3):
+            l2 = float(step().item())
+            torch.cuda.synchronize()
+            err = float((m1._grad_arena.flat - ref).norm() / ref.norm())
+            assert abs(l2 - l0) <= 1e-6 * max(1.0, abs(l0)) and err <= tol, (l2, l0, err)
+    finally:
+        TR._WGRAD_STREAM = old

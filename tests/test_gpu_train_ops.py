@@ -560,3 +560,57 @@ def test_col_tile_stats(rows, C, dt):
     var = ref.var(0, unbiased=False)
     got_var = 1.0 / rstd.cpu().double() ** 2 - 1e-5
     assert float(((got_var - var).abs() / var).max()) <= 2e-4
+
+
+@pytest.mark.parametrize("dt", DTYPES, ids=IDS)
+@pytest.mark.parametrize("rows,C,res,sl", [(6272, 256, False, False), (6272, 1024, True, False), (16384, 128, False, False), (130, 2048, True, False),
+                                           (32, 256, False, False), (1000, 72, True, True), (6272, 48, False, True)],
+                         ids=["l3_mid", "l3_out_res", "max_tiles", "wide_res", "pooled_B32", "ragged_slice_res", "narrow_slice"])
+def test_bn_apply_tiles(rows, C, res, sl, dt):
+    """cavp_bn_apply_tiles (statistics combine + scale / shift + residual + ReLU in ONE launch) against torch's training-mode
+    BatchNorm on the same (storage-rounded) input, and against the two-launch route it replaces: same normalised tensor, same
+    published scale / shift / mean / rstd, same running-statistics update (resnet.py:75-98)."""
+    ops, T = _mods()
+    if C % (8 if dt == torch.bfloat16 else 4):
+        pytest.skip("channel count must be a multiple of the 16-byte vector")
+    pad = 16 if sl else 0
+    x = _q(_rand(rows, C + pad, seed=51) * 0.7 + 3.0, dt)
+    r = _q(_rand(rows, C + pad, seed=52), dt) if res else None
+    g, b = _rand(C, seed=53) * 0.3 + 1.0, _rand(C, seed=54) * 0.2
+    xd = x.to(dt).to(DEV)[:, pad // 2:pad // 2 + C]
+    rd = r.to(dt).to(DEV)[:, pad // 2:pad // 2 + C] if res else None
+    ts, tiles, rpt = T.col_tile_stats(xd)
+    if rows == 6272 and C == 256:
+        # the layout a 64-row igemm tile emits: 98 tiles of 64 rows (f64 on the host, then f32)
+        xs64 = x[:, pad // 2:pad // 2 + C].double().view(98, 64, C)
+        mu = xs64.mean(1)
+        ts = torch.stack((mu, ((xs64 - mu[:, None, :]) ** 2).sum(1)), -1).float().to(DEV).contiguous()
+        tiles, rpt = 98, 64
+    assert T.bn_apply_tiles_supported(tiles) and not T.bn_apply_tiles_supported(129)
+    outs = []
+    for fused in (True, False):
+        rm, rv = torch.full((C,), 0.25, device=DEV), torch.full((C,), 2.0, device=DEV)
+        scale, shift, mean, rstd = (torch.empty(C, device=DEV) for _ in range(4))
+        y = torch.empty((rows, C + pad), dtype=dt, device=DEV)[:, pad // 2:pad // 2 + C]
+        if fused:
+            T.bn_apply_tiles(ts, tiles, rpt, rows, g.to(DEV), b.to(DEV), 1e-5, 0.1, rm, rv, scale, shift, mean, rstd, xd, y, ops.ACT_RELU, residual=rd)
+        else:
+            T.bn_finalize_tiles(ts, tiles, rpt, rows, g.to(DEV), b.to(DEV), 1e-5, 0.1, rm, rv, scale, shift, mean, rstd)
+            T.scale_shift_act(xd, scale, shift, y, ops.ACT_RELU, residual=rd)
+        outs.append([t.float().cpu() for t in (y, scale, shift, mean, rstd, rm, rv)])
+    xs = x[:, pad // 2:pad // 2 + C]
+    bn = torch.nn.BatchNorm1d(C, eps=1e-5, momentum=0.1)
+    with torch.no_grad():
+        bn.weight.copy_(g); bn.bias.copy_(b); bn.running_mean.fill_(0.25); bn.running_var.fill_(2.0)
+    bn.train()
+    ref = bn(xs)
+    if res:
+        ref = ref + r[:, pad // 2:pad // 2 + C]
+    ref = F.relu(ref).detach()
+    _check(outs[0][0], ref, dt, "bn_apply_tiles y", 1e-4, 1.5e-2)
+    _check(outs[0][5], bn.running_mean.detach(), torch.float32, "running_mean", 1e-5, 1e-5)
+    _check(outs[0][6], bn.running_var.detach(), torch.float32, "running_var", 2e-4, 2e-4)
+    for a_, b_, what in zip(outs[0][1:], outs[1][1:], ("scale", "shift", "mean", "rstd", "running_mean", "running_var")):
+        _check(a_, b_, torch.float32, "fused vs two launches: " + what, 2e-6, 2e-6)
+    # the normalised tensors of the two routes differ by the rounding of (scale, shift) only
+    _check(outs[0][0], outs[1][0], dt, "fused vs two launches: y", 2e-5, 8e-3)

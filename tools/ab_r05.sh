@@ -1,0 +1,34 @@
+#!/bin/bash
+# Round-5 same-box A/B runs.  usage: tools/ab_r05.sh part...   parts: tests | step | quick
+cd $GRAFT_REPO_ROOT
+export TMPDIR=/tmp
+O=gpurun_out/r05
+mkdir -p $O
+ms() { python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-roofline --no-f32 --no-eval-leg "$@" 2>/dev/null | python -c "import json,sys; print(json.loads(sys.stdin.read())['ms_per_step'])"; }
+for part in "$@"; do
+if [ "$part" = tests ]; then
+  timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | tail -15 > $O/pytest_gpu.txt; cat $O/pytest_gpu.txt
+fi
+if [ "$part" = quick ]; then
+  timeout 900 python -m pytest tests/test_gpu_train_ops.py tests/test_gpu_train_model.py tests/test_gpu_bench_configs.py -m gpu -x -q 2>&1 | tail -15 > $O/pytest_quick.txt; cat $O/pytest_quick.txt
+fi
+if [ "$part" = step ]; then
+  { for r in 1 2 3; do
+      echo "default                $(ms)"
+      echo "--no-bn-apply-fusion   $(ms --no-bn-apply-fusion)"
+      echo "--no-wgrad-stream      $(ms --no-wgrad-stream)"
+      echo "--no-wgrad-stream --no-bn-apply-fusion  $(ms --no-wgrad-stream --no-bn-apply-fusion)"
+    done; } > $O/ab_step.txt 2>&1
+  cat $O/ab_step.txt
+fi
+done
+# rocprof of the default step (graph replays only): per-kernel table -> gpurun_out/r05/kernel_trace_probe.txt
+if [ "$1" = trace ]; then
+  shift
+  rm -rf $O/prof_probe
+  (cd /tmp && timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$O/prof_probe -o train -- \
+     python $GRAFT_REPO_ROOT/bench.py --mode train --steps 16 --warmup 4 --no-cpu-baseline --no-roofline --no-f32 --no-eval-leg "$@" > $GRAFT_REPO_ROOT/$O/prof_probe.log 2>&1)
+  python tools/summarize_rocprof.py $O/prof_probe --replays-only > $O/kernel_trace_probe.txt 2>&1
+  rm -rf $O/prof_probe
+  head -60 $O/kernel_trace_probe.txt | cut -c1-150
+fi

@@ -25,6 +25,11 @@ def main():
     ap.add_argument("--igemm-json", default=None, help="write {steps, igemm_ms_per_step, ...} of the kernel trace (bench.py reads it as "
                                                        "roofline.igemm_ms_rocprof); steps = calls of --step-kernel")
     ap.add_argument("--step-kernel", default="head_fwd_kernel", help="a kernel that runs exactly once per step")
+    ap.add_argument("--replays-only", action="store_true",
+                    help="keep only the periodic tail of the dispatch sequence: the hipGraph replays.  The eager warm-up step, the capture's "
+                         "warm-up and the first replays (cold caches: 1 ms outliers on 23 us kernels) are cut off, so the per-step "
+                         "figures are those of the steady state the HIP-event timing in bench.py sees")
+    ap.add_argument("--stats-csv", default=None, help="with --replays-only: write the trimmed per-kernel statistics in rocprofv3's kernel_stats.csv columns")
     a = ap.parse_args()
     lines = []
     per_step = None
@@ -32,12 +37,34 @@ def main():
     for t in traces:
         agg = defaultdict(lambda: [0, 0.0, 1e30, 0.0])
         with open(t) as f:
-            for r in csv.DictReader(f):
-                d = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
-                g = agg[short(r["Kernel_Name"])]
-                g[0] += 1; g[1] += d; g[2] = min(g[2], d); g[3] = max(g[3], d)
+            rows = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), short(r["Kernel_Name"])) for r in csv.DictReader(f)]
+        rows.sort()
+        trimmed = ""
+        if a.replays_only:
+            # dispatch indices of the once-per-step kernel; the replays are the tail in which they are a constant number of
+            # dispatches apart (an eager step launches more kernels than its captured form: casts, packs, statistics fall-backs).
+            # The window runs from the second occurrence of that tail to the last one: whole periods, whatever the phase.
+            idx = [i for i, r in enumerate(rows) if r[2].startswith(a.step_kernel)]
+            if len(idx) >= 4:
+                period = idx[-1] - idx[-2]
+                k = len(idx) - 1
+                while k > 0 and idx[k] - idx[k - 1] == period:
+                    k -= 1
+                k = min(k + 1, len(idx) - 2)          # drop the first replay of the tail as well (cold instruction / L2 state)
+                rows_all = len(rows)
+                rows = rows[idx[k]:idx[-1]]
+                trimmed = f"  [replays only: {len(idx) - 1 - k} steps x {period} dispatches of {rows_all} traced]"
+        for s0, e0, nm in rows:
+            d = (e0 - s0) / 1e3
+            g = agg[nm]
+            g[0] += 1; g[1] += d; g[2] = min(g[2], d); g[3] = max(g[3], d)
         tot = sum(v[1] for v in agg.values())
-        lines.append(f"# kernel trace: {os.path.relpath(t, a.dir)}  total kernel time {tot / 1e3:.3f} ms")
+        lines.append(f"# kernel trace: {os.path.relpath(t, a.dir)}  total kernel time {tot / 1e3:.3f} ms{trimmed}")
+        if a.replays_only and a.stats_csv:
+            with open(a.stats_csv, "w") as f:
+                f.write('"Name","Calls","TotalDurationNs","AverageNs","Percentage","MinNs","MaxNs"\n')
+                for k_, v in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+                    f.write(f'"{k_}",{v[0]},{int(v[1] * 1e3)},{v[1] * 1e3 / v[0]:.1f},{100 * v[1] / tot:.2f},{int(v[2] * 1e3)},{int(v[3] * 1e3)}\n')
         lines.append(f"{'calls':>7} {'total_us':>12} {'avg_us':>10} {'min_us':>9} {'max_us':>9} {'%':>6}  kernel")
         for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1]):
             lines.append(f"{v[0]:7d} {v[1]:12.1f} {v[1] / v[0]:10.2f} {v[2]:9.2f} {v[3]:9.2f} {100 * v[1] / tot:6.2f}  {k}")
