@@ -72,7 +72,8 @@ def parse():
     ap.add_argument("--wgrad-big", default="", help="A/B: cavp_set_wgrad_big MODE:SCHEDULE (mode 0 = the 256x256 weight-gradient tile where it qualifies, "
                                                      "1 = never; schedule 2 = 16 waves, 1 / 0 = 8 waves)")
     ap.add_argument("--no-wgrad-stream", action="store_true", help="A/B: grouped weight gradients on the main stream instead of their own (round 3)")
-    ap.add_argument("--no-bn-apply-fusion", action="store_true", help="A/B: BatchNorm forward as finalize launch + apply launch for every layer (round 4)")
+    ap.add_argument("--no-bn-bwd-fusion", action="store_true", help="A/B: BatchNorm backward always as reduce launch + apply launch (rounds 1-4)")
+    ap.add_argument("--bn-apply-fusion", action="store_true", help="A/B: BatchNorm forward of the <= 128-tile tensors as one launch (cavp_bn_apply_tiles; default: finalize launch + apply launch)")
     ap.add_argument("--no-tail-split", action="store_true", help="A/B: never split a 256x256-tile launch with a nearly empty last round")
     ap.add_argument("--trainer-loop", action="store_true",
                     help="the reference trainer's call sequence instead of the fused step: out = model(image, audio) -> torch "
@@ -633,9 +634,12 @@ def main():
     if a.no_wgrad_stream:
         import cavp_amd.train as _tr
         _tr._WGRAD_STREAM = False
-    if a.no_bn_apply_fusion:
+    if a.no_bn_bwd_fusion:
         import cavp_amd.train as _tr
-        _tr._FUSE_BN_APPLY = False
+        _tr._FUSE_BN_BWD = False
+    if a.bn_apply_fusion:
+        import cavp_amd.train as _tr
+        _tr._FUSE_BN_APPLY = True
     if a.no_tail_split:
         from cavp_amd import _lib as _cl0
         _cl0.load().cavp_set_tail_split(0)

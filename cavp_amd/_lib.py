@@ -35,6 +35,13 @@ class WgradJob(C.Structure):
     _fields_ = [("desc", ConvDesc), ("x", C.c_void_p), ("dy", C.c_void_p), ("dw", C.c_void_p), ("dbias", C.c_void_p)]
 
 
+class BnBwdArgs(C.Structure):
+    """struct cavp_bnbwd_args (include/cavp_hip.h)."""
+    _fields_ = [("z", C.c_void_p), ("out", C.c_void_p), ("ld_z", C.c_int32), ("ld_out", C.c_int32), ("fwd_scale", C.c_void_p),
+                ("fwd_shift", C.c_void_p), ("mean", C.c_void_p), ("rstd", C.c_void_p), ("act", C.c_int32), ("pad_", C.c_int32),
+                ("partials", C.c_void_p), ("sum_g", C.c_void_p), ("sum_gz", C.c_void_p)]
+
+
 _vp, _i32, _i64, _f32, _sz = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_size_t
 
 # name -> (restype, argtypes): every symbol include/cavp_hip.h declares
@@ -91,11 +98,16 @@ PROTOTYPES = {
     "cavp_bn_apply_tiles_supported": (_i32, [_i32]),
     "cavp_bn_apply_tiles": (_i32, [_i32, _vp, _i32, _i32, _i64, _vp, _vp, _f32, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64,
                                    _i32, _i32, _i32, _i32, _i32, _vp]),
+    "cavp_conv2d_bnbwd_layout": (_i32, [_vp, _vp, _vp]),
+    "cavp_conv2d_nhwc_bnbwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "cavp_bn_bwd_sum_tiles": (_i32, [_vp, _i32, _i32, _vp, _vp, _vp]),
     "cavp_scale_shift_act": (_i32, [_i32, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _vp]),
     "cavp_bn_act_bwd_reduce": (_i32, [_i32, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp,
                                       _vp]),
     "cavp_bn_act_bwd_apply": (_i32, [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32,
                                      _vp, _i32, _vp, _i32, _vp, _vp, _vp]),
+    "cavp_bn_act_bwd_apply_acc": (_i32, [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32,
+                                         _vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp]),
     "cavp_act_bwd": (_i32, [_i32, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _vp]),
     "cavp_add": (_i32, [_i32, _vp, _vp, _vp, _i64, _vp]),
     "cavp_colsum": (_i32, [_i32, _vp, _i64, _i32, _i32, _vp, _vp]),

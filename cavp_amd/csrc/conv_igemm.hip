@@ -101,8 +101,10 @@ extern "C" int cavp_prof_igemm_timeline(unsigned long long* out8) {
 #define CAVP_TLI(stmt) do { } while (0)
 #endif
 
-template <typename T, int BC, int BP, int WC, int WP, bool UP, int NS>
-__global__ __launch_bounds__(64 * WC * WP, (WC * WP == 4 ? 2 : 1)) void igemm_kernel(const IgemmParams p) {
+// BNB: the instantiation whose staged epilogue carries the BatchNorm-backward statistics (IgemmParams.bnb_*).  A template flag, not a
+// run-time one: as a run-time branch the extra live ranges cost the plain launches 40 .. 230 spilled VGPRs per kernel.
+template <typename T, int BC, int BP, int WC, int WP, bool UP, int NS, bool BNB = false>
+__global__ __launch_bounds__(64 * WC * WP, (WC * WP == 4 ? (BC * BP <= 64 * 64 && sizeof(T) == 2 ? 4 : 2) : 1)) void igemm_kernel(const IgemmParams p) {
   constexpr int VE = Elem<T>::VE;
   constexpr int BK = 8 * VE;  // one 128-byte LDS row of K
   constexpr int TC = BC / WC, TP = BP / WP;
@@ -564,7 +566,7 @@ __global__ __launch_bounds__(64 * WC * WP, (WC * WP == 4 ? 2 : 1)) void igemm_ke
     float sc[VE], sh[VE];
 #pragma unroll
     for (int e = 0; e < VE; ++e) { sc[e] = 1.f; sh[e] = 0.f; }
-    if (ec_ok) {
+    if (!BNB && ec_ok) {
       if (p.scale) {
 #pragma unroll
         for (int q = 0; q < VE / 4; ++q) {
@@ -583,21 +585,26 @@ __global__ __launch_bounds__(64 * WC * WP, (WC * WP == 4 ? 2 : 1)) void igemm_ke
     // The residual of the thread's first G chunks is requested HERE, before the statistics and the staging round trip: issued
     // behind the staging barrier (rounds 1-4) every tile waited out one full memory latency (~2000 cycles of the ~14000-cycle
     // epilogue of a 128 x 128 bottleneck-output tile, profiles/r05_igemm_tile_timeline.txt) with nothing else to do.
-    constexpr int G = ITER < 8 ? ITER : 8;  // chunks finished per batch: all residual loads of a batch fly together
+    // chunks finished per batch: all residual loads of a batch fly together (the BatchNorm-backward instantiations also fetch z
+    // and the activation output per chunk: half-size batches keep them in registers)
+    constexpr int G = BNB ? (ITER < 4 ? ITER : 4) : (ITER < 8 ? ITER : 8);
     static_assert(ITER % G == 0, "chunk batches");
     const T* rp = p.res ? (const T*)p.res + (size_t)((p.res_rows ? p_base % p.res_rows : p_base) + eprow0) * p.ldr + ec : nullptr;
     const size_t rstep = (size_t)RSTR * p.ldr;
     const int rows_left = p.M - (p_base + eprow0);   // chunk k is in range iff k * RSTR < rows_left
-    u32x4_t rr0[G];
-    if (rp) {
+    // (not for the tiles with 64 accumulator registers per lane: hoisting a batch spilled 34 VGPRs in the 128 x 128 kernel, half a
+    // batch still 7)
+    constexpr int GH = (MC * MP * 4 >= 64) ? 0 : G;
+    u32x4_t rr0[GH > 0 ? GH : 1];
+    if (GH > 0 && rp) {
 #pragma unroll
-      for (int g = 0; g < G; ++g) {
+      for (int g = 0; g < GH; ++g) {
         rr0[g] = (u32x4_t){0u, 0u, 0u, 0u};
         if (ec_ok && g * RSTR < rows_left) rr0[g] = *(const u32x4_t*)(rp + (size_t)g * rstep);
       }
     }
     float2* wstat = (float2*)(smem + NS * TILE_BYTES);   // [WP][BC] per-wave (mean, M2) partials (launch_cfg adds the bytes)
-    if (p.tile_stats) {
+    if (!BNB && p.tile_stats) {
       // BatchNorm batch statistics for free, straight from the f32 accumulators IN REGISTERS: a lane holds 4 channels x MP
       // pixels per 16-row block; sums of (x - x0) and (x - x0)^2 about the wave's first row x0 (a sample of the same
       // distribution, so the one-pass form does not cancel), reduced over the 16 row lanes with DPP adds.  The WP waves
@@ -647,7 +654,7 @@ __global__ __launch_bounds__(64 * WC * WP, (WC * WP == 4 ? 2 : 1)) void igemm_ke
         if (!CAVP_DBG(p, 64)) *(f32x4_t*)(st + (size_t)prow * BC + ((slot ^ (prow & SWZ)) << 2)) = acc[a][b];
       }
     __syncthreads();
-    if (p.tile_stats && tid < BC && c_base + tid < p.Cout) {  // (BC <= NT for every tile)
+    if (!BNB && p.tile_stats && tid < BC && c_base + tid < p.Cout) {  // (BC <= NT for every tile)
       float n = 0.f, mean = 0.f, m2 = 0.f;
 #pragma unroll
       for (int w = 0; w < WP; ++w) {
@@ -674,18 +681,53 @@ __global__ __launch_bounds__(64 * WC * WP, (WC * WP == 4 ? 2 : 1)) void igemm_ke
     const float* lds1 = VE == 8 ? st + (size_t)eprow0 * BC + (((ecc / 4 + 1) ^ key) << 2) : lds0;  // second (bf16 only)
     T* yp = (T*)p.y + (size_t)(p_base + eprow0) * p.ldy + ec;
     // (res_rows: a multiple of every tile height, so a tile never straddles the wrap)
-    T* xp = p.aux_mode ? (T*)p.aux + (size_t)(p_base + eprow0) * p.ld_aux + ec : nullptr;
+    T* xp = (!BNB && p.aux_mode) ? (T*)p.aux + (size_t)(p_base + eprow0) * p.ld_aux + ec : nullptr;
     const size_t xstep = (size_t)RSTR * p.ld_aux;
     const size_t ystep = (size_t)RSTR * p.ldy;
-    const bool has_ss = p.scale != nullptr || p.shift != nullptr;
+    const bool has_ss = !BNB && (p.scale != nullptr || p.shift != nullptr);   // (BNB launches: plain data gradients)
+    // BatchNorm-backward statistics (IgemmParams.bnb_*): the thread's channel group is fixed, so its mask / zhat coefficients and
+    // its two running sums live in registers over all its chunks (loaded here, behind the staging barrier: the accumulators are
+    // dead, their registers free)
+    constexpr bool bnb = BNB;
+    const T* zp = bnb ? (const T*)p.bnb_z + (size_t)(p_base + eprow0) * p.ld_bnb_z + ec : nullptr;
+    const T* op = (bnb && p.bnb_out) ? (const T*)p.bnb_out + (size_t)(p_base + eprow0) * p.ld_bnb_out + ec : nullptr;
+    const size_t zstep = (size_t)RSTR * p.ld_bnb_z, ostep = (size_t)RSTR * p.ld_bnb_out;
+    // (sum g * zhat = rstd * (sum g * z - mean * sum g): mean / rstd enter once per thread behind the chunk loop - a thread sums at
+    // most 8 rows, so this costs no accuracy against (z - mean) per element - and are not live inside it)
+    // (f32, the parity path: 4 channels per thread, so the batch mean stays in registers and g * (z - mean) is formed per element)
+    float bfs[VE], bfh[VE], bs0[VE], bs1[VE], bmu[sizeof(T) == 4 ? VE : 1];
+#pragma unroll
+    for (int e = 0; e < VE; ++e) { bfs[e] = 1.f; bfh[e] = 0.f; bs0[e] = 0.f; bs1[e] = 0.f; }
+    if constexpr (sizeof(T) == 4) {
+#pragma unroll
+      for (int e = 0; e < VE; ++e) bmu[e] = (bnb && ec_ok) ? p.bnb_mean[ec + e] : 0.f;
+    }
+    if (bnb && ec_ok) {   // (bnb: compile-time)
+      if (!op && p.bnb_act != CAVP_ACT_NONE) {
+#pragma unroll
+        for (int e = 0; e < VE; ++e) { bfs[e] = p.bnb_scale[ec + e]; bfh[e] = p.bnb_shift[ec + e]; }
+      }
+    }
     for (int i0 = 0; i0 < ITER; i0 += G) {
       u32x4_t rr[G];
       if (rp) {
 #pragma unroll
         for (int g = 0; g < G; ++g) {
-          if (i0 == 0) { rr[g] = rr0[g]; continue; }
+          if (GH > 0 && i0 == 0 && g < GH) { rr[g] = rr0[g < GH ? g : 0]; continue; }
           rr[g] = (u32x4_t){0u, 0u, 0u, 0u};
           if (ec_ok && (i0 + g) * RSTR < rows_left) rr[g] = *(const u32x4_t*)(rp + (size_t)(i0 + g) * rstep);
+        }
+      }
+      u32x4_t zz[G], oo[G];
+      if constexpr (bnb) {
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+          zz[g] = (u32x4_t){0u, 0u, 0u, 0u};
+          oo[g] = (u32x4_t){0u, 0u, 0u, 0u};
+          if (ec_ok && (i0 + g) * RSTR < rows_left) {
+            zz[g] = *(const u32x4_t*)(zp + (size_t)(i0 + g) * zstep);
+            if (op) oo[g] = *(const u32x4_t*)(op + (size_t)(i0 + g) * ostep);
+          }
         }
       }
 #pragma unroll
@@ -701,7 +743,7 @@ __global__ __launch_bounds__(64 * WC * WP, (WC * WP == 4 ? 2 : 1)) void igemm_ke
           const f32x4_t t = *(const f32x4_t*)(lds1 + (size_t)k * RSTR * BC);
           v[4] = t[0]; v[5] = t[1]; v[6] = t[2]; v[7] = t[3];
         }
-        if (p.nbias) {
+        if (!BNB && p.nbias) {
           const float* nb = p.nbias + (size_t)fast_div(p_base + eprow0 + k * RSTR, p.div_hw_m, p.div_hw_s) * p.Cout + ec;
 #pragma unroll
           for (int e = 0; e < VE; ++e) v[e] += nb[e];
@@ -710,7 +752,7 @@ __global__ __launch_bounds__(64 * WC * WP, (WC * WP == 4 ? 2 : 1)) void igemm_ke
 #pragma unroll
           for (int e = 0; e < VE; ++e) v[e] = __fadd_rn(__fmul_rn(v[e], sc[e]), sh[e]);  // two roundings, as every other epilogue path
         }
-        if (p.aux_mode == 2) {   // d(pre) = d(hidden) * gelu'(pre): the multiplier tensor of the forward (aux_mode 1)
+        if (!BNB && p.aux_mode == 2) {   // d(pre) = d(hidden) * gelu'(pre): the multiplier tensor of the forward (aux_mode 1)
           float m[VE];
           VecT<T>::load(xp + (size_t)k * xstep, m);
 #pragma unroll
@@ -728,13 +770,39 @@ __global__ __launch_bounds__(64 * WC * WP, (WC * WP == 4 ? 2 : 1)) void igemm_ke
             }
           }
         }
-        if (p.aux_mode == 1) {   // GELU forward: the derivative goes to aux, the pre-activation is never stored
+        if constexpr (bnb) {   // v = gradient of the BatchNorm + activation output: g = v * act'(.), sums of g and g * zhat
+          float zf[VE], yf[VE];
+          if constexpr (sizeof(T) == 4) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { zf[e] = __uint_as_float(zz[g][e]); yf[e] = __uint_as_float(oo[g][e]); }
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              zf[2 * e] = __uint_as_float(zz[g][e] << 16); zf[2 * e + 1] = __uint_as_float(zz[g][e] & 0xffff0000u);
+              yf[2 * e] = __uint_as_float(oo[g][e] << 16); yf[2 * e + 1] = __uint_as_float(oo[g][e] & 0xffff0000u);
+            }
+          }
+          if (!op) {
+#pragma unroll
+            for (int e = 0; e < VE; ++e) yf[e] = zf[e] * bfs[e] + bfh[e];   // same expression (and contraction) as scale_shift_act
+          }
+#pragma unroll
+          for (int e = 0; e < VE; ++e) {
+            const float gm = p.bnb_act == CAVP_ACT_RELU ? (yf[e] > 0.f ? 1.f : 0.f) : (p.bnb_act == CAVP_ACT_LEAKY ? (yf[e] > 0.f ? 1.f : 0.01f) : 1.f);
+            const float gv = v[e] * gm;
+            bs0[e] += gv;
+            if constexpr (sizeof(T) == 4) bs1[e] = fmaf(gv, zf[e] - bmu[e], bs1[e]);
+            else bs1[e] = fmaf(gv, zf[e], bs1[e]);
+            v[e] = gv;
+          }
+        }
+        if (!BNB && p.aux_mode == 1) {   // GELU forward: the derivative goes to aux, the pre-activation is never stored
           float m[VE];
 #pragma unroll
           for (int e = 0; e < VE; ++e) gelu_and_grad(v[e], v[e], m[e]);
           VecT<T>::store(xp + (size_t)k * xstep, m);
         } else {
-          apply_act_vec<VE>(v, p.act);
+          if constexpr (!BNB) apply_act_vec<VE>(v, p.act);
         }
         u32x4_t o;
         if constexpr (sizeof(T) == 4) {
@@ -745,6 +813,33 @@ __global__ __launch_bounds__(64 * WC * WP, (WC * WP == 4 ? 2 : 1)) void igemm_ke
           for (int e = 0; e < 4; ++e) o[e] = pack2bf(v[2 * e], v[2 * e + 1]);
         }
         if (!CAVP_DBG(p, 32) || o[0] == 0x12345678u) *(u32x4_t*)(yp + (size_t)k * ystep) = o;
+      }
+    }
+    if constexpr (bnb) {
+      // the NT / CH threads of a channel group -> one pair per channel and pixel tile, in a fixed order (deterministic, no atomics);
+      // the staging buffer is free once every thread has read its chunks
+      __syncthreads();
+      float* red = (float*)smem;   // [RSTR][BC][2]
+#pragma unroll
+      for (int e = 0; e < VE; ++e) {
+        const float mu = ec_ok ? p.bnb_mean[ec + e] : 0.f, rs = ec_ok ? p.bnb_rstd[ec + e] : 0.f;
+        red[((size_t)eprow0 * BC + ecc + e) * 2] = bs0[e];
+        red[((size_t)eprow0 * BC + ecc + e) * 2 + 1] = sizeof(T) == 4 ? rs * bs1[e] : rs * (bs1[e] - mu * bs0[e]);
+      }
+      __syncthreads();
+      if (tid < BC && c_base + tid < p.Cout) {
+        float a0 = 0.f, a1 = 0.f;
+#pragma unroll 4
+        for (int r = 0; r < RSTR; ++r) {
+          const float2 q = *(const float2*)(red + ((size_t)r * BC + tid) * 2);
+          a0 += q.x; a1 += q.y;
+        }
+        if (p.bnb_part) {
+          *(float2*)(p.bnb_part + ((size_t)tp * p.Cout + c_base + tid) * 2) = make_float2(a0, a1);
+        } else {   // (no return value: fire and forget)
+          atomicAdd(p.bnb_sum_g + c_base + tid, a0);
+          atomicAdd(p.bnb_sum_gz + c_base + tid, a1);
+        }
       }
     }
     continue;
@@ -833,6 +928,7 @@ const TileCfg kTiles[] = {
 };
 inline int tile_stages(int id) { return id == 12 ? 8 : id >= 11 ? 4 : id == 10 ? 2 : id >= 8 ? 3 : 2; }
 inline bool tile_is_big(int id) { return id == 10; }
+inline bool tile_has_bnb(int id) { return id == 1 || id == 2 || id == 3 || id == 4 || id == 11 || id == 13 || id == 14; }   // launch_tile
 inline int tile_wp(int id) { return id == 5 ? 1 : (id == 6 || id == 7 || id == 9) ? 4 : 2; }   // waves along the pixel dimension (launch_tile)
 // A/B knob: CAVP_IGEMM_EFF="e1,e2,...,e9" overrides the efficiency column of kTiles (time-model sweeps without a rebuild)
 inline double tile_eff(const TileCfg& t) {
@@ -853,14 +949,14 @@ inline double tile_eff(const TileCfg& t) {
 }
 constexpr int kNumTiles = sizeof(kTiles) / sizeof(kTiles[0]);
 
-template <typename T, int BC, int BP, int WC, int WP, bool UP, int NS = 2>
+template <typename T, int BC, int BP, int WC, int WP, bool UP, int NS = 2, bool BNB = false>
 hipError_t launch_cfg(const IgemmParams& p, int nblk, hipStream_t s) {
   constexpr int lds = NS * (BC + BP) * 128 + WP * BC * 8;   // + the per-wave BatchNorm-statistics partials
   static_assert(BP * BC * 4 <= NS * (BC + BP) * 128, "epilogue staging must fit in the K-loop LDS");
   static_assert(BC <= 64 * WC * WP, "tile_stats: one thread per output channel of the tile");
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)igemm_kernel<T, BC, BP, WC, WP, UP, NS>,
+    (void)hipFuncSetAttribute((const void*)igemm_kernel<T, BC, BP, WC, WP, UP, NS, BNB>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr_set = true;
   }
@@ -873,12 +969,24 @@ hipError_t launch_cfg(const IgemmParams& p, int nblk, hipStream_t s) {
   const int grid = (persistent && nblk > bpc * 256) ? bpc * 256 : nblk;
   IgemmParams q = p;
   q.nblk = nblk;
-  igemm_kernel<T, BC, BP, WC, WP, UP, NS><<<dim3(grid), dim3(64 * WC * WP), lds, s>>>(q);
+  igemm_kernel<T, BC, BP, WC, WP, UP, NS, BNB><<<dim3(grid), dim3(64 * WC * WP), lds, s>>>(q);
   return hipGetLastError();
 }
 
 template <typename T, bool UP>
 hipError_t launch_tile(int id, const IgemmParams& p, int nblk, hipStream_t s) {
+  if (p.bnb_z) {   // BatchNorm-backward statistics: the tiles the backbone's data gradients run on (tile_has_bnb)
+    switch (id) {
+      case 1: return launch_cfg<T, 128, 128, 2, 2, UP, 2, true>(p, nblk, s);
+      case 2: return launch_cfg<T, 64, 128, 2, 2, UP, 2, true>(p, nblk, s);
+      case 3: return launch_cfg<T, 64, 64, 2, 2, UP, 2, true>(p, nblk, s);
+      case 4: return launch_cfg<T, 128, 64, 2, 2, UP, 2, true>(p, nblk, s);
+      case 11: return launch_cfg<T, 64, 64, 2, 2, UP, 4, true>(p, nblk, s);
+      case 13: return launch_cfg<T, 128, 64, 2, 2, UP, 4, true>(p, nblk, s);
+      case 14: return launch_cfg<T, 64, 128, 2, 2, UP, 4, true>(p, nblk, s);
+      default: return hipErrorInvalidValue;
+    }
+  }
   switch (id) {
     case 1: return launch_cfg<T, 128, 128, 2, 2, UP>(p, nblk, s);
     case 2: return launch_cfg<T, 64, 128, 2, 2, UP>(p, nblk, s);
@@ -1172,7 +1280,7 @@ extern "C" int cavp_conv2d_nhwc(const cavp_conv_desc* d, const void* x, const vo
 static int conv2d_launch(const cavp_conv_desc* d, const void* x, const void* w, const float* scale, const float* shift,
                          const float* nbias, const void* residual, void* y, void* aux, void* workspace, size_t workspace_bytes,
                          float* tile_stats, void* stream,
-                         bool allow_split = true);
+                         bool allow_split = true, const cavp_bnbwd_args* bnb = nullptr);
 
 extern "C" int cavp_conv2d_nhwc_aux(const cavp_conv_desc* d, const void* x, const void* w, const float* scale,
                                     const float* shift, const float* nbias, const void* residual, void* y, void* aux,
@@ -1180,10 +1288,34 @@ extern "C" int cavp_conv2d_nhwc_aux(const cavp_conv_desc* d, const void* x, cons
   return conv2d_launch(d, x, w, scale, shift, nbias, residual, y, aux, workspace, workspace_bytes, tile_stats, stream);
 }
 
+// Launches that can carry the fused BatchNorm-backward statistics: the LDS-staged epilogue of the 4-wave tiles, unsplit (the same
+// condition as the forward's fused statistics, minus the 256 x 256 tile, whose epilogue has no registers to spare).  Returns 1 and
+// the geometry of the partial sums, else 0 (caller: cavp_bn_act_bwd_reduce as before).
+extern "C" int cavp_conv2d_bnbwd_layout(const cavp_conv_desc* d, int32_t* tiles, int32_t* rows_per_tile) {
+  if (!d || d->aux_mode != 0 || d->res_rows != 0) return 0;
+  Plan pl = make_plan(d);
+  if (pl.status != CAVP_OK || !tile_has_bnb(pl.tile_id)) return 0;
+  return cavp_conv2d_tile_stats_layout(d, tiles, rows_per_tile);
+}
+
+extern "C" int cavp_conv2d_nhwc_bnbwd(const cavp_conv_desc* d, const void* x, const void* w, const void* residual, void* y,
+                                      const cavp_bnbwd_args* b, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!d || !b || !b->z || !b->mean || !b->rstd || (!b->partials && !(b->sum_g && b->sum_gz)) || d->aux_mode != 0 || d->res_rows != 0 || d->act != CAVP_ACT_NONE)
+    return CAVP_ERR_BAD_ARG;
+  if (b->act != CAVP_ACT_NONE && b->act != CAVP_ACT_RELU && b->act != CAVP_ACT_LEAKY) return CAVP_ERR_UNSUPPORTED;
+  if (!b->out && b->act != CAVP_ACT_NONE && (!b->fwd_scale || !b->fwd_shift)) return CAVP_ERR_BAD_ARG;
+  const int VE = d->dtype == CAVP_F32 ? 4 : 8;
+  if (b->ld_z < d->Cout || b->ld_z % VE || !aligned(b->z, 16) || (b->out && (b->ld_out < d->Cout || b->ld_out % VE || !aligned(b->out, 16))))
+    return CAVP_ERR_ALIGN;
+  int32_t tiles = 0, rpt = 0;
+  if (!cavp_conv2d_bnbwd_layout(d, &tiles, &rpt)) return CAVP_ERR_UNSUPPORTED;
+  return conv2d_launch(d, x, w, nullptr, nullptr, nullptr, residual, y, nullptr, workspace, workspace_bytes, nullptr, stream, false, b);
+}
+
 static int conv2d_launch(const cavp_conv_desc* d, const void* x, const void* w, const float* scale, const float* shift,
                          const float* nbias, const void* residual, void* y, void* aux, void* workspace, size_t workspace_bytes,
                          float* tile_stats, void* stream,
-                         bool allow_split) {
+                         bool allow_split, const cavp_bnbwd_args* bnb) {
   if (!d || !x || !w || !y) return CAVP_ERR_BAD_ARG;
   const bool fused = d->aux_mode != 0 || (residual && d->res_rows > 0);
   if (d->aux_mode < 0 || d->aux_mode > 2 || (d->aux_mode != 0) != (aux != nullptr) || (d->aux_mode == 1 && d->act != CAVP_ACT_GELU) ||
@@ -1244,6 +1376,13 @@ static int conv2d_launch(const cavp_conv_desc* d, const void* x, const void* w, 
                 (!shift || aligned(shift, 16));
   p.tile_stats = tile_stats;
   p.reg_epi = g_reg_epilogue && d->dtype == CAVP_BF16;
+  if (bnb) {
+    if (!p.coalesced || !tile_has_bnb(pl.tile_id)) return CAVP_ERR_UNSUPPORTED;   // see cavp_conv2d_bnbwd_layout
+    p.reg_epi = 0;
+    p.bnb_z = bnb->z; p.bnb_out = bnb->out; p.ld_bnb_z = bnb->ld_z; p.ld_bnb_out = bnb->ld_out;
+    p.bnb_scale = bnb->fwd_scale; p.bnb_shift = bnb->fwd_shift; p.bnb_mean = bnb->mean; p.bnb_rstd = bnb->rstd;
+    p.bnb_act = bnb->act; p.bnb_part = bnb->partials; p.bnb_sum_g = bnb->sum_g; p.bnb_sum_gz = bnb->sum_gz;
+  }
   p.aux = aux; p.aux_mode = d->aux_mode; p.ld_aux = d->ld_aux; p.res_rows = residual ? d->res_rows : 0;
   if (fused && !(p.coalesced && (!aux || (d->ld_aux % VE == 0 && aligned(aux, 16))))) return CAVP_ERR_UNSUPPORTED;
   if (p.res_rows > 0 && (long long)p.res_rows > p.M) return CAVP_ERR_BAD_ARG;

@@ -36,6 +36,19 @@ struct IgemmParams {
   int aux_mode, ld_aux;
   int res_rows;             // 0, or: output pixel p adds residual row p % res_rows (a multiple of 256)
   int reg_epi;              // bf16, 4-wave tiles: epilogue straight from the accumulator registers (v_permlane16_swap), no LDS staging
+  // BatchNorm-backward statistics fused into a data-gradient launch (cavp_conv2d_nhwc_bnbwd; staged 4-wave epilogue only): the launch
+  // produces the gradient of a BatchNorm + activation OUTPUT; the epilogue multiplies it by the activation's derivative, stores
+  // g = dy * act'(.) and emits per pixel tile the two sums the BatchNorm backward needs (sum g, sum g * zhat)
+  const void* bnb_z;        // the BatchNorm's input z (y's shape, pixel stride ld_bnb_z); nullptr = plain launch
+  const void* bnb_out;      // the activation's output (mask source), or nullptr: the mask is re-derived from z * bnb_scale + bnb_shift
+  const float* bnb_scale;   // the forward's folded scale / shift (mask without bnb_out)
+  const float* bnb_shift;
+  const float* bnb_mean;    // batch mean / 1 / sqrt(var + eps) of z: zhat = (z - mean) * rstd
+  const float* bnb_rstd;
+  float* bnb_part;          // f32 [tiles_p][Cout][2], or nullptr with bnb_sum_g / bnb_sum_gz:
+  float* bnb_sum_g;         // f32 [Cout] each: the tile sums are ADDED there with f32 atomics (pre-zeroed scratch; order not fixed)
+  float* bnb_sum_gz;
+  int ld_bnb_z, ld_bnb_out, bnb_act, pad2_;
 };
 
 template <typename T> struct Mma;

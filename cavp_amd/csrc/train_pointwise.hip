@@ -553,11 +553,14 @@ __global__ __launch_bounds__(256) void bn_apply_tiles_kernel(const float* __rest
     const int ch = threadIdx.x % CW, pt = threadIdx.x / CW;
     const int cc = blockIdx.y * CW + ch;
     const bool ok = cc < g.C;
+    // branch-free: every slot loads (a clamped tile of a clamped channel), dead slots get weight 0 below - the first version's
+    // predicated loads were issued one at a time (3 us for 49 tiles, 6 for 98: profiles/r05_bn_apply_microbench.txt)
     float2 q[QN];
+    const int ccl = ok ? cc : g.C - 1;
 #pragma unroll
     for (int u = 0; u < QN; ++u) {
       const int t = pt + NP * u;
-      q[u] = (ok && t < tiles) ? *(const float2*)(ts + ((size_t)t * g.C + cc) * 2) : make_float2(0.f, 0.f);
+      q[u] = *(const float2*)(ts + ((size_t)(t < tiles ? t : tiles - 1) * g.C + ccl) * 2);
     }
     // rows of tile t: rows_per_tile, the last tile the remainder, past the end 0
     const int last = tiles - 1;
@@ -576,8 +579,8 @@ __global__ __launch_bounds__(256) void bn_apply_tiles_kernel(const float* __rest
     float m2 = 0.f;
 #pragma unroll
     for (int u = 0; u < QN; ++u) {
-      const float d = q[u].x - mean;
-      m2 += q[u].y + nrows(pt + NP * u) * d * d;
+      const float d = q[u].x - mean, nr = nrows(pt + NP * u);
+      m2 += (nr > 0.f ? q[u].y : 0.f) + nr * d * d;
     }
     part[pt][ch] = m2;
     __syncthreads();
@@ -662,7 +665,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_flat_kernel(const T* __restr
                                                                 T* __restrict__ dz, T* __restrict__ g_out, long long rows,
                                                                 int rows_per_block, int CV, int ld_dy, int ld_y, int ld_z,
                                                                 int ld_dz, int ld_g, int act, const float* __restrict__ fscale,
-                                                                const float* __restrict__ fshift) {
+                                                                const float* __restrict__ fshift, float* acc_g, float* acc_gz) {
   constexpr int VE = VecT<T>::VE;
   const int cv = threadIdx.x % CV, rsub = threadIdx.x / CV, RPB = 256 / CV;
   const int c = cv * VE;
@@ -682,6 +685,12 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_flat_kernel(const T* __restr
       ca[e] = a;
       cb[e] = -a * rs[e] * sgz[e] * inv_m;
       cc[e] = -a * sg[e] * inv_m - cb[e] * mu[e];
+    }
+    // the sums ARE the affine gradients (dbeta = sum g, dgamma = sum g * zhat): when they arrive in scratch (summed by the
+    // data-gradient launch's epilogue, cavp_conv2d_nhwc_bnbwd) one thread per channel vector adds them to the parameter gradients
+    if (acc_g && blockIdx.x == 0 && rsub == 0) {
+#pragma unroll
+      for (int e = 0; e < VE; ++e) { acc_g[c + e] += sg[e]; acc_gz[c + e] += sgz[e]; }
     }
   }
   const bool from_z = y == nullptr;   // activation mask re-derived from z (layers without a residual): y is not read
@@ -726,7 +735,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
                                                            const float* __restrict__ sum_gz, float inv_m, T* __restrict__ dz,
                                                            T* __restrict__ g_out, RowLoop gm, int ld_dy, int ld_y,
                                                            int ld_z, int ld_dz, int ld_g, int act, const float* __restrict__ fscale,
-                                                                const float* __restrict__ fshift) {
+                                                                const float* __restrict__ fshift, float* acc_g, float* acc_gz) {
   constexpr int VE = VecT<T>::VE;
   const int cg = threadIdx.x & 15, rl = threadIdx.x >> 4;
   const int c = (blockIdx.y * 16 + cg) * VE;
@@ -738,6 +747,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
     ca[e] = a;
     cb[e] = -a * rs * sum_gz[c + e] * inv_m;
     cc[e] = -a * sum_g[c + e] * inv_m - cb[e] * mean[c + e];
+    if (acc_g && blockIdx.x == 0 && rl == 0) { acc_g[c + e] += sum_g[c + e]; acc_gz[c + e] += sum_gz[c + e]; }   // (see the flat kernel)
   }
   const bool from_z = y == nullptr;   // activation mask re-derived from z (layers without a residual): y is not read
   float fs[VE], fh[VE];
@@ -1691,6 +1701,46 @@ extern "C" int cavp_bn_apply_tiles(int32_t dtype, const float* tile_stats, int32
   CHECK_LAUNCH();
 }
 
+// Sum the per-tile (sum g, sum g * zhat) pairs a data-gradient launch wrote (cavp_conv2d_nhwc_bnbwd) over the tiles: 256 threads =
+// 16 channels x 16 tile lanes (a tile row of 16 channels is 128 contiguous bytes), lane sums in ascending tile order, then a fixed
+// tree over the 16 lanes through LDS.  Adds into sum_g / sum_gz (the BatchNorm's affine-gradient buffers).
+__global__ __launch_bounds__(256) void bn_bwd_sum_tiles_kernel(const float* __restrict__ part, int tiles, int C, float* __restrict__ sum_g,
+                                                               float* __restrict__ sum_gz) {
+  __shared__ float2 red[16][17];
+  const int ch = threadIdx.x & 15, tl = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + ch;
+  float a0 = 0.f, a1 = 0.f;
+  if (c < C) {
+    int t = tl;
+    for (; t + 16 * 7 < tiles; t += 16 * 8) {   // 8 loads in flight per thread
+      float2 q[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) q[u] = *(const float2*)(part + ((size_t)(t + 16 * u) * C + c) * 2);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { a0 += q[u].x; a1 += q[u].y; }
+    }
+    for (; t < tiles; t += 16) {
+      const float2 q = *(const float2*)(part + ((size_t)t * C + c) * 2);
+      a0 += q.x; a1 += q.y;
+    }
+  }
+  red[tl][ch] = make_float2(a0, a1);
+  __syncthreads();
+  if (tl == 0 && c < C) {
+    float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { s0 += red[k][ch].x; s1 += red[k][ch].y; }
+    sum_g[c] += s0;
+    sum_gz[c] += s1;
+  }
+}
+
+extern "C" int cavp_bn_bwd_sum_tiles(const float* partials, int32_t tiles, int32_t C, float* sum_g, float* sum_gz, void* stream) {
+  if (!partials || !sum_g || !sum_gz || tiles <= 0 || C <= 0) return CAVP_ERR_BAD_ARG;
+  bn_bwd_sum_tiles_kernel<<<(C + 15) / 16, 256, 0, (hipStream_t)stream>>>(partials, tiles, C, sum_g, sum_gz);
+  CHECK_LAUNCH();
+}
+
 extern "C" int cavp_bn_act_bwd_reduce(int32_t dtype, const void* dy, const void* y, const void* z, const float* mean,
                                       const float* rstd, int64_t rows, int32_t C, int32_t ld_dy, int32_t ld_y,
                                       int32_t ld_z, int32_t act, float* sum_g, float* sum_gz, const float* fwd_scale,
@@ -1708,12 +1758,26 @@ extern "C" int cavp_bn_act_bwd_reduce(int32_t dtype, const void* dy, const void*
   return launch_col_reduce<1>(dtype, a, (hipStream_t)stream);
 }
 
+extern "C" int cavp_bn_act_bwd_apply_acc(int32_t dtype, const void* dy, const void* y, const void* z, const float* mean,
+                                         const float* rstd, const float* gamma, const float* sum_g, const float* sum_gz,
+                                         int64_t rows, int32_t C, int32_t ld_dy, int32_t ld_y, int32_t ld_z, int32_t act,
+                                         void* dz, int32_t ld_dz, void* g_out, int32_t ld_g, const float* fwd_scale,
+                                         const float* fwd_shift, float* dbeta_acc, float* dgamma_acc, void* stream);
 extern "C" int cavp_bn_act_bwd_apply(int32_t dtype, const void* dy, const void* y, const void* z, const float* mean,
                                      const float* rstd, const float* gamma, const float* sum_g, const float* sum_gz,
                                      int64_t rows, int32_t C, int32_t ld_dy, int32_t ld_y, int32_t ld_z, int32_t act,
                                      void* dz, int32_t ld_dz, void* g_out, int32_t ld_g, const float* fwd_scale,
                                      const float* fwd_shift, void* stream) {
-  if (!dy || !z || !mean || !rstd || !gamma || !sum_g || !sum_gz || !dz || rows <= 0 || C <= 0)
+  return cavp_bn_act_bwd_apply_acc(dtype, dy, y, z, mean, rstd, gamma, sum_g, sum_gz, rows, C, ld_dy, ld_y, ld_z, act, dz, ld_dz, g_out,
+                                   ld_g, fwd_scale, fwd_shift, nullptr, nullptr, stream);
+}
+
+extern "C" int cavp_bn_act_bwd_apply_acc(int32_t dtype, const void* dy, const void* y, const void* z, const float* mean,
+                                         const float* rstd, const float* gamma, const float* sum_g, const float* sum_gz,
+                                         int64_t rows, int32_t C, int32_t ld_dy, int32_t ld_y, int32_t ld_z, int32_t act,
+                                         void* dz, int32_t ld_dz, void* g_out, int32_t ld_g, const float* fwd_scale,
+                                         const float* fwd_shift, float* dbeta_acc, float* dgamma_acc, void* stream) {
+  if (!dy || !z || !mean || !rstd || !gamma || !sum_g || !sum_gz || !dz || rows <= 0 || C <= 0 || (dbeta_acc == nullptr) != (dgamma_acc == nullptr))
     return CAVP_ERR_BAD_ARG;
   if (!y && act != CAVP_ACT_NONE && (!fwd_scale || !fwd_shift)) return CAVP_ERR_BAD_ARG;
   if (!dt_ok(dtype)) return CAVP_ERR_UNSUPPORTED;
@@ -1728,17 +1792,17 @@ extern "C" int cavp_bn_act_bwd_apply(int32_t dtype, const void* dy, const void* 
     const int rpb = flat_rows_per_block(rows, C, 16 / VE, CV, (long long)flat_kb << 10, 1 << 20);
     const int gx = (int)((rows + rpb - 1) / rpb);
     if (dtype == CAVP_F32)
-      bn_bwd_apply_flat_kernel<float><<<gx, 256, 0, s>>>((const float*)dy, (const float*)y, (const float*)z, mean, rstd, gamma, sum_g, sum_gz, inv_m, (float*)dz, (float*)g_out, rows, rpb, CV, ld_dy, ld_y, ld_z, ld_dz, ld_g, act, fwd_scale, fwd_shift);
+      bn_bwd_apply_flat_kernel<float><<<gx, 256, 0, s>>>((const float*)dy, (const float*)y, (const float*)z, mean, rstd, gamma, sum_g, sum_gz, inv_m, (float*)dz, (float*)g_out, rows, rpb, CV, ld_dy, ld_y, ld_z, ld_dz, ld_g, act, fwd_scale, fwd_shift, dbeta_acc, dgamma_acc);
     else
-      bn_bwd_apply_flat_kernel<bf16_t><<<gx, 256, 0, s>>>((const bf16_t*)dy, (const bf16_t*)y, (const bf16_t*)z, mean, rstd, gamma, sum_g, sum_gz, inv_m, (bf16_t*)dz, (bf16_t*)g_out, rows, rpb, CV, ld_dy, ld_y, ld_z, ld_dz, ld_g, act, fwd_scale, fwd_shift);
+      bn_bwd_apply_flat_kernel<bf16_t><<<gx, 256, 0, s>>>((const bf16_t*)dy, (const bf16_t*)y, (const bf16_t*)z, mean, rstd, gamma, sum_g, sum_gz, inv_m, (bf16_t*)dz, (bf16_t*)g_out, rows, rpb, CV, ld_dy, ld_y, ld_z, ld_dz, ld_g, act, fwd_scale, fwd_shift, dbeta_acc, dgamma_acc);
     CHECK_LAUNCH();
   }
   dim3 grid;
   const RowLoop g = row_loop_geometry(rows, C, VE, grid);
   if (dtype == CAVP_F32)
-    bn_bwd_apply_kernel<float><<<grid, 256, 0, s>>>((const float*)dy, (const float*)y, (const float*)z, mean, rstd, gamma, sum_g, sum_gz, inv_m, (float*)dz, (float*)g_out, g, ld_dy, ld_y, ld_z, ld_dz, ld_g, act, fwd_scale, fwd_shift);
+    bn_bwd_apply_kernel<float><<<grid, 256, 0, s>>>((const float*)dy, (const float*)y, (const float*)z, mean, rstd, gamma, sum_g, sum_gz, inv_m, (float*)dz, (float*)g_out, g, ld_dy, ld_y, ld_z, ld_dz, ld_g, act, fwd_scale, fwd_shift, dbeta_acc, dgamma_acc);
   else
-    bn_bwd_apply_kernel<bf16_t><<<grid, 256, 0, s>>>((const bf16_t*)dy, (const bf16_t*)y, (const bf16_t*)z, mean, rstd, gamma, sum_g, sum_gz, inv_m, (bf16_t*)dz, (bf16_t*)g_out, g, ld_dy, ld_y, ld_z, ld_dz, ld_g, act, fwd_scale, fwd_shift);
+    bn_bwd_apply_kernel<bf16_t><<<grid, 256, 0, s>>>((const bf16_t*)dy, (const bf16_t*)y, (const bf16_t*)z, mean, rstd, gamma, sum_g, sum_gz, inv_m, (bf16_t*)dz, (bf16_t*)g_out, g, ld_dy, ld_y, ld_z, ld_dz, ld_g, act, fwd_scale, fwd_shift, dbeta_acc, dgamma_acc);
   CHECK_LAUNCH();
 }
 

@@ -30,7 +30,8 @@ from ._lib import load as _lib_load
 class V:
     """An activation (NHWC / token / vector tensor) and its gradient.  A channel slice of a wider buffer is a child
     whose gradient is the matching slice of the parent's gradient (free concat in both directions)."""
-    __slots__ = ("t", "_g", "parent", "lo", "hi", "needs_grad", "tile_stats", "grad_mul", "g_premul", "dp_scale", "g_scaled")
+    __slots__ = ("t", "_g", "parent", "lo", "hi", "needs_grad", "tile_stats", "grad_mul", "g_premul", "dp_scale", "g_scaled",
+                 "bnb", "bnb_claim", "bnb_part")
 
     def __init__(self, t: torch.Tensor, parent: Optional["V"] = None, lo: int = 0, hi: int = 0, needs_grad: bool = True):
         self.t, self._g, self.parent, self.lo, self.hi, self.needs_grad = t, None, parent, lo, hi, needs_grad
@@ -42,6 +43,11 @@ class V:
         # LayerNorm backward - the branch's gradient factor * .g, written by that kernel as a second output (any later
         # accumulation into .g drops it again)
         self.dp_scale, self.g_scaled = None, None
+        # output of a local train-mode BatchNorm (+ residual) + ReLU (TrainPass.bn_act): what the data-gradient launch that completes
+        # this activation's gradient needs to fold the BatchNorm backward's two reductions into its epilogue (bnb), the first consumer
+        # in forward order = the last contributor in the backward (bnb_claim: that conv's token, or False), and - while .g is exactly
+        # what that launch wrote - its per-tile partial sums (bnb_part; any later accumulation into .g drops them)
+        self.bnb, self.bnb_claim, self.bnb_part = None, None, None
 
     @property
     def g(self) -> Optional[torch.Tensor]:
@@ -55,6 +61,7 @@ class V:
             raise CavpError("gradient of a slice is owned by its parent")
         self._g = g
         self.g_scaled = None
+        self.bnb_part = None
 
     def slice(self, lo: int, hi: int) -> "V":
         return V(self.t[..., lo:hi], parent=self, lo=lo, hi=hi)
@@ -276,7 +283,12 @@ _SIDE_STREAM = True      # False (tests / A-B only): the audio encoder on the ma
 # (cavp_conv2d_wgrad_group).  False (tests / A-B only): one launch (+ one slab reduce) per layer, where the layer's backward runs.
 _GROUP_WGRAD = True
 _WGRAD_STREAM = False    # False (tests / A-B only): grouped weight gradients on the main stream, between the data gradients (round 3)
-_FUSE_BN_APPLY = True    # False (tests / A-B only): BatchNorm forward always as finalize launch + apply launch (round 4)
+_FUSE_BN_BWD = True      # False (tests / A-B only): BatchNorm backward always as reduce launch + apply launch (rounds 1-4)
+_BNB_ATOMIC = False      # True (A/B only): the fused BatchNorm-backward sums by f32 atomics instead of per-tile partials + a summation launch
+_FUSE_BN_APPLY_MAX_TILES = 128
+_FUSE_BN_APPLY = False   # True (tests / A-B only): BatchNorm forward of tensors with <= _FUSE_BN_APPLY_MAX_TILES statistics tiles as ONE launch
+                         # (cavp_bn_apply_tiles).  Off: no gain for the 14 x 14 layers (profiles/r05_bn_apply_microbench.txt), and on the one
+                         # tensor where it saves 4 us - the pooled ASPP branch, B rows - its other summation order moves a B = 4 step by 2e-2
 _BN_BWD_READ_Y = False   # True (tests / A-B only): the BatchNorm backward always re-reads y instead of re-deriving the mask from z
 
 
@@ -415,12 +427,31 @@ class TrainPass:
         return t
 
     # ---- gradient accumulation -------------------------------------------------------------------------------
-    def acc(self, x: V, compute: Callable[[torch.Tensor, Optional[torch.Tensor]], None]) -> None:
-        """Run compute(out, residual) so that x.g += result (residual-add fused in the producing kernel)."""
+    def acc(self, x: V, compute: Callable[[torch.Tensor, Optional[torch.Tensor]], None], bnb_token=None) -> None:
+        """Run compute(out, residual) so that x.g += result (residual-add fused in the producing kernel).
+        bnb_token: the caller is a conv whose data gradient can carry the BatchNorm-backward statistics of x (compute accepts
+        bnb=...); used when this conv claimed x in the forward, i.e. when this contribution completes x.g."""
         if not x.needs_grad:
             return
         if x.parent is not None:
             raise CavpError("accumulating into a slice is not supported")
+        if bnb_token is not None and x.bnb is not None and x.bnb_claim is bnb_token and x.grad_mul is None:
+            if x.g is None:
+                g, r = self.empty(x.t.shape, x.t.dtype), None
+            elif self._pinned(x.g):
+                g, r = self.empty(x.t.shape, x.t.dtype), x.g
+            else:
+                g, r = x.g, x.g
+            bnb = x.bnb
+            if _BNB_ATOMIC and not _lib_load().cavp_get_deterministic():
+                # the tiles add their sums into pre-zeroed scratch with f32 atomics: no summation launch.  Measured SLOWER than the
+                # per-tile partials + the fixed-order sum (14.73 vs 14.55 ms per step: a 56 x 56 launch issues 200 k memory-side
+                # atomics), so it stays an A/B switch
+                bnb = dict(bnb, sums=self.zeros_f32(2, x.t.shape[-1]))
+            part = compute(g, r, bnb=bnb)   # (partials, tiles) / (sums, 0), or None: this launch could not carry them (g is the plain gradient)
+            x.set_g(g)
+            x.bnb_part = part
+            return
         if x.grad_mul is not None:
             # the single consumer of a fused-GELU hidden activation: d(pre) = d(hidden) * gelu'(pre) inside its epilogue
             if x.g is not None:
@@ -441,6 +472,12 @@ class TrainPass:
         else:
             compute(x.g, x.g)
             x.g_scaled = None
+            x.bnb_part = None
+
+    def _use(self, x: Optional[V]) -> None:
+        """A non-conv op consumes x: if it is the FIRST consumer of a BatchNorm output, no conv completes that gradient."""
+        if x is not None and x.bnb is not None and x.bnb_claim is None:
+            x.bnb_claim = False
 
     def acc_add(self, x: V, g: torch.Tensor) -> None:
         if not x.needs_grad:
@@ -458,6 +495,7 @@ class TrainPass:
             else:
                 T.add(x.g, gg, x.g)
                 x.g_scaled = None
+                x.bnb_part = None
 
     def _pinned(self, t: torch.Tensor) -> bool:
         """True while a deferred weight gradient reads t's storage: a conv with a fused residual hands its output gradient to
@@ -486,6 +524,11 @@ class TrainPass:
         p = self.P[key]
         x4 = _as4(x.t)
         n, h, w, _ = x4.shape
+        bnb_tok = None
+        if x.bnb is not None and x.bnb_claim is None:
+            # first consumer (forward order) of a BatchNorm + ReLU output = the LAST contributor to its gradient in the backward
+            x.bnb_claim = bnb_tok = object() if (_FUSE_BN_BWD and x.parent is None and x.needs_grad and x.t.dim() == 4) else False
+        self._use(residual)
         ho = (h + 2 * p.pad - p.dil * (p.kh - 1) - 1) // p.stride + 1
         wo = (w + 2 * p.pad - p.dil * (p.kw - 1) - 1) // p.stride + 1
         if out is None:
@@ -542,10 +585,11 @@ class TrainPass:
                 self.acc_add(nbias, nb)
             self.wgrad(p, x4, _as4(g))      # (+ the bias gradient: column sums of g taken inside the same kernel)
             if x.needs_grad:
-                def dg(o, r, mul=None):
-                    T.conv2d_dgrad(_as4(g), p.wT, _as4(o), kh=p.kh, kw=p.kw, stride=p.stride, pad=p.pad, dil=p.dil,
-                                   residual=_as4(r) if r is not None else None, mul=_as4(mul) if mul is not None else None)
-                self.acc(x, dg)
+                def dg(o, r, mul=None, bnb=None):
+                    return T.conv2d_dgrad(_as4(g), p.wT, _as4(o), kh=p.kh, kw=p.kw, stride=p.stride, pad=p.pad, dil=p.dil,
+                                          residual=_as4(r) if r is not None else None, mul=_as4(mul) if mul is not None else None,
+                                          bnb=bnb)
+                self.acc(x, dg, bnb_token=bnb_tok)
         self.tape.append(bwd)
         return y
 
@@ -692,8 +736,10 @@ class TrainPass:
             # ASPP pooled branch
             ts, tiles, rpt = z.tile_stats if z.tile_stats is not None else T.col_tile_stats(z.t)
             count = rows
-            if _FUSE_BN_APPLY and T.bn_apply_tiles_supported(tiles):
-                # few tiles (the 14 x 14 layers): combine + apply in ONE launch, every workgroup redoes the combine of its channels
+            if _FUSE_BN_APPLY and tiles <= _FUSE_BN_APPLY_MAX_TILES and T.bn_apply_tiles_supported(tiles):
+                # a handful of tiles (the pooled ASPP branch: B rows): combine + apply in ONE launch.  For the 14 x 14 layers (49 / 98
+                # tiles) the fused kernel costs what the two launches cost (profiles/r05_bn_apply_microbench.txt: the dependent
+                # chain statistics -> coefficients -> apply is the same length either way), so they keep the two launches
                 fused_apply = True
                 y = out if out is not None else V(self.empty(z.t.shape, z.t.dtype))
                 T.bn_apply_tiles(ts, tiles, rpt, rows, bn.weight.detach(), bn.bias.detach(), bn.eps, mom,
@@ -721,11 +767,35 @@ class TrainPass:
             y = out if out is not None else V(self.empty(z.t.shape, z.t.dtype))
             T.scale_shift_act(z.t, scale, shift, y.t, act, residual=residual.t if residual is not None else None)
 
+        self._use(residual)
+        if _FUSE_BN_BWD and not sync and not frozen and act in (ACT_RELU, ACT_LEAKY) and y.parent is None and z.t.dim() == 4:
+            y.bnb = dict(z=z.t, out=y.t if residual is not None else None, scale=scale, shift=shift, mean=mean, rstd=rstd, act=act)
+
         def bwd():
             dy = y.g
             if dy is None:
                 return
             direct = (not sync and id(bn.weight) not in self.grads and id(bn.bias) not in self.grads)
+            if y.bnb_part is not None:
+                # the launch that completed dy already applied the activation's derivative and summed g and g * zhat per tile:
+                # sum over the tiles, then the apply pass on the masked gradient (no mask, no second output: dy IS the skip gradient)
+                part, tiles = y.bnb_part
+                dz = self.empty(z.t.shape, z.t.dtype)
+                if tiles == 0:   # the sums arrived in scratch (atomic route): the apply pass adds them to the affine gradients
+                    sums = part
+                    T.bn_act_bwd_apply(dy, None, z.t, mean, rstd, bn.weight.detach(), sums[0], sums[1], ACT_NONE, dz,
+                                       acc=(self.grad_buffer(bn.bias), self.grad_buffer(bn.weight)) if direct else None)
+                else:
+                    sums = (self.grad_buffer(bn.bias), self.grad_buffer(bn.weight)) if direct else self.zeros_f32(2, c)
+                    T.bn_bwd_sum_tiles(part, tiles, sums[0], sums[1])
+                    T.bn_act_bwd_apply(dy, None, z.t, mean, rstd, bn.weight.detach(), sums[0], sums[1], ACT_NONE, dz)
+                z.set_g(dz)
+                if residual is not None and residual.needs_grad:
+                    self.acc_add(residual, dy)
+                if not direct:
+                    self.add_grad(bn.bias, sums[0].clone())
+                    self.add_grad(bn.weight, sums[1].clone())
+                return
             if direct:
                 # local BatchNorm: sum g -> dbeta and sum g*zhat -> dgamma ARE the affine gradients: reduce straight
                 # into their (zeroed) gradient buffers and let the apply kernel read them from there
@@ -777,6 +847,7 @@ class TrainPass:
         return y
 
     def maxpool(self, x: V, k: int, stride: int, pad: int) -> V:
+        self._use(x)
         n, h, w, c = x.t.shape
         y = V(self.empty((n, (h + 2 * pad - k) // stride + 1, (w + 2 * pad - k) // stride + 1, c)))
         am = torch.empty(y.t.shape, dtype=torch.uint8, device=self.dev)
@@ -792,6 +863,7 @@ class TrainPass:
         return y
 
     def gap(self, x: V) -> V:
+        self._use(x)
         n, h, w, c = x.t.shape
         y = V(self.empty((n, c), torch.float32))
         ops.global_avgpool(x.t, y.t)
@@ -804,6 +876,7 @@ class TrainPass:
             elif self._pinned(x.g):
                 self.flush_wgrads()   # in-place update of a gradient a pending weight gradient reads
             T.bcast_add(x.g, y.g, 1.0 / (h * w))
+            x.bnb_part = None   # (in-place accumulation)
         self.tape.append(bwd)
         return y
 
@@ -821,6 +894,7 @@ class TrainPass:
         return y
 
     def bilinear(self, x: V, out: V, align_corners: bool) -> V:
+        self._use(x)
         ops.bilinear(x.t, out.t, align_corners)
 
         def bwd():

@@ -46,10 +46,14 @@ def _s():
 
 def conv2d_dgrad(dy: torch.Tensor, w_t: torch.Tensor, dx: torch.Tensor, *, kh: int, kw: int, stride: int, pad: int,
                  dil: int, residual: Optional[torch.Tensor] = None, scale=None, shift=None, act: int = 0,
-                 mul: Optional[torch.Tensor] = None) -> torch.Tensor:
+                 mul: Optional[torch.Tensor] = None, bnb: Optional[dict] = None):
     """Data gradient of a forward conv (kh x kw, stride, pad, dil): dx = conv_transpose(dy, w) [* mul] (+ residual).
     mul (dx's shape): element-wise multiplier applied in the epilogue - the gelu' tensor of a fused fc1 + GELU forward.
-    dy: [N,Ho,Wo,Cout_f] view, w_t: cavp_pack_weight_dgrad weights [Cin_f][kh][kw][Cout_f], dx: [N,H,W,Cin_f] view."""
+    dy: [N,Ho,Wo,Cout_f] view, w_t: cavp_pack_weight_dgrad weights [Cin_f][kh][kw][Cout_f], dx: [N,H,W,Cin_f] view.
+    bnb (dx is the gradient of a BatchNorm + activation output): dict(z, out | None, scale, shift, mean, rstd, act) - the launch
+    stores dx * act'(.) and writes the BatchNorm-backward partial sums per pixel tile (cavp_conv2d_nhwc_bnbwd).  Returns
+    (partials f32 [tiles][C][2], tiles) then - or, with bnb["sums"] (pre-zeroed f32 [2][C]: the tiles add into it with atomics),
+    (sums, 0) - or None when this launch cannot carry them (dx is then the plain gradient)."""
     _need_gpu(dy, w_t, dx, residual)
     lib = _lib.load()
     n, ho, wo, cof, ldx = _nhwc(dy)
@@ -78,10 +82,37 @@ def conv2d_dgrad(dy: torch.Tensor, w_t: torch.Tensor, dx: torch.Tensor, *, kh: i
             raise _lib.CavpError(f"conv2d_dgrad: dx extent {(h, w)} != {(eh, ew)}")
     nbytes = lib.cavp_conv2d_workspace_bytes(C.byref(d))
     ws = ops.workspace(nbytes, dy.device)
+    if bnb is not None:
+        tiles, rpt = C.c_int32(0), C.c_int32(0)
+        zt = bnb["z"]
+        ot = bnb.get("out")
+        ok = (mul is None and scale is None and shift is None and act == 0 and zt.dtype == dx.dtype and
+              lib.cavp_conv2d_bnbwd_layout(C.byref(d), C.byref(tiles), C.byref(rpt)))
+        if ok:
+            zn, zh, zw, zc, ld_z = _nhwc(zt)
+            ld_out = 0
+            if ot is not None:
+                on, oh, ow, oc, ld_out = _nhwc(ot)
+                if (on, oh, ow, oc) != (n, h, w, cif) or ot.dtype != dx.dtype:
+                    raise _lib.CavpError("conv2d_dgrad: bnb['out'] must match dx")
+            if (zn, zh, zw, zc) != (n, h, w, cif):
+                raise _lib.CavpError("conv2d_dgrad: bnb['z'] must match dx")
+            _need_gpu(zt, ot, bnb["mean"], bnb["rstd"], bnb.get("scale"), bnb.get("shift"))
+            sums = bnb.get("sums")   # pre-zeroed f32 [2][C]: the tiles add their sums there with atomics (no summation launch)
+            part = None if sums is not None else torch.empty((tiles.value, cif, 2), dtype=torch.float32, device=dx.device)
+            pv = lambda t: None if t is None else t.data_ptr()   # noqa: E731  (c_void_p structure fields take an int or None)
+            ba = _lib.BnBwdArgs(z=pv(zt), out=pv(ot), ld_z=ld_z, ld_out=ld_out, fwd_scale=pv(bnb.get("scale")),
+                                fwd_shift=pv(bnb.get("shift")), mean=pv(bnb["mean"]), rstd=pv(bnb["rstd"]), act=int(bnb["act"]),
+                                pad_=0, partials=pv(part), sum_g=pv(sums[0]) if sums is not None else None,
+                                sum_gz=pv(sums[1]) if sums is not None else None)
+            st = lib.cavp_conv2d_nhwc_bnbwd(C.byref(d), _ptr(dy), _ptr(w_t), _ptr(residual), _ptr(dx), C.byref(ba), _ptr(ws),
+                                            C.c_size_t(ws.numel() if ws is not None else 0), _s())
+            _check(st, "cavp_conv2d_nhwc_bnbwd")
+            return (part, tiles.value) if sums is None else (sums, 0)
     st = lib.cavp_conv2d_nhwc_aux(C.byref(d), _ptr(dy), _ptr(w_t), _ptr(scale), _ptr(shift), None, _ptr(residual), _ptr(dx),
                                   _ptr(mul), _ptr(ws), C.c_size_t(ws.numel() if ws is not None else 0), None, _s())
     _check(st, "cavp_conv2d_nhwc(dgrad)")
-    return dx
+    return None if bnb is not None else dx
 
 
 def conv2d_wgrad(x: torch.Tensor, dy: torch.Tensor, dw_ohwi: torch.Tensor, *, kh: int, kw: int, stride: int, pad: int,
@@ -307,6 +338,12 @@ def scale_shift_act(x, scale, shift, y, act: int, residual=None) -> torch.Tensor
     return y
 
 
+def bn_bwd_sum_tiles(partials, tiles: int, sum_g, sum_gz) -> None:
+    """sum_g / sum_gz (f32 [C]) += the per-tile pairs of a conv2d_dgrad(bnb=...) launch, summed over the tiles."""
+    _need_gpu(partials, sum_g, sum_gz)
+    _check(_lib.load().cavp_bn_bwd_sum_tiles(_ptr(partials), tiles, sum_g.numel(), _ptr(sum_g), _ptr(sum_gz), _s()), "cavp_bn_bwd_sum_tiles")
+
+
 def bn_act_bwd_reduce(dy, y, z, mean, rstd, act: int, sum_g, sum_gz, fwd_scale=None, fwd_shift=None) -> None:
     """y=None (BN + activation without residual): the activation mask is re-derived from z with the forward's folded
     scale / shift, y is not read."""
@@ -321,16 +358,18 @@ def bn_act_bwd_reduce(dy, y, z, mean, rstd, act: int, sum_g, sum_gz, fwd_scale=N
 
 
 def bn_act_bwd_apply(dy, y, z, mean, rstd, gamma, sum_g, sum_gz, act: int, dz, g_out=None, fwd_scale=None,
-                     fwd_shift=None) -> torch.Tensor:
+                     fwd_shift=None, acc=None) -> torch.Tensor:
+    """acc = (dbeta, dgamma): the two sums are also ADDED to these affine-gradient buffers (sums that arrive in scratch memory)."""
     rows, c, ld_dy = _rows(dy)
     ld_y = _rows(y)[2] if y is not None else 0
     _, _, ld_z = _rows(z)
     _, _, ld_dz = _rows(dz)
     ld_g = _rows(g_out)[2] if g_out is not None else 0
     _need_gpu(dy, y, z, dz, g_out)
-    _check(_lib.load().cavp_bn_act_bwd_apply(dtype_code(dy.dtype), _ptr(dy), _ptr(y), _ptr(z), _ptr(mean), _ptr(rstd),
-                                             _ptr(gamma), _ptr(sum_g), _ptr(sum_gz), rows, c, ld_dy, ld_y, ld_z, act, _ptr(dz),
-                                             ld_dz, _ptr(g_out), ld_g, _ptr(fwd_scale), _ptr(fwd_shift), _s()),
+    _check(_lib.load().cavp_bn_act_bwd_apply_acc(dtype_code(dy.dtype), _ptr(dy), _ptr(y), _ptr(z), _ptr(mean), _ptr(rstd),
+                                                 _ptr(gamma), _ptr(sum_g), _ptr(sum_gz), rows, c, ld_dy, ld_y, ld_z, act, _ptr(dz),
+                                                 ld_dz, _ptr(g_out), ld_g, _ptr(fwd_scale), _ptr(fwd_shift),
+                                                 _ptr(acc[0]) if acc is not None else None, _ptr(acc[1]) if acc is not None else None, _s()),
            "cavp_bn_act_bwd_apply")
     return dz
 

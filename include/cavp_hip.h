@@ -115,6 +115,41 @@ int cavp_conv2d_nhwc(const cavp_conv_desc* d, const void* x, const void* w, cons
 int cavp_conv2d_nhwc_aux(const cavp_conv_desc* d, const void* x, const void* w, const float* scale, const float* shift,
                          const float* nbias, const void* residual, void* y, void* aux, void* workspace,
                          size_t workspace_bytes, float* tile_stats, void* stream);
+/* ABI 10: BatchNorm-backward statistics fused into the data-gradient launch that PRODUCES the gradient of a BatchNorm + activation
+ * output.  torch.autograd runs ReLU.backward and BatchNorm.backward as passes of their own behind every conv's backward
+ * (resnet.py:75-98 under trainer_cavp_vpo_mono.py:190 `loss.backward()`); here the conv launch (a data gradient: d = the
+ * transposed conv, see `up`) finishes v = conv(x, w) + residual, multiplies by the activation's derivative, stores
+ *   g = v * act'(.)                      (act' from `out`, the forward's activation output, or re-derived from z*fwd_scale + fwd_shift)
+ * and writes, per pixel tile, partials[tile][c] = (sum g, sum g * (z - mean) * rstd) over the tile's rows - the two reductions of
+ * cavp_bn_act_bwd_reduce, which then only have to be summed over the tiles (cavp_bn_bwd_sum_tiles; fixed order, no atomics).
+ * cavp_bn_act_bwd_apply runs on g with act = NONE.  cavp_conv2d_bnbwd_layout returns 0 when the launch cannot carry the
+ * statistics (split over K, 256 x 256 tile, unaligned operands): the caller keeps the separate reduce. */
+typedef struct cavp_bnbwd_args {
+  const void* z;            /* the BatchNorm's input (dtype and shape of y), pixel stride ld_z */
+  const void* out;          /* the activation's output (BN + residual + act), pixel stride ld_out; NULL: mask from z, fwd_scale, fwd_shift */
+  int32_t ld_z, ld_out;
+  const float* fwd_scale;   /* the forward's folded scale / shift (only read when out == NULL and act != NONE) */
+  const float* fwd_shift;
+  const float* mean;        /* batch mean and 1 / sqrt(var + eps) of z */
+  const float* rstd;
+  int32_t act;              /* CAVP_ACT_NONE / RELU / LEAKY */
+  int32_t pad_;
+  float* partials;          /* f32 [tiles][Cout][2] (cavp_conv2d_bnbwd_layout): deterministic route, summed by cavp_bn_bwd_sum_tiles */
+  float* sum_g;             /* with partials == NULL: f32 [Cout] each, pre-zeroed; every tile ADDS its two sums there with f32 atomics */
+  float* sum_gz;            /*   (no separate summation launch; the order of the additions is not fixed) */
+} cavp_bnbwd_args;
+int cavp_conv2d_bnbwd_layout(const cavp_conv_desc* d, int32_t* tiles, int32_t* rows_per_tile);
+int cavp_conv2d_nhwc_bnbwd(const cavp_conv_desc* d, const void* x, const void* w, const void* residual, void* y,
+                           const cavp_bnbwd_args* b, void* workspace, size_t workspace_bytes, void* stream);
+/* sum_g[c] += sum_t partials[t][c][0], sum_gz[c] += sum_t partials[t][c][1] (ascending tiles within 16 interleaved lanes, then a
+ * fixed tree: deterministic). */
+int cavp_bn_bwd_sum_tiles(const float* partials, int32_t tiles, int32_t C, float* sum_g, float* sum_gz, void* stream);
+/* cavp_bn_act_bwd_apply (below) that also adds the two sums to the BatchNorm's affine gradients (dbeta_acc += sum_g, dgamma_acc +=
+ * sum_gz; both or neither): for sums that arrive in scratch memory (the atomic route of cavp_conv2d_nhwc_bnbwd). */
+int cavp_bn_act_bwd_apply_acc(int32_t dtype, const void* dy, const void* y, const void* z, const float* mean, const float* rstd,
+                              const float* gamma, const float* sum_g, const float* sum_gz, int64_t rows, int32_t C, int32_t ld_dy,
+                              int32_t ld_y, int32_t ld_z, int32_t act, void* dz, int32_t ld_dz, void* g_out, int32_t ld_g,
+                              const float* fwd_scale, const float* fwd_shift, float* dbeta_acc, float* dgamma_acc, void* stream);
 /* An automatically planned launch of the 256x256 tile whose last round of 256 tiles is at most a quarter full (the decoder head
  * convs, encoder_decoder.py:62-75, at 2B x 56 x 56: 784 tiles = 3.06 rounds) is issued as the leading images on the 256x256 tile
  * + the remaining images on the small tiles.  Process-wide switch for A/B runs and tests (default on); results are identical

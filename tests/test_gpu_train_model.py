@@ -641,3 +641,57 @@ def test_wgrad_stream_equals_main_stream(dtype):
             assert abs(l2 - l0) <= 1e-6 * max(1.0, abs(l0)) and err <= tol, (l2, l0, err)
     finally:
         TR._WGRAD_STREAM = old
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+def test_fused_bn_backward_statistics_equal_separate_reduce(dtype):
+    """Round 5: the data-gradient launch that completes the gradient of a BatchNorm + ReLU output applies the ReLU mask and sums
+    g and g * zhat per tile in its epilogue (cavp_conv2d_nhwc_bnbwd); the BatchNorm backward then skips its reduce pass.  Whole
+    training step (batch statistics, B = 8) with the fusion == the step with the separate reduce: same loss, same gradients up
+    to summation order (f32) / up to the storage rounding of g (bf16), eagerly and as a graph replay; and the fusion is in use."""
+    import cavp_amd.train as TR
+    from cavp_amd import train_ops as T
+    cfg = dict(C=3, B=8, hw=(96, 96), lds=[False, False, False])
+    image, audio, label = [t.to(DEV) for t in synth_inputs(cfg["B"], cfg["hw"], audio_batch=2 * cfg["B"], num_classes=cfg["C"], seed=10)]
+    old, old_side = TR._FUSE_BN_BWD, TR._SIDE_STREAM
+    calls = {"n": 0}
+    orig = T.bn_act_bwd_reduce
+
+    def counted(*a, **k):   # the separate reduce passes that still run
+        calls["n"] += 1
+        return orig(*a, **k)
+    try:
+        TR._SIDE_STREAM = False
+        TR._FUSE_BN_BWD = False
+        T.bn_act_bwd_reduce = counted
+        m0, _ = _build(cfg)
+        m0.set_compute_dtype(dtype)
+        m0.train()
+        l0 = float(m0.train_step(image, audio, label, all_reduce=False).item())
+        ref = m0._grad_arena.flat.clone().double()
+        n_plain, calls["n"] = calls["n"], 0
+        TR._FUSE_BN_BWD = True
+        m1, _ = _build(cfg)
+        m1.set_compute_dtype(dtype)
+        m1.train()
+        l1 = float(m1.train_step(image, audio, label, all_reduce=False).item())
+        torch.cuda.synchronize()
+        assert n_plain - calls["n"] >= 20, f"only {n_plain - calls['n']} of {n_plain} BatchNorm layers took the fused statistics"
+        calls["n"] = n_plain - calls["n"]
+        g1 = m1._grad_arena.flat.clone().double()
+        cos = float((g1 @ ref) / (g1.norm() * ref.norm()))
+        rel = float((g1 - ref).norm() / ref.norm())
+        print(f"fused BN-backward statistics ({dtype}): {calls['n']} layers, loss {l1:.6f} vs {l0:.6f}, gradient cosine {cos:.6f}, rel err {rel:.2e}")
+        assert abs(l1 - l0) <= 1e-6 * max(1.0, abs(l0))          # the forward is untouched
+        assert (cos >= 0.99999 and rel <= 3e-3) if dtype == torch.float32 else (cos >= 0.995 and rel <= 0.1), (cos, rel)
+        T.bn_act_bwd_reduce = orig
+        step = m1.capture_train_step(image, audio, label)
+        for _ in range(2):
+            step()
+        torch.cuda.synchronize()
+        g2 = m1._grad_arena.flat.clone().double()
+        cos2 = float((g2 @ ref) / (g2.norm() * ref.norm()))
+        assert cos2 >= (0.99999 if dtype == torch.float32 else 0.995), cos2
+    finally:
+        T.bn_act_bwd_reduce = orig
+        TR._FUSE_BN_BWD, TR._SIDE_STREAM = old, old_side

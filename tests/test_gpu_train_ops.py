@@ -614,3 +614,101 @@ def test_bn_apply_tiles(rows, C, res, sl, dt):
         _check(a_, b_, torch.float32, "fused vs two launches: " + what, 2e-6, 2e-6)
     # the normalised tensors of the two routes differ by the rounding of (scale, shift) only
     _check(outs[0][0], outs[1][0], dt, "fused vs two launches: y", 2e-5, 8e-3)
+
+
+BNB_CASES = [
+    # name, N, H, W, Cin, Cout, k, s, p, d, with_out (mask from the activation output + accumulated residual: the bottleneck-output case)
+    ("1x1_mid", 8, 56, 56, 64, 256, 1, 1, 0, 1, False),
+    ("3x3_mid", 8, 56, 56, 64, 64, 3, 1, 1, 1, False),
+    ("3x3_s2", 4, 56, 56, 128, 128, 3, 2, 1, 1, False),
+    ("1x1_out_res", 8, 56, 56, 256, 64, 1, 1, 0, 1, True),
+    ("1x1_s2_out_res", 4, 56, 56, 256, 128, 1, 2, 0, 1, True),
+    ("ragged_1x1", 3, 13, 11, 72, 48, 1, 1, 0, 1, False),
+    ("wide_14", 8, 14, 14, 1024, 256, 1, 1, 0, 1, True),
+]
+
+
+@pytest.mark.parametrize("dt", DTYPES, ids=IDS)
+@pytest.mark.parametrize("case", BNB_CASES, ids=[c[0] for c in BNB_CASES])
+def test_conv_dgrad_fused_bn_backward_stats(case, dt):
+    """cavp_conv2d_nhwc_bnbwd: the data-gradient launch that produces the gradient of a BatchNorm + ReLU output stores
+    g = (dgrad + residual) * relu'(.) and emits the per-tile sums of cavp_bn_act_bwd_reduce.  Checked against the plain data
+    gradient followed by torch on the host: g itself, sum g and sum g * zhat (after cavp_bn_bwd_sum_tiles), and - end to end - the
+    BatchNorm input gradient cavp_bn_act_bwd_apply makes from them against torch.autograd through conv -> BN(train) -> ReLU
+    (resnet.py:75-98)."""
+    ops, T = _mods()
+    name, n, h, w, cin, cout, k, s, p, d, with_out = case
+    if cin % (8 if dt == torch.bfloat16 else 4):
+        pytest.skip("channel count must be a multiple of the 16-byte vector")
+    # forward chain on the host: a = relu(bn(z) [+ skip]); y = conv(a)
+    z = _q(_rand(n, cin, h, w, seed=61) * 0.8 + 0.3, dt)
+    gam, bet = _rand(cin, seed=62) * 0.3 + 1.0, _rand(cin, seed=63) * 0.3
+    skip = _q(_rand(n, cin, h, w, seed=64), dt) if with_out else None
+    mean = z.mean((0, 2, 3))
+    var = z.var((0, 2, 3), unbiased=False)
+    rstd = (var + 1e-5).rsqrt()
+    scale, shift = gam * rstd, bet - mean * gam * rstd
+    bn = F.batch_norm(z, None, None, gam, bet, True, 0.1, 1e-5)
+    a = F.relu(bn + skip) if with_out else F.relu(bn)
+    a_q = _q(a.detach(), dt)
+    wt = _q(_rand(cout, cin, k, k, seed=65, scale=(cin * k * k) ** -0.5), dt)
+    y = F.conv2d(a, wt, None, s, p, d)
+    dy = _q(_rand(*y.shape, seed=66), dt)
+    prev = _q(_rand(n, cin, h, w, seed=67) * 0.5, dt) if with_out else None    # the skip path's gradient already in a.g
+    # plain launch: gradient of a (+ what the skip path already put there)
+    dyv = _nhwc(dy, dt)
+    wT = T.pack_weight_dgrad(wt.to(DEV), dt)
+    plain = torch.empty((n, h, w, cin), dtype=dt, device=DEV)
+    T.conv2d_dgrad(dyv, wT, plain, kh=k, kw=k, stride=s, pad=p, dil=d, residual=_nhwc(prev, dt) if prev is not None else None)
+    # fused launch
+    zv = _nhwc(z, dt)
+    outv = _nhwc(a_q, dt) if with_out else None
+    g = torch.empty((n, h, w, cin), dtype=dt, device=DEV)
+    mean_d, rstd_d, sc_d, sh_d = (t.float().to(DEV) for t in (mean, rstd, scale, shift))
+    r = T.conv2d_dgrad(dyv, wT, g, kh=k, kw=k, stride=s, pad=p, dil=d, residual=_nhwc(prev, dt) if prev is not None else None,
+                       bnb=dict(z=zv, out=outv, scale=sc_d, shift=sh_d, mean=mean_d, rstd=rstd_d, act=ops.ACT_RELU))
+    if r is None:   # (the planner split this launch over K or chose a tile without the fused epilogue: the caller keeps the separate reduce)
+        assert name not in ("3x3_mid", "1x1_out_res"), "the backbone-shaped cases must carry the statistics"
+        pytest.skip("launch cannot carry the fused statistics")
+    part, tiles = r
+    # reference from the plain gradient (same storage rounding): mask from the stored activation / from z*scale + shift in f32
+    pl = plain.float().cpu()
+    zc = zv.float().cpu()
+    if with_out:
+        mask = (outv.float().cpu() > 0).float()
+    else:
+        mask = ((zc * scale.float() + shift.float()) > 0).float()
+    g_ref = pl * mask
+    got_g = g.float().cpu()
+    tol = 1e-5 if dt == torch.float32 else 1e-2
+    # (a pixel whose pre-activation rounds to +-0 may flip its mask between the fused multiply-add on the device and the host's two roundings)
+    bad = ((got_g - g_ref).abs() > tol * max(1.0, float(g_ref.abs().max()))).float().mean()
+    assert float(bad) <= 1e-4, f"{name}: {float(bad):.2e} of the masked gradient elements differ"
+    sums = torch.zeros(2, cin, device=DEV)
+    sums[0].fill_(0.25)   # cavp_bn_bwd_sum_tiles ADDS
+    T.bn_bwd_sum_tiles(part, tiles, sums[0], sums[1])
+    gq = got_g.double()   # the sums are taken from the f32 values BEFORE storage rounding; compare with a tolerance that covers it
+    zhat = (zc.double() - mean.double()) * rstd.double()
+    s0 = gq.sum((0, 1, 2)) + 0.25
+    s1 = (gq * zhat).sum((0, 1, 2))
+    rows = n * h * w
+    stol = (2e-4 if dt == torch.float32 else 6e-3) * (rows ** 0.5) * max(1.0, float(gq.abs().max()))
+    assert float((sums[0].cpu().double() - s0).abs().max()) <= stol, (name, float((sums[0].cpu().double() - s0).abs().max()), stol)
+    assert float((sums[1].cpu().double() - s1).abs().max()) <= 3 * stol, (name, float((sums[1].cpu().double() - s1).abs().max()), stol)
+    # the atomic route (tiles add their sums into pre-zeroed scratch, no summation launch): same sums up to the order of the additions
+    g2 = torch.empty_like(g)
+    asum = torch.zeros(2, cin, device=DEV)
+    r2 = T.conv2d_dgrad(dyv, wT, g2, kh=k, kw=k, stride=s, pad=p, dil=d, residual=_nhwc(prev, dt) if prev is not None else None,
+                        bnb=dict(z=zv, out=outv, scale=sc_d, shift=sh_d, mean=mean_d, rstd=rstd_d, act=ops.ACT_RELU, sums=asum))
+    assert r2 is not None and r2[1] == 0 and torch.equal(g2, g)
+    ref_sums = sums.clone()
+    ref_sums[0] -= 0.25
+    assert float((asum - ref_sums).abs().max()) <= 1e-3 * max(1.0, float(ref_sums.abs().max()))
+    # end to end: dz from the fused route == dz from the separate reduce on the plain gradient
+    sums_ref = torch.zeros(2, cin, device=DEV)
+    T.bn_act_bwd_reduce(plain, outv, zv, mean_d, rstd_d, ops.ACT_RELU, sums_ref[0], sums_ref[1], fwd_scale=sc_d, fwd_shift=sh_d)
+    sums[0] -= 0.25
+    dz_ref, dz = torch.empty_like(plain), torch.empty_like(plain)
+    T.bn_act_bwd_apply(plain, outv, zv, mean_d, rstd_d, gam.to(DEV), sums_ref[0], sums_ref[1], ops.ACT_RELU, dz_ref, fwd_scale=sc_d, fwd_shift=sh_d)
+    T.bn_act_bwd_apply(g, None, zv, mean_d, rstd_d, gam.to(DEV), sums[0], sums[1], ops.ACT_NONE, dz)
+    _check(dz, dz_ref.float().cpu(), dt, name + ".dz fused vs separate", 2e-4, 2e-2)

@@ -10,14 +10,13 @@ if [ "$part" = tests ]; then
   timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | tail -15 > $O/pytest_gpu.txt; cat $O/pytest_gpu.txt
 fi
 if [ "$part" = quick ]; then
-  timeout 900 python -m pytest tests/test_gpu_train_ops.py tests/test_gpu_train_model.py tests/test_gpu_bench_configs.py -m gpu -x -q 2>&1 | tail -15 > $O/pytest_quick.txt; cat $O/pytest_quick.txt
+  timeout 900 python -m pytest tests/test_gpu_train_ops.py tests/test_gpu_train_model.py tests/test_gpu_boundary.py -m gpu -x -q 2>&1 | tail -15 > $O/pytest_quick.txt; cat $O/pytest_quick.txt
 fi
 if [ "$part" = step ]; then
   { for r in 1 2 3; do
       echo "default                $(ms)"
-      echo "--no-bn-apply-fusion   $(ms --no-bn-apply-fusion)"
-      echo "--no-wgrad-stream      $(ms --no-wgrad-stream)"
-      echo "--no-wgrad-stream --no-bn-apply-fusion  $(ms --no-wgrad-stream --no-bn-apply-fusion)"
+      echo "--bn-apply-fusion      $(ms --bn-apply-fusion)"
+      echo "--no-bn-bwd-fusion     $(ms --no-bn-bwd-fusion)"
     done; } > $O/ab_step.txt 2>&1
   cat $O/ab_step.txt
 fi
