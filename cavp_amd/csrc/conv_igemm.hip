@@ -150,6 +150,17 @@ __global__ __launch_bounds__(64 * WC * WP, (WC * WP == 4 ? (BC * BP <= 64 * 64 &
   const int rem = sid - z * tiles;
   const int tp = fast_div(rem, p.div_tc_m, p.div_tc_s), tc = rem - tp * p.tiles_c;
   const int c_base = tc * BC, p_base = tp * BP;
+  // BatchNorm-backward instantiations: the tile's per-channel coefficients (mask scale / shift, batch mean, rstd) are requested HERE,
+  // one channel per thread, and parked in LDS behind the K loop - the epilogue then reads them with LDS latency instead of waiting
+  // out two rounds of dependent global loads per tile
+  float bcf[4] = {1.f, 0.f, 0.f, 1.f};
+  if constexpr (BNB) {
+    const int c = c_base + tid;
+    if (tid < BC && c < p.Cout) {
+      if (p.bnb_scale) { bcf[0] = p.bnb_scale[c]; bcf[1] = p.bnb_shift[c]; }
+      bcf[2] = p.bnb_mean[c]; bcf[3] = p.bnb_rstd[c];
+    }
+  }
   const int it_begin = p.splitk == 1 ? 0 : p.iters * z / p.splitk;   // iters * splitk < 2^31
   const int it_end = p.splitk == 1 ? p.iters : p.iters * (z + 1) / p.splitk;
 
@@ -603,6 +614,21 @@ __global__ __launch_bounds__(64 * WC * WP, (WC * WP == 4 ? (BC * BP <= 64 * 64 &
         if (ec_ok && g * RSTR < rows_left) rr0[g] = *(const u32x4_t*)(rp + (size_t)g * rstep);
       }
     }
+    // BatchNorm-backward instantiations: z (and the activation output) of the first batch travel with the residual
+    u32x4_t zz0[(BNB && GH > 0) ? GH : 1], oo0[(BNB && GH > 0) ? GH : 1];
+    if constexpr (BNB && GH > 0) {
+      const T* zp0 = (const T*)p.bnb_z + (size_t)(p_base + eprow0) * p.ld_bnb_z + ec;
+      const T* op0 = p.bnb_out ? (const T*)p.bnb_out + (size_t)(p_base + eprow0) * p.ld_bnb_out + ec : nullptr;
+#pragma unroll
+      for (int g = 0; g < GH; ++g) {
+        zz0[g] = (u32x4_t){0u, 0u, 0u, 0u};
+        oo0[g] = (u32x4_t){0u, 0u, 0u, 0u};
+        if (ec_ok && g * RSTR < rows_left) {
+          zz0[g] = *(const u32x4_t*)(zp0 + (size_t)g * RSTR * p.ld_bnb_z);
+          if (op0) oo0[g] = *(const u32x4_t*)(op0 + (size_t)g * RSTR * p.ld_bnb_out);
+        }
+      }
+    }
     float2* wstat = (float2*)(smem + NS * TILE_BYTES);   // [WP][BC] per-wave (mean, M2) partials (launch_cfg adds the bytes)
     if (!BNB && p.tile_stats) {
       // BatchNorm batch statistics for free, straight from the f32 accumulators IN REGISTERS: a lane holds 4 channels x MP
@@ -653,6 +679,13 @@ __global__ __launch_bounds__(64 * WC * WP, (WC * WP == 4 ? (BC * BP <= 64 * 64 &
         const int slot = (wc0 + a * 16) / 4 + lgrp;
         if (!CAVP_DBG(p, 64)) *(f32x4_t*)(st + (size_t)prow * BC + ((slot ^ (prow & SWZ)) << 2)) = acc[a][b];
       }
+    float* bcoef = (float*)(smem + NS * TILE_BYTES + WP * BC * 8);   // BNB: [4][BC] behind the statistics partials (launch_cfg adds the bytes)
+    if constexpr (BNB) {
+      if (tid < BC) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) bcoef[q * BC + tid] = bcf[q];
+      }
+    }
     __syncthreads();
     if (!BNB && p.tile_stats && tid < BC && c_base + tid < p.Cout) {  // (BC <= NT for every tile)
       float n = 0.f, mean = 0.f, m2 = 0.f;
@@ -698,14 +731,14 @@ __global__ __launch_bounds__(64 * WC * WP, (WC * WP == 4 ? (BC * BP <= 64 * 64 &
     float bfs[VE], bfh[VE], bs0[VE], bs1[VE], bmu[sizeof(T) == 4 ? VE : 1];
 #pragma unroll
     for (int e = 0; e < VE; ++e) { bfs[e] = 1.f; bfh[e] = 0.f; bs0[e] = 0.f; bs1[e] = 0.f; }
-    if constexpr (sizeof(T) == 4) {
+    if constexpr (bnb) {
+      if constexpr (sizeof(T) == 4) {
 #pragma unroll
-      for (int e = 0; e < VE; ++e) bmu[e] = (bnb && ec_ok) ? p.bnb_mean[ec + e] : 0.f;
-    }
-    if (bnb && ec_ok) {   // (bnb: compile-time)
+        for (int e = 0; e < VE; ++e) bmu[e] = bcoef[2 * BC + ecc + e];
+      }
       if (!op && p.bnb_act != CAVP_ACT_NONE) {
 #pragma unroll
-        for (int e = 0; e < VE; ++e) { bfs[e] = p.bnb_scale[ec + e]; bfh[e] = p.bnb_shift[ec + e]; }
+        for (int e = 0; e < VE; ++e) { bfs[e] = bcoef[ecc + e]; bfh[e] = bcoef[BC + ecc + e]; }
       }
     }
     for (int i0 = 0; i0 < ITER; i0 += G) {
@@ -722,6 +755,7 @@ __global__ __launch_bounds__(64 * WC * WP, (WC * WP == 4 ? (BC * BP <= 64 * 64 &
       if constexpr (bnb) {
 #pragma unroll
         for (int g = 0; g < G; ++g) {
+          if (GH > 0 && i0 == 0 && g < GH) { zz[g] = zz0[g < GH ? g : 0]; oo[g] = oo0[g < GH ? g : 0]; continue; }
           zz[g] = (u32x4_t){0u, 0u, 0u, 0u};
           oo[g] = (u32x4_t){0u, 0u, 0u, 0u};
           if (ec_ok && (i0 + g) * RSTR < rows_left) {
@@ -816,22 +850,39 @@ __global__ __launch_bounds__(64 * WC * WP, (WC * WP == 4 ? (BC * BP <= 64 * 64 &
       }
     }
     if constexpr (bnb) {
-      // the NT / CH threads of a channel group -> one pair per channel and pixel tile, in a fixed order (deterministic, no atomics);
-      // the staging buffer is free once every thread has read its chunks
-      __syncthreads();
-      float* red = (float*)smem;   // [RSTR][BC][2]
+      // the NT / CH threads of a channel group -> one pair per channel and pixel tile, in a fixed order (deterministic, no atomics):
+      // xor-shuffles over the 64 / CH lanes of a wave that share the group, then the NW wave sums through LDS (the staging buffer is
+      // free once every thread has read its chunks).  (First version: every thread's 2 VE sums to LDS and a serial loop over the
+      // NT / CH rows by BC threads - 4000 cycles per tile.)
 #pragma unroll
       for (int e = 0; e < VE; ++e) {
-        const float mu = ec_ok ? p.bnb_mean[ec + e] : 0.f, rs = ec_ok ? p.bnb_rstd[ec + e] : 0.f;
-        red[((size_t)eprow0 * BC + ecc + e) * 2] = bs0[e];
-        red[((size_t)eprow0 * BC + ecc + e) * 2 + 1] = sizeof(T) == 4 ? rs * bs1[e] : rs * (bs1[e] - mu * bs0[e]);
+        const float mu = bcoef[2 * BC + ecc + e], rs = bcoef[3 * BC + ecc + e];
+        bs1[e] = sizeof(T) == 4 ? rs * bs1[e] : rs * (bs1[e] - mu * bs0[e]);
+      }
+      if constexpr (CH < 64) {
+#pragma unroll
+        for (int m = CH; m < 64; m <<= 1) {
+#pragma unroll
+          for (int e = 0; e < VE; ++e) {
+            bs0[e] += __shfl_xor(bs0[e], m, 64);
+            bs1[e] += __shfl_xor(bs1[e], m, 64);
+          }
+        }
+      }
+      constexpr int GPW = CH < 64 ? 1 : CH / 64;   // (CH <= 64 for every tile: one channel-group set per wave)
+      static_assert(GPW == 1, "a wave covers all channel groups of the tile");
+      __syncthreads();
+      float* red = (float*)smem;   // [NW][BC][2]
+      if (lane < CH) {
+#pragma unroll
+        for (int e = 0; e < VE; ++e) *(float2*)(red + ((size_t)wave * BC + ecc + e) * 2) = make_float2(bs0[e], bs1[e]);
       }
       __syncthreads();
       if (tid < BC && c_base + tid < p.Cout) {
         float a0 = 0.f, a1 = 0.f;
-#pragma unroll 4
-        for (int r = 0; r < RSTR; ++r) {
-          const float2 q = *(const float2*)(red + ((size_t)r * BC + tid) * 2);
+#pragma unroll
+        for (int w = 0; w < NW; ++w) {
+          const float2 q = *(const float2*)(red + ((size_t)w * BC + tid) * 2);
           a0 += q.x; a1 += q.y;
         }
         if (p.bnb_part) {
@@ -951,7 +1002,7 @@ constexpr int kNumTiles = sizeof(kTiles) / sizeof(kTiles[0]);
 
 template <typename T, int BC, int BP, int WC, int WP, bool UP, int NS = 2, bool BNB = false>
 hipError_t launch_cfg(const IgemmParams& p, int nblk, hipStream_t s) {
-  constexpr int lds = NS * (BC + BP) * 128 + WP * BC * 8;   // + the per-wave BatchNorm-statistics partials
+  constexpr int lds = NS * (BC + BP) * 128 + WP * BC * 8 + (BNB ? BC * 16 : 0);   // + the per-wave BatchNorm-statistics partials (+ BNB: coefficients)
   static_assert(BP * BC * 4 <= NS * (BC + BP) * 128, "epilogue staging must fit in the K-loop LDS");
   static_assert(BC <= 64 * WC * WP, "tile_stats: one thread per output channel of the tile");
   static bool attr_set = false;
