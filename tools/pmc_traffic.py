@@ -20,7 +20,7 @@ def one_pass(counter, mode, steps, warmup, config="c1p", batch=32, dtype="bf16")
     subprocess.run(["rm", "-rf", d])
     cmd = ["timeout", "600", "rocprofv3", "--pmc", counter, "--output-format", "csv", "-d", d, "-o", "p", "--",
            sys.executable, os.path.join(REPO, "bench.py"), "--mode", mode, "--steps", str(steps), "--warmup", str(warmup),
-           "--config", config, "--batch", str(batch), "--dtype", dtype, "--no-graph", "--no-cpu-baseline", "--no-roofline", "--no-f32"]
+           "--config", config, "--batch", str(batch), "--dtype", dtype, "--no-graph", "--no-cpu-baseline", "--no-roofline", "--no-f32", "--no-eval-leg"]
     env = dict(os.environ, TMPDIR="/tmp")
     r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if r.returncode != 0:

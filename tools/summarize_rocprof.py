@@ -78,8 +78,9 @@ def main():
                         "wgrad_ms_per_step": round(wg[0], 3), "wgrad_launches_per_step": wg[1],
                         "all_kernels_ms_per_step": round(tot / steps / 1e3, 3),
                         "kernels_per_step": sum(v[0] for v in agg.values()) // steps,
-                        "note": "rocprofv3 --kernel-trace; igemm = igemm_kernel* + igemm_big_kernel + splitk_epilogue_kernel; sums include "
-                                "kernels that overlap on the side stream"}
+                        "note": "rocprofv3 --kernel-trace" + (", graph replays only" if a.replays_only else "") + "; igemm = igemm_kernel* + "
+                                "igemm_big_kernel + splitk_epilogue_kernel; bench.py --no-side-stream (one stream: durations are not "
+                                "inflated by co-running kernels)"}
     for t in glob.glob(os.path.join(a.dir, "**", "*_results.db"), recursive=True):   # rocprofv3 default (rocpd sqlite)
         import sqlite3
         con = sqlite3.connect(t)
