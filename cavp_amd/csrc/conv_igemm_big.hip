@@ -47,13 +47,18 @@ constexpr unsigned kOOB = 0x80000000u;
 static_assert(LDS_BYTES == 160 * 1024, "the whole LDS of a CU");
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
 
 }  // namespace
 
 // DBG: compile-time profiling switches (instantiated only under -DCAVP_PROFILE; a RUN-time test of such a flag inside the
 // phase loop splits its basic blocks and made the product kernel 1.8x slower): 1 taps outermost, 2 no stagger, 4 no
 // s_setprio, 8 no DMA, 16 no MFMA, 32 no fragment reads, 64 no epilogue.
-template <int DBG>
+// M32: the K loop multiplies with v_mfma_f32_32x32x16_bf16 (2.49 PF/s alone, tools/microbench/kloop_regb.hip) instead of
+// v_mfma_f32_16x16x32_bf16 (1.37 PF/s alone): at the 16x16x32 rate this tile's K loop was ~88 % matrix-pipe time.  Same LDS layout, same
+// number of fragment reads; a wave's quadrant (32 channels x 64 pixels x K 64) is 2 blocks x 4 K steps of 32x32x16 instead of 8 blocks x
+// 2 K steps of 16x16x32.  A lane of the 32x32 accumulator holds, for pixel (lane & 31), channels 8 g + 4 (lane >> 5) + j (g, j = 0..3).
+template <int DBG, bool M32>
 __global__ __launch_bounds__(512, 2) void igemm_big_kernel(const IgemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   cavp_prefetch_kernargs<(int)sizeof(IgemmParams)>();
@@ -181,43 +186,82 @@ __global__ __launch_bounds__(512, 2) void igemm_big_kernel(const IgemmParams p) 
   // ---------------------------------------------------------------------------------------------------------------
   // compute side
   // ---------------------------------------------------------------------------------------------------------------
+  // 16x16x32: acc[a][b] = 16-channel block a (4) x 16-pixel block b (8), 4 channels per lane;  32x32x16: the same 128 registers are
+  // acc32[HC][pb] = 32-channel half HC (2) x 32-pixel block pb (4), 16 values per lane (acc32[HC][pb] aliases acc[4 (2 HC + pb / 2) ..][..]
+  // only as storage: the two layouts are never mixed)
   f32x4_t acc[4][8];
+  f32x16_t acc32[2][4];
+  if constexpr (M32) {
 #pragma unroll
-  for (int a = 0; a < 4; ++a)
+    for (int a = 0; a < 2; ++a)
 #pragma unroll
-    for (int b = 0; b < 8; ++b) acc[a][b] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-  u32x4_t fa0[2][2], fa1[2][2], fb[4][2];   // [block][k sub-step]: weights low / high channel half, pixels of the current half
+      for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc32[a][b][e] = 0.f;
+  } else {
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 8; ++b) acc[a][b] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  }
+  u32x4_t fa0[2][2], fa1[2][2], fb[4][2];   // 16x16x32: [block][k sub-step]; 32x32x16: fa[q >> 1][q & 1], fb[2 b32 + (q >> 1)][q & 1], q = K step of 16
 
-  const int key = (lrow >> 1) & 7;
-  // byte offset of (row, slot) inside a half tile for k sub-step 0; sub-step 1 flips slot bit 2
-  const int a_off = (wc * 32 + lrow) * 128 + ((lgrp ^ key) << 4);
-  const int b_off = (wp * 64 + lrow) * 128 + ((lgrp ^ key) << 4);
+  const int r32 = lane & 31, h32 = lane >> 5;
+  const int key = M32 ? (r32 >> 1) & 7 : (lrow >> 1) & 7;
+  // byte offset of (row, slot) inside a half tile for k sub-step 0; 16x16x32: sub-step 1 flips slot bit 2; 32x32x16: K step q flips
+  // the slot bits 1-2 with 2 q (slot = (2 q + h) ^ key = (h ^ key) ^ 2 q)
+  const int a_off = M32 ? (wc * 32 + r32) * 128 + ((h32 ^ key) << 4) : (wc * 32 + lrow) * 128 + ((lgrp ^ key) << 4);
+  const int b_off = M32 ? (wp * 64 + r32) * 128 + ((h32 ^ key) << 4) : (wp * 64 + lrow) * 128 + ((lgrp ^ key) << 4);
   int cmp_buf = 0, cmp_k = 0, cmp_tile = 0;
 
   auto read_a = [&](u32x4_t (&f)[2][2], int half) {
-    const char* base = smem + cmp_buf * BUF_BYTES + (half ? 2 : 0) * HALF_BYTES + a_off;
+    const char* base = smem + cmp_buf * BUF_BYTES + (half ? 2 : 0) * HALF_BYTES;
+    if constexpr (M32) {
 #pragma unroll
-    for (int a = 0; a < 2; ++a) {
-      f[a][0] = *(const u32x4_t*)(base + a * 2048);
-      f[a][1] = *(const u32x4_t*)(base + a * 2048 + ((((lgrp ^ key) ^ 4) - (lgrp ^ key)) << 4));
+      for (int q = 0; q < 4; ++q) f[q >> 1][q & 1] = *(const u32x4_t*)(base + (a_off ^ (q << 5)));
+    } else {
+      base += a_off;
+#pragma unroll
+      for (int a = 0; a < 2; ++a) {
+        f[a][0] = *(const u32x4_t*)(base + a * 2048);
+        f[a][1] = *(const u32x4_t*)(base + a * 2048 + ((((lgrp ^ key) ^ 4) - (lgrp ^ key)) << 4));
+      }
     }
   };
   auto read_b = [&](int half) {
-    const char* base = smem + cmp_buf * BUF_BYTES + (half ? 3 : 1) * HALF_BYTES + b_off;
+    const char* base = smem + cmp_buf * BUF_BYTES + (half ? 3 : 1) * HALF_BYTES;
+    if constexpr (M32) {
 #pragma unroll
-    for (int b = 0; b < 4; ++b) {
-      fb[b][0] = *(const u32x4_t*)(base + b * 2048);
-      fb[b][1] = *(const u32x4_t*)(base + b * 2048 + ((((lgrp ^ key) ^ 4) - (lgrp ^ key)) << 4));
+      for (int b32 = 0; b32 < 2; ++b32)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) fb[2 * b32 + (q >> 1)][q & 1] = *(const u32x4_t*)(base + b32 * 4096 + (b_off ^ (q << 5)));
+    } else {
+      base += b_off;
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        fb[b][0] = *(const u32x4_t*)(base + b * 2048);
+        fb[b][1] = *(const u32x4_t*)(base + b * 2048 + ((((lgrp ^ key) ^ 4) - (lgrp ^ key)) << 4));
+      }
     }
   };
   auto mma_quadrant = [&](const u32x4_t (&f)[2][2], auto hc, auto hq) {
     constexpr int HC = decltype(hc)::value, HQ = decltype(hq)::value;
+    if constexpr (M32) {
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+      for (int q = 0; q < 4; ++q)
 #pragma unroll
-      for (int a = 0; a < 2; ++a)
+        for (int b32 = 0; b32 < 2; ++b32)
+          acc32[HC][HQ * 2 + b32] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, f[q >> 1][q & 1]),
+                                                                           __builtin_bit_cast(bf16x8_t, fb[2 * b32 + (q >> 1)][q & 1]),
+                                                                           acc32[HC][HQ * 2 + b32], 0, 0, 0);
+    } else {
 #pragma unroll
-        for (int b = 0; b < 4; ++b) Mma<bf16_t>::run(acc[HC * 2 + a][HQ * 4 + b], f[a][j], fb[b][j]);
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+          for (int b = 0; b < 4; ++b) Mma<bf16_t>::run(acc[HC * 2 + a][HQ * 4 + b], f[a][j], fb[b][j]);
+    }
   };
 
   // ---- epilogue of one wave: acc (64 channels x 128 pixels) -> y ----
@@ -227,7 +271,53 @@ __global__ __launch_bounds__(512, 2) void igemm_big_kernel(const IgemmParams p) 
     const int tp = fast_div(sid, p.div_tc_m, p.div_tc_s), tc = sid - tp * p.tiles_c;
     const int c_wave = tc * BC + wc * 64, p_wave = tp * BP + wp * 128;
     const int nvw = p.M - p_wave;   // valid pixel rows of this wave's slab (<= 0: none)
-    if (p.tile_stats) {
+    if (M32 && p.tile_stats) {
+      // per-channel (mean, M2) of this wave's <= 128 rows from the 32x32 accumulators: a lane owns pixel r32 of each 32-pixel block
+      // and channels 32 HC + 8 g + 4 h32 + j; sums about the slab's first pixel, reduced over the 32 pixel lanes (DPP row sums + one
+      // cross-row shuffle)
+#pragma unroll
+      for (int hc = 0; hc < 2; ++hc)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          float s1[4], s2[4], x0[4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            x0[i] = __shfl(acc32[hc][0][4 * g + i], lane & 32, 64);
+            s1[i] = 0.f; s2[i] = 0.f;
+          }
+#pragma unroll
+          for (int pb = 0; pb < 4; ++pb) {
+            const bool ok = pb * 32 + r32 < nvw;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              const float d = ok ? acc32[hc][pb][4 * g + i] - x0[i] : 0.f;
+              s1[i] += d;
+              s2[i] = fmaf(d, d, s2[i]);
+            }
+          }
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            s1[i] = row16_sum(s1[i]);
+            s2[i] = row16_sum(s2[i]);
+            s1[i] += __shfl_xor(s1[i], 16, 64);
+            s2[i] += __shfl_xor(s2[i], 16, 64);
+          }
+          const int c = c_wave + 32 * hc + 8 * g + 4 * h32;
+          if (r32 == 0 && nvw > 0 && c < p.Cout) {
+            const float n = (float)(nvw < 128 ? nvw : 128);
+            float4 o;
+            float m = s1[0] / n; o.x = x0[0] + m; o.y = fmaxf(s2[0] - s1[0] * m, 0.f);
+            m = s1[1] / n; o.z = x0[1] + m; o.w = fmaxf(s2[1] - s1[1] * m, 0.f);
+            float4 o2;
+            m = s1[2] / n; o2.x = x0[2] + m; o2.y = fmaxf(s2[2] - s1[2] * m, 0.f);
+            m = s1[3] / n; o2.z = x0[3] + m; o2.w = fmaxf(s2[3] - s1[3] * m, 0.f);
+            float* dst = p.tile_stats + ((size_t)(tp * 2 + wp) * p.Cout + c) * 2;
+            *(float4*)dst = o;
+            *(float4*)(dst + 4) = o2;
+          }
+        }
+    }
+    if (!M32 && p.tile_stats) {
       // per-channel (mean, M2) of this wave's <= 128 rows: one statistics tile per wave slab (see conv_igemm.hip)
 #pragma unroll
       for (int a = 0; a < 4; ++a) {
@@ -321,8 +411,22 @@ __global__ __launch_bounds__(512, 2) void igemm_big_kernel(const IgemmParams p) 
         }
       }
       // scratch [16 pixels][16 slots of 4 channels], slot index XOR pixel: conflict-free 16-byte writes and reads
+      if constexpr (M32) {
+        // the 16 pixels of block b sit in the lanes whose bit 4 equals b & 1 (pixel r32 of 32-pixel block b >> 1); each of those 32
+        // lanes writes its 8 channel quads (slot 8 HC + 2 g + h32)
+        if (((lane >> 4) & 1) == (b & 1)) {
 #pragma unroll
-      for (int a = 0; a < 4; ++a) *(f32x4_t*)(scr + lrow * 64 + (((a * 4 + lgrp) ^ lrow) << 2)) = acc[a][b];
+          for (int hc = 0; hc < 2; ++hc)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+              const f32x16_t& t = acc32[hc][b >> 1];
+              *(f32x4_t*)(scr + lrow * 64 + (((8 * hc + 2 * g + h32) ^ lrow) << 2)) = (f32x4_t){t[4 * g], t[4 * g + 1], t[4 * g + 2], t[4 * g + 3]};
+            }
+        }
+      } else {
+#pragma unroll
+        for (int a = 0; a < 4; ++a) *(f32x4_t*)(scr + lrow * 64 + (((a * 4 + lgrp) ^ lrow) << 2)) = acc[a][b];
+      }
       __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): the wave's own LDS writes are done before its reads
 #pragma unroll
       for (int k = 0; k < 2; ++k) {
@@ -383,10 +487,19 @@ __global__ __launch_bounds__(512, 2) void igemm_big_kernel(const IgemmParams p) 
       }
       __builtin_amdgcn_s_waitcnt(0xc07f);   // reads of this block retired before the next block overwrites the scratch
     }
+    if constexpr (M32) {
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
+      for (int a = 0; a < 2; ++a)
 #pragma unroll
-      for (int b = 0; b < 8; ++b) acc[a][b] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) acc32[a][b][e] = 0.f;
+    } else {
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 8; ++b) acc[a][b] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    }
   };
 
   // ---------------------------------------------------------------------------------------------------------------
@@ -441,18 +554,28 @@ __global__ __launch_bounds__(512, 2) void igemm_big_kernel(const IgemmParams p) 
   if (stagger && wp == 0) __builtin_amdgcn_s_barrier();
 }
 
-template <int DBG>
-static hipError_t launch_big(const IgemmParams& p, int nblk, hipStream_t s) {
+// 1: 32x32x16 MFMAs in the 256 x 256 tile; 0 (default): the 16x16x32 form of rounds 2-4.  Measured (profiles/r05_notes.md 7): bit-compatible
+// up to the K summation order, conflict-free fragment reads - and 4 .. 6 % SLOWER (head1 219 -> 232 us, fc1 + GELU 484 -> 512 us): the phase
+// period of this kernel is not set by the matrix-pipe time, so the faster instruction buys nothing and its half-masked epilogue writes cost
+static int g_big_m32 = 0;
+extern "C" int cavp_set_igemm_big_mfma(int m32) { g_big_m32 = m32 != 0; return CAVP_OK; }
+
+template <int DBG, bool M32>
+static hipError_t launch_big_m(const IgemmParams& p, int nblk, hipStream_t s) {
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)igemm_big_kernel<DBG>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    (void)hipFuncSetAttribute((const void*)igemm_big_kernel<DBG, M32>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     attr_set = true;
   }
   IgemmParams q = p;
   q.nblk = nblk;
   const int grid = nblk > 256 ? 256 : nblk;
-  igemm_big_kernel<DBG><<<dim3(grid), dim3(NT), LDS_BYTES, s>>>(q);
+  igemm_big_kernel<DBG, M32><<<dim3(grid), dim3(NT), LDS_BYTES, s>>>(q);
   return hipGetLastError();
+}
+template <int DBG>
+static hipError_t launch_big(const IgemmParams& p, int nblk, hipStream_t s) {
+  return g_big_m32 ? launch_big_m<DBG, true>(p, nblk, s) : launch_big_m<DBG, false>(p, nblk, s);
 }
 
 hipError_t cavp_launch_igemm_big(const IgemmParams& p, int nblk, hipStream_t s) {

@@ -283,6 +283,7 @@ _SIDE_STREAM = True      # False (tests / A-B only): the audio encoder on the ma
 # (cavp_conv2d_wgrad_group).  False (tests / A-B only): one launch (+ one slab reduce) per layer, where the layer's backward runs.
 _GROUP_WGRAD = True
 _WGRAD_STREAM = False    # False (tests / A-B only): grouped weight gradients on the main stream, between the data gradients (round 3)
+_SIDE_PACKS = True       # False (A/B only): the audio encoder's weight re-packs on the main stream with all the others (rounds 1-4)
 _FUSE_BN_BWD = True      # False (tests / A-B only): BatchNorm backward always as reduce launch + apply launch (rounds 1-4)
 _BNB_ATOMIC = False      # True (A/B only): the fused BatchNorm-backward sums by f32 atomics instead of per-tile partials + a summation launch
 _FUSE_BN_APPLY_MAX_TILES = 128
@@ -359,9 +360,15 @@ class TrainPass:
         self.P[key] = p
         return p
 
-    def flush_packs(self) -> None:
-        T.pack_weights_multi(self._pack_jobs, self.dt)
-        self._pack_jobs = []
+    def flush_packs(self, keep_from: Optional[int] = None) -> list:
+        """Issue the deferred re-packs; keep_from: the jobs from that index on are NOT issued but returned (the audio encoder's weights -
+        two thirds of the bytes - are re-packed by the side stream that uses them, off the main stream's critical path)."""
+        jobs, self._pack_jobs = self._pack_jobs, []
+        held = []
+        if keep_from is not None:
+            jobs, held = jobs[:keep_from], jobs[keep_from:]
+        T.pack_weights_multi(jobs, self.dt)
+        return held
 
     def finish_padded(self) -> None:
         self.flush_wgrads()
@@ -1248,13 +1255,18 @@ def run_train_forward(model, image: torch.Tensor, audio: torch.Tensor, tp: Train
     tp.pack("aspp.red", aspp.red_conv)
     tp.pack("reduce", m.segment.reduce[0])
     _pack_head(tp, m)
-    _pack_audio(tp, m)
     _pack_fusion(tp, m)
-    tp.flush_packs()
+    n_main = len(tp._pack_jobs)
+    _pack_audio(tp, m)
     ev_start = None
-    if tp.dev.type == "cuda":
+    if tp.dev.type == "cuda":   # (the side stream may start once the step's inputs / weights are final: before the main re-pack)
         ev_start = torch.cuda.Event()
         ev_start.record(torch.cuda.current_stream())
+    # the audio encoder's re-packs (73 M of the ~115 M weights: the 12288 x 4096 and 4096 x 4096 FC layers) go to the stream that runs
+    # the audio encoder - forward and backward - so the main stream only re-packs what it uses itself
+    side_packs_on = _SIDE_PACKS and tp.side_stream() is not None and not pvt
+    # (also moving the main stream's data-gradient layouts over was measured: no further gain, the weights are then read twice)
+    audio_packs = tp.flush_packs(keep_from=n_main if side_packs_on else None)
 
     dt = tp.dt
     if pvt:
@@ -1313,11 +1325,13 @@ def run_train_forward(model, image: torch.Tensor, audio: torch.Tensor, tp: Train
     side = tp.side_stream()
     t0 = len(tp.tape)
     if side is None:
+        assert not audio_packs
         fea_a = audio_encoder()
     else:
         side.wait_event(ev_start)
         with torch.cuda.stream(side), ops.workspace_slot(1):
             tp._slot = 1
+            T.pack_weights_multi(audio_packs, tp.dt)   # (held back by flush_packs above; the side section's backward runs on this stream too)
             fea_a = audio_encoder()
             tp._slot = 0
             ev_audio = torch.cuda.Event()

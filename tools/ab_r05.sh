@@ -15,7 +15,7 @@ fi
 if [ "$part" = step ]; then
   { for r in 1 2 3; do
       echo "default                $(ms)"
-      echo "--bn-apply-fusion      $(ms --bn-apply-fusion)"
+      echo "--no-side-packs        $(ms --no-side-packs)"
       echo "--no-bn-bwd-fusion     $(ms --no-bn-bwd-fusion)"
     done; } > $O/ab_step.txt 2>&1
   cat $O/ab_step.txt
