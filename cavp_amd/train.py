@@ -283,6 +283,7 @@ _SIDE_STREAM = True      # False (tests / A-B only): the audio encoder on the ma
 # (cavp_conv2d_wgrad_group).  False (tests / A-B only): one launch (+ one slab reduce) per layer, where the layer's backward runs.
 _GROUP_WGRAD = True
 _WGRAD_STREAM = False    # False (tests / A-B only): grouped weight gradients on the main stream, between the data gradients (round 3)
+_BRANCH_STREAM = True    # False (tests / A-B only): the down-sample branch of a bottleneck on the main stream (rounds 1-4)
 _SIDE_PACKS = True       # False (A/B only): the audio encoder's weight re-packs on the main stream with all the others (rounds 1-4)
 _FUSE_BN_BWD = True      # False (tests / A-B only): BatchNorm backward always as reduce launch + apply launch (rounds 1-4)
 _BNB_ATOMIC = False      # True (A/B only): the fused BatchNorm-backward sums by f32 atomics instead of per-tile partials + a summation launch
@@ -1083,6 +1084,17 @@ class TrainPass:
             self.m.__dict__["_side_stream"] = s
         return s
 
+    def branch_stream(self):
+        """Third stream: the down-sample branch of a layer's first bottleneck in the forward (None: CPU tensors, deterministic mode -
+        process-wide scratch -, SyncBatchNorm with live collectives - their order across ranks must not depend on stream timing -, A/B switch)."""
+        if self.dev.type != "cuda" or not _BRANCH_STREAM or _lib_load().cavp_get_deterministic() or collectives_on():
+            return None
+        s = getattr(self.m, "_branch_stream", None)
+        if s is None or s.device != self.dev:
+            s = torch.cuda.Stream(device=self.dev)
+            self.m.__dict__["_branch_stream"] = s
+        return s
+
     def join_side(self) -> None:
         """Make the current stream wait for the side section's backward (its parameter gradients are final after this)."""
         if self._side_done is not None:
@@ -1285,9 +1297,25 @@ def run_train_forward(model, image: torch.Tensor, audio: torch.Tensor, tp: Train
             for bi, (_, _, _, has_ds) in enumerate(stage):
                 blkm = getattr(rn, f"layer{si + 1}")[bi]
                 key = f"l{si + 1}.{bi}"
+                bs = tp.branch_stream() if has_ds else None
+                if bs is not None:   # the block input is final here: the down-sample branch may start
+                    ev_x = torch.cuda.Event()
+                    ev_x.record(torch.cuda.current_stream())
                 o = tp.bn_act(tp.conv(x, key + ".c1", stats=blkm.bn1), blkm.bn1, ACT_RELU)
                 o = tp.bn_act(tp.conv(o, key + ".c2", stats=blkm.bn2), blkm.bn2, ACT_RELU)
-                res = tp.bn_act(tp.conv(x, key + ".ds", stats=blkm.downsample[1]), blkm.downsample[1], ACT_NONE) if has_ds else x
+                if bs is not None:
+                    # down-sample conv + BatchNorm (resnet.py:84-90) depend on the block input only: three small launches that run on
+                    # a stream of their own beside conv1 -> conv2 (forward only; issued here so that the tape keeps the forward order)
+                    bs.wait_event(ev_x)
+                    with torch.cuda.stream(bs), ops.workspace_slot(2):
+                        tp._slot = 2
+                        res = tp.bn_act(tp.conv(x, key + ".ds", stats=blkm.downsample[1]), blkm.downsample[1], ACT_NONE)
+                        tp._slot = 0
+                        ev_r = torch.cuda.Event()
+                        ev_r.record(bs)
+                    torch.cuda.current_stream().wait_event(ev_r)
+                else:
+                    res = tp.bn_act(tp.conv(x, key + ".ds", stats=blkm.downsample[1]), blkm.downsample[1], ACT_NONE) if has_ds else x
                 x = tp.bn_act(tp.conv(o, key + ".c3", stats=blkm.bn3), blkm.bn3, ACT_RELU, residual=res)
                 tp.named[key] = x
             feats.append(x)

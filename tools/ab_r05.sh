@@ -16,7 +16,7 @@ if [ "$part" = step ]; then
   { for r in 1 2 3; do
       echo "default                $(ms)"
       echo "--no-side-packs        $(ms --no-side-packs)"
-      echo "--no-bn-bwd-fusion     $(ms --no-bn-bwd-fusion)"
+      echo "--no-branch-stream     $(ms --no-branch-stream)"
     done; } > $O/ab_step.txt 2>&1
   cat $O/ab_step.txt
 fi
