@@ -72,6 +72,7 @@ def parse():
     ap.add_argument("--wgrad-big", default="", help="A/B: cavp_set_wgrad_big MODE:SCHEDULE (mode 0 = the 256x256 weight-gradient tile where it qualifies, "
                                                      "1 = never; schedule 2 = 16 waves, 1 / 0 = 8 waves)")
     ap.add_argument("--no-wgrad-stream", action="store_true", help="A/B: grouped weight gradients on the main stream instead of their own (round 3)")
+    ap.add_argument("--branch-stream-bwd", action="store_true", help="A/B: also the down-sample branch's backward on the branch stream (default: main stream)")
     ap.add_argument("--no-branch-stream", action="store_true", help="A/B: the bottlenecks' down-sample branch on the main stream (rounds 1-4)")
     ap.add_argument("--no-side-packs", action="store_true", help="A/B: the audio encoder's weight re-packs on the main stream (rounds 1-4)")
     ap.add_argument("--no-bn-bwd-fusion", action="store_true", help="A/B: BatchNorm backward always as reduce launch + apply launch (rounds 1-4)")
@@ -637,6 +638,9 @@ def main():
     if a.no_wgrad_stream:
         import cavp_amd.train as _tr
         _tr._WGRAD_STREAM = False
+    if a.branch_stream_bwd:
+        import cavp_amd.train as _tr
+        _tr._BRANCH_STREAM_BWD = True
     if a.no_branch_stream:
         import cavp_amd.train as _tr
         _tr._BRANCH_STREAM = False

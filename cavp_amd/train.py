@@ -283,6 +283,7 @@ _SIDE_STREAM = True      # False (tests / A-B only): the audio encoder on the ma
 # (cavp_conv2d_wgrad_group).  False (tests / A-B only): one launch (+ one slab reduce) per layer, where the layer's backward runs.
 _GROUP_WGRAD = True
 _WGRAD_STREAM = False    # False (tests / A-B only): grouped weight gradients on the main stream, between the data gradients (round 3)
+_BRANCH_STREAM_BWD = False  # True (A-B only): also the down-sample branch's BACKWARD on that stream - measured slower (14.22 vs 14.12 ms: its weight gradient leaves the grouped launches)
 _BRANCH_STREAM = True    # False (tests / A-B only): the down-sample branch of a bottleneck on the main stream (rounds 1-4)
 _SIDE_PACKS = True       # False (A/B only): the audio encoder's weight re-packs on the main stream with all the others (rounds 1-4)
 _FUSE_BN_BWD = True      # False (tests / A-B only): BatchNorm backward always as reduce launch + apply launch (rounds 1-4)
@@ -311,6 +312,7 @@ class TrainPass:
         self.syncbn_poison: Optional[torch.Tensor] = None   # 0-dim 0.0 / NaN from _syncbn_shape_exchange, added to the logits
         # side section (the audio encoder): tape range run on a second stream, concurrently with the visual backbone
         self.side_range: Optional[tuple] = None
+        self.branch_ranges: list = []      # (first, past-last, join-before) tape indices of the down-sample branches (branch_stream())
         self._side_done = None
         self._slot = 0
         self._zpools: Dict[int, list] = {}
@@ -1105,7 +1107,27 @@ class TrainPass:
         side = self.side_stream() if self.side_range is not None else None
         i0, i1 = self.side_range if side is not None else (-1, -1)
         i = len(self.tape) - 1
+        bs = self.branch_stream() if self.branch_ranges else None
+        fork_at = {t1 - 1: (t0, t1, tj) for (t0, t1, tj) in self.branch_ranges} if bs is not None else {}
+        join_at: Dict[int, object] = {}
         while i >= 0:
+            if i in join_at:
+                torch.cuda.current_stream().wait_event(join_at.pop(i))
+            if i in fork_at:
+                t0b, t1b, tj = fork_at[i]
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream())
+                bs.wait_event(ev)
+                with torch.cuda.stream(bs), ops.workspace_slot(2):
+                    self._slot = 2
+                    for j in range(t1b - 1, t0b - 1, -1):
+                        self.tape[j]()
+                    self._slot = 0
+                    done = torch.cuda.Event()
+                    done.record(bs)
+                join_at[tj] = done
+                i = t0b - 1
+                continue
             if i == i1 - 1:
                 # fork: everything recorded after the side section (fusion, head) has been issued; its gradients feed both
                 # the side section's backward and the rest of the main tape, which now run concurrently
@@ -1123,6 +1145,8 @@ class TrainPass:
                 continue
             self.tape[i]()
             i -= 1
+        for ev in join_at.values():   # (a branch whose join point was never reached)
+            torch.cuda.current_stream().wait_event(ev)
         self.flush_wgrads()
         self.join_side()
         self.tape = []
@@ -1298,6 +1322,7 @@ def run_train_forward(model, image: torch.Tensor, audio: torch.Tensor, tp: Train
                 blkm = getattr(rn, f"layer{si + 1}")[bi]
                 key = f"l{si + 1}.{bi}"
                 bs = tp.branch_stream() if has_ds else None
+                t_c1 = len(tp.tape)
                 if bs is not None:   # the block input is final here: the down-sample branch may start
                     ev_x = torch.cuda.Event()
                     ev_x.record(torch.cuda.current_stream())
@@ -1309,7 +1334,13 @@ def run_train_forward(model, image: torch.Tensor, audio: torch.Tensor, tp: Train
                     bs.wait_event(ev_x)
                     with torch.cuda.stream(bs), ops.workspace_slot(2):
                         tp._slot = 2
+                        t_ds = len(tp.tape)
                         res = tp.bn_act(tp.conv(x, key + ".ds", stats=blkm.downsample[1]), blkm.downsample[1], ACT_NONE)
+                        if _BRANCH_STREAM_BWD:
+                            # backward: BatchNorm backward + data / weight gradient of the branch run on the same stream, beside
+                            # conv3 <- conv2 <- conv1's chain; conv1's data gradient (the next contribution to the block input's
+                            # gradient) waits for them
+                            tp.branch_ranges.append((t_ds, len(tp.tape), t_c1))
                         tp._slot = 0
                         ev_r = torch.cuda.Event()
                         ev_r.record(bs)

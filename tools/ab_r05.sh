@@ -15,7 +15,7 @@ fi
 if [ "$part" = step ]; then
   { for r in 1 2 3; do
       echo "default                $(ms)"
-      echo "--no-side-packs        $(ms --no-side-packs)"
+      echo "--branch-stream-bwd    $(ms --branch-stream-bwd)"
       echo "--no-branch-stream     $(ms --no-branch-stream)"
     done; } > $O/ab_step.txt 2>&1
   cat $O/ab_step.txt
