@@ -548,7 +548,7 @@ class CAVP(nn.Module):
         heads = blk.attn.num_heads
         attn = torch.empty((B, heads, T), dtype=torch.float32, device=dev)
         from . import train as _tr
-        if _tr._RANK1_ATTN and ops.attn1_supported(Cc, heads):
+        if _tr._RANK1_ATTN and ops.attn1_usable(blk.attn):
             # one key per batch item: q GEMM + gate + proj GEMM + residual in one pass over the tokens (csrc/attn_rank1.hip)
             u, pm = ops.attn1_prepare(blk.attn.q.weight.detach(), blk.attn.proj.weight.detach(), k, vv, heads, blk.attn.scale)
             r1 = ops.attn1_fwd(vn, u, pm, blk.attn.proj.bias.detach() if blk.attn.proj.bias is not None else None,

@@ -312,6 +312,14 @@ def attn_gate(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Tens
     return out
 
 
+def attn1_usable(attn_mod) -> bool:
+    """The one-key collapse fits this attention module: supported shape AND f32, contiguous q / proj weights (a model cast with
+    .bfloat16() / .half() keeps the q GEMM + gate + proj GEMM route instead of failing in attn1_prepare)."""
+    wq, wp = attn_mod.q.weight, attn_mod.proj.weight
+    return (attn1_supported(attn_mod.q.in_features, attn_mod.num_heads) and wq.dtype == torch.float32 and wp.dtype == torch.float32
+            and wq.is_contiguous() and wp.is_contiguous())
+
+
 def attn1_supported(c: int, heads: int) -> bool:
     """The one-key attention collapse (cavp_attn1_*) covers this shape (4 heads, C <= 512, C % 8 == 0)."""
     return bool(_lib.load().cavp_attn1_supported(int(c), int(heads)))

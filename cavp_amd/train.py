@@ -1178,7 +1178,7 @@ def _pack_fusion(tp: TrainPass, m) -> None:
     ca, blk = m.cross_att, m.cross_att.blocks[0]
     tp.pack("ca.pe_v", ca.patch_embed_v.proj)
     tp.pack("ca.pe_a", ca.patch_embed_a.proj)
-    rank1 = _RANK1_ATTN and ops.attn1_supported(blk.attn.q.in_features, blk.attn.num_heads)
+    rank1 = _RANK1_ATTN and ops.attn1_usable(blk.attn)
     for nme in (("k", "v") if rank1 else ("q", "k", "v", "proj")):   # (the one-key collapse reads attn.q / attn.proj as f32)
         tp.pack("ca." + nme, getattr(blk.attn, nme))
     tp.pack("ca.fc1", blk.mlp.fc1)
@@ -1224,7 +1224,7 @@ def _fusion_stage(tp: TrainPass, m, fea_v: V, fea_a: V, duplicate: bool):
     an = tp.layernorm(a0, blk.norm1)
     k = tp.conv(an, "ca.k")
     vv = tp.conv(an, "ca.v")
-    if _RANK1_ATTN and ops.attn1_supported(Cc, blk.attn.num_heads):
+    if _RANK1_ATTN and ops.attn1_usable(blk.attn):
         # one key per batch item: q-GEMM + gate + proj-GEMM + residual as ONE pass over the tokens (csrc/attn_rank1.hip); the 2B
         # rows of `vn` are never materialised (batch item b reads vn[b % Bv])
         r1, attn = tp.attn_rank1(vnB, k, vv, blk.attn)
