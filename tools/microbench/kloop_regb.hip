@@ -237,6 +237,13 @@ int main() {
   run<64, 64, 4, 1, 4, true>(wsrc, xsrc, x_bytes, sink);
   run<64, 64, 4, 1, 6, true>(wsrc, xsrc, x_bytes, sink);
   run<128, 128, 2, 2, 2, false>(wsrc, xsrc, x_bytes, sink);
+  run<128, 128, 2, 2, 3, false>(wsrc, xsrc, x_bytes, sink);
+  run<128, 128, 2, 2, 4, false>(wsrc, xsrc, x_bytes, sink);
+  run<128, 128, 2, 2, 5, false>(wsrc, xsrc, x_bytes, sink);
+  run<64, 128, 2, 2, 2, false>(wsrc, xsrc, x_bytes, sink);
+  run<64, 128, 2, 2, 4, false>(wsrc, xsrc, x_bytes, sink);
+  run<64, 128, 2, 2, 6, false>(wsrc, xsrc, x_bytes, sink);
+  run<64, 64, 2, 2, 8, false>(wsrc, xsrc, x_bytes, sink);
   run<128, 128, 2, 2, 3, true>(wsrc, xsrc, x_bytes, sink);
   run<128, 128, 2, 2, 4, true>(wsrc, xsrc, x_bytes, sink);
   run<128, 128, 4, 1, 3, true>(wsrc, xsrc, x_bytes, sink);
