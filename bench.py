@@ -77,7 +77,6 @@ def parse():
     ap.add_argument("--no-side-packs", action="store_true", help="A/B: the audio encoder's weight re-packs on the main stream (rounds 1-4)")
     ap.add_argument("--no-bn-bwd-fusion", action="store_true", help="A/B: BatchNorm backward always as reduce launch + apply launch (rounds 1-4)")
     ap.add_argument("--bn-apply-fusion", action="store_true", help="A/B: BatchNorm forward of the <= 128-tile tensors as one launch (cavp_bn_apply_tiles; default: finalize launch + apply launch)")
-    ap.add_argument("--big-mfma", type=int, default=-1, help="A/B: cavp_set_igemm_big_mfma (1 = 32x32x16 MFMAs in the 256x256 tile, 0 = 16x16x32)")
     ap.add_argument("--no-tail-split", action="store_true", help="A/B: never split a 256x256-tile launch with a nearly empty last round")
     ap.add_argument("--trainer-loop", action="store_true",
                     help="the reference trainer's call sequence instead of the fused step: out = model(image, audio) -> torch "
@@ -653,9 +652,6 @@ def main():
     if a.bn_apply_fusion:
         import cavp_amd.train as _tr
         _tr._FUSE_BN_APPLY = True
-    if a.big_mfma >= 0:
-        from cavp_amd import _lib as _cl4
-        assert _cl4.load().cavp_set_igemm_big_mfma(a.big_mfma) == 0
     if a.no_tail_split:
         from cavp_amd import _lib as _cl0
         _cl0.load().cavp_set_tail_split(0)

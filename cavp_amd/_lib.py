@@ -55,7 +55,6 @@ PROTOTYPES = {
     "cavp_conv2d_nhwc": (_i32, [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _vp]),
     "cavp_conv2d_nhwc_aux": (_i32, [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _vp]),
     "cavp_set_tail_split": (_i32, [_i32]),
-    "cavp_set_igemm_big_mfma": (_i32, [_i32]),
     "cavp_set_igemm_epilogue": (_i32, [_i32]),
     "cavp_set_wgrad_variant": (_i32, [_i32]),
     "cavp_set_wgrad_big": (_i32, [_i32, _i32]),

@@ -1,24 +1,24 @@
-// 256 x 256 implicit-GEMM tile for the large CAVP layers (bf16, gfx950): one 8-wave workgroup per CU, ping-pong wave groups.
+// 256 x 256 implicit-GEMM tile for the large CAVP layers (bf16, gfx950): one 8-wave workgroup per CU, 2-stage LDS-DMA ring.
 //
 // Why a second kernel: the 4-wave 128x128 tile of conv_igemm.hip moves 64 flop per operand byte through the LDS-DMA path
 // (~60 GB/s per CU), which caps it near 1 PF/s however its K loop is scheduled (profiles/r01_notes.md).  A 256x256 tile
-// needs half the operand bytes per flop; its 128 accumulator registers per lane leave room for only ONE workgroup per CU,
-// so the overlap that two co-resident workgroups gave for free has to be built into the schedule:
+// needs half the operand bytes per flop; its 128 accumulator registers per lane leave room for only ONE workgroup per CU.
 //
-//  * 8 waves = 4 (channel) x 2 (pixel); wave tile 64 channels x 128 pixels = 4 x 8 MFMA 16x16x32 blocks.  The two pixel
-//    halves are two wave GROUPS (waves 0-3 / 4-7, one wave of each per SIMD) that run half a phase apart: while one group
-//    issues its 16 MFMAs the other issues its LDS fragment reads and the LDS-DMA of a future K tile (one extra s_barrier
-//    for group 1 before the loop, one for group 0 after it).
-//  * a K tile (64 channels of one tap) = 4 phases, one quadrant (32 channels x 64 pixels x K 64 = 16 MFMAs) each, two raw
-//    s_barrier per phase.  Per phase every thread issues the two 16-byte LDS-DMA pieces of ONE half tile (16 KiB):
-//    H0 = weights rows of the low channel halves, H1 = pixels of the low pixel halves, H2 / H3 = the high halves - the
-//    order in which the quadrants (c0,p0) (c1,p0) (c1,p1) (c0,p1) consume them.
-//  * the LDS ring holds 2 K tiles = 8 half-tile regions (128 KiB).  The half tile issued in phase g is the one consumed 6
-//    phases later: 4 half tiles (64 KiB per CU) are in flight behind a counted s_waitcnt vmcnt(8) per phase, a region is
-//    re-filled >= 2 phases after its last fragment read was issued (the stagger costs one of them), and data is read one
-//    phase after the wait + barrier that retires it.
+//  * 8 waves = 4 (channel) x 2 (pixel); wave tile 64 channels x 128 pixels = 4 x 8 MFMA 16x16x32 blocks, multiplied as four
+//    quadrants (c0,p0) (c1,p0) (c1,p1) (c0,p1) of 16 MFMAs whose fragment reads the compiler interleaves with the MFMAs.
+//  * a K tile (64 channels of one tap) = four 16 KiB half tiles in LDS: H0 = weight rows of the low channel halves, H1 = pixels of
+//    the low pixel halves, H2 / H3 = the high halves; every thread issues the two 16-byte LDS-DMA pieces of each.
+//  * the K loop is a plain 2-stage ring (128 KiB): iteration u waits for ITS pieces of K tile u (vmcnt(0)), ONE s_barrier
+//    (everybody's pieces landed, everybody is done multiplying K tile u - 1), issues the 8 pieces of K tile u + 1 into the stage
+//    K tile u - 1 vacated, multiplies K tile u.  The two waves of a SIMD cover each other's fragment reads and MFMAs by themselves.
+//    Rounds 2-5 ran this tile as a hand-built ping-pong of two wave groups (4 phases and 8 barriers per K tile, DMA 6 phases ahead
+//    behind counted vmcnt); round 6's micro-benchmark (tools/microbench/kloop_rega.hip, profiles/r06_notes.md 1) showed the plain
+//    ring at or above it and the product A/B agreed (bit-identical outputs; 1x1 / linear launches -5 .. -7 %, 3x3 -0 .. -2 %, step
+//    -0.04 ms): the ping-pong schedule, its 32x32x16 variant (4 .. 6 % slower in both schedules) and a 16-wave variant of the ring
+//    (faster in the micro-benchmark, 10 .. 19 % slower as a product kernel: no registers for double-buffered fragments next to the
+//    conv's DMA descriptors at 128 VGPRs) were measured and removed.
 //  * the K-tile stream runs ACROSS the output tiles of the persistent workgroup: the loads of the next tile's first K
-//    tiles are in flight while the last quadrants of the current tile are multiplied and while its epilogue runs.
+//    tile are in flight while the epilogue of the current tile runs.
 //  * epilogue per WAVE, no workgroup barrier: 16-pixel x 64-channel f32 blocks go through a private 4 KiB LDS scratch (the
 //    last 32 KiB of the 160 KiB) and leave as 16-byte stores, 128 contiguous bytes per pixel; BatchNorm statistics come
 //    from the accumulators in registers (one 128-row statistics tile per wave slab).
@@ -47,18 +47,12 @@ constexpr unsigned kOOB = 0x80000000u;
 static_assert(LDS_BYTES == 160 * 1024, "the whole LDS of a CU");
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
-typedef __attribute__((ext_vector_type(16))) float f32x16_t;
 
 }  // namespace
 
 // DBG: compile-time profiling switches (instantiated only under -DCAVP_PROFILE; a RUN-time test of such a flag inside the
-// phase loop splits its basic blocks and made the product kernel 1.8x slower): 1 taps outermost, 2 no stagger, 4 no
-// s_setprio, 8 no DMA, 16 no MFMA, 32 no fragment reads, 64 no epilogue.
-// M32: the K loop multiplies with v_mfma_f32_32x32x16_bf16 (2.49 PF/s alone, tools/microbench/kloop_regb.hip) instead of
-// v_mfma_f32_16x16x32_bf16 (1.37 PF/s alone): at the 16x16x32 rate this tile's K loop was ~88 % matrix-pipe time.  Same LDS layout, same
-// number of fragment reads; a wave's quadrant (32 channels x 64 pixels x K 64) is 2 blocks x 4 K steps of 32x32x16 instead of 8 blocks x
-// 2 K steps of 16x16x32.  A lane of the 32x32 accumulator holds, for pixel (lane & 31), channels 8 g + 4 (lane >> 5) + j (g, j = 0..3).
-template <int DBG, bool M32>
+// K loop splits its basic blocks): 1 taps outermost, 8 no DMA, 16 no MFMA, 32 no fragment reads, 64 no epilogue.
+template <int DBG>
 __global__ __launch_bounds__(512, 2) void igemm_big_kernel(const IgemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   cavp_prefetch_kernargs<(int)sizeof(IgemmParams)>();
@@ -186,82 +180,44 @@ __global__ __launch_bounds__(512, 2) void igemm_big_kernel(const IgemmParams p) 
   // ---------------------------------------------------------------------------------------------------------------
   // compute side
   // ---------------------------------------------------------------------------------------------------------------
-  // 16x16x32: acc[a][b] = 16-channel block a (4) x 16-pixel block b (8), 4 channels per lane;  32x32x16: the same 128 registers are
-  // acc32[HC][pb] = 32-channel half HC (2) x 32-pixel block pb (4), 16 values per lane (acc32[HC][pb] aliases acc[4 (2 HC + pb / 2) ..][..]
-  // only as storage: the two layouts are never mixed)
+  // acc[a][b] = 16-channel block a (4) x 16-pixel block b (8), 4 channels per lane
   f32x4_t acc[4][8];
-  f32x16_t acc32[2][4];
-  if constexpr (M32) {
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+  for (int a = 0; a < 4; ++a)
 #pragma unroll
-      for (int b = 0; b < 4; ++b)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc32[a][b][e] = 0.f;
-  } else {
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-      for (int b = 0; b < 8; ++b) acc[a][b] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-  }
-  u32x4_t fa0[2][2], fa1[2][2], fb[4][2];   // 16x16x32: [block][k sub-step]; 32x32x16: fa[q >> 1][q & 1], fb[2 b32 + (q >> 1)][q & 1], q = K step of 16
+    for (int b = 0; b < 8; ++b) acc[a][b] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  u32x4_t fa0[2][2], fa1[2][2], fb[4][2];   // [block][k sub-step]
 
-  const int r32 = lane & 31, h32 = lane >> 5;
-  const int key = M32 ? (r32 >> 1) & 7 : (lrow >> 1) & 7;
-  // byte offset of (row, slot) inside a half tile for k sub-step 0; 16x16x32: sub-step 1 flips slot bit 2; 32x32x16: K step q flips
-  // the slot bits 1-2 with 2 q (slot = (2 q + h) ^ key = (h ^ key) ^ 2 q)
-  const int a_off = M32 ? (wc * 32 + r32) * 128 + ((h32 ^ key) << 4) : (wc * 32 + lrow) * 128 + ((lgrp ^ key) << 4);
-  const int b_off = M32 ? (wp * 64 + r32) * 128 + ((h32 ^ key) << 4) : (wp * 64 + lrow) * 128 + ((lgrp ^ key) << 4);
+  const int key = (lrow >> 1) & 7;
+  // byte offset of (row, slot) inside a half tile for k sub-step 0; sub-step 1 flips slot bit 2
+  const int a_off = (wc * 32 + lrow) * 128 + ((lgrp ^ key) << 4);
+  const int b_off = (wp * 64 + lrow) * 128 + ((lgrp ^ key) << 4);
   int cmp_buf = 0, cmp_k = 0, cmp_tile = 0;
 
   auto read_a = [&](u32x4_t (&f)[2][2], int half) {
-    const char* base = smem + cmp_buf * BUF_BYTES + (half ? 2 : 0) * HALF_BYTES;
-    if constexpr (M32) {
+    const char* base = smem + cmp_buf * BUF_BYTES + (half ? 2 : 0) * HALF_BYTES + a_off;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) f[q >> 1][q & 1] = *(const u32x4_t*)(base + (a_off ^ (q << 5)));
-    } else {
-      base += a_off;
-#pragma unroll
-      for (int a = 0; a < 2; ++a) {
-        f[a][0] = *(const u32x4_t*)(base + a * 2048);
-        f[a][1] = *(const u32x4_t*)(base + a * 2048 + ((((lgrp ^ key) ^ 4) - (lgrp ^ key)) << 4));
-      }
+    for (int a = 0; a < 2; ++a) {
+      f[a][0] = *(const u32x4_t*)(base + a * 2048);
+      f[a][1] = *(const u32x4_t*)(base + a * 2048 + ((((lgrp ^ key) ^ 4) - (lgrp ^ key)) << 4));
     }
   };
   auto read_b = [&](int half) {
-    const char* base = smem + cmp_buf * BUF_BYTES + (half ? 3 : 1) * HALF_BYTES;
-    if constexpr (M32) {
+    const char* base = smem + cmp_buf * BUF_BYTES + (half ? 3 : 1) * HALF_BYTES + b_off;
 #pragma unroll
-      for (int b32 = 0; b32 < 2; ++b32)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) fb[2 * b32 + (q >> 1)][q & 1] = *(const u32x4_t*)(base + b32 * 4096 + (b_off ^ (q << 5)));
-    } else {
-      base += b_off;
-#pragma unroll
-      for (int b = 0; b < 4; ++b) {
-        fb[b][0] = *(const u32x4_t*)(base + b * 2048);
-        fb[b][1] = *(const u32x4_t*)(base + b * 2048 + ((((lgrp ^ key) ^ 4) - (lgrp ^ key)) << 4));
-      }
+    for (int b = 0; b < 4; ++b) {
+      fb[b][0] = *(const u32x4_t*)(base + b * 2048);
+      fb[b][1] = *(const u32x4_t*)(base + b * 2048 + ((((lgrp ^ key) ^ 4) - (lgrp ^ key)) << 4));
     }
   };
   auto mma_quadrant = [&](const u32x4_t (&f)[2][2], auto hc, auto hq) {
     constexpr int HC = decltype(hc)::value, HQ = decltype(hq)::value;
-    if constexpr (M32) {
 #pragma unroll
-      for (int q = 0; q < 4; ++q)
+    for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int b32 = 0; b32 < 2; ++b32)
-          acc32[HC][HQ * 2 + b32] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, f[q >> 1][q & 1]),
-                                                                           __builtin_bit_cast(bf16x8_t, fb[2 * b32 + (q >> 1)][q & 1]),
-                                                                           acc32[HC][HQ * 2 + b32], 0, 0, 0);
-    } else {
+      for (int a = 0; a < 2; ++a)
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int a = 0; a < 2; ++a)
-#pragma unroll
-          for (int b = 0; b < 4; ++b) Mma<bf16_t>::run(acc[HC * 2 + a][HQ * 4 + b], f[a][j], fb[b][j]);
-    }
+        for (int b = 0; b < 4; ++b) Mma<bf16_t>::run(acc[HC * 2 + a][HQ * 4 + b], f[a][j], fb[b][j]);
   };
 
   // ---- epilogue of one wave: acc (64 channels x 128 pixels) -> y ----
@@ -271,53 +227,7 @@ __global__ __launch_bounds__(512, 2) void igemm_big_kernel(const IgemmParams p) 
     const int tp = fast_div(sid, p.div_tc_m, p.div_tc_s), tc = sid - tp * p.tiles_c;
     const int c_wave = tc * BC + wc * 64, p_wave = tp * BP + wp * 128;
     const int nvw = p.M - p_wave;   // valid pixel rows of this wave's slab (<= 0: none)
-    if (M32 && p.tile_stats) {
-      // per-channel (mean, M2) of this wave's <= 128 rows from the 32x32 accumulators: a lane owns pixel r32 of each 32-pixel block
-      // and channels 32 HC + 8 g + 4 h32 + j; sums about the slab's first pixel, reduced over the 32 pixel lanes (DPP row sums + one
-      // cross-row shuffle)
-#pragma unroll
-      for (int hc = 0; hc < 2; ++hc)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          float s1[4], s2[4], x0[4];
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            x0[i] = __shfl(acc32[hc][0][4 * g + i], lane & 32, 64);
-            s1[i] = 0.f; s2[i] = 0.f;
-          }
-#pragma unroll
-          for (int pb = 0; pb < 4; ++pb) {
-            const bool ok = pb * 32 + r32 < nvw;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-              const float d = ok ? acc32[hc][pb][4 * g + i] - x0[i] : 0.f;
-              s1[i] += d;
-              s2[i] = fmaf(d, d, s2[i]);
-            }
-          }
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            s1[i] = row16_sum(s1[i]);
-            s2[i] = row16_sum(s2[i]);
-            s1[i] += __shfl_xor(s1[i], 16, 64);
-            s2[i] += __shfl_xor(s2[i], 16, 64);
-          }
-          const int c = c_wave + 32 * hc + 8 * g + 4 * h32;
-          if (r32 == 0 && nvw > 0 && c < p.Cout) {
-            const float n = (float)(nvw < 128 ? nvw : 128);
-            float4 o;
-            float m = s1[0] / n; o.x = x0[0] + m; o.y = fmaxf(s2[0] - s1[0] * m, 0.f);
-            m = s1[1] / n; o.z = x0[1] + m; o.w = fmaxf(s2[1] - s1[1] * m, 0.f);
-            float4 o2;
-            m = s1[2] / n; o2.x = x0[2] + m; o2.y = fmaxf(s2[2] - s1[2] * m, 0.f);
-            m = s1[3] / n; o2.z = x0[3] + m; o2.w = fmaxf(s2[3] - s1[3] * m, 0.f);
-            float* dst = p.tile_stats + ((size_t)(tp * 2 + wp) * p.Cout + c) * 2;
-            *(float4*)dst = o;
-            *(float4*)(dst + 4) = o2;
-          }
-        }
-    }
-    if (!M32 && p.tile_stats) {
+    if (p.tile_stats) {
       // per-channel (mean, M2) of this wave's <= 128 rows: one statistics tile per wave slab (see conv_igemm.hip)
 #pragma unroll
       for (int a = 0; a < 4; ++a) {
@@ -411,22 +321,8 @@ __global__ __launch_bounds__(512, 2) void igemm_big_kernel(const IgemmParams p) 
         }
       }
       // scratch [16 pixels][16 slots of 4 channels], slot index XOR pixel: conflict-free 16-byte writes and reads
-      if constexpr (M32) {
-        // the 16 pixels of block b sit in the lanes whose bit 4 equals b & 1 (pixel r32 of 32-pixel block b >> 1); each of those 32
-        // lanes writes its 8 channel quads (slot 8 HC + 2 g + h32)
-        if (((lane >> 4) & 1) == (b & 1)) {
 #pragma unroll
-          for (int hc = 0; hc < 2; ++hc)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-              const f32x16_t& t = acc32[hc][b >> 1];
-              *(f32x4_t*)(scr + lrow * 64 + (((8 * hc + 2 * g + h32) ^ lrow) << 2)) = (f32x4_t){t[4 * g], t[4 * g + 1], t[4 * g + 2], t[4 * g + 3]};
-            }
-        }
-      } else {
-#pragma unroll
-        for (int a = 0; a < 4; ++a) *(f32x4_t*)(scr + lrow * 64 + (((a * 4 + lgrp) ^ lrow) << 2)) = acc[a][b];
-      }
+      for (int a = 0; a < 4; ++a) *(f32x4_t*)(scr + lrow * 64 + (((a * 4 + lgrp) ^ lrow) << 2)) = acc[a][b];
       __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): the wave's own LDS writes are done before its reads
 #pragma unroll
       for (int k = 0; k < 2; ++k) {
@@ -487,95 +383,60 @@ __global__ __launch_bounds__(512, 2) void igemm_big_kernel(const IgemmParams p) 
       }
       __builtin_amdgcn_s_waitcnt(0xc07f);   // reads of this block retired before the next block overwrites the scratch
     }
-    if constexpr (M32) {
 #pragma unroll
-      for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < 4; ++a)
 #pragma unroll
-        for (int b = 0; b < 4; ++b)
-#pragma unroll
-          for (int e = 0; e < 16; ++e) acc32[a][b][e] = 0.f;
-    } else {
-#pragma unroll
-      for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int b = 0; b < 8; ++b) acc[a][b] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-    }
+      for (int b = 0; b < 8; ++b) acc[a][b] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
   };
 
   // ---------------------------------------------------------------------------------------------------------------
-  // the phase stream
+  // the K-tile stream
   // ---------------------------------------------------------------------------------------------------------------
   setup_tile(0);
+  const int total_k = my_tiles * p.iters;
   issue_half(std::integral_constant<int, 0>{});
   issue_half(std::integral_constant<int, 1>{});
   issue_half(std::integral_constant<int, 2>{});
   issue_half(std::integral_constant<int, 3>{});
-  issue_half(std::integral_constant<int, 0>{});
-  issue_half(std::integral_constant<int, 1>{});
-  __builtin_amdgcn_s_waitcnt(vmcnt_imm(8));   // H0, H1 of K tile 0 landed (this thread's pieces)
-  __builtin_amdgcn_s_barrier();
-  constexpr bool stagger = !(DBG & 2);
-  if (stagger && wp == 1) __builtin_amdgcn_s_barrier();  // group 1 runs half a phase behind
-
-  const int total_k = my_tiles * p.iters;
-  // a phase: DMA of a later half tile, fragment reads, retire the half tile read next phase, rendezvous, multiply
-#define CAVP_BIG_PHASE(KISSUE, READS, FA, HC, HQ)                                      \
-  issue_half(std::integral_constant<int, KISSUE>{});                                  \
-  __builtin_amdgcn_sched_barrier(0);                                                  \
-  if constexpr (!(DBG & 32)) READS;                                                           \
-  __builtin_amdgcn_s_waitcnt(vmcnt_imm(8));                                           \
-  __builtin_amdgcn_s_barrier();                                                       \
-  __builtin_amdgcn_s_waitcnt(0xc07f);                                                 \
-  __builtin_amdgcn_sched_barrier(0);                                                  \
-  if constexpr (!(DBG & 4)) __builtin_amdgcn_s_setprio(1);                                    \
-  if constexpr (!(DBG & 16)) mma_quadrant(FA, std::integral_constant<int, HC>{}, std::integral_constant<int, HQ>{}); \
-  __builtin_amdgcn_s_setprio(0);                                                      \
-  __builtin_amdgcn_sched_barrier(0);                                                  \
-  __builtin_amdgcn_s_barrier();
-
   for (int u = 0; u < total_k; ++u) {
-    CAVP_BIG_PHASE(2, { read_b(0); read_a(fa0, 0); }, fa0, 0, 0)   // quadrant (c0, p0): needs H0 and H1
-    CAVP_BIG_PHASE(3, { read_a(fa1, 1); }, fa1, 1, 0)              // (c1, p0): needs H2
-    CAVP_BIG_PHASE(0, { read_b(1); }, fa1, 1, 1)                   // (c1, p1): needs H3
-    CAVP_BIG_PHASE(1, {}, fa0, 0, 1)                               // (c0, p1): everything in registers
+    // my pieces of K tile u landed; behind the barrier everybody's did, and everybody has finished multiplying K tile u - 1, whose stage the
+    // pieces of K tile u + 1 (the next output tile's first one behind a tile's last) now overwrite
+    __builtin_amdgcn_s_waitcnt(vmcnt_imm(0));
+    __builtin_amdgcn_s_barrier();
+    issue_half(std::integral_constant<int, 0>{});
+    issue_half(std::integral_constant<int, 1>{});
+    issue_half(std::integral_constant<int, 2>{});
+    issue_half(std::integral_constant<int, 3>{});
+    if constexpr (!(DBG & 32)) { read_b(0); read_a(fa0, 0); }
+    if constexpr (!(DBG & 16)) mma_quadrant(fa0, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});   // (c0, p0): H0 and H1
+    if constexpr (!(DBG & 32)) read_a(fa1, 1);
+    if constexpr (!(DBG & 16)) mma_quadrant(fa1, std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{});   // (c1, p0): H2
+    if constexpr (!(DBG & 32)) read_b(1);
+    if constexpr (!(DBG & 16)) {
+      mma_quadrant(fa1, std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{});                            // (c1, p1): H3
+      mma_quadrant(fa0, std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{});                            // (c0, p1)
+    }
     cmp_buf ^= 1;
     if (++cmp_k == p.iters) {
       cmp_k = 0;
-      // Both groups run their (latency-bound, ~5 us) epilogues AT THE SAME TIME: group 0 waits half a phase for group 1 to
-      // finish the tile, group 1 re-creates the stagger afterwards.  Left staggered, group 0 would sit in its next barrier
-      // for the whole of group 1's epilogue and vice versa (12.5 us per tile instead of ~6).
-      if (stagger && wp == 0) __builtin_amdgcn_s_barrier();
       if constexpr (!(DBG & 64)) epilogue(cmp_tile);
-      if (stagger && wp == 1) __builtin_amdgcn_s_barrier();
       ++cmp_tile;
     }
   }
-#undef CAVP_BIG_PHASE
-  if (stagger && wp == 0) __builtin_amdgcn_s_barrier();
 }
 
-// 1: 32x32x16 MFMAs in the 256 x 256 tile; 0 (default): the 16x16x32 form of rounds 2-4.  Measured (profiles/r05_notes.md 7): bit-compatible
-// up to the K summation order, conflict-free fragment reads - and 4 .. 6 % SLOWER (head1 219 -> 232 us, fc1 + GELU 484 -> 512 us): the phase
-// period of this kernel is not set by the matrix-pipe time, so the faster instruction buys nothing and its half-masked epilogue writes cost
-static int g_big_m32 = 0;
-extern "C" int cavp_set_igemm_big_mfma(int m32) { g_big_m32 = m32 != 0; return CAVP_OK; }
-
-template <int DBG, bool M32>
-static hipError_t launch_big_m(const IgemmParams& p, int nblk, hipStream_t s) {
+template <int DBG>
+static hipError_t launch_big(const IgemmParams& p, int nblk, hipStream_t s) {
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)igemm_big_kernel<DBG, M32>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    (void)hipFuncSetAttribute((const void*)igemm_big_kernel<DBG>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     attr_set = true;
   }
   IgemmParams q = p;
   q.nblk = nblk;
   const int grid = nblk > 256 ? 256 : nblk;
-  igemm_big_kernel<DBG, M32><<<dim3(grid), dim3(NT), LDS_BYTES, s>>>(q);
+  igemm_big_kernel<DBG><<<dim3(grid), dim3(NT), LDS_BYTES, s>>>(q);
   return hipGetLastError();
-}
-template <int DBG>
-static hipError_t launch_big(const IgemmParams& p, int nblk, hipStream_t s) {
-  return g_big_m32 ? launch_big_m<DBG, true>(p, nblk, s) : launch_big_m<DBG, false>(p, nblk, s);
 }
 
 hipError_t cavp_launch_igemm_big(const IgemmParams& p, int nblk, hipStream_t s) {
@@ -583,8 +444,6 @@ hipError_t cavp_launch_igemm_big(const IgemmParams& p, int nblk, hipStream_t s) 
     case 0: return launch_big<0>(p, nblk, s);
 #ifdef CAVP_PROFILE
     case 1: return launch_big<1>(p, nblk, s);
-    case 2: return launch_big<2>(p, nblk, s);
-    case 4: return launch_big<4>(p, nblk, s);
     case 8: return launch_big<8>(p, nblk, s);
     case 16: return launch_big<16>(p, nblk, s);
     case 32: return launch_big<32>(p, nblk, s);

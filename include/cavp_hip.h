@@ -155,11 +155,6 @@ int cavp_bn_act_bwd_apply_acc(int32_t dtype, const void* dy, const void* y, cons
  * + the remaining images on the small tiles.  Process-wide switch for A/B runs and tests (default on); results are identical
  * either way up to the summation order inside the tail images. */
 int cavp_set_tail_split(int32_t on);
-/* ABI 10: matrix instruction of the 256x256 conv / linear tile (the decoder head convs, encoder_decoder.py:62-75, and the token
- * linears of attn.py:136-150): 1 = v_mfma_f32_32x32x16_bf16, 0 (default) = v_mfma_f32_16x16x32_bf16.  Alone the former sustains
- * 2.49 PF/s on MI355X, the latter 1.37 (profiles/r05_kloop_regb_microbench.txt); inside this kernel it is 4 .. 6 % slower
- * (profiles/r05_notes.md section 7), so it stays a switch.  Same results up to the order of the K summation.  Process-wide. */
-int cavp_set_igemm_big_mfma(int32_t m32);
 /* Epilogue of the bf16 conv / linear launches on the 4-wave tiles: 1 = straight from the MFMA accumulator registers
  * (v_permlane16_swap pairs two 16-channel blocks into 16-byte vectors: no LDS staging, no workgroup barrier), 0 (default) = the
  * LDS-staged epilogue of rounds 1-3 (the two tie: training step 14.81 vs 14.90 ms, inference 3.11 vs 3.08 ms).  Same values either way.  Process-wide switch for A/B runs and tests. */

@@ -116,32 +116,83 @@ def test_bf16_step_vs_oracle_on_conditioned_weights(conditioned, oracle_step):
     assert r["cos_med"] >= 0.93 and r["cos_p05"] >= 0.80, r       # measured 0.958 / 0.891
 
 
-def test_bf16_forward_at_the_bench_shape_vs_oracle(conditioned):
-    """The benchmarked shape itself (B = 32 images + 64 audio clips, 224 x 224, bf16): train-mode forward logits and the CE loss of
-    the conditioned weights against the oracle's f32 forward (forward only on the CPU: the backward at this size is covered at
-    96 x 96 above and by the property tests of tests/test_gpu_fullsize.py)."""
+@pytest.fixture(scope="module")
+def oracle_step_b32(conditioned):
+    """ONE oracle training step (forward + autograd backward, f32, CPU) at the benchmarked shape - B = 32 images + 64 audio clips,
+    224 x 224 - on the conditioned weights: ~10 .. 50 s of CPU time and ~13 GB, paid once per suite.  Round-5 review: the benchmarked
+    dtype's gradients at the benchmarked shape must be held to the ORACLE, not to another HIP path."""
     from oracle import cavp_oracle as O
     B, hw = 32, (224, 224)
     sd = conditioned[0]
     image, audio, label = learnable_inputs(B, hw, CFG["C"], seed=17)
-    with torch.no_grad():
-        ref, _, _ = O.cavp_forward(dict(sd), image, audio, CFG["lds"], eval_mode=False)
-        ref_loss = float(O.ce_loss_train(ref, label, B).item())
-    m = _build(sd, torch.bfloat16)
-    loss = m.train_step(image.to(DEV), audio.to(DEV), label.to(DEV), want_pred=True)
+    params = {k: v.clone().requires_grad_(True) for k, v in sd.items() if v.is_floating_point() and "running_" not in k}
+    sd2 = dict(sd)
+    sd2.update(params)
+    out, _, _ = O.cavp_forward(sd2, image, audio, CFG["lds"], eval_mode=False)
+    loss = O.ce_loss_train(out, label, B)
+    loss.backward()
+    grads = {k: p.grad.detach().double().flatten() for k, p in params.items() if p.grad is not None}
+    return (image, audio, label), out.detach(), float(loss.item()), grads
+
+
+def _grad_stats(g_ref, g):
+    keys = [k for k in g_ref if k in g]
+    dot = sum(float(g_ref[k] @ g[k]) for k in keys)
+    na, nb = sum(float(g_ref[k] @ g_ref[k]) for k in keys), sum(float(g[k] @ g[k]) for k in keys)
+    cos = sorted(float((g_ref[k] @ g[k]) / (g_ref[k].norm() * g[k].norm())) for k in keys
+                 if float(g_ref[k].norm()) > 1e-12 * na ** 0.5 and g_ref[k].numel() >= 16 and float(g[k].norm()) > 0)
+    return dict(whole=dot / (na * nb) ** 0.5, ratio=(nb / na) ** 0.5, med=cos[len(cos) // 2], p05=cos[len(cos) // 20], n=len(cos), keys=len(keys))
+
+
+def _hip_step_b32(sd, dtype, batch):
+    image, audio, label = [t.to(DEV) for t in batch]
+    m = _build(sd, dtype)
+    loss = m.train_step(image, audio, label, want_pred=True)
     torch.cuda.synchronize()
     pred = m._last_outputs[0].float().cpu()
+    g = {k: p.grad.detach().double().flatten().cpu() for k, p in m.named_parameters() if p.grad is not None}
+    return float(loss.item()), pred, g
+
+
+def test_bf16_forward_at_the_bench_shape_vs_oracle(conditioned, oracle_step_b32):
+    """The benchmarked shape itself (B = 32 images + 64 audio clips, 224 x 224, bf16): train-mode forward logits and the CE loss of
+    the conditioned weights against the oracle's f32 forward."""
+    batch, ref, ref_loss, _ = oracle_step_b32
+    loss, pred, _ = _hip_step_b32(conditioned[0], torch.bfloat16, batch)
     rel = float((pred - ref).norm() / ref.norm())
-    print(f"bf16 @ B=32 224x224: logits rel L2 {rel:.3e} (std {float(ref.std()):.2f}), loss {float(loss.item()):.5f} vs oracle {ref_loss:.5f}")
+    print(f"bf16 @ B=32 224x224: logits rel L2 {rel:.3e} (std {float(ref.std()):.2f}), loss {loss:.5f} vs oracle {ref_loss:.5f}")
     assert float(ref.std()) > 1.0
     assert rel <= 2e-2, rel
-    assert abs(float(loss.item()) - ref_loss) <= 5e-3 * max(1.0, ref_loss)
+    assert abs(loss - ref_loss) <= 5e-3 * max(1.0, ref_loss)
+
+
+def test_gradients_at_the_bench_shape_vs_oracle(conditioned, oracle_step_b32):
+    """The backward at the benchmarked shape (B = 32, 224 x 224) against the ORACLE's autograd step, for the benchmarked dtype (bf16)
+    and for the f32 parity path.  No HIP kernel on the reference side: every parameter gradient of the hot path (backbone, ASPP,
+    audio encoder, cross-modal attention, decoder head) is compared with oracle/cavp_oracle.py, which tests/test_oracle_golden.py
+    pins to the reference's own outputs and gradients.  Bars: f32 as in the 96 x 96 case (whole-gradient cosine >= 0.9999); bf16 the
+    statistics measured on MI355X for this fixture (round 5, against the f32 HIP step: whole 0.994, median 0.968, p05 0.863)."""
+    batch, ref, ref_loss, g_ref = oracle_step_b32
+    sd = conditioned[0]
+    l32, p32, g32 = _hip_step_b32(sd, torch.float32, batch)
+    r32 = _grad_stats(g_ref, g32)
+    print(f"f32  vs ORACLE @ B=32 224x224: loss {l32:.6f} vs {ref_loss:.6f}; logits rel {float((p32 - ref).norm() / ref.norm()):.2e}; {r32}")
+    assert r32["keys"] == len(g_ref) == len(g32), (r32["keys"], len(g_ref), len(g32))   # the same parameter set has gradients on both sides
+    assert abs(l32 - ref_loss) <= 1e-4 * max(1.0, ref_loss)
+    assert float((p32 - ref).norm() / ref.norm()) <= 1e-4
+    assert r32["whole"] >= 0.9999 and r32["p05"] >= 0.999 and 0.999 <= r32["ratio"] <= 1.001, r32
+    l16, _, g16 = _hip_step_b32(sd, torch.bfloat16, batch)
+    r16 = _grad_stats(g_ref, g16)
+    print(f"bf16 vs ORACLE @ B=32 224x224: loss {l16:.5f} vs {ref_loss:.5f}; {r16}")
+    assert r16["keys"] == len(g_ref)
+    assert abs(l16 - ref_loss) <= 5e-3 * max(1.0, ref_loss)
+    assert r16["whole"] >= 0.985 and 0.97 <= r16["ratio"] <= 1.03, r16
+    assert r16["med"] >= 0.95 and r16["p05"] >= 0.80, r16
 
 
 def test_bf16_gradients_at_the_bench_shape_vs_f32_step(conditioned):
-    """The backward at the benchmarked shape (B = 32, 224 x 224) in the benchmarked dtype: the bf16 step's gradients against the
-    f32 HIP step's on the conditioned weights (the f32 step is the one held to the oracle / the reference at >= 0.9999 cosine by
-    the tests above and tests/test_gpu_train_model.py; the oracle's own backward at this size takes minutes of CPU time).
+    """HIP vs HIP consistency screen (NOT the parity anchor - that is test_gradients_at_the_bench_shape_vs_oracle above): the bf16
+    step's gradients against the f32 HIP step's on the conditioned weights at the benchmarked shape.
     Same statistics as the 96 x 96 case against the oracle; the larger batch averages the rounding noise down (measured
     whole-gradient cosine 0.994 here against 0.973 there)."""
     B, hw = 32, (224, 224)

@@ -1,4 +1,4 @@
-"""Parity of the 256x256 ping-pong implicit-GEMM tile (csrc/conv_igemm_big.hip, tile id 10) against a PyTorch fp32 CPU
+"""Parity of the 256x256 implicit-GEMM tile (csrc/conv_igemm_big.hip, tile id 10) against a PyTorch fp32 CPU
 reference of the same conv on bf16-rounded operands, plus race screens (bit-identical repeats, a run against the 2-stage
 128x128 tile on the same inputs).  MI355X box only; through cavp_amd.ops -> ctypes -> libcavp_hip.so."""
 import pytest
@@ -192,34 +192,3 @@ def test_tail_split_of_a_nearly_empty_last_round():
     assert float((mean.cpu() - conv.mean((0, 2, 3))).abs().max()) <= 2e-4, "mean over both launches"
     v_ref = conv.var((0, 2, 3), unbiased=False)
     assert float((rstd.cpu() - 1 / torch.sqrt(v_ref + 1e-5)).abs().max()) <= 2e-4 * float((1 / torch.sqrt(v_ref + 1e-5)).max())
-
-
-@pytest.mark.parametrize("case", [CASES[1], CASES[2], CASES[5], CASES[7]], ids=[CASES[1][0], CASES[2][0], CASES[5][0], CASES[7][0]])
-def test_big_tile_32x32x16_mfma_variant(case):
-    """cavp_set_igemm_big_mfma(1): the same tile on v_mfma_f32_32x32x16_bf16 (opt-in, round 5) - output against the PyTorch reference
-    and against the default 16x16x32 variant (same values up to the K summation order), fused BatchNorm statistics included."""
-    from cavp_amd import _lib
-    ops = _ops()
-    name, n, h, w, cin, cout, k, s, p, d = case
-    lib = _lib.load()
-    try:
-        out16, ref, (xv, wp) = _run(case, tile=BIG)
-        assert lib.cavp_set_igemm_big_mfma(1) == 0
-        out32 = torch.empty_like(out16)
-        _, stats = ops.conv2d(xv, wp, out32, kh=k, kw=k, stride=s, pad=p, dil=d, tile=BIG, want_tile_stats=True)
-        _check(out32.permute(0, 3, 1, 2), ref, BF, name + "/tile10/m32")
-        err = float((out32.float() - out16.float()).abs().max())
-        assert err <= 8e-3 * max(1.0, float(ref.abs().max())), (name, err)     # one bf16 ulp of the largest output
-        if stats is not None:
-            ts, tiles, rpt = stats
-            rows = out32.numel() // cout
-            ts = ts.cpu().double()
-            cnt = torch.tensor([min(rpt, rows - t * rpt) for t in range(tiles)], dtype=torch.float64)
-            mean = (ts[:, :, 0] * cnt[:, None]).sum(0) / rows
-            flat = ref.permute(0, 2, 3, 1).reshape(rows, cout).double()
-            assert float((mean - flat.mean(0)).abs().max()) <= 1e-4 * max(1.0, float(flat.abs().max()))
-            m2 = (ts[:, :, 1] + cnt[:, None] * (ts[:, :, 0] - mean[None]) ** 2).sum(0)
-            var_ref = flat.var(0, unbiased=False)
-            assert float(((m2 / rows) - var_ref).abs().max()) <= 1e-4 * max(1.0, float(var_ref.max()))
-    finally:
-        lib.cavp_set_igemm_big_mfma(0)

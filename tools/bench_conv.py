@@ -85,13 +85,10 @@ def main():
     ap.add_argument("--ldpad", type=int, default=0, help="round the channel stride of x / y / residual up to a multiple of this many elements")
     ap.add_argument("--lib", default="", help="load this build of the library (cavp_amd/libcavp_hip_profile.so: CAVP_IGEMM_* knobs; "
                                               "CAVP_IGEMM_DBG=256 prints the s_memtime timeline of workgroup 0 / wave 0 and the plan)")
-    ap.add_argument("--big-mfma", type=int, default=-1, help="cavp_set_igemm_big_mfma: 1 = 32x32x16 MFMAs in the 256x256 tile, 0 = 16x16x32")
     a = ap.parse_args()
     from cavp_amd import _lib
     if a.lib:
         _lib.LIB_PATH = os.path.abspath(a.lib)
-    if a.big_mfma >= 0:
-        assert _lib.load().cavp_set_igemm_big_mfma(a.big_mfma) == 0
     assert _lib.load().cavp_set_igemm_epilogue(a.epi) == 0
     dt = torch.bfloat16 if a.dtype == "bf16" else torch.float32
     dev = "cuda:0"
