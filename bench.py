@@ -67,16 +67,11 @@ def parse():
     ap.add_argument("--no-side-stream", action="store_true", help="A/B: the audio encoder on the main stream instead of a second one")
     ap.add_argument("--no-group-wgrad", action="store_true", help="A/B: one weight-gradient launch (+ slab reduce) per layer instead of grouped launches")
     ap.add_argument("--no-rank1-attn", action="store_true", help="A/B: the cross-modal attention as q GEMM + gate + proj GEMM (round 3) instead of the one-key collapse")
-    ap.add_argument("--igemm-epilogue", type=int, default=-1, help="A/B: cavp_set_igemm_epilogue (1 = register epilogue, 0 = LDS-staged)")
-    ap.add_argument("--wgrad-variant", type=int, default=0, help="A/B: cavp_set_wgrad_variant (0 = two 32-row stages, 1 = one 64-row stage)")
     ap.add_argument("--wgrad-big", default="", help="A/B: cavp_set_wgrad_big MODE:SCHEDULE (mode 0 = the 256x256 weight-gradient tile where it qualifies, "
                                                      "1 = never; schedule 2 = 16 waves, 1 / 0 = 8 waves)")
-    ap.add_argument("--no-wgrad-stream", action="store_true", help="A/B: grouped weight gradients on the main stream instead of their own (round 3)")
-    ap.add_argument("--branch-stream-bwd", action="store_true", help="A/B: also the down-sample branch's backward on the branch stream (default: main stream)")
     ap.add_argument("--no-branch-stream", action="store_true", help="A/B: the bottlenecks' down-sample branch on the main stream (rounds 1-4)")
     ap.add_argument("--no-side-packs", action="store_true", help="A/B: the audio encoder's weight re-packs on the main stream (rounds 1-4)")
     ap.add_argument("--no-bn-bwd-fusion", action="store_true", help="A/B: BatchNorm backward always as reduce launch + apply launch (rounds 1-4)")
-    ap.add_argument("--bn-apply-fusion", action="store_true", help="A/B: BatchNorm forward of the <= 128-tile tensors as one launch (cavp_bn_apply_tiles; default: finalize launch + apply launch)")
     ap.add_argument("--no-tail-split", action="store_true", help="A/B: never split a 256x256-tile launch with a nearly empty last round")
     ap.add_argument("--trainer-loop", action="store_true",
                     help="the reference trainer's call sequence instead of the fused step: out = model(image, audio) -> torch "
@@ -85,6 +80,8 @@ def parse():
     ap.add_argument("--no-f32", action="store_true", help="skip the secondary f32 (parity path) training-step measurement")
     ap.add_argument("--no-eval-leg", action="store_true", help="skip the secondary eval-forward measurement (`eval_forward` object of the default line)")
     ap.add_argument("--cpu-sample-batch", type=int, default=8)
+    ap.add_argument("--cpu-protocol-full", action="store_true",
+                    help="run every leg of SURVEY.md 8(d)'s CPU-baseline protocol to the letter (eval B=2 and B=32, train B=2; 5 warm-ups + 20 timed each: minutes)")
     return ap.parse_args()
 
 
@@ -187,7 +184,10 @@ class KernelTimer:
             for name in ("conv2d_dgrad", "conv2d_wgrad", "conv2d_wgrad_group", "colstats", "colsum", "scale_shift_act", "bn_act_bwd_reduce",
                          "bn_act_bwd_apply", "act_bwd", "add", "layernorm_bwd", "attn_gate_bwd", "maxpool_bwd",
                          "bilinear_bwd", "bilinear_bwd_from_nchw", "bcast_add", "ce_loss", "upsample_ce_head", "smallcin_wgrad",
-                         "unpack_weight_grad", "pack_weight_dgrad"):
+                         "unpack_weight_grad", "pack_weight_dgrad", "bn_finalize_tiles", "bn_bwd_sum_tiles", "col_tile_stats", "colsum_groups",
+                         "layernorm_bwd_add"):
+                if not hasattr(train_mod, name):
+                    continue
                 fn = getattr(train_mod, name)
                 self._orig[(train_mod, name)] = fn
                 setattr(train_mod, name, self._timed(name, fn))
@@ -237,6 +237,21 @@ class KernelTimer:
                 if k.get("residual") is not None:
                     nbytes += m * out.shape[3] * es
             desc = ""
+            if name not in ("conv2d", "conv2d_dgrad", "conv2d_wgrad", "conv2d_wgrad_group"):
+                # pointwise / reduction / pooling / resampling kernels (BatchNorm apply and backward, LayerNorm, max-pool, bilinear,
+                # CE head, casts ...): the byte floor of such a kernel is every tensor it is handed once - inputs read once, outputs
+                # written once (per-channel vectors included; an in-place accumulation counts its tensor once although it is read
+                # and written: the figure is a FLOOR).  Views count their own elements only (channel slices of a concat buffer).
+                def tb(v):
+                    if isinstance(v, torch.Tensor):
+                        return v.numel() * v.element_size()
+                    if isinstance(v, (tuple, list)):
+                        return sum(tb(q) for q in v)
+                    return 0
+                nbytes = sum(tb(v) for v in a) + sum(tb(v) for v in k.values())
+                big = max((v for v in list(a) + list(k.values()) if isinstance(v, torch.Tensor)), key=lambda t: t.numel(), default=None)
+                if big is not None:
+                    desc = f"{tuple(big.shape)} {str(big.dtype).replace('torch.', '')}"
             if name in ("conv2d_dgrad", "conv2d_wgrad"):
                 desc = f"{tuple(a[0].shape)} {tuple(a[1].shape)} -> {tuple(a[2].shape)} k{k.get('kh', 1)} s{k.get('stride', 1)} d{k.get('dil', 1)}"
             if name == "conv2d_wgrad_group":
@@ -362,6 +377,13 @@ def measure_roofline(model, run_step, image, dtype_name, reps=3, config="c1p", l
         # prices HBM-bound 1x1 layers and MFMA-bound 3x3 layers against one roof
         "launch_level": {"sum_of_launch_roofs_ms": round(roof_ms, 3), "measured_ms": round(ms, 3), "frac": round(roof_ms / ms, 4)},
         "other_kernels_ms": {k: round(v[1] / reps, 3) for k, v in agg.items() if k not in ("conv2d", "conv2d_dgrad")},
+        # the pointwise / reduction families against the HBM roof: byte floor = every tensor handed to the launch once (KernelTimer)
+        "other_kernels": {k: {"launches_per_step": v[0] // reps, "ms_per_step": round(v[1] / reps, 3),
+                              "floor_mb_per_step": round(v[3] / reps / 1e6, 1),
+                              "achieved_gbs": round(v[3] / max(v[1], 1e-9) / 1e6, 1),
+                              "frac_of_hbm_peak": round(v[3] / max(v[1], 1e-9) / 1e6 / HBM_PEAK_GBS, 4)}
+                          for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])
+                          if k not in ("conv2d", "conv2d_dgrad", "conv2d_wgrad", "conv2d_wgrad_group") and v[3] > 0},
     })
     step_flops = flops
     if "conv2d_wgrad" in agg or "conv2d_wgrad_group" in agg:
@@ -594,6 +616,57 @@ def cpu_baseline(sd, cfg, sample_batch):
                       f"same C1' model and synthetic inputs"}
 
 
+def cpu_baseline_survey(sd, cfg, full: bool):
+    """SURVEY.md section 8(d)'s CPU-baseline protocol beside the bounded sample above: median of >= 20 timed iterations after >= 5
+    warm-ups, threads = the CPUs this container may use (stated), fp32 - eval forward at B = 2 (and B = 32 with `full`), train
+    forward + backward at B = 2 - plus the iteration counts actually run.  The default bench line carries the legs that fit its time
+    budget (eval B = 2 in full; train B = 2 with as many of the 20 iterations as 20 s allow, count stated); `--cpu-protocol-full`
+    runs every leg to the letter (minutes) - its output is committed as profiles/r06_cpu_baseline_survey_protocol.json."""
+    from cavp_amd.synth import synth_inputs
+    from oracle import cavp_oracle as O
+    cores, cpu_model, sockets = _host_cpu()
+    quota = _cpu_quota()
+    usable = cores if quota is None else min(cores, quota)
+    torch.set_num_threads(usable)
+    out = {"threads": usable, "physical_cores": cores, "container_cpu_quota": quota, "cpu_model": cpu_model, "sockets": sockets,
+           "protocol": ">= 5 warm-ups, median of >= 20 timed iterations (SURVEY.md 8d); legs that stop early say so"}
+
+    def leg(fn, frames, budget_s, warmups=5, iters=20):
+        for _ in range(warmups):
+            fn()
+        ts, t_all = [], time.perf_counter()
+        while len(ts) < iters and (full or len(ts) < 3 or time.perf_counter() - t_all < budget_s):
+            t0 = time.perf_counter()
+            fn()
+            ts.append(time.perf_counter() - t0)
+        ts.sort()
+        return {"value": round(frames / ts[len(ts) // 2], 3), "unit": "frames/s", "warmup_iterations": warmups, "iterations": len(ts),
+                "complete": len(ts) >= iters}
+
+    for b in ((2, 32) if full else (2,)):
+        image, audio, _ = synth_inputs(b, cfg["hw"], num_classes=cfg["C"], seed=0)
+        with torch.no_grad():
+            out[f"eval_forward_B{b}"] = leg(lambda: O.cavp_forward(sd, image, audio, cfg["lds"], eval_mode=True), b, 20.0)
+    image, audio, label = synth_inputs(2, cfg["hw"], audio_batch=4, num_classes=cfg["C"], seed=0)
+    params = {k: v.clone().requires_grad_(True) for k, v in sd.items() if v.is_floating_point() and "running_" not in k}
+    sd2 = dict(sd)
+    sd2.update(params)
+
+    def step():
+        for q in params.values():
+            q.grad = None
+        o, _, _ = O.cavp_forward(sd2, image, audio, cfg["lds"], eval_mode=False)
+        O.ce_loss_train(o, label, 2).backward()
+    out["train_fwd_bwd_B2"] = leg(step, 2, 20.0, warmups=5 if full else 2)
+    torch.set_num_threads(1)
+    image1, audio1, _ = synth_inputs(1, cfg["hw"], num_classes=cfg["C"], seed=0)
+    with torch.no_grad():
+        out["eval_forward_B1_single_thread"] = leg(lambda: O.cavp_forward(sd, image1, audio1, cfg["lds"], eval_mode=True), 1, 6.0,
+                                                   warmups=5 if full else 1, iters=20 if full else 3)
+    torch.set_num_threads(usable)
+    return out
+
+
 def _free_port() -> int:
     import socket
     s = socket.socket()
@@ -634,12 +707,6 @@ def main():
     if a.no_group_wgrad:
         import cavp_amd.train as _tr
         _tr._GROUP_WGRAD = False
-    if a.no_wgrad_stream:
-        import cavp_amd.train as _tr
-        _tr._WGRAD_STREAM = False
-    if a.branch_stream_bwd:
-        import cavp_amd.train as _tr
-        _tr._BRANCH_STREAM_BWD = True
     if a.no_branch_stream:
         import cavp_amd.train as _tr
         _tr._BRANCH_STREAM = False
@@ -649,24 +716,15 @@ def main():
     if a.no_bn_bwd_fusion:
         import cavp_amd.train as _tr
         _tr._FUSE_BN_BWD = False
-    if a.bn_apply_fusion:
-        import cavp_amd.train as _tr
-        _tr._FUSE_BN_APPLY = True
     if a.no_tail_split:
         from cavp_amd import _lib as _cl0
         _cl0.load().cavp_set_tail_split(0)
     if a.no_rank1_attn:
         import cavp_amd.train as _tr
         _tr._RANK1_ATTN = False
-    if a.igemm_epilogue >= 0:
-        from cavp_amd import _lib as _cl2
-        _cl2.load().cavp_set_igemm_epilogue(a.igemm_epilogue)
     if a.wgrad_big:
         from cavp_amd import _lib as _cl1b
         assert _cl1b.load().cavp_set_wgrad_big(*(int(v) for v in a.wgrad_big.split(":"))) == 0
-    if a.wgrad_variant:
-        from cavp_amd import _lib as _cl1
-        _cl1.load().cavp_set_wgrad_variant(a.wgrad_variant)
     if a.grad_allreduce == "bf16":
         import cavp_amd.train as _tr
         _tr.set_grad_allreduce_dtype(torch.bfloat16)
@@ -925,6 +983,7 @@ def main():
             if a.config in ("c1p", "c1"):
                 line["cpu_baseline"] = (cpu_baseline_train(sd, cfg, max(2, a.cpu_sample_batch)) if train
                                         else cpu_baseline(sd, cfg, a.cpu_sample_batch))
+                line["cpu_baseline"]["survey_8d_protocol"] = cpu_baseline_survey(sd, cfg, a.cpu_protocol_full)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

@@ -15,7 +15,8 @@ LIB_PATH = os.path.join(HERE, "libcavp_hip.so")
 
 F32, BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_LEAKY, ACT_GELU = 0, 1, 2, 3
-ABI_VERSION = 10
+ABI_VERSION = 11
+ERR_BAD_ARG, ERR_UNSUPPORTED, ERR_ALIGN, ERR_WORKSPACE, ERR_LAUNCH = -1, -2, -3, -4, -5   # cavp_status_t
 WGRAD_GROUP_MAX = 16   # CAVP_WGRAD_GROUP_MAX
 
 
@@ -39,7 +40,7 @@ class BnBwdArgs(C.Structure):
     """struct cavp_bnbwd_args (include/cavp_hip.h)."""
     _fields_ = [("z", C.c_void_p), ("out", C.c_void_p), ("ld_z", C.c_int32), ("ld_out", C.c_int32), ("fwd_scale", C.c_void_p),
                 ("fwd_shift", C.c_void_p), ("mean", C.c_void_p), ("rstd", C.c_void_p), ("act", C.c_int32), ("pad_", C.c_int32),
-                ("partials", C.c_void_p), ("sum_g", C.c_void_p), ("sum_gz", C.c_void_p)]
+                ("partials", C.c_void_p)]
 
 
 _vp, _i32, _i64, _f32, _sz = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_size_t
@@ -49,14 +50,14 @@ PROTOTYPES = {
     "cavp_abi_version": (_i32, []),
     "cavp_set_deterministic": (_i32, [_vp, _sz]),
     "cavp_zero_ranges_f32": (_i32, [_vp, _vp, _i32, _i64, _vp]),
+    "cavp_zero_bytes": (_i32, [_vp, _sz, _vp]),
+    "cavp_i64_add_table": (_i32, [_vp, _i32, _i64, _vp]),
     "cavp_get_deterministic": (_i32, []),
     "cavp_error_string": (C.c_char_p, [_i32]),
     "cavp_conv2d_workspace_bytes": (_sz, [C.POINTER(ConvDesc)]),
     "cavp_conv2d_nhwc": (_i32, [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _vp]),
     "cavp_conv2d_nhwc_aux": (_i32, [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _vp]),
     "cavp_set_tail_split": (_i32, [_i32]),
-    "cavp_set_igemm_epilogue": (_i32, [_i32]),
-    "cavp_set_wgrad_variant": (_i32, [_i32]),
     "cavp_set_wgrad_big": (_i32, [_i32, _i32]),
     "cavp_attn1_supported": (_i32, [_i32, _i32]),
     "cavp_attn1_prepare": (_i32, [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _f32, _vp]),
@@ -95,9 +96,6 @@ PROTOTYPES = {
     "cavp_colstats": (_i32, [_i32, _vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp]),
     "cavp_scale_f32": (_i32, [_vp, _f32, _vp, _i32, _vp]),
     "cavp_bn_finalize": (_i32, [_vp, _vp, _vp, _i64, _vp, _vp, _f32, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp]),
-    "cavp_bn_apply_tiles_supported": (_i32, [_i32]),
-    "cavp_bn_apply_tiles": (_i32, [_i32, _vp, _i32, _i32, _i64, _vp, _vp, _f32, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64,
-                                   _i32, _i32, _i32, _i32, _i32, _vp]),
     "cavp_conv2d_bnbwd_layout": (_i32, [_vp, _vp, _vp]),
     "cavp_conv2d_nhwc_bnbwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "cavp_bn_bwd_sum_tiles": (_i32, [_vp, _i32, _i32, _vp, _vp, _vp]),

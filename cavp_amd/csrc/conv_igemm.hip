@@ -409,153 +409,6 @@ __global__ __launch_bounds__(64 * WC * WP, (WC * WP == 4 ? (BC * BP <= 64 * 64 &
 
   // ---- epilogue ----
   if (CAVP_DBG(p, 16)) continue;
-  if constexpr (sizeof(T) == 2 && NW == 4 && MC % 2 == 0) {
-    if (p.coalesced && p.reg_epi) {
-      // Register epilogue (bf16).  A lane of the MFMA layout holds 4 consecutive channels of one pixel per 16-channel block, the four
-      // lanes p, p + 16, p + 32, p + 48 together the block's 16 channels.  ONE v_permlane16_swap per register pair of two neighbouring
-      // blocks (a, a + 1) - it exchanges the odd 16-lane rows of the first register with the even rows of the second - leaves lane
-      // (p, g) with 8 CONSECUTIVE channels of block a + (g & 1): channels 8 (g >> 1) .. + 7 (probed on hardware,
-      // tools/microbench/permlane_probe).  That is a 16-byte bf16 vector: scale / shift / residual / activation run on it in
-      // registers and it is stored directly - 64 contiguous bytes per pixel and instruction, no LDS round trip (64 KiB of f32
-      // staging writes + reads per 128 x 128 tile), no workgroup barrier, and the LDS is free for the next tile's first stage.
-      float2* wstat = (float2*)(smem + NS * TILE_BYTES);
-      if (p.tile_stats) {   // BatchNorm statistics from the accumulators, as in the staged epilogue below
-        const int nvw = p.M - (p_base + wp0);
-#pragma unroll
-        for (int a = 0; a < MC; ++a) {
-          float s1[4], s2[4], x0[4];
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            x0[i] = __shfl(acc[a][0][i], lane & 48, 64);
-            s1[i] = 0.f; s2[i] = 0.f;
-          }
-#pragma unroll
-          for (int b = 0; b < MP; ++b) {
-            const bool ok = b * 16 + lrow < nvw;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-              const float d = ok ? acc[a][b][i] - x0[i] : 0.f;
-              s1[i] += d;
-              s2[i] = fmaf(d, d, s2[i]);
-            }
-          }
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            s1[i] = row16_sum(s1[i]);
-            s2[i] = row16_sum(s2[i]);
-          }
-          if (lrow == 0) {
-            const float n = (float)(nvw < TP ? (nvw > 0 ? nvw : 1) : TP);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-              const float m = s1[i] / n;
-              wstat[(wave / WC) * BC + wc0 + a * 16 + lgrp * 4 + i] = make_float2(x0[i] + m, fmaxf(s2[i] - s1[i] * m, 0.f));
-            }
-          }
-        }
-        __syncthreads();
-        if (tid < BC && c_base + tid < p.Cout) {
-          float n = 0.f, mean = 0.f, m2 = 0.f;
-#pragma unroll
-          for (int w = 0; w < WP; ++w) {
-            int nb = p.M - (p_base + w * TP);
-            nb = nb < TP ? nb : TP;
-            if (nb > 0) {
-              const float2 q = wstat[w * BC + tid];
-              const float fb = (float)nb, nt = n + fb, dlt = q.x - mean;
-              mean += dlt * (fb / nt);
-              m2 += q.y + dlt * dlt * (n * fb / nt);
-              n = nt;
-            }
-          }
-          float* o = p.tile_stats + ((size_t)tp * p.Cout + c_base + tid) * 2;
-          o[0] = mean;
-          o[1] = m2;
-        }
-      }
-      constexpr int NQ = MC / 2;
-      const bool has_ss = p.scale != nullptr || p.shift != nullptr;
-      int cch[NQ];
-      float sc[NQ][8], sh[NQ][8];
-#pragma unroll
-      for (int q = 0; q < NQ; ++q) {
-        cch[q] = c_base + wc0 + (2 * q + (lgrp & 1)) * 16 + 8 * (lgrp >> 1);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) { sc[q][e] = 1.f; sh[q][e] = 0.f; }
-        if (cch[q] < p.Cout) {
-          if (p.scale) {
-            const float4 t0 = *(const float4*)(p.scale + cch[q]), t1 = *(const float4*)(p.scale + cch[q] + 4);
-            sc[q][0] = t0.x; sc[q][1] = t0.y; sc[q][2] = t0.z; sc[q][3] = t0.w; sc[q][4] = t1.x; sc[q][5] = t1.y; sc[q][6] = t1.z; sc[q][7] = t1.w;
-          }
-          if (p.shift) {
-            const float4 t0 = *(const float4*)(p.shift + cch[q]), t1 = *(const float4*)(p.shift + cch[q] + 4);
-            sh[q][0] = t0.x; sh[q][1] = t0.y; sh[q][2] = t0.z; sh[q][3] = t0.w; sh[q][4] = t1.x; sh[q][5] = t1.y; sh[q][6] = t1.z; sh[q][7] = t1.w;
-          }
-        }
-      }
-      const int res_base = p.res_rows ? p_base % p.res_rows : p_base;
-#pragma unroll
-      for (int b = 0; b < MP; ++b) {
-        const int prow = wp0 + b * 16 + lrow, pix = p_base + prow;
-        const bool pok = pix < p.M;
-        u32x4_t rr[NQ];
-        if (p.res) {
-#pragma unroll
-          for (int q = 0; q < NQ; ++q) {
-            rr[q] = (u32x4_t){0u, 0u, 0u, 0u};
-            if (pok && cch[q] < p.Cout) rr[q] = *(const u32x4_t*)((const T*)p.res + (size_t)(res_base + prow) * p.ldr + cch[q]);
-          }
-        }
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-          float v[8];
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(acc[2 * q][b][i]), __float_as_uint(acc[2 * q + 1][b][i]), false, false);
-            v[i] = __uint_as_float(sw[0]);
-            v[4 + i] = __uint_as_float(sw[1]);
-          }
-          if (!(pok && cch[q] < p.Cout)) continue;
-          if (p.nbias) {
-            const float* nb = p.nbias + (size_t)fast_div(pix, p.div_hw_m, p.div_hw_s) * p.Cout + cch[q];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] += nb[e];
-          }
-          if (has_ss) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = __fadd_rn(__fmul_rn(v[e], sc[q][e]), sh[q][e]);
-          }
-          T* xp = p.aux_mode ? (T*)p.aux + (size_t)pix * p.ld_aux + cch[q] : nullptr;
-          if (p.aux_mode == 2) {
-            float m[8];
-            VecT<T>::load(xp, m);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] *= m[e];
-          }
-          if (p.res) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              v[2 * e] += __uint_as_float(rr[q][e] << 16);
-              v[2 * e + 1] += __uint_as_float(rr[q][e] & 0xffff0000u);
-            }
-          }
-          if (p.aux_mode == 1) {
-            float m[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) gelu_and_grad(v[e], v[e], m[e]);
-            VecT<T>::store(xp, m);
-          } else {
-            apply_act_vec<8>(v, p.act);
-          }
-          u32x4_t o;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) o[e] = pack2bf(v[2 * e], v[2 * e + 1]);
-          *(u32x4_t*)((T*)p.y + (size_t)pix * p.ldy + cch[q]) = o;
-        }
-      }
-      continue;
-    }
-  }
   if (p.coalesced) {
     // Stage the f32 accumulators in LDS as [pixel][cout] (16-byte slots XOR-swizzled by pixel & 7), then let each
     // thread finish VE consecutive channels of one pixel: scale/shift/bias/residual are 16-byte vector loads and the
@@ -885,12 +738,7 @@ __global__ __launch_bounds__(64 * WC * WP, (WC * WP == 4 ? (BC * BP <= 64 * 64 &
           const float2 q = *(const float2*)(red + ((size_t)w * BC + tid) * 2);
           a0 += q.x; a1 += q.y;
         }
-        if (p.bnb_part) {
-          *(float2*)(p.bnb_part + ((size_t)tp * p.Cout + c_base + tid) * 2) = make_float2(a0, a1);
-        } else {   // (no return value: fire and forget)
-          atomicAdd(p.bnb_sum_g + c_base + tid, a0);
-          atomicAdd(p.bnb_sum_gz + c_base + tid, a1);
-        }
+        *(float2*)(p.bnb_part + ((size_t)tp * p.Cout + c_base + tid) * 2) = make_float2(a0, a1);
       }
     }
     continue;
@@ -1248,16 +1096,6 @@ inline bool aligned(const void* ptr, size_t a) { return ((uintptr_t)ptr % a) == 
 // the big tile and the remaining images (here 2 of 64) to an ordinary launch of the small tiles (~25 us).  Returns the number
 // of leading images, 0 = no split.
 static bool g_tail_split = true;
-// 1: bf16 launches on the 4-wave tiles finish their tiles from the accumulator registers (v_permlane16_swap) instead of staging them
-// through LDS.  Process-wide switch for A/B runs and tests.  Measured (round 4, same box, 3 alternating runs): training step 14.81 ->
-// 14.90 ms, inference 3.112 -> 3.084 ms, per layer +-2 % either way (profiles/r04_notes.md): the staged epilogue is not bound by its LDS
-// round trip, and 64-byte store pieces are no better than 256-byte ones.  Default: the staged epilogue.
-static int g_reg_epilogue = 0;
-extern "C" int cavp_set_igemm_epilogue(int mode) {
-  if (mode < 0 || mode > 1) return CAVP_ERR_BAD_ARG;
-  g_reg_epilogue = mode;
-  return CAVP_OK;
-}
 extern "C" int cavp_set_tail_split(int on) { g_tail_split = on != 0; return CAVP_OK; }
 
 static int tail_split_images(const cavp_conv_desc* d, const Plan& pl, bool with_tile_stats) {
@@ -1351,7 +1189,7 @@ extern "C" int cavp_conv2d_bnbwd_layout(const cavp_conv_desc* d, int32_t* tiles,
 
 extern "C" int cavp_conv2d_nhwc_bnbwd(const cavp_conv_desc* d, const void* x, const void* w, const void* residual, void* y,
                                       const cavp_bnbwd_args* b, void* workspace, size_t workspace_bytes, void* stream) {
-  if (!d || !b || !b->z || !b->mean || !b->rstd || (!b->partials && !(b->sum_g && b->sum_gz)) || d->aux_mode != 0 || d->res_rows != 0 || d->act != CAVP_ACT_NONE)
+  if (!d || !b || !b->z || !b->mean || !b->rstd || !b->partials || d->aux_mode != 0 || d->res_rows != 0 || d->act != CAVP_ACT_NONE)
     return CAVP_ERR_BAD_ARG;
   if (b->act != CAVP_ACT_NONE && b->act != CAVP_ACT_RELU && b->act != CAVP_ACT_LEAKY) return CAVP_ERR_UNSUPPORTED;
   if (!b->out && b->act != CAVP_ACT_NONE && (!b->fwd_scale || !b->fwd_shift)) return CAVP_ERR_BAD_ARG;
@@ -1426,13 +1264,11 @@ static int conv2d_launch(const cavp_conv_desc* d, const void* x, const void* w, 
                 (!residual || (d->ldr % VE == 0 && aligned(residual, 16))) && (!scale || aligned(scale, 16)) &&
                 (!shift || aligned(shift, 16));
   p.tile_stats = tile_stats;
-  p.reg_epi = g_reg_epilogue && d->dtype == CAVP_BF16;
   if (bnb) {
     if (!p.coalesced || !tile_has_bnb(pl.tile_id)) return CAVP_ERR_UNSUPPORTED;   // see cavp_conv2d_bnbwd_layout
-    p.reg_epi = 0;
     p.bnb_z = bnb->z; p.bnb_out = bnb->out; p.ld_bnb_z = bnb->ld_z; p.ld_bnb_out = bnb->ld_out;
     p.bnb_scale = bnb->fwd_scale; p.bnb_shift = bnb->fwd_shift; p.bnb_mean = bnb->mean; p.bnb_rstd = bnb->rstd;
-    p.bnb_act = bnb->act; p.bnb_part = bnb->partials; p.bnb_sum_g = bnb->sum_g; p.bnb_sum_gz = bnb->sum_gz;
+    p.bnb_act = bnb->act; p.bnb_part = bnb->partials;
   }
   p.aux = aux; p.aux_mode = d->aux_mode; p.ld_aux = d->ld_aux; p.res_rows = residual ? d->res_rows : 0;
   if (fused && !(p.coalesced && (!aux || (d->ld_aux % VE == 0 && aligned(aux, 16))))) return CAVP_ERR_UNSUPPORTED;

@@ -364,15 +364,8 @@ __global__ __launch_bounds__(256, 4) void wgrad_group_kernel(const WgradGroupArg
   wgrad_tile<T, BK, BIAS, NSTG>(g.job[j], bid - (j ? g.blk_end[j - 1] : 0), smem);
 }
 
-// A/B switch (bench / tests): 0 = two 32-row stages per workgroup, 1 = one 64-row stage (bf16).  Both keep four 32 KiB workgroups
-// per CU and give bit-identical results (same products, same summation order within a workgroup).
-static int g_wgrad_variant = 0;
-extern "C" int cavp_set_wgrad_variant(int v) {
-  if (v < 0 || v > 1) return CAVP_ERR_BAD_ARG;
-  g_wgrad_variant = v;
-  return CAVP_OK;
-}
-
+// (bf16: two 32-row stages per workgroup.  The one-64-row-stage variant of rounds 3-5 - bit-identical, never faster - and its switch
+// cavp_set_wgrad_variant were removed in round 6.)
 // The 256 x 256 tile of conv_wgrad_big.hip (bf16).  mode 0 (default): the jobs big enough for it (wgrad_big_eligible), 1: never
 // (the 128 x 128 tile everywhere: A/B baseline), 2: every bf16 job (tests: tiny shapes through the big tile).  pipelined: its
 // software-pipelined schedule (conv_wgrad_big.hip; 0 = read, barrier, multiply).  The choice depends on the job alone, never on the group it travels in, so a grouped
@@ -501,7 +494,7 @@ struct WgradPlan { WgradParams p; int nblk; size_t ws_bytes; int status; int bas
 // and 28 x 28 layers of the backbone stay on the 128 x 128 tile: four co-resident workgroups per CU fill the chip with fewer
 // pixel splits there).
 bool wgrad_big_eligible(const cavp_conv_desc* d) {
-  if (!d || d->dtype != CAVP_BF16 || g_wgrad_big_mode == 1 || g_wgrad_variant != 0) return false;
+  if (!d || d->dtype != CAVP_BF16 || g_wgrad_big_mode == 1) return false;
   if (g_wgrad_big_mode == 2) return true;
   const long long Ho = (d->H + 2 * d->pad - d->dil * (d->KH - 1) - 1) / d->stride + 1;
   const long long Wo = (d->W + 2 * d->pad - d->dil * (d->KW - 1) - 1) / d->stride + 1;
@@ -650,9 +643,6 @@ extern "C" int cavp_conv2d_wgrad_nhwc(const cavp_conv_desc* d, const void* x, co
   if (d->dtype == CAVP_F32) {
     if (bk == 32) { if (bi) WG_LAUNCH(float, 32, true); else WG_LAUNCH(float, 32, false); }
     else { if (bi) WG_LAUNCH(float, 64, true); else WG_LAUNCH(float, 64, false); }
-  } else if (g_wgrad_variant == 1 && bk == 32) {
-    if (bi) wgrad_kernel<bf16_t, 64, true, 1><<<pl.nblk, 256, lds, s>>>(p);
-    else wgrad_kernel<bf16_t, 64, false, 1><<<pl.nblk, 256, lds, s>>>(p);
   } else {
     if (bk == 32) { if (bi) WG_LAUNCH(bf16_t, 32, true); else WG_LAUNCH(bf16_t, 32, false); }
     else { if (bi) WG_LAUNCH(bf16_t, 64, true); else WG_LAUNCH(bf16_t, 64, false); }
@@ -864,9 +854,6 @@ extern "C" int cavp_conv2d_wgrad_group(const cavp_wgrad_job* jobs, int32_t njobs
     if (f32) {
       if (sbias) wgrad_group_kernel<float, true><<<sblocks, 256, lds, s>>>(gs);
       else wgrad_group_kernel<float, false><<<sblocks, 256, lds, s>>>(gs);
-    } else if (g_wgrad_variant == 1) {
-      if (sbias) wgrad_group_kernel<bf16_t, true, 64, 1><<<sblocks, 256, lds, s>>>(gs);
-      else wgrad_group_kernel<bf16_t, false, 64, 1><<<sblocks, 256, lds, s>>>(gs);
     } else {
       if (sbias) wgrad_group_kernel<bf16_t, true><<<sblocks, 256, lds, s>>>(gs);
       else wgrad_group_kernel<bf16_t, false><<<sblocks, 256, lds, s>>>(gs);

@@ -35,7 +35,6 @@ struct IgemmParams {
   void* aux;                // aux_mode 1: gelu'(t) is stored here; 2: the result is multiplied by it
   int aux_mode, ld_aux;
   int res_rows;             // 0, or: output pixel p adds residual row p % res_rows (a multiple of 256)
-  int reg_epi;              // bf16, 4-wave tiles: epilogue straight from the accumulator registers (v_permlane16_swap), no LDS staging
   // BatchNorm-backward statistics fused into a data-gradient launch (cavp_conv2d_nhwc_bnbwd; staged 4-wave epilogue only): the launch
   // produces the gradient of a BatchNorm + activation OUTPUT; the epilogue multiplies it by the activation's derivative, stores
   // g = dy * act'(.) and emits per pixel tile the two sums the BatchNorm backward needs (sum g, sum g * zhat)
@@ -45,9 +44,7 @@ struct IgemmParams {
   const float* bnb_shift;
   const float* bnb_mean;    // batch mean / 1 / sqrt(var + eps) of z: zhat = (z - mean) * rstd
   const float* bnb_rstd;
-  float* bnb_part;          // f32 [tiles_p][Cout][2], or nullptr with bnb_sum_g / bnb_sum_gz:
-  float* bnb_sum_g;         // f32 [Cout] each: the tile sums are ADDED there with f32 atomics (pre-zeroed scratch; order not fixed)
-  float* bnb_sum_gz;
+  float* bnb_part;          // f32 [tiles_p][Cout][2]: per pixel tile (sum g, sum g * zhat)
   int ld_bnb_z, ld_bnb_out, bnb_act, pad2_;
 };
 

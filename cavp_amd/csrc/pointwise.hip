@@ -495,6 +495,39 @@ static __global__ __launch_bounds__(256) void zero_ranges_kernel(float* __restri
   for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) p4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
+// clear a 4-byte-aligned buffer of a multiple of 4 bytes (16-byte stores over the aligned middle, 4-byte ones at the ragged ends)
+static __global__ __launch_bounds__(256) void zero_bytes_kernel(unsigned* __restrict__ p, long long nwords) {
+  const long long head = (4 - (((uintptr_t)p >> 2) & 3)) & 3;   // words in front of the first 16-byte boundary
+  const long long h = head < nwords ? head : nwords, n4 = (nwords - h) >> 2, tail0 = h + 4 * n4;
+  uint4* p4 = (uint4*)(p + h);
+  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) p4[i] = make_uint4(0u, 0u, 0u, 0u);
+  if (blockIdx.x == 0) {
+    if ((long long)threadIdx.x < h) p[threadIdx.x] = 0u;
+    if (tail0 + threadIdx.x < nwords) p[tail0 + threadIdx.x] = 0u;
+  }
+}
+
+extern "C" int cavp_zero_bytes(void* p, size_t nbytes, void* stream) {
+  if (!p || nbytes == 0) return nbytes == 0 ? CAVP_OK : CAVP_ERR_BAD_ARG;
+  if (((uintptr_t)p & 3) || (nbytes & 3)) return CAVP_ERR_ALIGN;
+  long long nb = ((long long)(nbytes / 16) + 255) / 256;
+  nb = nb < 1 ? 1 : (nb > 2048 ? 2048 : nb);
+  zero_bytes_kernel<<<dim3((unsigned)nb), 256, 0, (hipStream_t)stream>>>((unsigned*)p, (long long)(nbytes / 4));
+  return hipGetLastError() == hipSuccess ? CAVP_OK : CAVP_ERR_LAUNCH;
+}
+
+// *table[i] += inc for n int64 counters scattered in device memory (nn.BatchNorm2d.num_batches_tracked of every layer: one launch)
+static __global__ __launch_bounds__(256) void i64_add_table_kernel(const long long* __restrict__ table, int n, long long inc) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) *(long long*)(uintptr_t)table[i] += inc;
+}
+
+extern "C" int cavp_i64_add_table(const int64_t* table_dev, int32_t n, int64_t inc, void* stream) {
+  if (!table_dev || n <= 0) return CAVP_ERR_BAD_ARG;
+  i64_add_table_kernel<<<dim3((unsigned)((n + 255) / 256)), 256, 0, (hipStream_t)stream>>>((const long long*)table_dev, n, (long long)inc);
+  return hipGetLastError() == hipSuccess ? CAVP_OK : CAVP_ERR_LAUNCH;
+}
+
 extern "C" int cavp_zero_ranges_f32(float* base, const int64_t* table_dev, int32_t nranges, int64_t max_len, void* stream) {
   if (!base || !table_dev || nranges <= 0 || max_len <= 0) return CAVP_ERR_BAD_ARG;
   if ((uintptr_t)base & 15) return CAVP_ERR_ALIGN;

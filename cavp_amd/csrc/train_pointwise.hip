@@ -514,147 +514,6 @@ __global__ __launch_bounds__(256) void scale_shift_act_flat_kernel(const T* __re
   }
 }
 
-// Train-mode BatchNorm forward in ONE launch for tensors with at most 128 statistics tiles (the 14 x 14 layers at B = 32: 49 tiles
-// of 128 rows or 98 of 64; the pooled ASPP branch: 1): the separate bn_finalize_tiles launch costs 5.8 us + a dependent-launch gap in front of a
-// 3 us apply pass there.  Every workgroup first combines the per-tile (mean, M2) pairs of ITS 8 * VE channels and keeps scale /
-// shift in LDS, then runs the scale_shift_act row loop; the first rows of x (and of the residual) are requested BEFORE the combine,
-// so the statistics' and the tensor's memory latencies overlap.
-// Combine (two passes over the <= 16 pairs a thread holds in registers, 256 / (8 VE) threads per channel): mean = sum n_t mean_t / M,
-// then M2 = sum M2_t + n_t (mean_t - mean)^2 - deviations from the GLOBAL mean, so nothing cancels - with the cross-thread sums in a
-// fixed order.  All workgroups of a column chunk compute identical coefficients; row chunk 0 publishes scale / shift / mean / rstd
-// (the backward reads them) and updates the running statistics.
-template <typename T>
-__global__ __launch_bounds__(256) void bn_apply_tiles_kernel(const float* __restrict__ ts, int tiles, int rows_per_tile, long long M,
-                                                             const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
-                                                             float momentum, float* rmean, float* rvar, float* scale_out,
-                                                             float* shift_out, float* mean_out, float* rstd_out,
-                                                             const T* __restrict__ x, const T* __restrict__ res, T* __restrict__ y,
-                                                             RowLoop g, int ldx, int ldr, int ldy, int act) {
-  constexpr int VE = VecT<T>::VE;
-  constexpr int CGN = 8, RL = 256 / CGN;          // 8 column groups x 32 row lanes
-  constexpr int CW = CGN * VE, NP = 256 / CW;     // channels per workgroup, threads per channel in the combine
-  constexpr int QN = 128 / NP;                    // pairs per thread (tiles <= 128)
-  __shared__ float part[NP][CW];
-  __shared__ float coef[2][CW];
-  const int cg = threadIdx.x % CGN, rl = threadIdx.x / CGN;
-  const int c = (blockIdx.y * CGN + cg) * VE;
-  const bool col_ok = c < g.C;
-  const long long r0 = (long long)blockIdx.x * g.rows_per_block;
-  long long r1 = r0 + g.rows_per_block;
-  if (r1 > g.rows) r1 = g.rows;
-  // first two rows of this thread: in flight while the statistics are combined
-  const long long ra = r0 + rl, rb = ra + RL;
-  float va[VE], vb[VE], qa[VE], qb[VE];
-#pragma unroll
-  for (int e = 0; e < VE; ++e) va[e] = vb[e] = qa[e] = qb[e] = 0.f;
-  if (col_ok && ra < r1) { VecT<T>::load(x + ra * ldx + c, va); if (res) VecT<T>::load(res + ra * ldr + c, qa); }
-  if (col_ok && rb < r1) { VecT<T>::load(x + rb * ldx + c, vb); if (res) VecT<T>::load(res + rb * ldr + c, qb); }
-  {
-    const int ch = threadIdx.x % CW, pt = threadIdx.x / CW;
-    const int cc = blockIdx.y * CW + ch;
-    const bool ok = cc < g.C;
-    // branch-free: every slot loads (a clamped tile of a clamped channel), dead slots get weight 0 below - the first version's
-    // predicated loads were issued one at a time (3 us for 49 tiles, 6 for 98: profiles/r05_bn_apply_microbench.txt)
-    float2 q[QN];
-    const int ccl = ok ? cc : g.C - 1;
-#pragma unroll
-    for (int u = 0; u < QN; ++u) {
-      const int t = pt + NP * u;
-      q[u] = *(const float2*)(ts + ((size_t)(t < tiles ? t : tiles - 1) * g.C + ccl) * 2);
-    }
-    // rows of tile t: rows_per_tile, the last tile the remainder, past the end 0
-    const int last = tiles - 1;
-    const float n_full = (float)rows_per_tile, n_last = (float)(M - (long long)last * rows_per_tile);
-    auto nrows = [&](int t) { return t < last ? n_full : (t == last ? n_last : 0.f); };
-    float s = 0.f;
-#pragma unroll
-    for (int u = 0; u < QN; ++u) s = fmaf(nrows(pt + NP * u), q[u].x, s);
-    part[pt][ch] = s;
-    __syncthreads();
-    float tot = part[0][ch];
-#pragma unroll
-    for (int w = 1; w < NP; ++w) tot += part[w][ch];
-    const float mean = tot / (float)M;
-    __syncthreads();
-    float m2 = 0.f;
-#pragma unroll
-    for (int u = 0; u < QN; ++u) {
-      const float d = q[u].x - mean, nr = nrows(pt + NP * u);
-      m2 += (nr > 0.f ? q[u].y : 0.f) + nr * d * d;
-    }
-    part[pt][ch] = m2;
-    __syncthreads();
-    if (pt == 0 && ok) {
-      float m2t = part[0][ch];
-#pragma unroll
-      for (int w = 1; w < NP; ++w) m2t += part[w][ch];
-      const float var = m2t / (float)M;
-      const float rstd = 1.f / sqrtf(var + eps);
-      const float sc = gamma[cc] * rstd, sh = beta[cc] - mean * sc;
-      coef[0][ch] = sc; coef[1][ch] = sh;
-      if (blockIdx.x == 0) {
-        scale_out[cc] = sc; shift_out[cc] = sh; mean_out[cc] = mean; rstd_out[cc] = rstd;
-        if (rmean) {
-          const float unbias = M > 1 ? (float)((double)M / (double)(M - 1)) : 1.f;
-          rmean[cc] = (1.f - momentum) * rmean[cc] + momentum * mean;
-          rvar[cc] = (1.f - momentum) * rvar[cc] + momentum * var * unbias;
-        }
-      }
-    }
-    __syncthreads();
-  }
-  if (!col_ok) return;
-  float sc[VE], sh[VE];
-#pragma unroll
-  for (int e = 0; e < VE; ++e) { sc[e] = coef[0][cg * VE + e]; sh[e] = coef[1][cg * VE + e]; }
-  // (same expression and contraction as scale_shift_act_kernel: the backward re-derives the activation mask from it)
-  if (ra < r1) {
-#pragma unroll
-    for (int e = 0; e < VE; ++e) va[e] = va[e] * sc[e] + sh[e];
-    if (res) {
-#pragma unroll
-      for (int e = 0; e < VE; ++e) va[e] += qa[e];
-    }
-#pragma unroll
-    for (int e = 0; e < VE; ++e) va[e] = apply_act(va[e], act);
-    VecT<T>::store(y + ra * ldy + c, va);
-  }
-  if (rb < r1) {
-#pragma unroll
-    for (int e = 0; e < VE; ++e) vb[e] = vb[e] * sc[e] + sh[e];
-    if (res) {
-#pragma unroll
-      for (int e = 0; e < VE; ++e) vb[e] += qb[e];
-    }
-#pragma unroll
-    for (int e = 0; e < VE; ++e) vb[e] = apply_act(vb[e], act);
-    VecT<T>::store(y + rb * ldy + c, vb);
-  }
-  // the remaining rows, three per trip with all their loads in flight together
-  for (long long r = rb + RL; r < r1; r += 3 * RL) {
-    float v[3][VE], rr[3][VE];
-#pragma unroll
-    for (int u = 0; u < 3; ++u)
-      if (r + u * RL < r1) {
-        VecT<T>::load(x + (r + u * RL) * ldx + c, v[u]);
-        if (res) VecT<T>::load(res + (r + u * RL) * ldr + c, rr[u]);
-      }
-#pragma unroll
-    for (int u = 0; u < 3; ++u)
-      if (r + u * RL < r1) {
-#pragma unroll
-        for (int e = 0; e < VE; ++e) v[u][e] = v[u][e] * sc[e] + sh[e];
-        if (res) {
-#pragma unroll
-          for (int e = 0; e < VE; ++e) v[u][e] += rr[u][e];
-        }
-#pragma unroll
-        for (int e = 0; e < VE; ++e) v[u][e] = apply_act(v[u][e], act);
-        VecT<T>::store(y + (r + u * RL) * ldy + c, v[u]);
-      }
-  }
-}
-
 template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_apply_flat_kernel(const T* __restrict__ dy, const T* __restrict__ y,
                                                                 const T* __restrict__ z, const float* __restrict__ mean,
@@ -1657,47 +1516,6 @@ extern "C" int cavp_scale_shift_act(int32_t dtype, const void* x, const float* s
     scale_shift_act_kernel<float><<<grid, 256, 0, s>>>((const float*)x, scale, shift, (const float*)residual, (float*)y, g, ldx, ldr, ldy, act);
   else
     scale_shift_act_kernel<bf16_t><<<grid, 256, 0, s>>>((const bf16_t*)x, scale, shift, (const bf16_t*)residual, (bf16_t*)y, g, ldx, ldr, ldy, act);
-  CHECK_LAUNCH();
-}
-
-extern "C" int cavp_bn_apply_tiles_supported(int32_t tiles) { return tiles > 0 && tiles <= 128; }
-
-// BatchNorm (batch statistics) + residual + activation in one launch: cavp_bn_finalize_tiles + cavp_scale_shift_act for tensors with
-// at most 128 statistics tiles (bn_apply_tiles_kernel above).  Same outputs as the two calls.
-extern "C" int cavp_bn_apply_tiles(int32_t dtype, const float* tile_stats, int32_t tiles, int32_t rows_per_tile, int64_t count,
-                                   const float* gamma, const float* beta, float eps, float momentum, float* running_mean,
-                                   float* running_var, float* scale, float* shift, float* mean, float* rstd, const void* x,
-                                   const void* residual, void* y, int64_t rows, int32_t C, int32_t ldx, int32_t ldr, int32_t ldy,
-                                   int32_t act, void* stream) {
-  if (!tile_stats || !gamma || !beta || !scale || !shift || !mean || !rstd || tiles <= 0 || rows_per_tile <= 0 || count <= 0 || C <= 0 ||
-      (long long)tiles * rows_per_tile < count || !x || !y || rows <= 0 || ldx < C || ldy < C || (residual && ldr < C))
-    return CAVP_ERR_BAD_ARG;
-  if ((running_mean == nullptr) != (running_var == nullptr)) return CAVP_ERR_BAD_ARG;
-  if (!dt_ok(dtype) || !cavp_bn_apply_tiles_supported(tiles)) return CAVP_ERR_UNSUPPORTED;
-  const int VE = dtype == CAVP_F32 ? 4 : 8;
-  if (C % VE || ldx % VE || ldy % VE || (residual && ldr % VE)) return CAVP_ERR_UNSUPPORTED;
-  if (!al16(x) || !al16(y) || (residual && !al16(residual))) return CAVP_ERR_ALIGN;
-  // Row chunks: every workgroup repeats the combine of its column chunk (tiles x 8 VE pairs of 8 bytes out of L2) next to
-  // rows_per_block x 8 VE tensor elements, so a chunk is at least 4 rows per tile (first version: 64 rows for 49 tiles - three bytes
-  // of statistics per tensor byte, 14 us per launch); at most ~2048 workgroups
-  const int gy = cdiv_h(C, 8 * VE);
-  static const int max_blocks = cavp_knob_int("CAVP_BN_APPLY_BLOCKS", 2048);
-  static const int rows_per_tile_stat = cavp_knob_int("CAVP_BN_APPLY_ROWS_PER_TILE", 4);
-  long long rpb = ((long long)rows_per_tile_stat * tiles + 63) / 64 * 64;
-  if (rpb < 64) rpb = 64;
-  while ((rows + rpb - 1) / rpb * gy > max_blocks) rpb += 64;
-  RowLoop g;
-  g.rows = rows; g.C = C; g.rows_per_block = (int)rpb;
-  const dim3 grid((unsigned)((rows + rpb - 1) / rpb), (unsigned)gy);
-  hipStream_t s = (hipStream_t)stream;
-  if (dtype == CAVP_F32)
-    bn_apply_tiles_kernel<float><<<grid, 256, 0, s>>>(tile_stats, tiles, rows_per_tile, count, gamma, beta, eps, momentum, running_mean,
-                                                      running_var, scale, shift, mean, rstd, (const float*)x, (const float*)residual,
-                                                      (float*)y, g, ldx, ldr, ldy, act);
-  else
-    bn_apply_tiles_kernel<bf16_t><<<grid, 256, 0, s>>>(tile_stats, tiles, rows_per_tile, count, gamma, beta, eps, momentum, running_mean,
-                                                       running_var, scale, shift, mean, rstd, (const bf16_t*)x, (const bf16_t*)residual,
-                                                       (bf16_t*)y, g, ldx, ldr, ldy, act);
   CHECK_LAUNCH();
 }
 

@@ -282,17 +282,30 @@ _SIDE_STREAM = True      # False (tests / A-B only): the audio encoder on the ma
 # Weight gradients are not consumed inside the backward: TrainPass collects them and issues up to 16 per launch
 # (cavp_conv2d_wgrad_group).  False (tests / A-B only): one launch (+ one slab reduce) per layer, where the layer's backward runs.
 _GROUP_WGRAD = True
-_WGRAD_STREAM = False    # False (tests / A-B only): grouped weight gradients on the main stream, between the data gradients (round 3)
-_BRANCH_STREAM_BWD = False  # True (A-B only): also the down-sample branch's BACKWARD on that stream - measured slower (14.22 vs 14.12 ms: its weight gradient leaves the grouped launches)
 _BRANCH_STREAM = True    # False (tests / A-B only): the down-sample branch of a bottleneck on the main stream (rounds 1-4)
 _SIDE_PACKS = True       # False (A/B only): the audio encoder's weight re-packs on the main stream with all the others (rounds 1-4)
 _FUSE_BN_BWD = True      # False (tests / A-B only): BatchNorm backward always as reduce launch + apply launch (rounds 1-4)
-_BNB_ATOMIC = False      # True (A/B only): the fused BatchNorm-backward sums by f32 atomics instead of per-tile partials + a summation launch
-_FUSE_BN_APPLY_MAX_TILES = 128
-_FUSE_BN_APPLY = False   # True (tests / A-B only): BatchNorm forward of tensors with <= _FUSE_BN_APPLY_MAX_TILES statistics tiles as ONE launch
-                         # (cavp_bn_apply_tiles).  Off: no gain for the 14 x 14 layers (profiles/r05_bn_apply_microbench.txt), and on the one
-                         # tensor where it saves 4 us - the pooled ASPP branch, B rows - its other summation order moves a B = 4 step by 2e-2
 _BN_BWD_READ_Y = False   # True (tests / A-B only): the BatchNorm backward always re-reads y instead of re-deriving the mask from z
+
+
+def bump_counters(model, counters) -> None:
+    """BatchNorm's num_batches_tracked += 1 for every layer that tracked statistics this step: ONE cavp_i64_add_table launch over a
+    device table of the counters' addresses (cached on the model per counter set; the buffers keep their addresses)."""
+    if not counters:
+        return
+    if counters[0].device.type != "cuda" or any(c.dtype != torch.int64 or c.numel() != 1 for c in counters):
+        torch._foreach_add_(counters, 1)
+        return
+    key = tuple(c.data_ptr() for c in counters)
+    cache = model.__dict__.setdefault("_cavp_nbt_tables", {})
+    tab = cache.get(key)
+    if tab is None:
+        if torch.cuda.is_current_stream_capturing():
+            torch._foreach_add_(counters, 1)   # (first sight of this counter set inside a capture: no host -> device copy here)
+            return
+        tab = torch.tensor(key, dtype=torch.int64).to(counters[0].device)
+        cache[key] = tab
+    T.i64_add_table(tab, 1)
 
 
 class TrainPass:
@@ -312,7 +325,6 @@ class TrainPass:
         self.syncbn_poison: Optional[torch.Tensor] = None   # 0-dim 0.0 / NaN from _syncbn_shape_exchange, added to the logits
         # side section (the audio encoder): tape range run on a second stream, concurrently with the visual backbone
         self.side_range: Optional[tuple] = None
-        self.branch_ranges: list = []      # (first, past-last, join-before) tape indices of the down-sample branches (branch_stream())
         self._side_done = None
         self._slot = 0
         self._zpools: Dict[int, list] = {}
@@ -320,11 +332,6 @@ class TrainPass:
         self._wg_dst: set = set()
         self._wg_src: set = set()      # storages of their dy operands (see _pinned)
         self._wg_after: list = []      # callbacks run right behind the next grouped launch (defer_wgrad)
-        # grouped launches in flight on the weight-gradient stream (wgrad_stream()): storages they still read, references that keep
-        # their operands from being recycled, the event behind the last of them
-        self._wg_src_async: set = set()
-        self._wg_keep: list = []
-        self._wg_done = None
 
     # ---- parameter helpers -----------------------------------------------------------------------------------
     def pack(self, key: str, mod, need_dgrad: bool = True, raw: bool = False, pad_cout_to: int = 0) -> _P:
@@ -412,9 +419,9 @@ class TrainPass:
             if self.arena is not None and k in self.arena.views:
                 self.grads[k] = self.arena.views[k]       # zeroed once per step by GradArena.zero() ...
                 if k in self.arena.no_zero and not _overwrite:
-                    self.grads[k].zero_()                 # ... unless it is an overwrite-on-first-touch weight reached another way
+                    T.zero_(self.grads[k])                # ... unless it is an overwrite-on-first-touch weight reached another way
             else:
-                self.grads[k] = torch.zeros(param.shape, dtype=torch.float32, device=self.dev)
+                self.grads[k] = T.zeros(param.shape, torch.float32, self.dev)
         return self.grads[k]
 
     def empty(self, shape, dtype=None) -> torch.Tensor:
@@ -427,10 +434,10 @@ class TrainPass:
         for d in shape:
             n *= d
         if n > (1 << 16):
-            return torch.zeros(shape, dtype=torch.float32, device=self.dev)
+            return T.zeros(shape, torch.float32, self.dev)
         st = self._zpools.setdefault(self._slot, [None, 0])   # one pool per stream slot: a pool's fill is ordered on ITS stream only
         if st[0] is None or st[1] + n + 4 > st[0].numel():
-            st[0] = torch.zeros(1 << 21 if self._slot == 0 else 1 << 18, dtype=torch.float32, device=self.dev)
+            st[0] = T.zeros((1 << 21 if self._slot == 0 else 1 << 18,), torch.float32, self.dev)
             st[1] = 0
         t = st[0][st[1]:st[1] + n].view(shape)
         st[1] += (n + 3) // 4 * 4     # keep every carve 16-byte aligned
@@ -452,13 +459,7 @@ class TrainPass:
                 g, r = self.empty(x.t.shape, x.t.dtype), x.g
             else:
                 g, r = x.g, x.g
-            bnb = x.bnb
-            if _BNB_ATOMIC and not _lib_load().cavp_get_deterministic():
-                # the tiles add their sums into pre-zeroed scratch with f32 atomics: no summation launch.  Measured SLOWER than the
-                # per-tile partials + the fixed-order sum (14.73 vs 14.55 ms per step: a 56 x 56 launch issues 200 k memory-side
-                # atomics), so it stays an A/B switch
-                bnb = dict(bnb, sums=self.zeros_f32(2, x.t.shape[-1]))
-            part = compute(g, r, bnb=bnb)   # (partials, tiles) / (sums, 0), or None: this launch could not carry them (g is the plain gradient)
+            part = compute(g, r, bnb=x.bnb)   # (partials, tiles), or None: this launch could not carry them (g is the plain gradient)
             x.set_g(g)
             x.bnb_part = part
             return
@@ -485,7 +486,8 @@ class TrainPass:
             x.bnb_part = None
 
     def _use(self, x: Optional[V]) -> None:
-        """A non-conv op consumes x: if it is the FIRST consumer of a BatchNorm output, no conv completes that gradient."""
+        """A non-conv op consumes x: if it is the FIRST consumer of a BatchNorm output, no conv completes that gradient.  EVERY tape
+        op that takes a V calls this (or, conv: makes the claim itself) before it registers its backward."""
         if x is not None and x.bnb is not None and x.bnb_claim is None:
             x.bnb_claim = False
 
@@ -511,10 +513,9 @@ class TrainPass:
         """True while a deferred weight gradient reads t's storage: a conv with a fused residual hands its output gradient to
         the residual branch WITHOUT a copy (acc_add: x.g = g), so a later in-place accumulation into that branch's gradient
         would change the dy of the pending job.  The accumulation then goes into a fresh tensor (same traffic, no extra pass)."""
-        if not self._wg_src and not self._wg_src_async:
+        if not self._wg_src:
             return False
-        q = t.untyped_storage().data_ptr()
-        return q in self._wg_src or q in self._wg_src_async
+        return t.untyped_storage().data_ptr() in self._wg_src
 
     def _dense_copy(self, g: torch.Tensor) -> torch.Tensor:
         out = self.empty(g.shape, g.dtype)
@@ -632,72 +633,28 @@ class TrainPass:
         # a second contribution to a destination that is already pending would race inside the launch: flush first
         dst = {dw.data_ptr()} | ({db.data_ptr()} if db is not None else set())
         if dst & self._wg_dst:
-            self.flush_wgrads(join=False)
+            self.flush_wgrads()
         self._wg_jobs.append(job)
         self._wg_dst |= dst
         self._wg_src.add(g4.untyped_storage().data_ptr())
         if after is not None:
             self._wg_after.append(after)
         if len(self._wg_jobs) >= 16:
-            self.flush_wgrads(join=False)
+            self.flush_wgrads()
 
-    def wgrad_stream(self):
-        """Third stream: the grouped weight gradients.  Nothing in the backward CHAIN reads a weight gradient, and the chain is a
-        sequence of small, latency-bound launches (14 x 14 / 28 x 28 data gradients and BatchNorm passes on <= 1.5 workgroups per
-        CU) that leaves most of the chip idle, while a grouped weight-gradient launch is pure throughput: run on a stream of their
-        own, the groups fill the CUs the chain leaves free instead of standing in its way.  None: CPU tensors, deterministic mode
-        (process-wide scratch), A/B switch."""
-        if self.dev.type != "cuda" or not _WGRAD_STREAM or _lib_load().cavp_get_deterministic():
-            return None
-        s = getattr(self.m, "_wgrad_stream", None)
-        if s is None or s.device != self.dev:
-            s = torch.cuda.Stream(device=self.dev)
-            self.m.__dict__["_wgrad_stream"] = s
-        return s
-
-    def flush_wgrads(self, join: bool = True) -> None:
-        """Issue the pending weight gradients.  join=True (before anything reads a parameter gradient or overwrites an operand:
-        finish_padded, the early / late gradient collectives, the end of the backward) also waits for the weight-gradient stream;
-        join=False (a full group, a second contribution to a pending destination) only queues the launch there - launches on that
-        stream are ordered among themselves."""
+    def flush_wgrads(self) -> None:
+        """Issue the pending weight gradients as one grouped launch on the current stream (before anything reads a parameter gradient or
+        overwrites an operand: finish_padded, the early / late gradient collectives, the end of the backward; also a full group and a
+        second contribution to a pending destination).  (Rounds 3-5 could put the groups on a stream of their own: measured slower
+        both times - a resident weight-gradient workgroup owns its CU's LDS, the two streams serialise at workgroup granularity
+        (profiles/r05_notes.md 4d) - and removed in round 6.)"""
         if self._wg_jobs:
             jobs, self._wg_jobs, self._wg_dst = self._wg_jobs, [], set()
             after, self._wg_after = self._wg_after, []
-            ws = self.wgrad_stream() if self._slot == 0 else None
-            if ws is None:
-                self._wg_src = set()
-                T.conv2d_wgrad_group(jobs)
-                for fn in after:
-                    fn()
-            else:
-                # operands stay pinned (no in-place accumulation into a dy the launch still reads) and referenced (their memory
-                # is not handed to a later allocation of the main stream) until join_wgrads()
-                self._wg_src_async |= self._wg_src
-                self._wg_src = set()
-                self._wg_keep.append(jobs)
-                ev = torch.cuda.Event()
-                ev.record(torch.cuda.current_stream())
-                ws.wait_event(ev)
-                with torch.cuda.stream(ws), ops.workspace_slot(2):
-                    self._slot = 2
-                    try:
-                        T.conv2d_wgrad_group(jobs)
-                        for fn in after:
-                            fn()
-                    finally:
-                        self._slot = 0
-                    self._wg_done = torch.cuda.Event()
-                    self._wg_done.record(ws)
-        if join:
-            self.join_wgrads()
-
-    def join_wgrads(self) -> None:
-        """The current stream waits for every grouped weight gradient issued so far (their destinations are final after this)."""
-        if self._wg_done is not None:
-            torch.cuda.current_stream().wait_event(self._wg_done)
-            self._wg_done = None
-        self._wg_src_async = set()
-        self._wg_keep = []
+            self._wg_src = set()
+            T.conv2d_wgrad_group(jobs)
+            for fn in after:
+                fn()
 
     def conv_smallcin(self, x_nchw: torch.Tensor, key: str, stride: int, act: int) -> V:
         """First stem conv (raw, BN follows) / first VGG conv (bias + ReLU fused).  Input needs no gradient."""
@@ -730,7 +687,6 @@ class TrainPass:
         mom = bn.momentum if bn.momentum is not None else 0.1
         sync = isinstance(bn, nn.SyncBatchNorm) and collectives_on()   # (a forced single-rank group runs the collectives too)
         frozen = (not bn.training) and bn.running_mean is not None   # torch: eval-mode BatchNorm normalises with the running statistics
-        fused_apply = False
         if frozen:
             # fine-tuning with frozen statistics: y = gamma (z - running_mean) rstd + beta, no update of the running buffers;
             # backward dz = gamma rstd g, dgamma = sum g zhat, dbeta = sum g (no batch-mean terms)
@@ -746,19 +702,9 @@ class TrainPass:
             # ASPP pooled branch
             ts, tiles, rpt = z.tile_stats if z.tile_stats is not None else T.col_tile_stats(z.t)
             count = rows
-            if _FUSE_BN_APPLY and tiles <= _FUSE_BN_APPLY_MAX_TILES and T.bn_apply_tiles_supported(tiles):
-                # a handful of tiles (the pooled ASPP branch: B rows): combine + apply in ONE launch.  For the 14 x 14 layers (49 / 98
-                # tiles) the fused kernel costs what the two launches cost (profiles/r05_bn_apply_microbench.txt: the dependent
-                # chain statistics -> coefficients -> apply is the same length either way), so they keep the two launches
-                fused_apply = True
-                y = out if out is not None else V(self.empty(z.t.shape, z.t.dtype))
-                T.bn_apply_tiles(ts, tiles, rpt, rows, bn.weight.detach(), bn.bias.detach(), bn.eps, mom,
-                                 bn.running_mean if track else None, bn.running_var if track else None, scale, shift, mean, rstd,
-                                 z.t, y.t, act, residual=residual.t if residual is not None else None)
-            else:
-                T.bn_finalize_tiles(ts, tiles, rpt, rows, bn.weight.detach(), bn.bias.detach(), bn.eps, mom,
-                                    bn.running_mean if track else None, bn.running_var if track else None, scale, shift,
-                                    mean, rstd)
+            T.bn_finalize_tiles(ts, tiles, rpt, rows, bn.weight.detach(), bn.bias.detach(), bn.eps, mom,
+                                bn.running_mean if track else None, bn.running_var if track else None, scale, shift,
+                                mean, rstd)
         else:
             # SyncBatchNorm (main_vpo_mono.py:130): this rank's (mean, M2) -> ONE all-gather -> Chan combine over the ranks (the
             # same kernel that combines tiles; every rank holds `rows` samples).  Round 1 issued three all-reduces per layer.
@@ -773,12 +719,14 @@ class TrainPass:
                                 mean, rstd)
         if track and bn.num_batches_tracked is not None:
             self._nbt.append(bn.num_batches_tracked)
-        if not fused_apply:
-            y = out if out is not None else V(self.empty(z.t.shape, z.t.dtype))
-            T.scale_shift_act(z.t, scale, shift, y.t, act, residual=residual.t if residual is not None else None)
+        y = out if out is not None else V(self.empty(z.t.shape, z.t.dtype))
+        T.scale_shift_act(z.t, scale, shift, y.t, act, residual=residual.t if residual is not None else None)
 
         self._use(residual)
-        if _FUSE_BN_BWD and not sync and not frozen and act in (ACT_RELU, ACT_LEAKY) and y.parent is None and z.t.dim() == 4:
+        # (ReLU only: its mask is idempotent, so the fallback - a later contribution drops the partial sums and the separate reduce / apply
+        # passes mask the already-masked sum once more - stays exact; a LeakyReLU slope would be applied twice.  No LeakyReLU layer
+        # of the CAVP graph qualified anyway: ASPP's outputs are concat slices.)
+        if _FUSE_BN_BWD and not sync and not frozen and act == ACT_RELU and y.parent is None and z.t.dim() == 4:
             y.bnb = dict(z=z.t, out=y.t if residual is not None else None, scale=scale, shift=shift, mean=mean, rstd=rstd, act=act)
 
         def bwd():
@@ -791,14 +739,9 @@ class TrainPass:
                 # sum over the tiles, then the apply pass on the masked gradient (no mask, no second output: dy IS the skip gradient)
                 part, tiles = y.bnb_part
                 dz = self.empty(z.t.shape, z.t.dtype)
-                if tiles == 0:   # the sums arrived in scratch (atomic route): the apply pass adds them to the affine gradients
-                    sums = part
-                    T.bn_act_bwd_apply(dy, None, z.t, mean, rstd, bn.weight.detach(), sums[0], sums[1], ACT_NONE, dz,
-                                       acc=(self.grad_buffer(bn.bias), self.grad_buffer(bn.weight)) if direct else None)
-                else:
-                    sums = (self.grad_buffer(bn.bias), self.grad_buffer(bn.weight)) if direct else self.zeros_f32(2, c)
-                    T.bn_bwd_sum_tiles(part, tiles, sums[0], sums[1])
-                    T.bn_act_bwd_apply(dy, None, z.t, mean, rstd, bn.weight.detach(), sums[0], sums[1], ACT_NONE, dz)
+                sums = (self.grad_buffer(bn.bias), self.grad_buffer(bn.weight)) if direct else self.zeros_f32(2, c)
+                T.bn_bwd_sum_tiles(part, tiles, sums[0], sums[1])
+                T.bn_act_bwd_apply(dy, None, z.t, mean, rstd, bn.weight.detach(), sums[0], sums[1], ACT_NONE, dz)
                 z.set_g(dz)
                 if residual is not None and residual.needs_grad:
                     self.acc_add(residual, dy)
@@ -839,6 +782,7 @@ class TrainPass:
         return y
 
     def gelu(self, x: V) -> V:
+        self._use(x)
         y = V(self.empty(x.t.shape, x.t.dtype))
         T.scale_shift_act(x.t, None, None, y.t, ACT_GELU)
 
@@ -882,7 +826,7 @@ class TrainPass:
             if y.g is None:
                 return
             if x.g is None:
-                x.set_g(torch.zeros(x.t.shape, dtype=x.t.dtype, device=self.dev))
+                x.set_g(T.zeros(x.t.shape, x.t.dtype, self.dev))
             elif self._pinned(x.g):
                 self.flush_wgrads()   # in-place update of a gradient a pending weight gradient reads
             T.bcast_add(x.g, y.g, 1.0 / (h * w))
@@ -891,6 +835,7 @@ class TrainPass:
         return y
 
     def cast(self, x: V, dtype: torch.dtype) -> V:
+        self._use(x)
         if x.t.dtype == dtype:
             return x
         y = V(ops.cast(x.t.contiguous(), self.empty(x.t.shape, dtype)))
@@ -918,6 +863,7 @@ class TrainPass:
 
     def layernorm(self, x: V, ln, _done: Optional[V] = None) -> V:
         """_done: the normalised tensor when a fused kernel already produced it (pvt_train: residual + DropPath + LayerNorm)."""
+        self._use(x)
         y = _done if _done is not None else V(self.empty(x.t.shape, x.t.dtype))
         if _done is None:
             ops.layernorm(x.t, ln.weight.detach(), ln.bias.detach(), y.t, ln.eps)
@@ -953,6 +899,9 @@ class TrainPass:
     def attn_gate(self, q: V, k: V, v: V, heads: int, scale: float):
         """q may hold only the first 1/k of the batch (the query projection of the un-duplicated images): batch item b reads
         q[b % q_batch]; dq is then the sum over the k parts."""
+        self._use(q)
+        self._use(k)
+        self._use(v)
         qb, t, c = q.t.shape
         b = k.t.shape[0]
         attn = V(self.empty((b, heads, t), torch.float32))
@@ -984,6 +933,9 @@ class TrainPass:
         (csrc/attn_rank1.hip; attn.py:73-106, 153-156): r1 = x + proj(sigmoid(scale q k^T) v) with q = attn.q(x).  x: [xb, T, C]
         (xb divides the batch of k / v: forward_train's duplicated images are read, never copied); returns (r1 [B, T, C], attn).
         The weights are read as f32 (no bf16 re-pack of attn.q / attn.proj); their gradients land in the flat arena."""
+        self._use(x)
+        self._use(k)
+        self._use(v)
         heads, scale = attn_mod.num_heads, attn_mod.scale
         wq, wp, bp = attn_mod.q.weight.detach(), attn_mod.proj.weight.detach(), attn_mod.proj.bias
         xb, t, c = x.t.shape
@@ -1010,6 +962,7 @@ class TrainPass:
 
     def dup2(self, x: V) -> V:
         """torch.cat((x, x.clone()), 0) (cavp_model.py:181)."""
+        self._use(x)
         n = x.t.shape[0]
         y = V(self.empty((2 * n,) + tuple(x.t.shape[1:]), x.t.dtype))
         ops.cast(x.t, y.t[:n])
@@ -1027,6 +980,7 @@ class TrainPass:
     def gather_cat(self, x: V, idx: torch.Tensor) -> V:
         """torch.cat((x, x[idx])) over rows (forward_audio, cavp_model.py:171-173); backward: dx = g[:B] + scatter-add of
         g[B:] by idx, accumulated row by row with the add kernel (B rows of 304 values, once per step)."""
+        self._use(x)
         n = x.t.shape[0]
         y = V(torch.cat((x.t, x.t.index_select(0, idx)), dim=0))
         rows = [int(i) for i in idx.tolist()]
@@ -1043,6 +997,7 @@ class TrainPass:
 
     def flatten(self, x: V) -> V:
         """[B, H, W, C] -> [B, H*W*C] view (VGG NHWC flatten)."""
+        self._use(x)
         y = V(x.t.reshape(x.t.shape[0], -1))
         shape = x.t.shape
 
@@ -1053,6 +1008,7 @@ class TrainPass:
         return y
 
     def reshape(self, x: V, shape) -> V:
+        self._use(x)
         y = V(x.t.view(shape))
         old = x.t.shape
 
@@ -1107,27 +1063,7 @@ class TrainPass:
         side = self.side_stream() if self.side_range is not None else None
         i0, i1 = self.side_range if side is not None else (-1, -1)
         i = len(self.tape) - 1
-        bs = self.branch_stream() if self.branch_ranges else None
-        fork_at = {t1 - 1: (t0, t1, tj) for (t0, t1, tj) in self.branch_ranges} if bs is not None else {}
-        join_at: Dict[int, object] = {}
         while i >= 0:
-            if i in join_at:
-                torch.cuda.current_stream().wait_event(join_at.pop(i))
-            if i in fork_at:
-                t0b, t1b, tj = fork_at[i]
-                ev = torch.cuda.Event()
-                ev.record(torch.cuda.current_stream())
-                bs.wait_event(ev)
-                with torch.cuda.stream(bs), ops.workspace_slot(2):
-                    self._slot = 2
-                    for j in range(t1b - 1, t0b - 1, -1):
-                        self.tape[j]()
-                    self._slot = 0
-                    done = torch.cuda.Event()
-                    done.record(bs)
-                join_at[tj] = done
-                i = t0b - 1
-                continue
             if i == i1 - 1:
                 # fork: everything recorded after the side section (fusion, head) has been issued; its gradients feed both
                 # the side section's backward and the rest of the main tape, which now run concurrently
@@ -1136,17 +1072,17 @@ class TrainPass:
                 side.wait_event(ev)
                 with torch.cuda.stream(side), ops.workspace_slot(1):
                     self._slot = 1
-                    for j in range(i1 - 1, i0 - 1, -1):
-                        self.tape[j]()
-                    self._slot = 0
+                    try:
+                        for j in range(i1 - 1, i0 - 1, -1):
+                            self.tape[j]()
+                    finally:
+                        self._slot = 0
                     self._side_done = torch.cuda.Event()
                     self._side_done.record(side)
                 i = i0 - 1
                 continue
             self.tape[i]()
             i -= 1
-        for ev in join_at.values():   # (a branch whose join point was never reached)
-            torch.cuda.current_stream().wait_event(ev)
         self.flush_wgrads()
         self.join_side()
         self.tape = []
@@ -1322,7 +1258,6 @@ def run_train_forward(model, image: torch.Tensor, audio: torch.Tensor, tp: Train
                 blkm = getattr(rn, f"layer{si + 1}")[bi]
                 key = f"l{si + 1}.{bi}"
                 bs = tp.branch_stream() if has_ds else None
-                t_c1 = len(tp.tape)
                 if bs is not None:   # the block input is final here: the down-sample branch may start
                     ev_x = torch.cuda.Event()
                     ev_x.record(torch.cuda.current_stream())
@@ -1334,14 +1269,10 @@ def run_train_forward(model, image: torch.Tensor, audio: torch.Tensor, tp: Train
                     bs.wait_event(ev_x)
                     with torch.cuda.stream(bs), ops.workspace_slot(2):
                         tp._slot = 2
-                        t_ds = len(tp.tape)
-                        res = tp.bn_act(tp.conv(x, key + ".ds", stats=blkm.downsample[1]), blkm.downsample[1], ACT_NONE)
-                        if _BRANCH_STREAM_BWD:
-                            # backward: BatchNorm backward + data / weight gradient of the branch run on the same stream, beside
-                            # conv3 <- conv2 <- conv1's chain; conv1's data gradient (the next contribution to the block input's
-                            # gradient) waits for them
-                            tp.branch_ranges.append((t_ds, len(tp.tape), t_c1))
-                        tp._slot = 0
+                        try:
+                            res = tp.bn_act(tp.conv(x, key + ".ds", stats=blkm.downsample[1]), blkm.downsample[1], ACT_NONE)
+                        finally:
+                            tp._slot = 0
                         ev_r = torch.cuda.Event()
                         ev_r.record(bs)
                     torch.cuda.current_stream().wait_event(ev_r)
@@ -1390,9 +1321,11 @@ def run_train_forward(model, image: torch.Tensor, audio: torch.Tensor, tp: Train
         side.wait_event(ev_start)
         with torch.cuda.stream(side), ops.workspace_slot(1):
             tp._slot = 1
-            T.pack_weights_multi(audio_packs, tp.dt)   # (held back by flush_packs above; the side section's backward runs on this stream too)
-            fea_a = audio_encoder()
-            tp._slot = 0
+            try:
+                T.pack_weights_multi(audio_packs, tp.dt)   # (held back by flush_packs above; the side section's backward runs on this stream too)
+                fea_a = audio_encoder()
+            finally:
+                tp._slot = 0
             ev_audio = torch.cuda.Event()
             ev_audio.record(side)
         torch.cuda.current_stream().wait_event(ev_audio)
@@ -1403,7 +1336,7 @@ def run_train_forward(model, image: torch.Tensor, audio: torch.Tensor, tp: Train
     lo = _head_stage(tp, m, fusion)
     tp.named.update(fea_v=fea_v, f4=f4, f1=f1, fea_a=fea_a, asp=asp, cat=cat, zcat=zcat)
     if tp._nbt:
-        torch._foreach_add_(tp._nbt, 1)   # 61 counters, one launch
+        bump_counters(model, tp._nbt)   # 61 counters, one launch
         tp._nbt = []
     if tp.syncbn_poison is not None:   # ranks with unequal shapes in this step (_syncbn_shape_exchange): NaN logits -> NaN loss and gradients
         lo.t.add_(tp.syncbn_poison.to(lo.t.dtype))
@@ -1469,7 +1402,7 @@ class CAVPTrainFunction(torch.autograd.Function):
         tp, lo, fusion = ctx.tp, ctx.lo, ctx.fusion
         with torch.no_grad():
             if d_pred is not None:
-                g = torch.zeros(lo.t.shape, dtype=lo.t.dtype, device=lo.t.device)
+                g = T.zeros(lo.t.shape, lo.t.dtype, lo.t.device)
                 T.bilinear_bwd_from_nchw(d_pred.contiguous().float(), g[..., :d_pred.shape[1]], n_valid=lo.t.shape[0],
                                          align_corners=False)
                 lo.set_g(g)
@@ -1536,7 +1469,7 @@ class CAVPStageFunction(torch.autograd.Function):
             else:
                 raise CavpError(f"unknown stage {kind!r}")
             if tp._nbt:
-                torch._foreach_add_(tp._nbt, 1)
+                bump_counters(model, tp._nbt)
                 tp._nbt = []
         model.params_changed()   # batch-statistics BatchNorm wrote running_mean / running_var through raw pointers
         ctx.set_materialize_grads(False)
@@ -1558,7 +1491,7 @@ class CAVPStageFunction(torch.autograd.Function):
             if kind == "cls":
                 lo = ctx.vout[0]
                 if douts[0] is not None:
-                    g = torch.zeros(lo.t.shape, dtype=lo.t.dtype, device=lo.t.device)
+                    g = T.zeros(lo.t.shape, lo.t.dtype, lo.t.device)
                     T.bilinear_bwd_from_nchw(douts[0].contiguous().float(), g[..., :douts[0].shape[1]], n_valid=lo.t.shape[0],
                                              align_corners=False)
                     lo.set_g(g)
@@ -1668,7 +1601,7 @@ class GraphedTrainStep:
 
     def _backward_body(self, st):
         tp, lo, fusion = st["tp"], st["lo"], st["fusion"]
-        g = torch.zeros(lo.t.shape, dtype=lo.t.dtype, device=lo.t.device)
+        g = T.zeros(lo.t.shape, lo.t.dtype, lo.t.device)
         T.bilinear_bwd_from_nchw(self.d_pred, g[..., :self.d_pred.shape[1]], n_valid=lo.t.shape[0], align_corners=False)
         lo.set_g(g)
         # (d_fusion is NHWC memory, so this "conversion" is a view of the STATIC buffer: the head's data gradient is accumulated into

@@ -98,17 +98,18 @@ def conv2d_dgrad(dy: torch.Tensor, w_t: torch.Tensor, dx: torch.Tensor, *, kh: i
             if (zn, zh, zw, zc) != (n, h, w, cif):
                 raise _lib.CavpError("conv2d_dgrad: bnb['z'] must match dx")
             _need_gpu(zt, ot, bnb["mean"], bnb["rstd"], bnb.get("scale"), bnb.get("shift"))
-            sums = bnb.get("sums")   # pre-zeroed f32 [2][C]: the tiles add their sums there with atomics (no summation launch)
-            part = None if sums is not None else torch.empty((tiles.value, cif, 2), dtype=torch.float32, device=dx.device)
+            part = torch.empty((tiles.value, cif, 2), dtype=torch.float32, device=dx.device)
             pv = lambda t: None if t is None else t.data_ptr()   # noqa: E731  (c_void_p structure fields take an int or None)
             ba = _lib.BnBwdArgs(z=pv(zt), out=pv(ot), ld_z=ld_z, ld_out=ld_out, fwd_scale=pv(bnb.get("scale")),
                                 fwd_shift=pv(bnb.get("shift")), mean=pv(bnb["mean"]), rstd=pv(bnb["rstd"]), act=int(bnb["act"]),
-                                pad_=0, partials=pv(part), sum_g=pv(sums[0]) if sums is not None else None,
-                                sum_gz=pv(sums[1]) if sums is not None else None)
+                                pad_=0, partials=pv(part))
             st = lib.cavp_conv2d_nhwc_bnbwd(C.byref(d), _ptr(dy), _ptr(w_t), _ptr(residual), _ptr(dx), C.byref(ba), _ptr(ws),
                                             C.c_size_t(ws.numel() if ws is not None else 0), _s())
-            _check(st, "cavp_conv2d_nhwc_bnbwd")
-            return (part, tiles.value) if sums is None else (sums, 0)
+            if st not in (_lib.ERR_UNSUPPORTED, _lib.ERR_ALIGN):
+                _check(st, "cavp_conv2d_nhwc_bnbwd")
+                return part, tiles.value
+            # (the launch-time predicate - 16-byte alignment of y / the residual - is stricter than the layout query's: the launch
+            # cannot carry the statistics after all; fall through to the plain gradient and return None as the contract says)
     st = lib.cavp_conv2d_nhwc_aux(C.byref(d), _ptr(dy), _ptr(w_t), _ptr(scale), _ptr(shift), None, _ptr(residual), _ptr(dx),
                                   _ptr(mul), _ptr(ws), C.c_size_t(ws.numel() if ws is not None else 0), None, _s())
     _check(st, "cavp_conv2d_nhwc(dgrad)")
@@ -272,6 +273,34 @@ def colstats(x: torch.Tensor, sums: torch.Tensor, sumsq: torch.Tensor, shift: Op
            "cavp_colstats")
 
 
+def zeros(shape, dtype, device) -> torch.Tensor:
+    """torch.zeros without a framework fill kernel on the path (cavp_zero_bytes)."""
+    t = torch.empty(shape, dtype=dtype, device=device)
+    nb = t.numel() * t.element_size()
+    if t.device.type != "cuda":
+        return t.zero_()
+    if nb % 4:
+        return t.zero_()    # (odd byte counts never occur on the CAVP path)
+    if nb:
+        _check(_lib.load().cavp_zero_bytes(_ptr(t), C.c_size_t(nb), _s()), "cavp_zero_bytes")
+    return t
+
+
+def zero_(t: torch.Tensor) -> torch.Tensor:
+    """t.zero_() for a dense tensor without a framework fill kernel (cavp_zero_bytes)."""
+    nb = t.numel() * t.element_size()
+    if t.device.type != "cuda" or nb % 4 or not t.is_contiguous():
+        return t.zero_()
+    if nb:
+        _check(_lib.load().cavp_zero_bytes(_ptr(t), C.c_size_t(nb), _s()), "cavp_zero_bytes")
+    return t
+
+
+def i64_add_table(table_dev: torch.Tensor, inc: int = 1) -> None:
+    """*(int64*)table_dev[i] += inc: BatchNorm's num_batches_tracked counters in one launch (table of device addresses)."""
+    _check(_lib.load().cavp_i64_add_table(_ptr(table_dev), table_dev.numel(), inc, _s()), "cavp_i64_add_table")
+
+
 def scale_f32(src: torch.Tensor, alpha: float, dst: torch.Tensor) -> torch.Tensor:
     _need_gpu(src, dst)
     _check(_lib.load().cavp_scale_f32(_ptr(src), C.c_float(alpha), _ptr(dst), src.numel(), _s()), "cavp_scale_f32")
@@ -300,28 +329,6 @@ def bn_finalize_tiles(tile_stats, tiles: int, rows_per_tile: int, count: int, ga
                                               C.c_float(eps), C.c_float(momentum), _ptr(running_mean), _ptr(running_var),
                                               _ptr(scale), _ptr(shift), _ptr(mean), _ptr(rstd), gamma.numel(), _s()),
            "cavp_bn_finalize_tiles")
-
-
-def bn_apply_tiles_supported(tiles: int) -> bool:
-    return bool(_lib.load().cavp_bn_apply_tiles_supported(int(tiles)))
-
-
-def bn_apply_tiles(tile_stats, tiles: int, rows_per_tile: int, count: int, gamma, beta, eps: float, momentum: float, running_mean,
-                   running_var, scale, shift, mean, rstd, x, y, act: int, residual=None) -> torch.Tensor:
-    """bn_finalize_tiles + scale_shift_act in one launch (tensors with <= 128 statistics tiles)."""
-    rows, c, ldx = _rows(x)
-    r2, c2, ldy = _rows(y)
-    ldr = 0
-    if residual is not None:
-        _, _, ldr = _rows(residual)
-    _need_gpu(tile_stats, gamma, beta, scale, shift, mean, rstd, x, y, residual)
-    if (rows, c) != (r2, c2) or y.dtype != x.dtype or gamma.numel() != c:
-        raise _lib.CavpError("bn_apply_tiles: shape mismatch")
-    _check(_lib.load().cavp_bn_apply_tiles(dtype_code(x.dtype), _ptr(tile_stats), tiles, rows_per_tile, count, _ptr(gamma), _ptr(beta),
-                                           C.c_float(eps), C.c_float(momentum), _ptr(running_mean), _ptr(running_var), _ptr(scale),
-                                           _ptr(shift), _ptr(mean), _ptr(rstd), _ptr(x), _ptr(residual), _ptr(y), rows, c, ldx, ldr, ldy,
-                                           act, _s()), "cavp_bn_apply_tiles")
-    return y
 
 
 def scale_shift_act(x, scale, shift, y, act: int, residual=None) -> torch.Tensor:

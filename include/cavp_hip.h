@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define CAVP_ABI_VERSION 10
+#define CAVP_ABI_VERSION 11
 
 typedef enum { CAVP_F32 = 0, CAVP_BF16 = 1 } cavp_dtype_t;
 typedef enum { CAVP_ACT_NONE = 0, CAVP_ACT_RELU = 1, CAVP_ACT_LEAKY = 2, CAVP_ACT_GELU = 3 } cavp_act_t;
@@ -45,6 +45,12 @@ int cavp_abi_version(void);
 /* Clear nranges [start, end) element ranges (table_dev: int64 pairs in device memory; 4-float aligned) of one f32 buffer in one
  * launch: the per-step reset of the flat gradient arena.  max_len = the longest range (sizes the grid). */
 int cavp_zero_ranges_f32(float* base, const int64_t* table_dev, int32_t nranges, int64_t max_len, void* stream);
+/* ABI 11: clear nbytes (a multiple of 4, 4-byte aligned) of device memory: the training step's scratch pools and zero-initialised
+ * gradients without a framework fill kernel on the path. */
+int cavp_zero_bytes(void* p, size_t nbytes, void* stream);
+/* ABI 11: *(int64_t*)table_dev[i] += inc for the n device addresses in table_dev (device memory): nn.BatchNorm2d's
+ * num_batches_tracked counters of all layers (resnet.py:75-98 in train mode) in one launch. */
+int cavp_i64_add_table(const int64_t* table_dev, int32_t n, int64_t inc, void* stream);
 /* Opt-in deterministic training (the reference runs with cudnn.deterministic = True, main_vpo_mono.py:39-41).  With a scratch
  * buffer registered (>= 1 MiB, 16-byte aligned device memory that stays alive; 8 MiB covers every CAVP shape) the reductions
  * that otherwise finish with f32 atomics - cavp_colsum / cavp_colstats / cavp_bn_act_bwd_reduce, the dgamma / dbeta of
@@ -134,10 +140,8 @@ typedef struct cavp_bnbwd_args {
   const float* rstd;
   int32_t act;              /* CAVP_ACT_NONE / RELU / LEAKY */
   int32_t pad_;
-  float* partials;          /* f32 [tiles][Cout][2] (cavp_conv2d_bnbwd_layout): deterministic route, summed by cavp_bn_bwd_sum_tiles */
-  float* sum_g;             /* with partials == NULL: f32 [Cout] each, pre-zeroed; every tile ADDS its two sums there with f32 atomics */
-  float* sum_gz;            /*   (no separate summation launch; the order of the additions is not fixed) */
-} cavp_bnbwd_args;
+  float* partials;          /* f32 [tiles][Cout][2] (cavp_conv2d_bnbwd_layout): per pixel tile (sum g, sum g * zhat), summed by cavp_bn_bwd_sum_tiles */
+} cavp_bnbwd_args;   /* (ABI 11: the f32-atomic route of ABI 10 - sum_g / sum_gz - is gone: measured slower, profiles/r05_notes.md 3) */
 int cavp_conv2d_bnbwd_layout(const cavp_conv_desc* d, int32_t* tiles, int32_t* rows_per_tile);
 int cavp_conv2d_nhwc_bnbwd(const cavp_conv_desc* d, const void* x, const void* w, const void* residual, void* y,
                            const cavp_bnbwd_args* b, void* workspace, size_t workspace_bytes, void* stream);
@@ -155,14 +159,6 @@ int cavp_bn_act_bwd_apply_acc(int32_t dtype, const void* dy, const void* y, cons
  * + the remaining images on the small tiles.  Process-wide switch for A/B runs and tests (default on); results are identical
  * either way up to the summation order inside the tail images. */
 int cavp_set_tail_split(int32_t on);
-/* Epilogue of the bf16 conv / linear launches on the 4-wave tiles: 1 = straight from the MFMA accumulator registers
- * (v_permlane16_swap pairs two 16-channel blocks into 16-byte vectors: no LDS staging, no workgroup barrier), 0 (default) = the
- * LDS-staged epilogue of rounds 1-3 (the two tie: training step 14.81 vs 14.90 ms, inference 3.11 vs 3.08 ms).  Same values either way.  Process-wide switch for A/B runs and tests. */
-int cavp_set_igemm_epilogue(int32_t mode);
-/* Weight-gradient kernel variant of the bf16 path (cavp_conv2d_wgrad_nhwc / cavp_conv2d_wgrad_group; the weight gradients
- * torch.autograd computes for trainer_cavp_vpo_mono.py:190): 0 = two 32-row LDS stages per workgroup, 1 = one 64-row stage.
- * Both keep four 32 KiB workgroups per CU and give bit-identical results.  Process-wide switch for A/B runs and tests. */
-int cavp_set_wgrad_variant(int32_t variant);
 /* ABI 9: the 256 x 256 weight-gradient tile (csrc/conv_wgrad_big.hip; bf16: one workgroup per CU, four-stage LDS-DMA
  * ring, v_mfma_f32_32x32x16_bf16) for the weight gradients of encoder_decoder.py:62-75 (decoder head), models/attn.py:136-143 and
  * cavp_model.py:123-128 (token / projector Mlp) - the jobs with >= 16384 pixel rows and >= 192 input and output channels.
@@ -314,17 +310,6 @@ int cavp_bn_tiles_to_moments(const float* tile_stats, int32_t tiles, int32_t row
 int cavp_scale_shift_act(int32_t dtype, const void* x, const float* scale, const float* shift, const void* residual,
                          void* y, int64_t rows, int32_t C, int32_t ldx, int32_t ldr, int32_t ldy, int32_t act,
                          void* stream);
-/* ABI 10: train-mode BatchNorm forward in one launch - cavp_bn_finalize_tiles + cavp_scale_shift_act (same arguments, same outputs:
- * scale / shift / mean / rstd are published for the backward, the running statistics updated once) for tensors with at most 128
- * statistics tiles (cavp_bn_apply_tiles_supported): the 14 x 14 layers of the ResNet at B = 32, where the separate finalize launch
- * cost twice the apply pass.  Replaces nn.BatchNorm2d.forward (training) + ReLU (+ the bottleneck's residual add) of
- * /root/reference/models/visual/backbones/resnet.py:75-98. */
-int cavp_bn_apply_tiles_supported(int32_t tiles);
-int cavp_bn_apply_tiles(int32_t dtype, const float* tile_stats, int32_t tiles, int32_t rows_per_tile, int64_t count,
-                        const float* gamma, const float* beta, float eps, float momentum, float* running_mean,
-                        float* running_var, float* scale, float* shift, float* mean, float* rstd, const void* x,
-                        const void* residual, void* y, int64_t rows, int32_t C, int32_t ldx, int32_t ldr, int32_t ldy,
-                        int32_t act, void* stream);
 /* y may be NULL for a BN + activation WITHOUT residual: the activation mask is then re-derived from z with the forward's
  * folded fwd_scale / fwd_shift (y = act(z*scale + shift) > 0 <=> z*scale + shift > 0), which saves reading y in both passes */
 int cavp_bn_act_bwd_reduce(int32_t dtype, const void* dy, const void* y, const void* z, const float* mean,

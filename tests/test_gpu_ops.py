@@ -333,60 +333,3 @@ def test_dwconv_and_patch_embed_and_sr_conv(dtype):
         out = torch.empty((2, 16 // sr, 32 // sr, C), dtype=dtype, device=DEV)
         ops.conv2d(xin, ops.pack_weight(ws.to(DEV), dtype), out, kh=sr, kw=1, stride=sr, stride_w=1, shift=bs.to(DEV))
         _check(out.permute(0, 3, 1, 2), ref, dtype, f"sr_conv{sr}")
-
-
-@pytest.mark.parametrize("tile", [1, 2, 3, 4, 11])
-def test_register_epilogue_equals_staged_epilogue(tile):
-    """cavp_set_igemm_epilogue(1): the bf16 epilogue straight from the MFMA accumulator registers (v_permlane16_swap pairs two
-    16-channel blocks into 16-byte vectors) against the LDS-staged one, bit for bit: plain scale / shift / ReLU, residual with a
-    ragged 304-channel output and a ragged pixel count, per-image bias, the GELU + gelu' pair (aux_mode 1), the gelu' multiply
-    (aux_mode 2), a batch-periodic residual, and the per-tile BatchNorm statistics."""
-    from cavp_amd import _lib, ops
-    lib = _lib.load()
-    g = torch.Generator(device="cpu").manual_seed(77 + tile)
-    dev, dt = "cuda:0", torch.bfloat16
-
-    def rnd(*shape, s=1.0):
-        return (torch.randn(shape, generator=g) * s).to(dev)
-
-    cases = [
-        dict(n=3, h=19, w=23, cin=64, cout=304, k=1, pad=0, res=True, act=ops.ACT_RELU),
-        dict(n=2, h=17, w=17, cin=96, cout=128, k=3, pad=1, res=False, act=ops.ACT_RELU, nbias=True),
-        dict(n=2, h=1, w=512, cin=304, cout=1216, k=1, pad=0, res=False, act=ops.ACT_GELU, aux_mode=1),
-        dict(n=2, h=1, w=512, cin=304, cout=1216, k=1, pad=0, res=False, act=ops.ACT_NONE, aux_mode=2),
-        dict(n=4, h=1, w=256, cin=128, cout=304, k=1, pad=0, res=True, act=ops.ACT_NONE, res_rows=512),
-        dict(n=2, h=28, w=28, cin=64, cout=256, k=3, pad=1, res=False, act=ops.ACT_NONE, stats=True),
-    ]
-    try:
-        for c in cases:
-            x = rnd(c["n"], c["h"], c["w"], c["cin"]).to(dt)
-            wt = rnd(c["cout"], c["k"], c["k"], c["cin"], s=(c["cin"] * c["k"] ** 2) ** -0.5).to(dt)
-            m_rows = c["n"] * c["h"] * c["w"]
-            plain = c.get("stats", False)
-            sc = None if (plain or c.get("aux_mode")) else torch.rand(c["cout"], generator=g).to(dev) + 0.5
-            sh = None if plain else rnd(c["cout"])
-            nb = rnd(c["n"], c["cout"]) if c.get("nbias") else None
-            res_rows = c.get("res_rows", 0)
-            res = (rnd(res_rows if res_rows else m_rows, c["cout"]).to(dt).view((-1,) if False else (1, 1, -1, c["cout"])) if c["res"] else None)
-            if res is not None and not res_rows:
-                res = res.view(c["n"], c["h"], c["w"], c["cout"])
-            aux_in = rnd(c["n"], c["h"], c["w"], c["cout"]).to(dt) if c.get("aux_mode") == 2 else None
-            outs = []
-            for mode in (0, 1):
-                assert lib.cavp_set_igemm_epilogue(mode) == 0
-                y = torch.empty((c["n"], c["h"], c["w"], c["cout"]), dtype=dt, device=dev)
-                aux = aux_in.clone() if aux_in is not None else (torch.empty_like(y) if c.get("aux_mode") == 1 else None)
-                r = ops.conv2d(x, wt, y, kh=c["k"], kw=c["k"], pad=c["pad"], scale=sc, shift=sh, nbias=nb, residual=res, act=c["act"],
-                               tile=tile, splitk=1, want_tile_stats=plain, res_rows=res_rows, aux=aux, aux_mode=c.get("aux_mode", 0))
-                torch.cuda.synchronize()
-                outs.append((y, aux if c.get("aux_mode") == 1 else None, r[1][0] if plain and r[1] is not None else None))
-            (y0, a0, s0), (y1, a1, s1) = outs
-            assert torch.equal(y0, y1), (tile, c, float((y0.float() - y1.float()).abs().max()))
-            if a0 is not None:
-                assert torch.equal(a0, a1), (tile, c)
-            if plain:
-                assert (s0 is None) == (s1 is None)
-                if s0 is not None:
-                    assert torch.equal(s0, s1), (tile, c)
-    finally:
-        lib.cavp_set_igemm_epilogue(0)

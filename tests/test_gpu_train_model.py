@@ -599,56 +599,16 @@ def test_second_stream_equals_single_stream():
         TR._SIDE_STREAM = old
 
 
+@pytest.mark.parametrize("streams", [False, True], ids=["one_stream", "default_streams"])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
-def test_wgrad_stream_equals_main_stream(dtype):
-    """The grouped weight gradients run on a stream of their own, concurrently with the backward chain (round 5).  Same set-up as
-    the second-stream test (frozen BatchNorm: no chaotic amplifier): gradients with the weight-gradient stream == gradients with the
-    groups issued on the main stream, eagerly, over repeated steps (operands must stay pinned and referenced until the join) and as
-    graph replays.  A missing dependency, a recycled operand or a shared scratch buffer would show."""
-    import cavp_amd.train as TR
-    cfg = dict(C=3, B=4, hw=(96, 96), lds=[False, False, False])
-    image, audio, label = [t.to(DEV) for t in synth_inputs(cfg["B"], cfg["hw"], audio_batch=2 * cfg["B"], num_classes=cfg["C"], seed=9)]
-
-    def build():
-        m, _ = _build(cfg)
-        m.set_compute_dtype(dtype)
-        for mod in m.modules():
-            if isinstance(mod, torch.nn.modules.batchnorm._BatchNorm):
-                mod.eval()
-        return m
-
-    tol = 1e-5 if dtype == torch.float32 else 2e-3
-    old = TR._WGRAD_STREAM
-    try:
-        TR._WGRAD_STREAM = False
-        m0 = build()
-        l0 = float(m0.train_step(image, audio, label, all_reduce=False).item())
-        ref = m0._grad_arena.flat.clone()
-        assert getattr(m0, "_wgrad_stream", None) is None
-        TR._WGRAD_STREAM = True
-        m1 = build()
-        for _ in range(3):
-            l1 = float(m1.train_step(image, audio, label, all_reduce=False).item())
-            torch.cuda.synchronize()
-            assert m1._wgrad_stream is not None
-            err = float((m1._grad_arena.flat - ref).norm() / ref.norm())
-            assert abs(l1 - l0) <= 1e-6 * max(1.0, abs(l0)) and err <= tol, (l1, l0, err)
-        step = m1.capture_train_step(image, audio, label)
-        for _ in range(3):
-            l2 = float(step().item())
-            torch.cuda.synchronize()
-            err = float((m1._grad_arena.flat - ref).norm() / ref.norm())
-            assert abs(l2 - l0) <= 1e-6 * max(1.0, abs(l0)) and err <= tol, (l2, l0, err)
-    finally:
-        TR._WGRAD_STREAM = old
-
-
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
-def test_fused_bn_backward_statistics_equal_separate_reduce(dtype):
+def test_fused_bn_backward_statistics_equal_separate_reduce(dtype, streams):
     """Round 5: the data-gradient launch that completes the gradient of a BatchNorm + ReLU output applies the ReLU mask and sums
     g and g * zhat per tile in its epilogue (cavp_conv2d_nhwc_bnbwd); the BatchNorm backward then skips its reduce pass.  Whole
     training step (batch statistics, B = 8) with the fusion == the step with the separate reduce: same loss, same gradients up
-    to summation order (f32) / up to the storage rounding of g (bf16), eagerly and as a graph replay; and the fusion is in use."""
+    to summation order (f32) / up to the storage rounding of g (bf16), eagerly and as a graph replay; and the fusion is in use.
+    `default_streams`: the product configuration (audio encoder on the side stream, down-sample branches on the branch stream).
+    HIP on both sides - a consistency screen of the fused route; the parity anchors of the route are the reference-golden train steps
+    (test_train_step_b8_matches_reference_f32 and friends), which run with it as the default."""
     import cavp_amd.train as TR
     from cavp_amd import train_ops as T
     cfg = dict(C=3, B=8, hw=(96, 96), lds=[False, False, False])
@@ -661,7 +621,7 @@ def test_fused_bn_backward_statistics_equal_separate_reduce(dtype):
         calls["n"] += 1
         return orig(*a, **k)
     try:
-        TR._SIDE_STREAM = False
+        TR._SIDE_STREAM = streams
         TR._FUSE_BN_BWD = False
         T.bn_act_bwd_reduce = counted
         m0, _ = _build(cfg)
@@ -683,7 +643,8 @@ def test_fused_bn_backward_statistics_equal_separate_reduce(dtype):
         rel = float((g1 - ref).norm() / ref.norm())
         print(f"fused BN-backward statistics ({dtype}): {calls['n']} layers, loss {l1:.6f} vs {l0:.6f}, gradient cosine {cos:.6f}, rel err {rel:.2e}")
         assert abs(l1 - l0) <= 1e-6 * max(1.0, abs(l0))          # the forward is untouched
-        assert (cos >= 0.99999 and rel <= 3e-3) if dtype == torch.float32 else (cos >= 0.995 and rel <= 0.1), (cos, rel)
+        # f32: summation order only (measured 3e-6 .. 2e-5 on MI355X); bf16: g is stored rounded once more on the fused route
+        assert (cos >= 0.9999999 and rel <= 2e-4) if dtype == torch.float32 else (cos >= 0.995 and rel <= 0.1), (cos, rel)
         T.bn_act_bwd_reduce = orig
         step = m1.capture_train_step(image, audio, label)
         for _ in range(2):

@@ -562,60 +562,6 @@ def test_col_tile_stats(rows, C, dt):
     assert float(((got_var - var).abs() / var).max()) <= 2e-4
 
 
-@pytest.mark.parametrize("dt", DTYPES, ids=IDS)
-@pytest.mark.parametrize("rows,C,res,sl", [(6272, 256, False, False), (6272, 1024, True, False), (16384, 128, False, False), (130, 2048, True, False),
-                                           (32, 256, False, False), (1000, 72, True, True), (6272, 48, False, True)],
-                         ids=["l3_mid", "l3_out_res", "max_tiles", "wide_res", "pooled_B32", "ragged_slice_res", "narrow_slice"])
-def test_bn_apply_tiles(rows, C, res, sl, dt):
-    """cavp_bn_apply_tiles (statistics combine + scale / shift + residual + ReLU in ONE launch) against torch's training-mode
-    BatchNorm on the same (storage-rounded) input, and against the two-launch route it replaces: same normalised tensor, same
-    published scale / shift / mean / rstd, same running-statistics update (resnet.py:75-98)."""
-    ops, T = _mods()
-    if C % (8 if dt == torch.bfloat16 else 4):
-        pytest.skip("channel count must be a multiple of the 16-byte vector")
-    pad = 16 if sl else 0
-    x = _q(_rand(rows, C + pad, seed=51) * 0.7 + 3.0, dt)
-    r = _q(_rand(rows, C + pad, seed=52), dt) if res else None
-    g, b = _rand(C, seed=53) * 0.3 + 1.0, _rand(C, seed=54) * 0.2
-    xd = x.to(dt).to(DEV)[:, pad // 2:pad // 2 + C]
-    rd = r.to(dt).to(DEV)[:, pad // 2:pad // 2 + C] if res else None
-    ts, tiles, rpt = T.col_tile_stats(xd)
-    if rows == 6272 and C == 256:
-        # the layout a 64-row igemm tile emits: 98 tiles of 64 rows (f64 on the host, then f32)
-        xs64 = x[:, pad // 2:pad // 2 + C].double().view(98, 64, C)
-        mu = xs64.mean(1)
-        ts = torch.stack((mu, ((xs64 - mu[:, None, :]) ** 2).sum(1)), -1).float().to(DEV).contiguous()
-        tiles, rpt = 98, 64
-    assert T.bn_apply_tiles_supported(tiles) and not T.bn_apply_tiles_supported(129)
-    outs = []
-    for fused in (True, False):
-        rm, rv = torch.full((C,), 0.25, device=DEV), torch.full((C,), 2.0, device=DEV)
-        scale, shift, mean, rstd = (torch.empty(C, device=DEV) for _ in range(4))
-        y = torch.empty((rows, C + pad), dtype=dt, device=DEV)[:, pad // 2:pad // 2 + C]
-        if fused:
-            T.bn_apply_tiles(ts, tiles, rpt, rows, g.to(DEV), b.to(DEV), 1e-5, 0.1, rm, rv, scale, shift, mean, rstd, xd, y, ops.ACT_RELU, residual=rd)
-        else:
-            T.bn_finalize_tiles(ts, tiles, rpt, rows, g.to(DEV), b.to(DEV), 1e-5, 0.1, rm, rv, scale, shift, mean, rstd)
-            T.scale_shift_act(xd, scale, shift, y, ops.ACT_RELU, residual=rd)
-        outs.append([t.float().cpu() for t in (y, scale, shift, mean, rstd, rm, rv)])
-    xs = x[:, pad // 2:pad // 2 + C]
-    bn = torch.nn.BatchNorm1d(C, eps=1e-5, momentum=0.1)
-    with torch.no_grad():
-        bn.weight.copy_(g); bn.bias.copy_(b); bn.running_mean.fill_(0.25); bn.running_var.fill_(2.0)
-    bn.train()
-    ref = bn(xs)
-    if res:
-        ref = ref + r[:, pad // 2:pad // 2 + C]
-    ref = F.relu(ref).detach()
-    _check(outs[0][0], ref, dt, "bn_apply_tiles y", 1e-4, 1.5e-2)
-    _check(outs[0][5], bn.running_mean.detach(), torch.float32, "running_mean", 1e-5, 1e-5)
-    _check(outs[0][6], bn.running_var.detach(), torch.float32, "running_var", 2e-4, 2e-4)
-    for a_, b_, what in zip(outs[0][1:], outs[1][1:], ("scale", "shift", "mean", "rstd", "running_mean", "running_var")):
-        _check(a_, b_, torch.float32, "fused vs two launches: " + what, 2e-6, 2e-6)
-    # the normalised tensors of the two routes differ by the rounding of (scale, shift) only
-    _check(outs[0][0], outs[1][0], dt, "fused vs two launches: y", 2e-5, 8e-3)
-
-
 BNB_CASES = [
     # name, N, H, W, Cin, Cout, k, s, p, d, with_out (mask from the activation output + accumulated residual: the bottleneck-output case)
     ("1x1_mid", 8, 56, 56, 64, 256, 1, 1, 0, 1, False),
@@ -695,15 +641,6 @@ def test_conv_dgrad_fused_bn_backward_stats(case, dt):
     stol = (2e-4 if dt == torch.float32 else 6e-3) * (rows ** 0.5) * max(1.0, float(gq.abs().max()))
     assert float((sums[0].cpu().double() - s0).abs().max()) <= stol, (name, float((sums[0].cpu().double() - s0).abs().max()), stol)
     assert float((sums[1].cpu().double() - s1).abs().max()) <= 3 * stol, (name, float((sums[1].cpu().double() - s1).abs().max()), stol)
-    # the atomic route (tiles add their sums into pre-zeroed scratch, no summation launch): same sums up to the order of the additions
-    g2 = torch.empty_like(g)
-    asum = torch.zeros(2, cin, device=DEV)
-    r2 = T.conv2d_dgrad(dyv, wT, g2, kh=k, kw=k, stride=s, pad=p, dil=d, residual=_nhwc(prev, dt) if prev is not None else None,
-                        bnb=dict(z=zv, out=outv, scale=sc_d, shift=sh_d, mean=mean_d, rstd=rstd_d, act=ops.ACT_RELU, sums=asum))
-    assert r2 is not None and r2[1] == 0 and torch.equal(g2, g)
-    ref_sums = sums.clone()
-    ref_sums[0] -= 0.25
-    assert float((asum - ref_sums).abs().max()) <= 1e-3 * max(1.0, float(ref_sums.abs().max()))
     # end to end: dz from the fused route == dz from the separate reduce on the plain gradient
     sums_ref = torch.zeros(2, cin, device=DEV)
     T.bn_act_bwd_reduce(plain, outv, zv, mean_d, rstd_d, ops.ACT_RELU, sums_ref[0], sums_ref[1], fwd_scale=sc_d, fwd_shift=sh_d)

@@ -81,7 +81,6 @@ def main():
     ap.add_argument("--shapes", default="")
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--aux", type=int, default=0, help="1: fc1-style epilogue (GELU + gelu' stored, no scale/shift); 2: fc2-dgrad style (result x aux)")
-    ap.add_argument("--epi", type=int, default=0, help="cavp_set_igemm_epilogue: 1 = register epilogue, 0 = LDS-staged (default)")
     ap.add_argument("--ldpad", type=int, default=0, help="round the channel stride of x / y / residual up to a multiple of this many elements")
     ap.add_argument("--lib", default="", help="load this build of the library (cavp_amd/libcavp_hip_profile.so: CAVP_IGEMM_* knobs; "
                                               "CAVP_IGEMM_DBG=256 prints the s_memtime timeline of workgroup 0 / wave 0 and the plan)")
@@ -89,7 +88,6 @@ def main():
     from cavp_amd import _lib
     if a.lib:
         _lib.LIB_PATH = os.path.abspath(a.lib)
-    assert _lib.load().cavp_set_igemm_epilogue(a.epi) == 0
     dt = torch.bfloat16 if a.dtype == "bf16" else torch.float32
     dev = "cuda:0"
     variants = [int(v) for v in a.variants.split(",")]

@@ -40,14 +40,12 @@ def main():
     ap.add_argument("--shapes", default="")
     ap.add_argument("--splitk", default="0")
     ap.add_argument("--reps", type=int, default=10)
-    ap.add_argument("--variant", type=int, default=0, help="cavp_set_wgrad_variant: 0 = two 32-row stages, 1 = one 64-row stage")
     ap.add_argument("--big", default="0:2", help="cavp_set_wgrad_big mode:pipelined (mode 0 auto, 1 never, 2 always)")
     ap.add_argument("--lib", default="", help="load this build of the library (cavp_amd/libcavp_hip_profile.so: CAVP_WGRAD_DBG knobs)")
     a = ap.parse_args()
     from cavp_amd import _lib
     if a.lib:
         _lib.LIB_PATH = os.path.abspath(a.lib)
-    assert _lib.load().cavp_set_wgrad_variant(a.variant) == 0
     assert _lib.load().cavp_set_wgrad_big(*(int(v) for v in a.big.split(":"))) == 0
     dt = torch.bfloat16 if a.dtype == "bf16" else torch.float32
     dev = "cuda:0"
