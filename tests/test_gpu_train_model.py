@@ -643,8 +643,9 @@ def test_fused_bn_backward_statistics_equal_separate_reduce(dtype, streams):
         rel = float((g1 - ref).norm() / ref.norm())
         print(f"fused BN-backward statistics ({dtype}): {calls['n']} layers, loss {l1:.6f} vs {l0:.6f}, gradient cosine {cos:.6f}, rel err {rel:.2e}")
         assert abs(l1 - l0) <= 1e-6 * max(1.0, abs(l0))          # the forward is untouched
-        # f32: summation order only (measured 3e-6 .. 2e-5 on MI355X); bf16: g is stored rounded once more on the fused route
-        assert (cos >= 0.9999999 and rel <= 2e-4) if dtype == torch.float32 else (cos >= 0.995 and rel <= 0.1), (cos, rel)
+        # f32: summation order only (measured 2.7e-6 on MI355X); bf16: g is stored rounded once more on the fused route (measured
+        # cosine 0.99980, relative error 1.9e-2)
+        assert (cos >= 0.9999999 and rel <= 5e-5) if dtype == torch.float32 else (cos >= 0.999 and rel <= 5e-2), (cos, rel)
         T.bn_act_bwd_reduce = orig
         step = m1.capture_train_step(image, audio, label)
         for _ in range(2):
@@ -652,7 +653,7 @@ def test_fused_bn_backward_statistics_equal_separate_reduce(dtype, streams):
         torch.cuda.synchronize()
         g2 = m1._grad_arena.flat.clone().double()
         cos2 = float((g2 @ ref) / (g2.norm() * ref.norm()))
-        assert cos2 >= (0.99999 if dtype == torch.float32 else 0.995), cos2
+        assert cos2 >= (0.9999999 if dtype == torch.float32 else 0.999), cos2
     finally:
         T.bn_act_bwd_reduce = orig
         TR._FUSE_BN_BWD, TR._SIDE_STREAM = old, old_side
