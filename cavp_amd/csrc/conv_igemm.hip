@@ -130,40 +130,9 @@ __global__ __launch_bounds__(64 * WC * WP, (WC * WP == 4 ? (BC * BP <= 64 * 64 &
   unsigned long long tl_entry = 0, tl_t0 = 0, tl_t1 = 0, tl_t2 = 0, tl_t3 = 0, tl_s[4] = {0, 0, 0, 0}, tl_tiles = 0, tl_iters = 0, tl_first = 0;
   CAVP_TLI(tl_entry = __builtin_readcyclecounter());
 #endif
-  // persistent workgroups: gridDim.x (a multiple of 8, so a workgroup keeps its XCD) physical workgroups walk the
-  // p.nblk logical ones: launch, kernel-argument load and teardown are paid once per physical workgroup
-  for (int vb = blockIdx.x; vb < p.nblk; vb += gridDim.x) {
-  if (vb != (int)blockIdx.x) __syncthreads();   // the previous tile's epilogue is done with the LDS
-#ifdef CAVP_PROFILE
-  CAVP_TLI({
-    const unsigned long long now = __builtin_readcyclecounter();
-    if (tl_tiles) { tl_s[0] += tl_t1 - tl_t0; tl_s[1] += tl_t2 - tl_t1; tl_s[2] += tl_t3 - tl_t2; tl_s[3] += now - tl_t3; } else { tl_first = now - tl_entry; }
-    tl_t0 = now; tl_t2 = 0;
-    ++tl_tiles;
-  });
-#endif
-  const int sid = xcd_remap(vb, p.nblk);
-  const int tiles = p.tiles_c * p.tiles_p;
-  // (wave-uniform, but integer division has no scalar instruction: each `/` below used to be a ~40-instruction VALU
-  // sequence, the 64-bit ones more, paid by every wave for every tile)
-  const int z = p.splitk == 1 ? 0 : sid / tiles;
-  const int rem = sid - z * tiles;
-  const int tp = fast_div(rem, p.div_tc_m, p.div_tc_s), tc = rem - tp * p.tiles_c;
-  const int c_base = tc * BC, p_base = tp * BP;
-  // BatchNorm-backward instantiations: the tile's per-channel coefficients (mask scale / shift, batch mean, rstd) are requested HERE,
-  // one channel per thread, and parked in LDS behind the K loop - the epilogue then reads them with LDS latency instead of waiting
-  // out two rounds of dependent global loads per tile
-  float bcf[4] = {1.f, 0.f, 0.f, 1.f};
-  if constexpr (BNB) {
-    const int c = c_base + tid;
-    if (tid < BC && c < p.Cout) {
-      if (p.bnb_scale) { bcf[0] = p.bnb_scale[c]; bcf[1] = p.bnb_shift[c]; }
-      bcf[2] = p.bnb_mean[c]; bcf[3] = p.bnb_rstd[c];
-    }
-  }
-  const int it_begin = p.splitk == 1 ? 0 : p.iters * z / p.splitk;   // iters * splitk < 2^31
-  const int it_end = p.splitk == 1 ? p.iters : p.iters * (z + 1) / p.splitk;
-
+  // Buffer descriptors, DMA geometry and the tile state that the K loop and the epilogue share.  The state of a tile (ids, per-thread
+  // DMA descriptors, K-loop position) is set up by start_tile(), which also issues the tile's FIRST stage(s): it runs once in front of
+  // the tile loop and then at the END of every tile for the next one - see the tail of the loop body.
   // Buffer descriptors (wave-uniform, from kernel arguments): the hardware bounds check returns 0 for any offset
   // >= num_records, so padding taps / K tails / M and Cout tails are "loaded" as zeros by pointing the lane at
   // kOOB instead of branching or selecting on the loaded data.
@@ -171,76 +140,19 @@ __global__ __launch_bounds__(64 * WC * WP, (WC * WP == 4 ? (BC * BP <= 64 * 64 &
   const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.w_bytes, 0x00020000);
 
-  // ---- per-thread load descriptors (fixed for the whole K loop) ----
-  // LDS-DMA geometry: a wave-instruction writes 1 KiB = rows 8g..8g+7 LINEARLY (lane l -> byte 16 l), g = wave + NW i,
-  // so the bank swizzle moves to the SOURCE: lane l fetches logical slot (l & 7) ^ ((row >> 1) & 7) of its row.
-  // Everything that does not change over the K loop is folded into one byte offset + one tap-validity bitmask per
-  // row, so a K iteration costs ~4 VALU per load (the first version redid the bounds tests and two integer
-  // divisions every iteration: 80 VALU + 134 SALU per 32 MFMAs, i.e. the address math, not the MFMAs, set the pace).
   const int row0 = 8 * wave + (lane >> 3);
   const int kslot = ((lane & 7) ^ ((4 * wave + (lane >> 4)) & 7)) * VE;
   const int kbyte = kslot * (int)sizeof(T);
   unsigned w_off[LW];  // byte offset of (cout row, k = kslot) or kOOB
-#pragma unroll
-  for (int i = 0; i < LW; ++i) {
-    const int row = row0 + RSTEP * i;
-    const int c = c_base + row;
-    const bool ok = (row < BC) && (c < p.Cout);
-    w_off[i] = ok ? (unsigned)(((size_t)c * p.K + kslot) * sizeof(T)) : kOOB;
-  }
   unsigned x_off[LX];   // byte offset of (pixel @ tap displacement 0, channel kslot); wraps are harmless (masked)
   unsigned x_mask[LX];  // bit ti = live tap ti reads inside the image for this row
   int x_h0[LX], x_w0[LX], x_nb[LX];  // x_nb: UP only
   const int HoWo = p.Ho * p.Wo;
-  // pointwise layers (1x1, stride 1, no padding: two thirds of the conv / linear launches of a CAVP step): output pixel = input
-  // pixel, the one tap is always inside the image - no (n, ho, wo) split (two multiply-shift divisions per row) and no tap loop.
-  // Short-K layers pay this set-up once per tile next to a handful of K steps.
-  // (also a dilated 3x3 whose only live tap is the centre one: ASPP d = 18 on 14 x 14)
   const bool pointwise = !UP && p.ntaps == 1 && p.stride == 1 && p.stride_w == 1 && p.tap_dh[0] == p.pad && p.tap_dw[0] == p.pad &&
                          p.Ho == p.H && p.Wo == p.W;
-  if (pointwise) {
-#pragma unroll
-    for (int i = 0; i < LX; ++i) {
-      const int row = row0 + RSTEP * i;
-      const int pix = p_base + row;
-      const bool ok = (row < BP) && (pix < p.M);
-      x_h0[i] = 0; x_w0[i] = 0; x_nb[i] = 0;
-      x_mask[i] = ok ? 1u : 0u;
-      x_off[i] = (unsigned)pix * (unsigned)(p.ldx * (int)sizeof(T)) + (unsigned)kbyte - (unsigned)p.tap_xoff[0];   // (gdma adds tap_xoff back)
-    }
-  } else {
-#pragma unroll
-  for (int i = 0; i < LX; ++i) {
-    const int row = row0 + RSTEP * i;
-    const int pix = p_base + row;
-    const bool ok = (row < BP) && (pix < p.M);
-    const int pp = ok ? pix : 0;
-    const int n = fast_div(pp, p.div_hw_m, p.div_hw_s), r = pp - n * HoWo;
-    const int ho = fast_div(r, p.div_w_m, p.div_w_s), wo = r - ho * p.Wo;
-    const int h0 = ho * p.stride - p.pad, w0 = wo * p.stride_w - p.pad;
-    x_h0[i] = ok ? h0 : -0x10000000;  // a dead row fails every bounds test below
-    x_w0[i] = w0;
-    x_mask[i] = 0;
-    if constexpr (UP) {
-      x_nb[i] = n * p.H * p.W;
-      x_off[i] = 0;
-    } else {
-      x_off[i] = (unsigned)((n * p.H + h0) * p.W + w0) * (unsigned)(p.ldx * (int)sizeof(T)) + (unsigned)kbyte;
-    }
-  }
-  if constexpr (!UP) {
-    for (int t = 0; t < p.ntaps; ++t) {  // tap outermost: its two scalar table loads are shared by the LX rows
-      const int dh = p.tap_dh[t], dw = p.tap_dw[t];
-#pragma unroll
-      for (int i = 0; i < LX; ++i)
-        x_mask[i] |= ((unsigned)(x_h0[i] + dh) < (unsigned)p.H && (unsigned)(x_w0[i] + dw) < (unsigned)p.W) ? (1u << t) : 0u;
-    }
-  }
-  }
-
-  // K-loop position (tap index, channel tile) kept incrementally: no division in the loop
-  int g_ti = it_begin == 0 ? 0 : it_begin / p.cpt;
-  int g_cc = it_begin - g_ti * p.cpt;
+  int z = 0, tc = 0, tp = 0, c_base = 0, p_base = 0, it_begin = 0, it_end = 0;   // logical workgroup: split-K slice, channel tile, pixel tile
+  float bcf[4] = {1.f, 0.f, 0.f, 1.f};
+  int g_ti = 0, g_cc = 0;
 
   // global -> LDS directly (buffer_load ... lds), no VGPR staging, no ds_write; out-of-range lanes land zeros.
   // `live` = false issues the same number of DMA instructions with every lane out of range (zero fill, no memory
@@ -288,6 +200,125 @@ __global__ __launch_bounds__(64 * WC * WP, (WC * WP == 4 ? (BC * BP <= 64 * 64 &
     if (++g_cc == p.cpt) { g_cc = 0; ++g_ti; }
   };
 
+  auto start_tile = [&](int vb) {
+    const int sid = xcd_remap(vb, p.nblk);
+    const int tiles = p.tiles_c * p.tiles_p;
+    // (wave-uniform, but integer division has no scalar instruction: each `/` below used to be a ~40-instruction VALU
+    // sequence, the 64-bit ones more, paid by every wave for every tile)
+    z = p.splitk == 1 ? 0 : sid / tiles;
+    const int rem = sid - z * tiles;
+    tp = fast_div(rem, p.div_tc_m, p.div_tc_s);
+    tc = rem - tp * p.tiles_c;
+    c_base = tc * BC;
+    p_base = tp * BP;
+    // BatchNorm-backward instantiations: the tile's per-channel coefficients (mask scale / shift, batch mean, rstd) are requested HERE,
+    // one channel per thread, and parked in LDS behind the K loop - the epilogue then reads them with LDS latency instead of waiting
+    // out two rounds of dependent global loads per tile
+    bcf[0] = 1.f; bcf[1] = 0.f; bcf[2] = 0.f; bcf[3] = 1.f;
+    if constexpr (BNB) {
+      const int c = c_base + tid;
+      if (tid < BC && c < p.Cout) {
+        if (p.bnb_scale) { bcf[0] = p.bnb_scale[c]; bcf[1] = p.bnb_shift[c]; }
+        bcf[2] = p.bnb_mean[c]; bcf[3] = p.bnb_rstd[c];
+      }
+    }
+    it_begin = p.splitk == 1 ? 0 : p.iters * z / p.splitk;   // iters * splitk < 2^31
+    it_end = p.splitk == 1 ? p.iters : p.iters * (z + 1) / p.splitk;
+
+    // ---- per-thread load descriptors (fixed for the whole K loop) ----
+    // LDS-DMA geometry: a wave-instruction writes 1 KiB = rows 8g..8g+7 LINEARLY (lane l -> byte 16 l), g = wave + NW i,
+    // so the bank swizzle moves to the SOURCE: lane l fetches logical slot (l & 7) ^ ((row >> 1) & 7) of its row.
+    // Everything that does not change over the K loop is folded into one byte offset + one tap-validity bitmask per
+    // row, so a K iteration costs ~4 VALU per load (the first version redid the bounds tests and two integer
+    // divisions every iteration: 80 VALU + 134 SALU per 32 MFMAs, i.e. the address math, not the MFMAs, set the pace).
+  #pragma unroll
+    for (int i = 0; i < LW; ++i) {
+      const int row = row0 + RSTEP * i;
+      const int c = c_base + row;
+      const bool ok = (row < BC) && (c < p.Cout);
+      w_off[i] = ok ? (unsigned)(((size_t)c * p.K + kslot) * sizeof(T)) : kOOB;
+    }
+    // pointwise layers (1x1, stride 1, no padding: two thirds of the conv / linear launches of a CAVP step): output pixel = input
+    // pixel, the one tap is always inside the image - no (n, ho, wo) split (two multiply-shift divisions per row) and no tap loop.
+    // Short-K layers pay this set-up once per tile next to a handful of K steps.
+    // (also a dilated 3x3 whose only live tap is the centre one: ASPP d = 18 on 14 x 14)
+    if (pointwise) {
+  #pragma unroll
+      for (int i = 0; i < LX; ++i) {
+        const int row = row0 + RSTEP * i;
+        const int pix = p_base + row;
+        const bool ok = (row < BP) && (pix < p.M);
+        x_h0[i] = 0; x_w0[i] = 0; x_nb[i] = 0;
+        x_mask[i] = ok ? 1u : 0u;
+        x_off[i] = (unsigned)pix * (unsigned)(p.ldx * (int)sizeof(T)) + (unsigned)kbyte - (unsigned)p.tap_xoff[0];   // (gdma adds tap_xoff back)
+      }
+    } else {
+  #pragma unroll
+    for (int i = 0; i < LX; ++i) {
+      const int row = row0 + RSTEP * i;
+      const int pix = p_base + row;
+      const bool ok = (row < BP) && (pix < p.M);
+      const int pp = ok ? pix : 0;
+      const int n = fast_div(pp, p.div_hw_m, p.div_hw_s), r = pp - n * HoWo;
+      const int ho = fast_div(r, p.div_w_m, p.div_w_s), wo = r - ho * p.Wo;
+      const int h0 = ho * p.stride - p.pad, w0 = wo * p.stride_w - p.pad;
+      x_h0[i] = ok ? h0 : -0x10000000;  // a dead row fails every bounds test below
+      x_w0[i] = w0;
+      x_mask[i] = 0;
+      if constexpr (UP) {
+        x_nb[i] = n * p.H * p.W;
+        x_off[i] = 0;
+      } else {
+        x_off[i] = (unsigned)((n * p.H + h0) * p.W + w0) * (unsigned)(p.ldx * (int)sizeof(T)) + (unsigned)kbyte;
+      }
+    }
+    if constexpr (!UP) {
+      for (int t = 0; t < p.ntaps; ++t) {  // tap outermost: its two scalar table loads are shared by the LX rows
+        const int dh = p.tap_dh[t], dw = p.tap_dw[t];
+  #pragma unroll
+        for (int i = 0; i < LX; ++i)
+          x_mask[i] |= ((unsigned)(x_h0[i] + dh) < (unsigned)p.H && (unsigned)(x_w0[i] + dw) < (unsigned)p.W) ? (1u << t) : 0u;
+      }
+    }
+    }
+
+    // K-loop position (tap index, channel tile) kept incrementally: no division in the loop
+    g_ti = it_begin == 0 ? 0 : it_begin / p.cpt;
+    g_cc = it_begin - g_ti * p.cpt;
+
+    // the tile's first stage(s): requested here, i.e. for every tile but a workgroup's first one right behind the previous tile's
+    // epilogue - the round trip of these loads overlaps the acknowledgement of that tile's global stores (hipcc parks an
+    // s_waitcnt vmcnt(0) at the tile loop's latch whatever the source does, profiles/r06_notes.md 3: before this, a workgroup sat out
+    // its stores' acknowledgement and only THEN set up and requested the next tile)
+    if (it_begin < it_end) {
+      if constexpr (NS == 2) {
+        gdma(0, true);
+      } else if constexpr (NW == 4) {
+        const int n = it_end - it_begin;
+#pragma unroll
+        for (int s = 0; s < NS - 1; ++s) gdma(s, s < n);
+      } else {
+        const int n = it_end - it_begin;
+        gdma(0, true);
+        gdma(1, 1 < n);
+        gdma(2, 2 < n);
+      }
+    }
+  };
+  start_tile((int)blockIdx.x);
+
+  // persistent workgroups: gridDim.x (a multiple of 8, so a workgroup keeps its XCD) physical workgroups walk the
+  // p.nblk logical ones: launch, kernel-argument load and teardown are paid once per physical workgroup
+  for (int vb = blockIdx.x; vb < p.nblk; vb += gridDim.x) {
+  do {   // (`continue` below = this tile is finished: on to the loop tail)
+#ifdef CAVP_PROFILE
+  CAVP_TLI({
+    const unsigned long long now = __builtin_readcyclecounter();
+    if (tl_tiles) { tl_s[0] += tl_t1 - tl_t0; tl_s[1] += tl_t2 - tl_t1; tl_s[2] += tl_t3 - tl_t2; tl_s[3] += now - tl_t3; } else { tl_first = now - tl_entry; }
+    tl_t0 = now; tl_t2 = 0;
+    ++tl_tiles;
+  });
+#endif
   const int wc0 = (wave % WC) * TC, wp0 = (wave / WC) * TP;
   const int lrow = lane & 15, lgrp = lane >> 4;
 
@@ -325,8 +356,7 @@ __global__ __launch_bounds__(64 * WC * WP, (WC * WP == 4 ? (BC * BP <= 64 * 64 &
     if constexpr (NS == 2) {
       // two stages, two workgroups per CU.  Iteration `it`: wait for MY loads of tile `it`, barrier (=> everybody's
       // tile `it` landed and everybody finished multiplying tile it-1), issue tile it+1 into the stage tile it-1
-      // vacated, multiply tile `it`.
-      gdma(0, true);
+      // vacated, multiply tile `it`.  (Tile 0 of the ring was requested by start_tile.)
       int buf = 0;
       for (int it = it_begin; it < it_end; ++it) {
         __builtin_amdgcn_s_waitcnt(vmcnt_imm(0));
@@ -349,9 +379,7 @@ __global__ __launch_bounds__(64 * WC * WP, (WC * WP == 4 ? (BC * BP <= 64 * 64 &
       // barrier per K tile: it proves that everybody's tile `it` landed AND that everybody finished tile it-1, whose stage
       // is refilled right after it.
       constexpr int LD = LW + LX;
-      const int n = it_end - it_begin;
-#pragma unroll
-      for (int s = 0; s < NS - 1; ++s) gdma(s, s < n);
+      const int n = it_end - it_begin;   // (stages 0 .. NS-2 were requested by start_tile)
       int buf = 0, fill = NS - 1;
       for (int it = 0; it < n; ++it) {
         __builtin_amdgcn_s_waitcnt(vmcnt_imm((NS - 2) * LD));
@@ -377,10 +405,7 @@ __global__ __launch_bounds__(64 * WC * WP, (WC * WP == 4 ? (BC * BP <= 64 * 64 &
       //   tail:  multiply the j=1 fragments of tile `it`
       static_assert(NS == 3, "ring arithmetic below is written for 3 stages");
       constexpr int LD = LW + LX;
-      const int n = it_end - it_begin;
-      gdma(0, true);
-      gdma(1, 1 < n);
-      gdma(2, 2 < n);
+      const int n = it_end - it_begin;   // (stages 0 .. 2 were requested by start_tile)
       u32x4_t a0[MC] = {}, b0[MP] = {}, a1[MC] = {}, b1[MP] = {};
       __builtin_amdgcn_s_waitcnt(vmcnt_imm(2 * LD));
       __builtin_amdgcn_s_barrier();
@@ -620,7 +645,11 @@ __global__ __launch_bounds__(64 * WC * WP, (WC * WP == 4 ? (BC * BP <= 64 * 64 &
 #pragma unroll
       for (int g = 0; g < G; ++g) {
         const int k = i0 + g;
-        if (!(ec_ok && k * RSTR < rows_left)) continue;
+        // (no `continue` for out-of-range chunks: every register a predicated load above may have filled is CONSUMED on every path -
+        // a loaded value that stays unused on some static path is still "pending" at the tile loop's latch for hipcc's wait-count
+        // pass, which then parks an s_waitcnt vmcnt(0) there: every tile waited for the acknowledgement of its own global stores
+        // before the next tile's operands were requested.  Dead chunks compute on zeros; only their stores and sums are masked.)
+        const bool live = ec_ok && k * RSTR < rows_left;
         float v[VE];
         {
           const f32x4_t t = *(const f32x4_t*)(lds0 + (size_t)k * RSTR * BC);
@@ -630,7 +659,7 @@ __global__ __launch_bounds__(64 * WC * WP, (WC * WP == 4 ? (BC * BP <= 64 * 64 &
           const f32x4_t t = *(const f32x4_t*)(lds1 + (size_t)k * RSTR * BC);
           v[4] = t[0]; v[5] = t[1]; v[6] = t[2]; v[7] = t[3];
         }
-        if (!BNB && p.nbias) {
+        if (!BNB && p.nbias && live) {
           const float* nb = p.nbias + (size_t)fast_div(p_base + eprow0 + k * RSTR, p.div_hw_m, p.div_hw_s) * p.Cout + ec;
 #pragma unroll
           for (int e = 0; e < VE; ++e) v[e] += nb[e];
@@ -639,7 +668,7 @@ __global__ __launch_bounds__(64 * WC * WP, (WC * WP == 4 ? (BC * BP <= 64 * 64 &
 #pragma unroll
           for (int e = 0; e < VE; ++e) v[e] = __fadd_rn(__fmul_rn(v[e], sc[e]), sh[e]);  // two roundings, as every other epilogue path
         }
-        if (!BNB && p.aux_mode == 2) {   // d(pre) = d(hidden) * gelu'(pre): the multiplier tensor of the forward (aux_mode 1)
+        if (!BNB && p.aux_mode == 2 && live) {   // d(pre) = d(hidden) * gelu'(pre): the multiplier tensor of the forward (aux_mode 1)
           float m[VE];
           VecT<T>::load(xp + (size_t)k * xstep, m);
 #pragma unroll
@@ -676,7 +705,7 @@ __global__ __launch_bounds__(64 * WC * WP, (WC * WP == 4 ? (BC * BP <= 64 * 64 &
 #pragma unroll
           for (int e = 0; e < VE; ++e) {
             const float gm = p.bnb_act == CAVP_ACT_RELU ? (yf[e] > 0.f ? 1.f : 0.f) : (p.bnb_act == CAVP_ACT_LEAKY ? (yf[e] > 0.f ? 1.f : 0.01f) : 1.f);
-            const float gv = v[e] * gm;
+            const float gv = live ? v[e] * gm : 0.f;
             bs0[e] += gv;
             if constexpr (sizeof(T) == 4) bs1[e] = fmaf(gv, zf[e] - bmu[e], bs1[e]);
             else bs1[e] = fmaf(gv, zf[e], bs1[e]);
@@ -687,7 +716,7 @@ __global__ __launch_bounds__(64 * WC * WP, (WC * WP == 4 ? (BC * BP <= 64 * 64 &
           float m[VE];
 #pragma unroll
           for (int e = 0; e < VE; ++e) gelu_and_grad(v[e], v[e], m[e]);
-          VecT<T>::store(xp + (size_t)k * xstep, m);
+          if (live) VecT<T>::store(xp + (size_t)k * xstep, m);
         } else {
           if constexpr (!BNB) apply_act_vec<VE>(v, p.act);
         }
@@ -699,7 +728,7 @@ __global__ __launch_bounds__(64 * WC * WP, (WC * WP == 4 ? (BC * BP <= 64 * 64 &
 #pragma unroll
           for (int e = 0; e < 4; ++e) o[e] = pack2bf(v[2 * e], v[2 * e + 1]);
         }
-        if (!CAVP_DBG(p, 32) || o[0] == 0x12345678u) *(u32x4_t*)(yp + (size_t)k * ystep) = o;
+        if (live && (!CAVP_DBG(p, 32) || o[0] == 0x12345678u)) *(u32x4_t*)(yp + (size_t)k * ystep) = o;
       }
     }
     if constexpr (bnb) {
@@ -724,13 +753,16 @@ __global__ __launch_bounds__(64 * WC * WP, (WC * WP == 4 ? (BC * BP <= 64 * 64 &
       }
       constexpr int GPW = CH < 64 ? 1 : CH / 64;   // (CH <= 64 for every tile: one channel-group set per wave)
       static_assert(GPW == 1, "a wave covers all channel groups of the tile");
-      __syncthreads();
+      // (raw barriers: the chunk loop's global stores need not be acknowledged before the tile sums go through LDS)
+      __builtin_amdgcn_s_waitcnt(0xc07f);
+      __builtin_amdgcn_s_barrier();
       float* red = (float*)smem;   // [NW][BC][2]
       if (lane < CH) {
 #pragma unroll
         for (int e = 0; e < VE; ++e) *(float2*)(red + ((size_t)wave * BC + ecc + e) * 2) = make_float2(bs0[e], bs1[e]);
       }
-      __syncthreads();
+      __builtin_amdgcn_s_waitcnt(0xc07f);
+      __builtin_amdgcn_s_barrier();
       if (tid < BC && c_base + tid < p.Cout) {
         float a0 = 0.f, a1 = 0.f;
 #pragma unroll
@@ -764,6 +796,14 @@ __global__ __launch_bounds__(64 * WC * WP, (WC * WP == 4 ? (BC * BP <= 64 * 64 &
         epilogue_store4<T>(p, v[0], v[1], v[2], v[3], pix, c);
       }
     }
+  }
+  } while (0);
+  // tail: when everybody has finished reading the staging LDS, set up the next tile and request its first stage(s) - behind this
+  // tile's global stores, which are still on their way
+  if (vb + (int)gridDim.x < p.nblk) {
+    __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0)
+    __builtin_amdgcn_s_barrier();
+    start_tile(vb + (int)gridDim.x);
   }
   }  // persistent loop
 #ifdef CAVP_PROFILE

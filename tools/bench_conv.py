@@ -62,6 +62,18 @@ SHAPES = {
     "P1_fc2_512_64": (16, 1, 16384, 512, 64, 1, 1, 0, 1, True),
     "P4_fc1_512_2048": (16, 1, 256, 512, 2048, 1, 1, 0, 1, False),
     "P4_fc2_2048_512": (16, 1, 256, 2048, 512, 1, 1, 0, 1, True),
+    # skinny-K pointwise layers of the backbone (round 6: 1.2 .. 1.9 TB/s in the step): forward expansions / reductions and the
+    # stride-1 data gradients of the same layers (a dgrad of Cout -> Cin is a forward conv Cin <- Cout)
+    "S_l1_64_256@56": (32, 56, 56, 64, 256, 1, 1, 0, 1, False),
+    "S_l1_128_256@56": (32, 56, 56, 128, 256, 1, 1, 0, 1, False),
+    "S_l1_128_64@56": (32, 56, 56, 128, 64, 1, 1, 0, 1, False),
+    "S_l1_256_64@56": (32, 56, 56, 256, 64, 1, 1, 0, 1, False),
+    "S_l1_256_128@56": (32, 56, 56, 256, 128, 1, 1, 0, 1, False),
+    "S_l2_128_512@28": (32, 28, 28, 128, 512, 1, 1, 0, 1, False),
+    "S_l2_512_128@28": (32, 28, 28, 512, 128, 1, 1, 0, 1, False),
+    "S_l2_512_256@28": (32, 28, 28, 512, 256, 1, 1, 0, 1, False),
+    "S_clsdg_8_256@56": (64, 56, 56, 8, 256, 1, 1, 0, 1, False),
+    "S_red_48_256@56": (32, 56, 56, 48, 256, 1, 1, 0, 1, False),
     # K sweep at a fixed output (anatomy of the per-tile fixed costs)
     "K_64_1216": (32, 1, 3136, 64, 1216, 1, 1, 0, 1, False),
     "K_128_1216": (32, 1, 3136, 128, 1216, 1, 1, 0, 1, False),
@@ -82,6 +94,7 @@ def main():
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--aux", type=int, default=0, help="1: fc1-style epilogue (GELU + gelu' stored, no scale/shift); 2: fc2-dgrad style (result x aux)")
     ap.add_argument("--ldpad", type=int, default=0, help="round the channel stride of x / y / residual up to a multiple of this many elements")
+    ap.add_argument("--plain", type=int, default=0, help="1: no scale / shift / residual / activation (the training forward's conv); 2: the same + fused BatchNorm tile statistics")
     ap.add_argument("--lib", default="", help="load this build of the library (cavp_amd/libcavp_hip_profile.so: CAVP_IGEMM_* knobs; "
                                               "CAVP_IGEMM_DBG=256 prints the s_memtime timeline of workgroup 0 / wave 0 and the plan)")
     a = ap.parse_args()
@@ -114,6 +127,8 @@ def main():
                     auxt = torch.randn_like(y) if a.aux == 2 else torch.empty_like(y)
                     f = lambda: ops.conv2d(x, wt, y, kh=k, kw=k, stride=s, pad=p, dil=d, shift=sh,
                                            act=ops.ACT_GELU if a.aux == 1 else ops.ACT_NONE, tile=v, aux=auxt, aux_mode=a.aux)
+                elif a.plain:
+                    f = lambda: ops.conv2d(x, wt, y, kh=k, kw=k, stride=s, pad=p, dil=d, tile=v, want_tile_stats=a.plain == 2)
                 else:
                     f = lambda: ops.conv2d(x, wt, y, kh=k, kw=k, stride=s, pad=p, dil=d, scale=sc, shift=sh, residual=r,
                                            act=ops.ACT_RELU, tile=v)
