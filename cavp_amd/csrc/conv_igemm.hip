@@ -362,7 +362,9 @@ __global__ __launch_bounds__(64 * WC * WP, (WC * WP == 4 ? (BC * BP <= 64 * 64 &
         __builtin_amdgcn_s_waitcnt(vmcnt_imm(0));
         __builtin_amdgcn_s_barrier();
         CAVP_TLI(if (tl_t2 == 0) tl_t2 = __builtin_readcyclecounter());
-        if (!CAVP_DBG(p, 8)) gdma(buf ^ 1, it + 1 < it_end && !CAVP_DBG(p, 1));
+        // (no dummy DMA behind a tile's LAST K tile: with vmcnt(0) per iteration the count need not stay uniform, and the barrier that
+        // ends the K loop would wait for its zero fill - ~0.5 k cycles in front of every epilogue of the one-K-tile 1x1 layers)
+        if (it + 1 < it_end && !CAVP_DBG(p, 8)) gdma(buf ^ 1, !CAVP_DBG(p, 1));
         if (!CAVP_DBG(p, 2)) {
           u32x4_t af[MC], bfv[MP];
 #pragma unroll
@@ -521,7 +523,7 @@ __global__ __launch_bounds__(64 * WC * WP, (WC * WP == 4 ? (BC * BP <= 64 * 64 &
         float s1[4], s2[4], x0[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          x0[i] = __shfl(acc[a][0][i], lane & 48, 64);
+          x0[i] = row16_first(acc[a][0][i]);
           s1[i] = 0.f; s2[i] = 0.f;
         }
 #pragma unroll
@@ -540,10 +542,12 @@ __global__ __launch_bounds__(64 * WC * WP, (WC * WP == 4 ? (BC * BP <= 64 * 64 &
           s2[i] = row16_sum(s2[i]);
         }
         if (lrow == 0) {
-          const float n = (float)(nvw < TP ? (nvw > 0 ? nvw : 1) : TP);
+          // (one reciprocal per wave and tile instead of an IEEE division per channel: this block is VALU time in front of every
+          // store of a store-bound layer, profiles/r06_skinny_epilogue_anatomy.txt)
+          const float inv_n = __frcp_rn((float)(nvw < TP ? (nvw > 0 ? nvw : 1) : TP));
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
-            const float m = s1[i] / n;
+            const float m = s1[i] * inv_n;
             wstat[(wave / WC) * BC + wc0 + a * 16 + lgrp * 4 + i] = make_float2(x0[i] + m, fmaxf(s2[i] - s1[i] * m, 0.f));
           }
         }
@@ -573,9 +577,9 @@ __global__ __launch_bounds__(64 * WC * WP, (WC * WP == 4 ? (BC * BP <= 64 * 64 &
         nb = nb < TP ? nb : TP;
         if (nb > 0) {
           const float2 q = wstat[w * BC + tid];
-          const float fb = (float)nb, nt = n + fb, dlt = q.x - mean;
-          mean += dlt * (fb / nt);
-          m2 += q.y + dlt * dlt * (n * fb / nt);
+          const float fb = (float)nb, nt = n + fb, dlt = q.x - mean, fr = fb * __frcp_rn(nt);   // (one reciprocal instead of two divisions)
+          mean += dlt * fr;
+          m2 += q.y + dlt * dlt * (n * fr);
           n = nt;
         }
       }

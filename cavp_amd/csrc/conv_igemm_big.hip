@@ -234,7 +234,7 @@ __global__ __launch_bounds__(512, 2) void igemm_big_kernel(const IgemmParams p) 
         float s1[4], s2[4], x0[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          x0[i] = __shfl(acc[a][0][i], lane & 48, 64);
+          x0[i] = row16_first(acc[a][0][i]);
           s1[i] = 0.f; s2[i] = 0.f;
         }
 #pragma unroll
@@ -254,13 +254,13 @@ __global__ __launch_bounds__(512, 2) void igemm_big_kernel(const IgemmParams p) 
         }
         const int c = c_wave + a * 16 + lgrp * 4;
         if (lrow == 0 && nvw > 0 && c < p.Cout) {
-          const float n = (float)(nvw < 128 ? nvw : 128);
+          const float inv_n = __frcp_rn((float)(nvw < 128 ? nvw : 128));
           float4 o;
-          float m = s1[0] / n; o.x = x0[0] + m; o.y = fmaxf(s2[0] - s1[0] * m, 0.f);
-          m = s1[1] / n; o.z = x0[1] + m; o.w = fmaxf(s2[1] - s1[1] * m, 0.f);
+          float m = s1[0] * inv_n; o.x = x0[0] + m; o.y = fmaxf(s2[0] - s1[0] * m, 0.f);
+          m = s1[1] * inv_n; o.z = x0[1] + m; o.w = fmaxf(s2[1] - s1[1] * m, 0.f);
           float4 o2;
-          m = s1[2] / n; o2.x = x0[2] + m; o2.y = fmaxf(s2[2] - s1[2] * m, 0.f);
-          m = s1[3] / n; o2.z = x0[3] + m; o2.w = fmaxf(s2[3] - s1[3] * m, 0.f);
+          m = s1[2] * inv_n; o2.x = x0[2] + m; o2.y = fmaxf(s2[2] - s1[2] * m, 0.f);
+          m = s1[3] * inv_n; o2.z = x0[3] + m; o2.w = fmaxf(s2[3] - s1[3] * m, 0.f);
           float* dst = p.tile_stats + ((size_t)(tp * 2 + wp) * p.Cout + c) * 2;
           *(float4*)dst = o;
           *(float4*)(dst + 4) = o2;

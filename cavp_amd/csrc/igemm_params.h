@@ -1,5 +1,5 @@
 // Kernel-argument block and MFMA wrappers shared by the implicit-GEMM kernels (conv_igemm.hip: the 2-stage 4-wave tiles,
-// conv_igemm_big.hip: the 256x256 ping-pong tile).
+// conv_igemm_big.hip: the 256x256 tile).
 #pragma once
 #include "common.h"
 
@@ -75,6 +75,12 @@ __device__ __forceinline__ float row16_sum(float v) {
 }
 
 
+
+// value of lane 0 of the lane's 16-lane DPP row in every lane of the row (row_newbcast:0, gfx90a+): one VALU move where __shfl(v,
+// lane & 48) is an LDS-crossbar ds_bpermute + an lgkmcnt wait
+__device__ __forceinline__ float row16_first(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x150, 0xf, 0xf, true));
+}
 
 // conv_igemm_big.hip
 hipError_t cavp_launch_igemm_big(const IgemmParams& p, int nblk, hipStream_t s);
