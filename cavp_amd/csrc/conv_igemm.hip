@@ -745,7 +745,10 @@ __global__ __launch_bounds__(64 * WC * WP, (WC * WP == 4 ? (BC * BP <= 64 * 64 &
         const float mu = bcoef[2 * BC + ecc + e], rs = bcoef[3 * BC + ecc + e];
         bs1[e] = sizeof(T) == 4 ? rs * bs1[e] : rs * (bs1[e] - mu * bs0[e]);
       }
-      if constexpr (CH < 64) {
+      static_assert(CH == 8 || CH == 16 || CH == 32 || CH == 64, "lanes of a wave that share a channel group");
+      if constexpr (MC * MP * 4 >= 64) {
+        // (the 128 x 128 tile sits at 256 VGPRs: the two-register results of the lane swaps below spilled 67 of them - 14.0 -> 14.2 ms
+        // per step; it keeps the LDS-crossbar shuffles)
 #pragma unroll
         for (int m = CH; m < 64; m <<= 1) {
 #pragma unroll
@@ -753,6 +756,13 @@ __global__ __launch_bounds__(64 * WC * WP, (WC * WP == 4 ? (BC * BP <= 64 * 64 &
             bs0[e] += __shfl_xor(bs0[e], m, 64);
             bs1[e] += __shfl_xor(bs1[e], m, 64);
           }
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < VE; ++e) {
+          if constexpr (CH <= 8) { bs0[e] = xor_add<8>(bs0[e]); bs1[e] = xor_add<8>(bs1[e]); }
+          if constexpr (CH <= 16) { bs0[e] = xor_add<16>(bs0[e]); bs1[e] = xor_add<16>(bs1[e]); }
+          if constexpr (CH <= 32) { bs0[e] = xor_add<32>(bs0[e]); bs1[e] = xor_add<32>(bs1[e]); }
         }
       }
       constexpr int GPW = CH < 64 ? 1 : CH / 64;   // (CH <= 64 for every tile: one channel-group set per wave)
