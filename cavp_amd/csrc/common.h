@@ -62,11 +62,17 @@ template <> struct VecT<float> {
     v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
   }
   __device__ static __forceinline__ void store(float* p, const float* v) { *(float4*)p = make_float4(v[0], v[1], v[2], v[3]); }
+  // the 16 raw bytes now, the VE floats later (loads of the NEXT row parked in 4 registers while the current row is reduced)
+  __device__ static __forceinline__ uint4 load_raw(const float* p) { return *(const uint4*)p; }
+  __device__ static __forceinline__ void unpack(const uint4& t, float* v) {
+    v[0] = __uint_as_float(t.x); v[1] = __uint_as_float(t.y); v[2] = __uint_as_float(t.z); v[3] = __uint_as_float(t.w);
+  }
 };
 template <> struct VecT<bf16_t> {
   static constexpr int VE = 8;
-  __device__ static __forceinline__ void load(const bf16_t* p, float* v) {
-    const uint4 t = *(const uint4*)p;
+  __device__ static __forceinline__ void load(const bf16_t* p, float* v) { unpack(*(const uint4*)p, v); }
+  __device__ static __forceinline__ uint4 load_raw(const bf16_t* p) { return *(const uint4*)p; }
+  __device__ static __forceinline__ void unpack(const uint4& t, float* v) {
     const unsigned u[4] = {t.x, t.y, t.z, t.w};
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -118,8 +124,23 @@ __device__ __forceinline__ void gelu_and_grad(float x, float& g, float& dg) {
   dg = fmaf(x * e, 0.3989422804014327f, cdf);
 }
 
-// activation of N values with ONE (wave-uniform) dispatch on the activation code
-template <int N>
+// gelu(x) alone in gelu_and_grad's form (one exp, one reciprocal, |error of the CDF| <= 1.5e-7: three orders of magnitude below the bf16
+// rounding of the stored result).  The bf16 inference epilogues use it: with erff the 304 -> 1216 token linear of the eval forward ran
+// 252 us against 138 us for its 1216 -> 304 partner (profiles/r06_layers_eval_bf16.txt rows 90 / 91); the f32 parity path keeps erff.
+__device__ __forceinline__ float gelu_fast(float x) {
+  const float ax = fabsf(x);
+  const float e = __expf(-0.5f * x * x);
+  const float t = __frcp_rn(fmaf(0.3275911f * 0.70710678118654752f, ax, 1.f));
+  float poly = fmaf(1.061405429f, t, -1.453152027f);
+  poly = fmaf(poly, t, 1.421413741f);
+  poly = fmaf(poly, t, -0.284496736f);
+  poly = fmaf(poly, t, 0.254829592f);
+  const float h = 0.5f * poly * t * e;                         // 0.5 * erfc(|x| / sqrt 2)
+  return x * (x >= 0.f ? 1.f - h : h);
+}
+
+// activation of N values with ONE (wave-uniform) dispatch on the activation code (FAST_GELU: gelu_fast instead of erff - bf16 outputs)
+template <int N, bool FAST_GELU = false>
 __device__ __forceinline__ void apply_act_vec(float* v, int act) {
   switch (act) {
     case CAVP_ACT_RELU:
@@ -132,9 +153,47 @@ __device__ __forceinline__ void apply_act_vec(float* v, int act) {
       break;
     case CAVP_ACT_GELU:
 #pragma unroll
-      for (int e = 0; e < N; ++e) v[e] = 0.5f * v[e] * (1.f + erff(v[e] * 0.70710678118654752f));
+      for (int e = 0; e < N; ++e) v[e] = FAST_GELU ? gelu_fast(v[e]) : 0.5f * v[e] * (1.f + erff(v[e] * 0.70710678118654752f));
       break;
     default: break;
+  }
+}
+
+
+// sum over the 16 lanes of a DPP row (lanes 16k .. 16k+15): xor 1, xor 2 (quad_perm), then half-row and row mirrors, which
+// swap quads / half-rows and so act as xor 4 / xor 8 once the lower levels are uniform.  Every lane ends with the total.
+__device__ __forceinline__ float row16_sum(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true));   // quad_perm [1,0,3,2]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, true));   // quad_perm [2,3,0,1]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, true));  // row_half_mirror
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xf, 0xf, true));  // row_mirror
+  return v;
+}
+
+
+
+// value of lane 0 of the lane's 16-lane DPP row in every lane of the row (row_newbcast:0, gfx90a+): one VALU move where __shfl(v,
+// lane & 48) is an LDS-crossbar ds_bpermute + an lgkmcnt wait
+__device__ __forceinline__ float row16_first(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x150, 0xf, 0xf, true));
+}
+
+// v + (v of lane ^ M) for M = 8 / 16 / 32 without the LDS crossbar: xor 8 stays inside a 16-lane DPP row (row_ror:8); xor 16 / xor 32 pair
+// rows / halves, which v_permlane16_swap / v_permlane32_swap of a register WITH ITSELF produce (swap(a, a) = (rows [0 0 2 2], rows
+// [1 1 3 3]) resp. (halves [lo lo], [hi hi]): their sum is v + xor).  __shfl_xor is a ds_bpermute_b32 + address arithmetic + an
+// lgkmcnt wait per value; the BatchNorm-backward tile sums do 16 of them per step of the tree.
+template <int M>
+__device__ __forceinline__ float xor_add(float v) {
+  const unsigned u = __float_as_uint(v);
+  if constexpr (M == 8) {
+    return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, (int)u, 0x128, 0xf, 0xf, true));   // row_ror:8
+  } else if constexpr (M == 16) {
+    const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+  } else {
+    static_assert(M == 32, "xor_add: 8, 16 or 32");
+    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
   }
 }
 

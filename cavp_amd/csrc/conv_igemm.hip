@@ -722,7 +722,7 @@ __global__ __launch_bounds__(64 * WC * WP, (WC * WP == 4 ? (BC * BP <= 64 * 64 &
           for (int e = 0; e < VE; ++e) gelu_and_grad(v[e], v[e], m[e]);
           if (live) VecT<T>::store(xp + (size_t)k * xstep, m);
         } else {
-          if constexpr (!BNB) apply_act_vec<VE>(v, p.act);
+          if constexpr (!BNB) apply_act_vec<VE, sizeof(T) == 2>(v, p.act);
         }
         u32x4_t o;
         if constexpr (sizeof(T) == 4) {

@@ -372,7 +372,7 @@ __global__ __launch_bounds__(512, 2) void igemm_big_kernel(const IgemmParams p) 
           for (int e = 0; e < 4; ++e) d[e] = pack2bf(dgv[2 * e], dgv[2 * e + 1]);
           __builtin_nontemporal_store(d, (u32x4_t*)(xp + (size_t)(b * 16 + 8 * k) * p.ld_aux));
         } else {
-          apply_act_vec<8>(v, p.act);
+          apply_act_vec<8, true>(v, p.act);
         }
         u32x4_t o;
 #pragma unroll

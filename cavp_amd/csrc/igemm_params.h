@@ -64,42 +64,5 @@ template <> struct Mma<bf16_t> {
   }
 };
 
-// sum over the 16 lanes of a DPP row (lanes 16k .. 16k+15): xor 1, xor 2 (quad_perm), then half-row and row mirrors, which
-// swap quads / half-rows and so act as xor 4 / xor 8 once the lower levels are uniform.  Every lane ends with the total.
-__device__ __forceinline__ float row16_sum(float v) {
-  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true));   // quad_perm [1,0,3,2]
-  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, true));   // quad_perm [2,3,0,1]
-  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, true));  // row_half_mirror
-  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xf, 0xf, true));  // row_mirror
-  return v;
-}
-
-
-
-// value of lane 0 of the lane's 16-lane DPP row in every lane of the row (row_newbcast:0, gfx90a+): one VALU move where __shfl(v,
-// lane & 48) is an LDS-crossbar ds_bpermute + an lgkmcnt wait
-__device__ __forceinline__ float row16_first(float v) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x150, 0xf, 0xf, true));
-}
-
-// v + (v of lane ^ M) for M = 8 / 16 / 32 without the LDS crossbar: xor 8 stays inside a 16-lane DPP row (row_ror:8); xor 16 / xor 32 pair
-// rows / halves, which v_permlane16_swap / v_permlane32_swap of a register WITH ITSELF produce (swap(a, a) = (rows [0 0 2 2], rows
-// [1 1 3 3]) resp. (halves [lo lo], [hi hi]): their sum is v + xor).  __shfl_xor is a ds_bpermute_b32 + address arithmetic + an
-// lgkmcnt wait per value; the BatchNorm-backward tile sums do 16 of them per step of the tree.
-template <int M>
-__device__ __forceinline__ float xor_add(float v) {
-  const unsigned u = __float_as_uint(v);
-  if constexpr (M == 8) {
-    return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, (int)u, 0x128, 0xf, 0xf, true));   // row_ror:8
-  } else if constexpr (M == 16) {
-    const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
-    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
-  } else {
-    static_assert(M == 32, "xor_add: 8, 16 or 32");
-    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
-    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
-  }
-}
-
 // conv_igemm_big.hip
 hipError_t cavp_launch_igemm_big(const IgemmParams& p, int nblk, hipStream_t s);

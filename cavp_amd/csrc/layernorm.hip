@@ -14,10 +14,19 @@
 
 namespace {
 
+// Sum over the G lanes of a row group (G = 8 / 16 / 32 / 64 consecutive lanes), every lane ends with the total.  DPP inside a 16-lane row
+// (quad_perm xor 1 / xor 2, then the half-row and row mirrors), v_permlane16_swap / v_permlane32_swap across rows: no LDS crossbar.  The
+// first version walked an xor tree of __shfl_xor = ds_bpermute_b32 + address arithmetic + an lgkmcnt wait per step; the backward does four
+// such sums per row, every one on the critical path between a row's loads and its store.
 template <int G>
 __device__ __forceinline__ float group_sum(float v) {
-#pragma unroll
-  for (int o = G / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true));   // quad_perm [1,0,3,2]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, true));   // quad_perm [2,3,0,1]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, true));  // row_half_mirror
+  if constexpr (G >= 16) v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xf, 0xf, true));  // row_mirror
+  if constexpr (G >= 32) v = xor_add<16>(v);
+  if constexpr (G >= 64) v = xor_add<32>(v);
+  static_assert(G == 8 || G == 16 || G == 32 || G == 64, "row group = 8 .. 64 lanes");
   return v;
 }
 
@@ -125,23 +134,61 @@ __global__ __launch_bounds__(256) void layernorm_bwd_vec_kernel(const T* __restr
   const int r_begin = blockIdx.x * rows_per_block;
   int r_end = r_begin + rows_per_block;
   if (r_end > rows) r_end = rows;
-  for (int row = r_begin + wv * RW + g; row < r_end; row += 4 * RW) {
+  // Software pipeline over the wave's rows: the NEXT row's x / dy vectors are requested (raw, 4 registers each) before the current row
+  // is reduced, so a wave always has loads in flight - the first version issued a row's loads, waited, reduced (three dependent
+  // cross-lane sums), stored and only then asked for the next row: 2.5 .. 3.3 TB/s on the 2B x 3136 x 304 token tensors.
+  // (two rows ahead: 48 KB of loads in flight per CU with one row ahead left the launch at 3.9 TB/s; the raw vectors cost 4 registers each
+  // and the kernel sits at two waves per SIMD either way)
+  uint4 nx[2][PLV], nd[2][PLV];
+  int row = r_begin + wv * RW + g;
+#pragma unroll
+  for (int d = 0; d < 2; ++d) {
+    const int r = row + d * 4 * RW;
+    if (r < r_end) {
+#pragma unroll
+      for (int i = 0; i < PLV; ++i)
+        if (ok[i]) {
+          nx[d][i] = VecT<T>::load_raw(x + (size_t)r * ld_x + (l + G * i) * VE);
+          nd[d][i] = VecT<T>::load_raw(dy + (size_t)r * ld_dy + (l + G * i) * VE);
+        }
+    }
+  }
+  for (; row < r_end; row += 4 * RW) {
     float xv[PLV][VE], dv[PLV][VE];
-    float s = 0.f;
+    float s = 0.f, s1 = 0.f;
 #pragma unroll
     for (int i = 0; i < PLV; ++i) {
       if (ok[i]) {
-        VecT<T>::load(x + (size_t)row * ld_x + (l + G * i) * VE, xv[i]);
-        VecT<T>::load(dy + (size_t)row * ld_dy + (l + G * i) * VE, dv[i]);
+        VecT<T>::unpack(nx[0][i], xv[i]);
+        VecT<T>::unpack(nd[0][i], dv[i]);
+        nx[0][i] = nx[1][i];
+        nd[0][i] = nd[1][i];
       } else {
 #pragma unroll
         for (int e = 0; e < VE; ++e) xv[i][e] = dv[i][e] = 0.f;
       }
-#pragma unroll
-      for (int e = 0; e < VE; ++e) s += xv[i][e];
     }
+    const int nrow = row + 8 * RW;
+    if (nrow < r_end) {
+#pragma unroll
+      for (int i = 0; i < PLV; ++i)
+        if (ok[i]) {
+          nx[1][i] = VecT<T>::load_raw(x + (size_t)nrow * ld_x + (l + G * i) * VE);
+          nd[1][i] = VecT<T>::load_raw(dy + (size_t)nrow * ld_dy + (l + G * i) * VE);
+        }
+    }
+    // two rounds of two independent sums: (sum x, sum dy gamma), then with the mean (sum d^2, sum dy gamma d), d = x - mean
+#pragma unroll
+    for (int i = 0; i < PLV; ++i)
+#pragma unroll
+      for (int e = 0; e < VE; ++e) {
+        s += xv[i][e];
+        const float dg = dv[i][e] * ga[i][e];   // (padding lanes: gamma = 0)
+        s1 += dg;
+      }
     const float mean = group_sum<G>(s) * invC;
-    float q = 0.f;
+    s1 = group_sum<G>(s1) * invC;
+    float q = 0.f, s2 = 0.f;
 #pragma unroll
     for (int i = 0; i < PLV; ++i)
 #pragma unroll
@@ -149,30 +196,21 @@ __global__ __launch_bounds__(256) void layernorm_bwd_vec_kernel(const T* __restr
         const float d = ok[i] ? xv[i][e] - mean : 0.f;
         xv[i][e] = d;
         q += d * d;
+        s2 = fmaf(dv[i][e] * ga[i][e], d, s2);
       }
     const float rstd = rsqrtf(group_sum<G>(q) * invC + eps);
-    float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-    for (int i = 0; i < PLV; ++i)
-#pragma unroll
-      for (int e = 0; e < VE; ++e) {
-        const float xh = xv[i][e] * rstd;       // (padding lanes: 0)
-        const float dg = dv[i][e] * ga[i][e];
-        s1 += dg;
-        s2 += dg * xh;
-        ag[i][e] += dv[i][e] * xh;
-        ab[i][e] += dv[i][e];
-        xv[i][e] = xh;
-        dv[i][e] = dg;
-      }
-    s1 = group_sum<G>(s1) * invC;
-    s2 = group_sum<G>(s2) * invC;
+    s2 = group_sum<G>(s2) * invC * rstd;       // mean over the row of dy gamma xhat, xhat = d rstd
 #pragma unroll
     for (int i = 0; i < PLV; ++i) {
       if (ok[i]) {
         float o[VE];
 #pragma unroll
-        for (int e = 0; e < VE; ++e) o[e] = rstd * (dv[i][e] - s1 - xv[i][e] * s2);
+        for (int e = 0; e < VE; ++e) {
+          const float xh = xv[i][e] * rstd;
+          ag[i][e] = fmaf(dv[i][e], xh, ag[i][e]);
+          ab[i][e] += dv[i][e];
+          o[e] = rstd * (dv[i][e] * ga[i][e] - s1 - xh * s2);
+        }
         if (add) {   // the gradient the input already holds (residual branch): one pass instead of a separate add
           float r[VE];
           VecT<T>::load(add + (size_t)row * ld_add + (l + G * i) * VE, r);

@@ -126,6 +126,133 @@ __global__ __launch_bounds__(256) void conv3x3_smallcin_kernel(const float* __re
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// The same conv on the matrix cores, for bf16 outputs with Cout = 64 (the image stem 3 -> 64 stride 2 and the audio stem 1 -> 64):
+// K = 9 Cin <= 27 is ONE v_mfma_f32_16x16x32_bf16 K step.  The VALU version above spends 864 FMAs + 108 ds_read_b128 per thread on a
+// layer whose HBM floor is 14 us (19 MB in, 51 MB out at B = 32) and runs 69 .. 71 us; here a thread does 8 ds_read_b32 per 16 pixels.
+// * f32 inputs and weights enter as bf16 hi + lo pairs (x = hi + lo to 2^-17): acc = Whi Xhi + Wlo Xhi + Whi Xlo with f32 accumulation, i.e.
+//   the f32 products of the VALU version to ~1e-5 relative - the stem keeps reading the f32 image, not a bf16 rounding of it.
+// * weights = the A operand with the rows permuted (row 4 g + i of block a = channel 16 g + 4 a + i), so a lane's four accumulators
+//   of the four channel blocks are 16 CONSECUTIVE channels of one pixel: two 16-byte stores per lane and pixel.
+// * persistent workgroups walk (image row, 128-pixel run) items: the weight fragments (32 VGPRs) are built once per workgroup.
+// ------------------------------------------------------------------------------------------------------------
+template <int STRIDE>
+__global__ __launch_bounds__(256) void conv3x3_smallcin_mfma_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                                    const float* __restrict__ scale, const float* __restrict__ shift,
+                                                                    bf16_t* __restrict__ y, int N, int Cin, int H, int W, int Ho, int Wo,
+                                                                    int act, int tiles_w, int total) {
+  constexpr int TW = 128, PW = (TW - 1) * STRIDE + 3, COUT = 64;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float* patch = (float*)smem_raw;   // [Cin * 3][PW]
+  const int K = Cin * 9;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int col = lane & 15, g = lane >> 4, kbase = g * 8;
+  // A fragments: block a, row (lane & 15) = channel 16 (row >> 2) + 4 a + (row & 3), k = kbase .. kbase + 7 (zero beyond K)
+  u32x4_t ahi[4], alo[4];
+  int poff[8];   // patch offset of k = kbase + j for pixel 0: row (k / 3) = ci * 3 + kh, column kw = k % 3
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int k = kbase + j;
+    poff[j] = k < K ? (k / 3) * PW + (k % 3) : 0;   // (k >= K: any finite value, its weight is zero)
+  }
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    const int co = 16 * (col >> 2) + 4 * a + (col & 3);
+    float wv[8], wl[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) wv[j] = (kbase + j) < K ? w[co * K + kbase + j] : 0.f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      ahi[a][q] = pack2bf(wv[2 * q], wv[2 * q + 1]);
+      wl[2 * q] = wv[2 * q] - __uint_as_float(ahi[a][q] << 16);
+      wl[2 * q + 1] = wv[2 * q + 1] - __uint_as_float(ahi[a][q] & 0xffff0000u);
+      alo[a][q] = pack2bf(wl[2 * q], wl[2 * q + 1]);
+    }
+  }
+  // The patch of the NEXT item travels in registers while the current item is multiplied: a wave owns patch rows wave, wave + 4, wave + 8
+  // (<= 3 of the Cin * 3 rows) and NC = ceil(PW / 64) columns per lane; the loads are issued behind the second barrier and written to
+  // LDS at the top of the next trip.  (As a load -> wait -> ds_write loop inside the item - the VALU version's form - the five
+  // dependent round trips per row were the launch: 44 us.)
+  constexpr int NC = (PW + 63) / 64;
+  float pv[3][NC];
+  auto fetch = [&](int it) {
+    const int tw_ = it % tiles_w, row_ = it / tiles_w;
+    const int ho_ = row_ % Ho, n_ = row_ / Ho;
+    const int wi0_ = tw_ * TW * STRIDE - 1, hi0_ = ho_ * STRIDE - 1;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      const int r = wave + 4 * q;
+      const int ci = r / 3, kh = r - ci * 3;
+      const int hi = hi0_ + kh;
+      const bool rok = r < Cin * 3 && (unsigned)hi < (unsigned)H;
+      const float* xr = x + (((size_t)n_ * Cin + (rok ? ci : 0)) * H + (rok ? hi : 0)) * W;
+#pragma unroll
+      for (int u = 0; u < NC; ++u) {
+        const int wi = wi0_ + lane + 64 * u;
+        pv[q][u] = (rok && (unsigned)wi < (unsigned)W) ? xr[wi] : 0.f;
+      }
+    }
+  };
+  if ((int)blockIdx.x < total) fetch((int)blockIdx.x);
+  for (int item = blockIdx.x; item < total; item += gridDim.x) {
+    const int tw = item % tiles_w;
+    const int row = item / tiles_w;          // = n * Ho + ho
+    const int wo0 = tw * TW;
+    __syncthreads();                         // the previous item's fragment reads are done
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      const int r = wave + 4 * q;
+      if (r < Cin * 3) {
+#pragma unroll
+        for (int u = 0; u < NC; ++u)
+          if (lane + 64 * u < PW) patch[r * PW + lane + 64 * u] = pv[q][u];
+      }
+    }
+    __syncthreads();
+    if (item + (int)gridDim.x < total) fetch(item + (int)gridDim.x);
+    const int nblk = (min(TW, Wo - wo0) + 15) >> 4;
+    for (int blk = wave; blk < nblk; blk += 4) {
+      const int px = blk * 16 + col;
+      float xv[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) xv[j] = patch[poff[j] + px * STRIDE];
+      u32x4_t bhi, blo;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        bhi[q] = pack2bf(xv[2 * q], xv[2 * q + 1]);
+        blo[q] = pack2bf(xv[2 * q] - __uint_as_float(bhi[q] << 16), xv[2 * q + 1] - __uint_as_float(bhi[q] & 0xffff0000u));
+      }
+      float o[16];
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, alo[a]), __builtin_bit_cast(bf16x8_t, bhi), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, ahi[a]), __builtin_bit_cast(bf16x8_t, blo), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, ahi[a]), __builtin_bit_cast(bf16x8_t, bhi), acc, 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[4 * a + i] = acc[i];
+      }
+      const int wo = wo0 + px;
+      if (wo < Wo) {
+        // (scale / shift re-read per pixel block, 16-byte L1 hits: as 32 resident registers they put the kernel at 130 VGPRs = three
+        // waves per SIMD instead of four)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float4 s4 = scale ? *(const float4*)(scale + g * 16 + 4 * q) : make_float4(1.f, 1.f, 1.f, 1.f);
+          const float4 h4 = shift ? *(const float4*)(shift + g * 16 + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+          o[4 * q] = apply_act(o[4 * q] * s4.x + h4.x, act);
+          o[4 * q + 1] = apply_act(o[4 * q + 1] * s4.y + h4.y, act);
+          o[4 * q + 2] = apply_act(o[4 * q + 2] * s4.z + h4.z, act);
+          o[4 * q + 3] = apply_act(o[4 * q + 3] * s4.w + h4.w, act);
+        }
+        bf16_t* yp = y + ((size_t)row * Wo + wo) * COUT + g * 16;
+        Vec<bf16_t>::store(yp, o);
+        Vec<bf16_t>::store(yp + 8, o + 8);
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // max pool NHWC.  thread = (output pixel, 16-byte channel vector)
 // ------------------------------------------------------------------------------------------------------------
 template <typename T>
@@ -362,6 +489,19 @@ extern "C" int cavp_conv3x3_smallcin_nchw(int32_t dtype, const float* x, const f
   const size_t lds = ((size_t)Cin * 9 * Cout + (size_t)Cin * 3 * ((TW - 1) * stride + 3)) * sizeof(float);
   if (lds > 64 * 1024) return CAVP_ERR_UNSUPPORTED;
   hipStream_t s = (hipStream_t)stream;
+  if (dtype == CAVP_BF16 && Cout == 64 && (stride == 1 || stride == 2)) {   // both stems of the model: the matrix-core version
+    const int tw = (Wo + 127) / 128;
+    const long long items = (long long)N * Ho * tw;
+    if (items <= 0x7fffffffll) {
+      const int grid = items > 1024 ? 1024 : (int)items;   // 4 resident workgroups per CU (109 .. 116 VGPRs)
+      const size_t l2 = (size_t)Cin * 3 * (127 * stride + 3) * sizeof(float);
+      if (stride == 2)
+        conv3x3_smallcin_mfma_kernel<2><<<grid, 256, l2, s>>>(x, w, scale, shift, (bf16_t*)y, N, Cin, H, W, Ho, Wo, act, tw, (int)items);
+      else
+        conv3x3_smallcin_mfma_kernel<1><<<grid, 256, l2, s>>>(x, w, scale, shift, (bf16_t*)y, N, Cin, H, W, Ho, Wo, act, tw, (int)items);
+      CHECK_LAUNCH();
+    }
+  }
   if (dtype == CAVP_F32)
     conv3x3_smallcin_kernel<float><<<(int)nb, 256, lds, s>>>(x, w, scale, shift, (float*)y, N, Cin, H, W, Cout, stride, Ho, Wo, act, tiles_w);
   else

@@ -160,6 +160,22 @@ def test_conv3x3_smallcin(cin, stride, hw, dtype):
     _check(out.permute(0, 3, 1, 2), ref, dtype, "smallcin")
 
 
+@pytest.mark.parametrize("cin,stride,hw", [(3, 2, (224, 224)), (1, 1, (96, 64)), (3, 2, (31, 45)), (2, 1, (5, 131))])
+def test_conv3x3_smallcin_bf16_matrix_core_path_keeps_f32_inputs(cin, stride, hw):
+    """The bf16 stem conv (Cout = 64) runs on the MFMA with the f32 image and weights split into bf16 hi + lo pairs (round 6): every output
+    must be the f32 convolution rounded ONCE to bf16 - |err| <= 2^-8 |ref| + 2e-4 per element, i.e. no bf16 rounding of the inputs
+    (that would be ~27 products x 2^-9 each: ~1e-2 on these inputs; the hi + lo split leaves ~2^-18 per product)."""
+    ops = _ops()
+    x, wt = _rand(2, cin, *hw, seed=118) * 2.0, _rand(64, cin, 3, 3, seed=119, scale=0.5)
+    ref = F.conv2d(x.double(), wt.double(), None, stride, 1).float()
+    out = torch.empty((2, ref.shape[2], ref.shape[3], 64), dtype=torch.bfloat16, device=DEV)
+    ops.conv3x3_smallcin_nchw(x.to(DEV), wt.to(DEV), out, stride=stride, scale=None, shift=None, act=ops.ACT_NONE)
+    got = out.permute(0, 3, 1, 2).float().cpu()
+    err = (got - ref).abs()
+    bound = ref.abs() * 2.0 ** -8 + 2e-4
+    assert bool((err <= bound).all()), f"max excess {float((err - bound).max()):.3e} at scale {float(ref.abs().max()):.2f}"
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
 @pytest.mark.parametrize("k,s,p,hw", [(3, 2, 1, (112, 112)), (2, 2, 0, (96, 64)), (3, 2, 1, (15, 21))])
 def test_maxpool(k, s, p, hw, dtype):
