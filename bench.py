@@ -353,7 +353,7 @@ def measure_roofline(model, run_step, image, dtype_name, reps=3, config="c1p", l
     else:
         cname = "" if config == "c1p" else config + "_"
         tname = f"traffic_{cname}{dtype_name}.json" if mode_name == "eval" else f"traffic_{cname}train_{dtype_name}.json"
-        tpath = next((q for q in (os.path.join(REPO, "profiles", r + tname) for r in ("r05_", "r04_", "r03_", "r02_", "r01_")) if os.path.exists(q)), "")
+        tpath = next((q for q in (os.path.join(REPO, "profiles", r + tname) for r in ("r06_", "r05_", "r04_", "r03_", "r02_", "r01_")) if os.path.exists(q)), "")
         if tpath:
             with open(tpath) as f:
                 tj = json.load(f)
@@ -425,7 +425,7 @@ def rocprof_igemm_ms(config, mode_name, dtype_name):
     """igemm kernel time per step from the committed rocprofv3 --kernel-trace --stats summary of this command
     (profiles/rNN_rocprof_igemm_<cfg><mode>_<dtype>.json, written by tools/summarize_rocprof.py --igemm-json), newest round first."""
     cname = "" if config == "c1p" else config + "_"
-    for r in ("r05_", "r04_", "r03_"):
+    for r in ("r06_", "r05_", "r04_", "r03_"):
         q = os.path.join(REPO, "profiles", f"{r}rocprof_igemm_{cname}{mode_name}_{dtype_name}.json")
         if os.path.exists(q):
             with open(q) as f:
@@ -467,7 +467,7 @@ def eval_forward_leg(model, image, audio, B, dtype_name, steps=30, warmup=5):
     out = {"value": round(B / ms * 1e3, 1), "unit": "frames/s", "ms_per_step": round(ms, 3), "steps": steps, "warmup": warmup, "dtype": dtype_name,
            "launch": "hipGraph replay", "bound": "hbm", "fused_min_gb": round(min_gb, 3), "achieved_gbs": round(min_gb / ms * 1e3, 1),
            "frac_of_hbm_peak": round(min_gb / ms * 1e3 / HBM_PEAK_GBS, 4), "target": {"frames_per_s": 400, "frac_of_hbm_peak": 0.60}}
-    tpath = next((q for q in (os.path.join(REPO, "profiles", f"{r}traffic_{dtype_name}.json") for r in ("r05_", "r04_", "r03_")) if os.path.exists(q)), "")
+    tpath = next((q for q in (os.path.join(REPO, "profiles", f"{r}traffic_{dtype_name}.json") for r in ("r06_", "r05_", "r04_", "r03_")) if os.path.exists(q)), "")
     if tpath:
         with open(tpath) as f:
             tj = json.load(f)

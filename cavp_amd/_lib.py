@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(HERE, "libcavp_hip.so")
 
 F32, BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_LEAKY, ACT_GELU = 0, 1, 2, 3
-ABI_VERSION = 11
+ABI_VERSION = 12
 ERR_BAD_ARG, ERR_UNSUPPORTED, ERR_ALIGN, ERR_WORKSPACE, ERR_LAUNCH = -1, -2, -3, -4, -5   # cavp_status_t
 WGRAD_GROUP_MAX = 16   # CAVP_WGRAD_GROUP_MAX
 
@@ -70,6 +70,7 @@ PROTOTYPES = {
     "cavp_bn_tiles_to_moments": (_i32, [_vp, _i32, _i32, _i64, _vp, _i32, _vp]),
     "cavp_conv3x3_smallcin_nchw": (_i32, [_i32, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "cavp_maxpool_nhwc": (_i32, [_i32, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "cavp_maxpool_affine_nhwc": (_i32, [_i32, _vp, _vp, _vp, _i32, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "cavp_global_avgpool_nhwc": (_i32, [_i32, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "cavp_bilinear_nhwc": (_i32, [_i32, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "cavp_bilinear_nhwc_to_nchw": (_i32, [_i32, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),

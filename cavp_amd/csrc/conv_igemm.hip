@@ -151,6 +151,7 @@ __global__ __launch_bounds__(64 * WC * WP, (WC * WP == 4 ? (BC * BP <= 64 * 64 &
   const bool pointwise = !UP && p.ntaps == 1 && p.stride == 1 && p.stride_w == 1 && p.tap_dh[0] == p.pad && p.tap_dw[0] == p.pad &&
                          p.Ho == p.H && p.Wo == p.W;
   int z = 0, tc = 0, tp = 0, c_base = 0, p_base = 0, it_begin = 0, it_end = 0;   // logical workgroup: split-K slice, channel tile, pixel tile
+  int pq = 0;   // UP, parity-ordered tiles (igemm_params.h): the tile's output parity class
   float bcf[4] = {1.f, 0.f, 0.f, 1.f};
   int g_ti = 0, g_cc = 0;
 
@@ -158,7 +159,14 @@ __global__ __launch_bounds__(64 * WC * WP, (WC * WP == 4 ? (BC * BP <= 64 * 64 &
   // `live` = false issues the same number of DMA instructions with every lane out of range (zero fill, no memory
   // traffic): the ring's tail keeps the per-iteration vmcnt arithmetic uniform.
   auto gdma = [&](int buf, bool live) {
-    const int ti = g_ti < p.ntaps ? g_ti : p.ntaps - 1, c0 = g_cc * BK;
+    int ti = g_ti < p.ntaps ? g_ti : p.ntaps - 1;
+    if constexpr (UP) {
+      if (p.up_par) {   // the class's own tap list (4 bits per launch tap index)
+        const int nt = p.par_nt[pq], gi = g_ti < nt ? g_ti : nt - 1;
+        ti = (int)((p.par_taps[pq] >> (4 * gi)) & 15ull);
+      }
+    }
+    const int c0 = g_cc * BK;
     const bool c_ok = live && (c0 + kslot) < p.Cin;
     const unsigned oobm = c_ok ? 0u : kOOB;  // OR-ed into the offset: any offset >= 2^31 is out of range (tensors < 2 GiB)
     const unsigned wk = (unsigned)(p.tap_woff[ti] + c0 * (int)sizeof(T));
@@ -209,6 +217,12 @@ __global__ __launch_bounds__(64 * WC * WP, (WC * WP == 4 ? (BC * BP <= 64 * 64 &
     const int rem = sid - z * tiles;
     tp = fast_div(rem, p.div_tc_m, p.div_tc_s);
     tc = rem - tp * p.tiles_c;
+    if constexpr (UP) {
+      // parity-ordered tiles: consecutive tile ids cycle through the four classes.  In class-major order the XCD remap hands the one class
+      // of a 1x1 stride-2 gradient that has any tap (a quarter of the tiles, all of the K loops) to two of the eight XCDs: 74 us where
+      // the image-order launch took 69.
+      if (p.up_par) tp = (tp & 3) * (p.tiles_p >> 2) + (tp >> 2);
+    }
     c_base = tc * BC;
     p_base = tp * BP;
     // BatchNorm-backward instantiations: the tile's per-channel coefficients (mask scale / shift, batch mean, rstd) are requested HERE,
@@ -224,6 +238,13 @@ __global__ __launch_bounds__(64 * WC * WP, (WC * WP == 4 ? (BC * BP <= 64 * 64 &
     }
     it_begin = p.splitk == 1 ? 0 : p.iters * z / p.splitk;   // iters * splitk < 2^31
     it_end = p.splitk == 1 ? p.iters : p.iters * (z + 1) / p.splitk;
+    if constexpr (UP) {
+      if (p.up_par) {   // a tile lies inside one parity class and walks that class's live taps only (possibly none: the K loop is skipped)
+        pq = fast_div(p_base, p.div_mq_m, p.div_mq_s);
+        it_begin = 0;
+        it_end = p.par_nt[pq] * p.cpt;
+      }
+    }
 
     // ---- per-thread load descriptors (fixed for the whole K loop) ----
     // LDS-DMA geometry: a wave-instruction writes 1 KiB = rows 8g..8g+7 LINEARLY (lane l -> byte 16 l), g = wave + NW i,
@@ -259,10 +280,18 @@ __global__ __launch_bounds__(64 * WC * WP, (WC * WP == 4 ? (BC * BP <= 64 * 64 &
       const int pix = p_base + row;
       const bool ok = (row < BP) && (pix < p.M);
       const int pp = ok ? pix : 0;
-      const int n = fast_div(pp, p.div_hw_m, p.div_hw_s), r = pp - n * HoWo;
-      const int ho = fast_div(r, p.div_w_m, p.div_w_s), wo = r - ho * p.Wo;
+      int n, ho, wo;
+      bool rok = ok;
+      if (UP && p.up_par) {
+        rok = ok && par_out_pixel(p, pp, n, ho, wo) >= 0;   // (padding slots of a class are dead rows)
+      } else {
+        n = fast_div(pp, p.div_hw_m, p.div_hw_s);
+        const int r = pp - n * HoWo;
+        ho = fast_div(r, p.div_w_m, p.div_w_s);
+        wo = r - ho * p.Wo;
+      }
       const int h0 = ho * p.stride - p.pad, w0 = wo * p.stride_w - p.pad;
-      x_h0[i] = ok ? h0 : -0x10000000;  // a dead row fails every bounds test below
+      x_h0[i] = rok ? h0 : -0x10000000;  // a dead row fails every bounds test below
       x_w0[i] = w0;
       x_mask[i] = 0;
       if constexpr (UP) {
@@ -483,6 +512,15 @@ __global__ __launch_bounds__(64 * WC * WP, (WC * WP == 4 ? (BC * BP <= 64 * 64 &
     const T* rp = p.res ? (const T*)p.res + (size_t)((p.res_rows ? p_base % p.res_rows : p_base) + eprow0) * p.ldr + ec : nullptr;
     const size_t rstep = (size_t)RSTR * p.ldr;
     const int rows_left = p.M - (p_base + eprow0);   // chunk k is in range iff k * RSTR < rows_left
+    // UP instantiations (stride-2 data gradients: four launches of a step) address every chunk row through its OUTPUT pixel index, which the
+    // parity-ordered tiles (igemm_params.h) do not get by adding a constant: -1 = no such pixel (tile tail / padding slot of a class)
+    auto opix_of = [&](int k) -> int {
+      const int r = p_base + eprow0 + k * RSTR;
+      if (r >= p.M) return -1;
+      if (!p.up_par) return r;
+      int n_, h_, w_;
+      return par_out_pixel(p, r, n_, h_, w_);
+    };
     // (not for the tiles with 64 accumulator registers per lane: hoisting a batch spilled 34 VGPRs in the 128 x 128 kernel, half a
     // batch still 7)
     constexpr int GH = (MC * MP * 4 >= 64) ? 0 : G;
@@ -491,7 +529,12 @@ __global__ __launch_bounds__(64 * WC * WP, (WC * WP == 4 ? (BC * BP <= 64 * 64 &
 #pragma unroll
       for (int g = 0; g < GH; ++g) {
         rr0[g] = (u32x4_t){0u, 0u, 0u, 0u};
-        if (ec_ok && g * RSTR < rows_left) rr0[g] = *(const u32x4_t*)(rp + (size_t)g * rstep);
+        if constexpr (UP) {
+          const int op_ = opix_of(g);
+          if (ec_ok && op_ >= 0) rr0[g] = *(const u32x4_t*)((const T*)p.res + (size_t)op_ * p.ldr + ec);
+        } else {
+          if (ec_ok && g * RSTR < rows_left) rr0[g] = *(const u32x4_t*)(rp + (size_t)g * rstep);
+        }
       }
     }
     // BatchNorm-backward instantiations: z (and the activation output) of the first batch travel with the residual
@@ -503,7 +546,13 @@ __global__ __launch_bounds__(64 * WC * WP, (WC * WP == 4 ? (BC * BP <= 64 * 64 &
       for (int g = 0; g < GH; ++g) {
         zz0[g] = (u32x4_t){0u, 0u, 0u, 0u};
         oo0[g] = (u32x4_t){0u, 0u, 0u, 0u};
-        if (ec_ok && g * RSTR < rows_left) {
+        if constexpr (UP) {
+          const int op_ = opix_of(g);
+          if (ec_ok && op_ >= 0) {
+            zz0[g] = *(const u32x4_t*)((const T*)p.bnb_z + (size_t)op_ * p.ld_bnb_z + ec);
+            if (op0) oo0[g] = *(const u32x4_t*)((const T*)p.bnb_out + (size_t)op_ * p.ld_bnb_out + ec);
+          }
+        } else if (ec_ok && g * RSTR < rows_left) {
           zz0[g] = *(const u32x4_t*)(zp0 + (size_t)g * RSTR * p.ld_bnb_z);
           if (op0) oo0[g] = *(const u32x4_t*)(op0 + (size_t)g * RSTR * p.ld_bnb_out);
         }
@@ -630,7 +679,12 @@ __global__ __launch_bounds__(64 * WC * WP, (WC * WP == 4 ? (BC * BP <= 64 * 64 &
         for (int g = 0; g < G; ++g) {
           if (GH > 0 && i0 == 0 && g < GH) { rr[g] = rr0[g < GH ? g : 0]; continue; }
           rr[g] = (u32x4_t){0u, 0u, 0u, 0u};
-          if (ec_ok && (i0 + g) * RSTR < rows_left) rr[g] = *(const u32x4_t*)(rp + (size_t)(i0 + g) * rstep);
+          if constexpr (UP) {
+            const int op_ = opix_of(i0 + g);
+            if (ec_ok && op_ >= 0) rr[g] = *(const u32x4_t*)((const T*)p.res + (size_t)op_ * p.ldr + ec);
+          } else {
+            if (ec_ok && (i0 + g) * RSTR < rows_left) rr[g] = *(const u32x4_t*)(rp + (size_t)(i0 + g) * rstep);
+          }
         }
       }
       u32x4_t zz[G], oo[G];
@@ -640,7 +694,13 @@ __global__ __launch_bounds__(64 * WC * WP, (WC * WP == 4 ? (BC * BP <= 64 * 64 &
           if (GH > 0 && i0 == 0 && g < GH) { zz[g] = zz0[g < GH ? g : 0]; oo[g] = oo0[g < GH ? g : 0]; continue; }
           zz[g] = (u32x4_t){0u, 0u, 0u, 0u};
           oo[g] = (u32x4_t){0u, 0u, 0u, 0u};
-          if (ec_ok && (i0 + g) * RSTR < rows_left) {
+          if constexpr (UP) {
+            const int op_ = opix_of(i0 + g);
+            if (ec_ok && op_ >= 0) {
+              zz[g] = *(const u32x4_t*)((const T*)p.bnb_z + (size_t)op_ * p.ld_bnb_z + ec);
+              if (op) oo[g] = *(const u32x4_t*)((const T*)p.bnb_out + (size_t)op_ * p.ld_bnb_out + ec);
+            }
+          } else if (ec_ok && (i0 + g) * RSTR < rows_left) {
             zz[g] = *(const u32x4_t*)(zp + (size_t)(i0 + g) * zstep);
             if (op) oo[g] = *(const u32x4_t*)(op + (size_t)(i0 + g) * ostep);
           }
@@ -653,7 +713,8 @@ __global__ __launch_bounds__(64 * WC * WP, (WC * WP == 4 ? (BC * BP <= 64 * 64 &
         // a loaded value that stays unused on some static path is still "pending" at the tile loop's latch for hipcc's wait-count
         // pass, which then parks an s_waitcnt vmcnt(0) there: every tile waited for the acknowledgement of its own global stores
         // before the next tile's operands were requested.  Dead chunks compute on zeros; only their stores and sums are masked.)
-        const bool live = ec_ok && k * RSTR < rows_left;
+        const int opk = UP ? opix_of(k) : 0;   // (UP: this chunk's output pixel)
+        const bool live = ec_ok && (UP ? opk >= 0 : k * RSTR < rows_left);
         float v[VE];
         {
           const f32x4_t t = *(const f32x4_t*)(lds0 + (size_t)k * RSTR * BC);
@@ -732,7 +793,10 @@ __global__ __launch_bounds__(64 * WC * WP, (WC * WP == 4 ? (BC * BP <= 64 * 64 &
 #pragma unroll
           for (int e = 0; e < 4; ++e) o[e] = pack2bf(v[2 * e], v[2 * e + 1]);
         }
-        if (live && (!CAVP_DBG(p, 32) || o[0] == 0x12345678u)) *(u32x4_t*)(yp + (size_t)k * ystep) = o;
+        if (live && (!CAVP_DBG(p, 32) || o[0] == 0x12345678u)) {
+          if constexpr (UP) *(u32x4_t*)((T*)p.y + (size_t)opk * p.ldy + ec) = o;
+          else *(u32x4_t*)(yp + (size_t)k * ystep) = o;
+        }
       }
     }
     if constexpr (bnb) {
@@ -794,8 +858,15 @@ __global__ __launch_bounds__(64 * WC * WP, (WC * WP == 4 ? (BC * BP <= 64 * 64 &
 #pragma unroll
     for (int b = 0; b < MP; ++b) {
       const int c = c_base + wc0 + a * 16 + lgrp * 4;
-      const int pix = p_base + wp0 + b * 16 + lrow;
+      int pix = p_base + wp0 + b * 16 + lrow;
       if (pix >= p.M) continue;
+      if constexpr (UP) {
+        if (p.up_par) {   // (never with split-K: the planner keeps parity-ordered launches unsplit)
+          int n_, h_, w_;
+          pix = par_out_pixel(p, pix, n_, h_, w_);
+          if (pix < 0) continue;
+        }
+      }
       const f32x4_t v = acc[a][b];
       if (p.splitk > 1) {
         float* dst = p.partial + ((size_t)z * p.M + pix) * p.Cout + c;
@@ -972,7 +1043,7 @@ struct Plan {
 
 inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
-Plan make_plan(const cavp_conv_desc* d_in, bool allow_big = true) {
+Plan make_plan(const cavp_conv_desc* d_in, bool allow_big = true, bool allow_par = true) {
   cavp_conv_desc dd{};
   if (d_in) dd = *d_in;
   if (dd.aux_mode != 0 || dd.res_rows > 0) dd.splitk = 1;   // the fused token-path epilogues live in the 16-byte epilogue only
@@ -1125,6 +1196,36 @@ Plan make_plan(const cavp_conv_desc* d_in, bool allow_big = true) {
   pl.tile_id = t.id;
   p.tiles_c = cdiv(p.Cout, t.BC);
   fast_div_prepare(p.tiles_c, &p.div_tc_m, &p.div_tc_s);
+  // Stride-2 data gradients (up = 2): parity-ordered pixel tiles (igemm_params.h).  As one pixel stream in image order every tile holds
+  // all four output parities and so walks all live taps with three quarters of its rows zero-filled: 9 of 36 tap visits of a 3x3 do
+  // any work, 1 of 4 of a 1x1 down-sample (profiles/r06_notes.md: 226 us per step in four launches whose roofs add up to 22).
+  static const bool par_on = cavp_knob_int("CAVP_IGEMM_UP_PARITY", 1) != 0;   // A/B knob (profile builds)
+  p.up_par = 0;
+  if (par_on && allow_par && up == 2 && d->splitk <= 1) {
+    const int hq = (p.Ho + 1) / 2, wq = (p.Wo + 1) / 2;
+    const long long mq = ((long long)d->N * hq * wq + t.BP - 1) / t.BP * t.BP;
+    if (4 * mq <= 0x7fffffffll / 4) {
+      p.up_par = 1;
+      p.par_m = p.M;
+      p.par_mq = (int)mq; p.par_hq = hq; p.par_wq = wq;
+      p.M = (int)(4 * mq);
+      fast_div_prepare(p.par_mq, &p.div_mq_m, &p.div_mq_s);
+      fast_div_prepare(hq * wq, &p.div_hwq_m, &p.div_hwq_s);
+      fast_div_prepare(wq, &p.div_wq_m, &p.div_wq_s);
+      for (int q = 0; q < 4; ++q) {
+        const int a = q >> 1, b = q & 1;
+        p.par_nt[q] = 0;
+        p.par_taps[q] = 0;
+        for (int ti = 0; ti < p.ntaps; ++ti) {   // the tap reads input position (ho - pad + dh) / 2: live iff that is even in both directions
+          if (((a - d->pad + p.tap_dh[ti]) & 1) == 0 && ((b - d->pad + p.tap_dw[ti]) & 1) == 0) {
+            p.par_taps[q] |= (unsigned long long)ti << (4 * p.par_nt[q]);
+            ++p.par_nt[q];
+          }
+        }
+      }
+      best_sk = 1;
+    }
+  }
   p.tiles_p = cdiv(p.M, t.BP);
   const int nwg = p.tiles_c * p.tiles_p;
   int sk = best_sk;
@@ -1266,14 +1367,17 @@ static int conv2d_launch(const cavp_conv_desc* d, const void* x, const void* w, 
     return CAVP_ERR_BAD_ARG;
   if (fused && (tile_stats || d->splitk > 1)) return CAVP_ERR_UNSUPPORTED;
   if (tile_stats && (scale || shift || nbias || residual || d->act != CAVP_ACT_NONE)) return CAVP_ERR_BAD_ARG;
-  Plan pl = make_plan(d);
+  // (the parity-ordered tiles of a stride-2 data gradient address rows by output pixel: not with the per-image bias, the forward's
+  // tile statistics or the token-path fusions, none of which a data gradient carries)
+  const bool par_ok = !(tile_stats || nbias || aux || fused);
+  Plan pl = make_plan(d, true, par_ok);
   if (pl.status != CAVP_OK) return pl.status;
   if (!aligned(x, 16) || !aligned(w, 16)) return CAVP_ERR_ALIGN;
   if (tile_is_big(pl.tile_id) && d->tile % 100 == 0 &&
       !(aligned(y, 16) && (!residual || aligned(residual, 16)) && (!scale || aligned(scale, 16)) && (!shift || aligned(shift, 16)) &&
         (!nbias || aligned(nbias, 16)))) {
     if (tile_stats) return CAVP_ERR_ALIGN;   // the statistics layout was sized for the 256x256 tile
-    pl = make_plan(d, false);                // automatically chosen big tile, but an operand is not 16-byte aligned
+    pl = make_plan(d, false, par_ok);        // automatically chosen big tile, but an operand is not 16-byte aligned
     if (pl.status != CAVP_OK) return pl.status;
   }
   if (residual && d->ldr < d->Cout) return CAVP_ERR_BAD_ARG;

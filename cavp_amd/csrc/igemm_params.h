@@ -46,7 +46,29 @@ struct IgemmParams {
   const float* bnb_rstd;
   float* bnb_part;          // f32 [tiles_p][Cout][2]: per pixel tile (sum g, sum g * zhat)
   int ld_bnb_z, ld_bnb_out, bnb_act, pad2_;
+  // Parity-ordered pixel tiles of a stride-2 data gradient (up = 2; conv_igemm.hip): the launch's logical pixel m runs over the four
+  // output parity classes q = (ho & 1) * 2 + (wo & 1) one after the other, par_mq (a multiple of every tile height) logical pixels per
+  // class, m = q * par_mq + (n * par_hq + i) * par_wq + j  <->  output pixel (n, 2 i + (q >> 1), 2 j + (q & 1)).  A tile then lies inside
+  // ONE class and walks only the taps that can hit the zero-upsampled input for that parity (par_nt[q] of them, launch tap indices
+  // 4 bits each in par_taps[q]; 3x3 stride 2: 1 / 2 / 2 / 4 instead of 9 for every pixel; 1x1 stride 2: 1 / 0 / 0 / 0).
+  int up_par;               // 0: linear pixel order (M = N Ho Wo)
+  int par_mq, par_hq, par_wq, par_m;   // par_m: N * Ho * Wo (p.M is 4 * par_mq in this mode)
+  unsigned div_mq_m, div_mq_s, div_hwq_m, div_hwq_s, div_wq_m, div_wq_s;
+  int par_nt[4];
+  unsigned long long par_taps[4];
 };
+
+// parity mode: logical pixel m -> linear output pixel (n * Ho + ho) * Wo + wo, or -1 for a padding slot; (n, ho, wo) returned too
+__device__ __forceinline__ int par_out_pixel(const IgemmParams& p, int m, int& n, int& ho, int& wo) {
+  const int q = fast_div(m, p.div_mq_m, p.div_mq_s), idx = m - q * p.par_mq;
+  n = fast_div(idx, p.div_hwq_m, p.div_hwq_s);
+  const int r = idx - n * (p.par_hq * p.par_wq);
+  const int i = fast_div(r, p.div_wq_m, p.div_wq_s), j = r - i * p.par_wq;
+  ho = 2 * i + (q >> 1);
+  wo = 2 * j + (q & 1);
+  const bool ok = n < p.N && ho < p.Ho && wo < p.Wo;
+  return ok ? (n * p.Ho + ho) * p.Wo + wo : -1;
+}
 
 template <typename T> struct Mma;
 template <> struct Mma<float> {

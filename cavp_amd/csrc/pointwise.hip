@@ -255,10 +255,15 @@ __global__ __launch_bounds__(256) void conv3x3_smallcin_mfma_kernel(const float*
 // ------------------------------------------------------------------------------------------------------------
 // max pool NHWC.  thread = (output pixel, 16-byte channel vector)
 // ------------------------------------------------------------------------------------------------------------
-template <typename T>
+// AFF: the pooled tensor is act(x * scale + shift) rounded to T - the BatchNorm apply + ReLU of the training stem folded into its max pool
+// (cavp_maxpool_affine_nhwc): same expression, contraction and rounding as scale_shift_act, so values and arg-max are those of the
+// two-launch route, without the [32][112][112][128] activation written and read back (206 MB per step).
+template <typename T, bool AFF = false>
 __global__ __launch_bounds__(256) void maxpool_kernel(const T* __restrict__ x, T* __restrict__ y,
                                                       unsigned char* __restrict__ argmax, int N, int H, int W,
-                                                      int C, int k, int stride, int pad, int Ho, int Wo) {
+                                                      int C, int k, int stride, int pad, int Ho, int Wo,
+                                                      const float* __restrict__ scale = nullptr, const float* __restrict__ shift = nullptr,
+                                                      int act = 0) {
   constexpr int VE = Vec<T>::VE;
   const int CV = C / VE;
   const long long total = (long long)N * Ho * Wo * CV;
@@ -266,6 +271,11 @@ __global__ __launch_bounds__(256) void maxpool_kernel(const T* __restrict__ x, T
     int cv, wo, ho, n;
     long long pix;
     split_index(idx, CV, Wo, Ho, cv, pix, wo, ho, n);
+    float sc[AFF ? VE : 1], sh[AFF ? VE : 1];
+    if constexpr (AFF) {
+#pragma unroll
+      for (int j = 0; j < VE; ++j) { sc[j] = scale[cv * VE + j]; sh[j] = shift[cv * VE + j]; }
+    }
     float m[VE];
     int am[VE];   // window-relative position kh * k + kw of the FIRST maximum (strict >, scan order: as ATen)
     bool first = true;
@@ -279,6 +289,14 @@ __global__ __launch_bounds__(256) void maxpool_kernel(const T* __restrict__ x, T
         if ((unsigned)wi >= (unsigned)W) continue;
         float v[VE];
         Vec<T>::load(x + ((size_t)(n * H + hi) * W + wi) * C + cv * VE, v);
+        if constexpr (AFF) {
+#pragma unroll
+          for (int j = 0; j < VE; ++j) {
+            const float t = apply_act(v[j] * sc[j] + sh[j], act);
+            if constexpr (sizeof(T) == 2) v[j] = __uint_as_float(pack2bf(t, 0.f) << 16);   // the value scale_shift_act would have stored
+            else v[j] = t;
+          }
+        }
 #pragma unroll
         for (int j = 0; j < VE; ++j) {
           const bool take = first || v[j] > m[j];
@@ -526,6 +544,27 @@ extern "C" int cavp_maxpool_nhwc(int32_t dtype, const void* x, void* y, uint8_t*
     maxpool_kernel<float><<<nb, 256, 0, s>>>((const float*)x, (float*)y, (unsigned char*)argmax, N, H, W, C, k, stride, pad, Ho, Wo);
   else
     maxpool_kernel<bf16_t><<<nb, 256, 0, s>>>((const bf16_t*)x, (bf16_t*)y, (unsigned char*)argmax, N, H, W, C, k, stride, pad, Ho, Wo);
+  CHECK_LAUNCH();
+}
+
+extern "C" int cavp_maxpool_affine_nhwc(int32_t dtype, const void* x, const float* scale, const float* shift, int32_t act, void* y,
+                                        uint8_t* argmax, int32_t N, int32_t H, int32_t W, int32_t C, int32_t k, int32_t stride,
+                                        int32_t pad, void* stream) {
+  if (!x || !y || !scale || !shift || N <= 0 || H <= 0 || W <= 0 || C <= 0 || k <= 0 || k > 15 || stride <= 0 || pad < 0) return CAVP_ERR_BAD_ARG;
+  if (argmax && ((uintptr_t)argmax & 7)) return CAVP_ERR_ALIGN;
+  if (!dtype_ok(dtype)) return CAVP_ERR_UNSUPPORTED;
+  const int VE = dtype == CAVP_F32 ? 4 : 8;
+  if (C % VE) return CAVP_ERR_UNSUPPORTED;
+  if (!al16(x) || !al16(y)) return CAVP_ERR_ALIGN;
+  const int Ho = (H + 2 * pad - k) / stride + 1, Wo = (W + 2 * pad - k) / stride + 1;
+  if (Ho <= 0 || Wo <= 0) return CAVP_ERR_BAD_ARG;
+  const long long total = (long long)N * Ho * Wo * (C / VE);
+  const int nb = nblocks(total, 256, 16384);
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == CAVP_F32)
+    maxpool_kernel<float, true><<<nb, 256, 0, s>>>((const float*)x, (float*)y, (unsigned char*)argmax, N, H, W, C, k, stride, pad, Ho, Wo, scale, shift, act);
+  else
+    maxpool_kernel<bf16_t, true><<<nb, 256, 0, s>>>((const bf16_t*)x, (bf16_t*)y, (unsigned char*)argmax, N, H, W, C, k, stride, pad, Ho, Wo, scale, shift, act);
   CHECK_LAUNCH();
 }
 

@@ -740,6 +740,51 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const unsigned char* _
   }
 }
 
+// The same gather for stride 2 (every pool of the model), one grid row per input row: (n, hi) come from blockIdx.y and the window bounds are
+// shifts.  The flat version above pays three 32-bit divisions (channel vector / W / H split) + four by the stride per 16-byte vector:
+// the stem pool's backward ran 56 us on a 141 MB problem.
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_bwd_s2_rows_kernel(const unsigned char* __restrict__ argmax, const T* __restrict__ dy,
+                                                                  T* __restrict__ dx, int H, int W, int C, int k, int pad, int Ho, int Wo,
+                                                                  int cv_shift) {
+  constexpr int VE = VecT<T>::VE;
+  const int CV = C / VE;
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= W * CV) return;
+  const int wi = cv_shift >= 0 ? t >> cv_shift : t / CV;
+  const int cv = t - wi * CV;
+  const int row = blockIdx.y;              // n * H + hi
+  const int n = row / H, hi = row - n * H;
+  float acc[VE];
+#pragma unroll
+  for (int e = 0; e < VE; ++e) acc[e] = 0.f;
+  const int ho_lo = hi + pad - k + 1 <= 0 ? 0 : (hi + pad - k + 2) >> 1;
+  const int ho_hi = min((hi + pad) >> 1, Ho - 1);
+  const int wo_lo = wi + pad - k + 1 <= 0 ? 0 : (wi + pad - k + 2) >> 1;
+  const int wo_hi = min((wi + pad) >> 1, Wo - 1);
+  for (int ho = ho_lo; ho <= ho_hi; ++ho) {
+    for (int wo = wo_lo; wo <= wo_hi; ++wo) {
+      const unsigned code = (unsigned)((hi - (ho * 2 - pad)) * k + (wi - (wo * 2 - pad)));
+      const size_t o = ((size_t)(n * Ho + ho) * Wo + wo) * C + cv * VE;
+      unsigned am[VE];
+      if constexpr (VE == 8) {
+        const uint2 q = *(const uint2*)(argmax + o);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { am[e] = (q.x >> (8 * e)) & 255u; am[4 + e] = (q.y >> (8 * e)) & 255u; }
+      } else {
+        const unsigned q = *(const unsigned*)(argmax + o);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) am[e] = (q >> (8 * e)) & 255u;
+      }
+      float g[VE];
+      VecT<T>::load(dy + o, g);
+#pragma unroll
+      for (int e = 0; e < VE; ++e) acc[e] += am[e] == code ? g[e] : 0.f;
+    }
+  }
+  VecT<T>::store(dx + ((size_t)row * W + wi) * C + cv * VE, acc);
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // bilinear backward (gather form): dx[hi, wi] = sum_{ho, wo} wh(ho -> hi) * ww(wo -> wi) * dy[ho, wo]
 // ------------------------------------------------------------------------------------------------------------
@@ -809,16 +854,51 @@ __global__ __launch_bounds__(256) void bilinear_bwd_nhwc_kernel(const T* __restr
     float acc[VE];
 #pragma unroll
     for (int e = 0; e < VE; ++e) acc[e] = 0.f;
-    for (int ho = hlo; ho <= hhi; ++ho) {
-      const float wh = tap_weight(ho, hi, Hi, Ho, align);
-      if (wh == 0.f) continue;
-      for (int wo = wlo; wo <= whi; ++wo) {
-        const float ww = tap_weight(wo, wi, Wi, Wo, align);
-        if (ww == 0.f) continue;
-        float g[VE];
-        VecT<T>::load(dy + ((size_t)(n * Ho + ho) * Wo + wo) * ld_dy + cv * VE, g);
+    // Footprints of <= NWM columns (every up-sampling ratio <= 4: the decoder's 14 -> 56): the column weights are computed ONCE per
+    // thread instead of once per footprint row (tap_weight is ~30 float / integer instructions; 8 x 8 footprints spent more time there
+    // than on their 64 loads: 49 us for a 55 MB problem), and a row's loads are issued together.
+    constexpr int NWM = 12;
+    const int nw = whi - wlo + 1;
+    if (nw <= NWM) {
+      float wwv[NWM];
+      int wof[NWM];   // column offsets, clamped into the footprint: every load below is unconditional (weight 0 beyond the footprint)
 #pragma unroll
-        for (int e = 0; e < VE; ++e) acc[e] += wh * ww * g[e];
+      for (int j = 0; j < NWM; ++j) {
+        wwv[j] = j < nw ? tap_weight(wlo + j, wi, Wi, Wo, align) : 0.f;
+        wof[j] = (j < nw ? j : nw - 1) * ld_dy;
+      }
+      for (int ho = hlo; ho <= hhi; ++ho) {
+        const float wh = tap_weight(ho, hi, Hi, Ho, align);
+        if (wh == 0.f) continue;
+        const T* row = dy + ((size_t)(n * Ho + ho) * Wo + wlo) * ld_dy + cv * VE;
+        uint4 graw[NWM];   // (raw 16-byte vectors: unpacked at use, 48 instead of 96 registers for the row)
+#pragma unroll
+        for (int j = 0; j < NWM; ++j) graw[j] = VecT<T>::load_raw(row + wof[j]);
+        float r[VE];
+#pragma unroll
+        for (int e = 0; e < VE; ++e) r[e] = 0.f;
+#pragma unroll
+        for (int j = 0; j < NWM; ++j) {
+          float g[VE];
+          VecT<T>::unpack(graw[j], g);
+#pragma unroll
+          for (int e = 0; e < VE; ++e) r[e] += wwv[j] * g[e];
+        }
+#pragma unroll
+        for (int e = 0; e < VE; ++e) acc[e] += wh * r[e];
+      }
+    } else {
+      for (int ho = hlo; ho <= hhi; ++ho) {
+        const float wh = tap_weight(ho, hi, Hi, Ho, align);
+        if (wh == 0.f) continue;
+        for (int wo = wlo; wo <= whi; ++wo) {
+          const float ww = tap_weight(wo, wi, Wi, Wo, align);
+          if (ww == 0.f) continue;
+          float g[VE];
+          VecT<T>::load(dy + ((size_t)(n * Ho + ho) * Wo + wo) * ld_dy + cv * VE, g);
+#pragma unroll
+          for (int e = 0; e < VE; ++e) acc[e] += wh * ww * g[e];
+        }
       }
     }
     VecT<T>::store(dx + (size_t)pix * ld_dx + cv * VE, acc);
@@ -1253,6 +1333,147 @@ __global__ __launch_bounds__(256) void smallcin_im2col_kernel(const float* __res
 __global__ void smallcin_scatter_kernel(const float* __restrict__ t, float* __restrict__ dw, int Cout, int K, int KP) {
   const int i = blockIdx.x * 256 + threadIdx.x;   // dw[co][ci][kh][kw] flat = co * K + j
   if (i < Cout * K) dw[i] += t[(i / K) * KP + (i % K)];
+}
+
+// The same weight gradient for bf16 / Cout = 64 (both stems) WITHOUT the [pixels][32] matrix in memory: one persistent launch on the matrix
+// cores + a fixed-order sum of its per-workgroup partials.  D[co][k] += sum_px dy[px][co] * x[px @ tap k]: the pixels are the MFMA's
+// K dimension, so both operands are read "down the columns" of LDS tiles - dy[128 px][64 co] (row pitch 136 B: the four lane groups of
+// a fragment land on banks 0 / 16 / 32 / 48) with ds_read_u16, the taps from the f32 patch of the forward kernel (conv3x3_smallcin_mfma)
+// rounded to bf16 exactly as the im2col matrix was.  A wave owns 32 of an item's 128 pixels = one K step of the 16x16x32 MFMA for
+// 4 channel blocks x 2 tap blocks; patch and dy rows of the NEXT item travel in registers.  im2col + zero + GEMM + reduce + scatter
+// (5 launches, 26 MB written and read back) took 44 .. 56 us per stem.
+constexpr int kSmallcinWG = 512;   // persistent workgroups = rows of the partials buffer
+template <int STRIDE>
+__global__ __launch_bounds__(256) void smallcin_wgrad_mfma_kernel(const float* __restrict__ x, const bf16_t* __restrict__ dy,
+                                                                  float* __restrict__ part, int N, int Cin, int H, int W, int Ho, int Wo,
+                                                                  int tiles_w, int total) {
+  constexpr int TW = 128, PW = (TW - 1) * STRIDE + 3, NC = (PW + 63) / 64, DP = 68;   // DP: dy tile row pitch in bf16
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float* patch = (float*)smem_raw;                                   // [Cin * 3][PW]
+  bf16_t* dyt = (bf16_t*)(smem_raw + ((9 * PW * 4 + 15) & ~15));     // [TW][DP]
+  const int K = Cin * 9;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int col = lane & 15, g = lane >> 4;
+  int poff[2];
+#pragma unroll
+  for (int kb = 0; kb < 2; ++kb) {
+    const int k = kb * 16 + col;
+    poff[kb] = k < K ? (k / 3) * PW + (k % 3) : 0;   // (k >= K: a finite value, the column is never stored)
+  }
+  f32x4_t acc[4][2];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) acc[a][kb] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  float pv[3][NC];
+  uint4 dv[4];
+  auto fetch = [&](int it) {
+    const int tw_ = it % tiles_w, row_ = it / tiles_w;
+    const int ho_ = row_ % Ho, n_ = row_ / Ho;
+    const int wi0_ = tw_ * TW * STRIDE - 1, hi0_ = ho_ * STRIDE - 1;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      const int r = wave + 4 * q;
+      const int ci = r / 3, kh = r - ci * 3;
+      const int hi = hi0_ + kh;
+      const bool rok = r < Cin * 3 && (unsigned)hi < (unsigned)H;
+      const float* xr = x + (((size_t)n_ * Cin + (rok ? ci : 0)) * H + (rok ? hi : 0)) * W;
+#pragma unroll
+      for (int u = 0; u < NC; ++u) {
+        const int wi = wi0_ + lane + 64 * u;
+        pv[q][u] = (rok && (unsigned)wi < (unsigned)W) ? xr[wi] : 0.f;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {   // dy rows of the run: 128 pixels x 8 chunks of 8 channels
+      const int idx = threadIdx.x + 256 * u, px = idx >> 3, c8 = idx & 7;
+      const int wo = tw_ * TW + px;
+      dv[u] = wo < Wo ? *(const uint4*)(dy + ((size_t)row_ * Wo + wo) * 64 + c8 * 8) : make_uint4(0u, 0u, 0u, 0u);
+    }
+  };
+  if ((int)blockIdx.x < total) fetch((int)blockIdx.x);
+  for (int item = blockIdx.x; item < total; item += gridDim.x) {
+    __syncthreads();                         // the previous item's fragment reads are done
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      const int r = wave + 4 * q;
+      if (r < Cin * 3) {
+#pragma unroll
+        for (int u = 0; u < NC; ++u)
+          if (lane + 64 * u < PW) patch[r * PW + lane + 64 * u] = pv[q][u];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int idx = threadIdx.x + 256 * u, px = idx >> 3, c8 = idx & 7;
+      uint2* d = (uint2*)(dyt + px * DP + c8 * 8);   // (pitch 136 B: 8-byte aligned)
+      d[0] = make_uint2(dv[u].x, dv[u].y);
+      d[1] = make_uint2(dv[u].z, dv[u].w);
+    }
+    __syncthreads();
+    if (item + (int)gridDim.x < total) fetch(item + (int)gridDim.x);
+    const int px0 = wave * 32 + g * 8;       // the lane's 8 K-dimension pixels
+    u32x4_t bf[2];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      float xv[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) xv[j] = patch[poff[kb] + (px0 + j) * STRIDE];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) bf[kb][q] = pack2bf(xv[2 * q], xv[2 * q + 1]);
+    }
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      const bf16_t* ap = dyt + px0 * DP + a * 16 + col;
+      u32x4_t af;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) af[q] = (unsigned)ap[(2 * q) * DP] | ((unsigned)ap[(2 * q + 1) * DP] << 16);
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+        acc[a][kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, af), __builtin_bit_cast(bf16x8_t, bf[kb]),
+                                                             acc[a][kb], 0, 0, 0);
+    }
+  }
+  // the 4 waves' accumulators -> one [64 co][32 k] partial per workgroup (row co = 16 a + 4 g + i, column k = 16 kb + col)
+  __syncthreads();
+  float* red = (float*)smem_raw;   // [4][64][33]
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) red[(wave * 64 + a * 16 + 4 * g + i) * 33 + kb * 16 + col] = acc[a][kb][i];
+  __syncthreads();
+  for (int i = threadIdx.x; i < 64 * 32; i += 256) {
+    const int co = i >> 5, k = i & 31;
+    part[(size_t)blockIdx.x * 2048 + i] = (red[co * 33 + k] + red[(64 + co) * 33 + k]) + (red[(128 + co) * 33 + k] + red[(192 + co) * 33 + k]);
+  }
+}
+// dw[co][k] += sum over the workgroups' partials in a fixed order: 16 threads per output (each sums every 16th row, 8 loads in flight),
+// 16 consecutive outputs per workgroup.  (4 threads x 128 rows with 4 loads in flight was 32 dependent L2 round trips: the sum cost
+// more than the matrix-core launch in front of it.)
+__global__ __launch_bounds__(256) void smallcin_wgrad_sum_kernel(const float* __restrict__ part, int rows, float* __restrict__ dw, int K) {
+  __shared__ float red[16][17];
+  const int ol = threadIdx.x & 15, q = threadIdx.x >> 4;
+  const int o = blockIdx.x * 16 + ol;   // index into the [64][32] partial layout
+  float s[8];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) s[u] = 0.f;
+  int r = q;
+  for (; r + 16 * 7 < rows; r += 16 * 8) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s[u] += part[(size_t)(r + 16 * u) * 2048 + o];
+  }
+  for (; r < rows; r += 16) s[0] += part[(size_t)r * 2048 + o];
+  red[q][ol] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
+  __syncthreads();
+  if (q == 0) {
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) t += red[i][ol];
+    const int co = o >> 5, k = o & 31;
+    if (k < K) dw[co * K + k] += t;
+  }
 }
 
 // OHWI f32 gradient -> OIHW f32 parameter gradient (accumulate = add into existing .grad)
@@ -1809,6 +2030,17 @@ extern "C" int cavp_maxpool_bwd_nhwc(int32_t dtype, const uint8_t* argmax, const
   long long nb = ((long long)N * H * W * (C / VE) + 255) / 256;
   if (nb > 32768) nb = 32768;
   hipStream_t s = (hipStream_t)stream;
+  if (stride == 2 && (long long)N * H <= 65535) {   // the model's pools: one grid row per input row, no per-element divisions
+    const int CV = C / VE;
+    int sh = -1;
+    if ((CV & (CV - 1)) == 0) { sh = 0; while ((1 << sh) < CV) ++sh; }
+    const dim3 grid((W * CV + 255) / 256, N * H);
+    if (dtype == CAVP_F32)
+      maxpool_bwd_s2_rows_kernel<float><<<grid, 256, 0, s>>>(argmax, (const float*)dy, (float*)dx, H, W, C, k, pad, Ho, Wo, sh);
+    else
+      maxpool_bwd_s2_rows_kernel<bf16_t><<<grid, 256, 0, s>>>(argmax, (const bf16_t*)dy, (bf16_t*)dx, H, W, C, k, pad, Ho, Wo, sh);
+    CHECK_LAUNCH();
+  }
   if (dtype == CAVP_F32)
     maxpool_bwd_kernel<float><<<(int)nb, 256, 0, s>>>(argmax, (const float*)dy, (float*)dx, N, H, W, C, k, stride, pad, Ho, Wo);
   else
@@ -1996,6 +2228,24 @@ extern "C" int cavp_conv3x3_smallcin_wgrad(int32_t dtype, const float* x_nchw, c
   float* tmp = (float*)(col + pl.col_bytes);
   void* ws = (char*)tmp + pl.tmp_bytes;
   hipStream_t s = (hipStream_t)stream;
+  if (dtype == CAVP_BF16 && Cout == 64 && (stride == 1 || stride == 2) && al16(dy_nhwc)) {   // both stems: fused matrix-core version
+    const int tw = (pl.Wo + 127) / 128;
+    const long long items = (long long)N * pl.Ho * tw;
+    const int grid = items > kSmallcinWG ? kSmallcinWG : (int)items;
+    if (items <= 0x7fffffffll && workspace_bytes >= (size_t)grid * 2048 * 4) {
+      const int PW = 127 * stride + 3;
+      size_t lds = ((size_t)9 * PW * 4 + 15) / 16 * 16 + (size_t)128 * 68 * 2;
+      if (lds < (size_t)4 * 64 * 33 * 4) lds = (size_t)4 * 64 * 33 * 4;
+      float* part = (float*)workspace;
+      if (stride == 2)
+        smallcin_wgrad_mfma_kernel<2><<<grid, 256, lds, s>>>(x_nchw, (const bf16_t*)dy_nhwc, part, N, Cin, H, W, pl.Ho, pl.Wo, tw, (int)items);
+      else
+        smallcin_wgrad_mfma_kernel<1><<<grid, 256, lds, s>>>(x_nchw, (const bf16_t*)dy_nhwc, part, N, Cin, H, W, pl.Ho, pl.Wo, tw, (int)items);
+      if (hipGetLastError() != hipSuccess) return CAVP_ERR_LAUNCH;
+      smallcin_wgrad_sum_kernel<<<128, 256, 0, s>>>(part, grid, dw_oihw, Cin * 9);
+      CHECK_LAUNCH();
+    }
+  }
   long long nb = (pl.M + 255) / 256;
   if (nb > 16384) nb = 16384;
   if (dtype == CAVP_F32)

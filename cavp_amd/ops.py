@@ -203,9 +203,11 @@ def conv3x3_smallcin_nchw(x_nchw: torch.Tensor, w_oihw: torch.Tensor, out: torch
 
 
 def maxpool(x: torch.Tensor, out: torch.Tensor, k: int, stride: int, pad: int,
-            argmax: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """argmax (optional): uint8 tensor of out's shape receiving the window-relative arg-max (for maxpool_bwd)."""
-    _need_gpu(x, out)
+            argmax: Optional[torch.Tensor] = None, scale: Optional[torch.Tensor] = None, shift: Optional[torch.Tensor] = None,
+            act: int = ACT_NONE) -> torch.Tensor:
+    """argmax (optional): uint8 tensor of out's shape receiving the window-relative arg-max (for maxpool_bwd).
+    scale / shift (f32 [C], both or neither) + act: the pool runs over act(x * scale + shift) - cavp_maxpool_affine_nhwc."""
+    _need_gpu(x, out, scale, shift)
     n, h, w, c, ld = _nhwc(x)
     no, ho, wo, co, ldo = _nhwc(out)
     if ld != c or ldo != co or co != c or out.dtype != x.dtype:
@@ -215,6 +217,15 @@ def maxpool(x: torch.Tensor, out: torch.Tensor, k: int, stride: int, pad: int,
     if argmax is not None and (argmax.dtype != torch.uint8 or not argmax.is_contiguous() or argmax.numel() != out.numel()
                                or argmax.device != x.device):
         raise _lib.CavpError("maxpool: argmax must be a dense uint8 tensor of the output's shape")
+    if (scale is None) != (shift is None):
+        raise _lib.CavpError("maxpool: scale and shift come together")
+    if scale is not None:
+        if scale.dtype != torch.float32 or shift.dtype != torch.float32 or scale.numel() != c or shift.numel() != c:
+            raise _lib.CavpError("maxpool: scale / shift must be f32 [C]")
+        st = _lib.load().cavp_maxpool_affine_nhwc(dtype_code(x.dtype), _ptr(x), _ptr(scale), _ptr(shift), act, _ptr(out), _ptr(argmax),
+                                                  n, h, w, c, k, stride, pad, C.c_void_p(_stream()))
+        _lib.check(st, "cavp_maxpool_affine_nhwc")
+        return out
     st = _lib.load().cavp_maxpool_nhwc(dtype_code(x.dtype), _ptr(x), _ptr(out), _ptr(argmax), n, h, w, c, k, stride, pad,
                                        C.c_void_p(_stream()))
     _lib.check(st, "cavp_maxpool_nhwc")

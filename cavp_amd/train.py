@@ -16,7 +16,7 @@ Semantics kept from the reference:
 from __future__ import annotations
 
 import os
-from typing import Callable, Dict, List, Optional
+from typing import Callable, Dict, List, Optional, Tuple
 
 import torch
 import torch.nn as nn
@@ -286,6 +286,7 @@ _BRANCH_STREAM = True    # False (tests / A-B only): the down-sample branch of a
 _SIDE_PACKS = True       # False (A/B only): the audio encoder's weight re-packs on the main stream with all the others (rounds 1-4)
 _FUSE_BN_BWD = True      # False (tests / A-B only): BatchNorm backward always as reduce launch + apply launch (rounds 1-4)
 _BN_BWD_READ_Y = False   # True (tests / A-B only): the BatchNorm backward always re-reads y instead of re-deriving the mask from z
+_FUSE_STEM_POOL = True   # False (tests / A-B only): stem bn1 + ReLU and the max pool as two launches with the activation in memory (rounds 1-5)
 
 
 def bump_counters(model, counters) -> None:
@@ -678,8 +679,12 @@ class TrainPass:
         self.tape.append(bwd)
         return y
 
-    def bn_act(self, z: V, bn, act: int, residual: Optional[V] = None, out: Optional[V] = None) -> V:
-        """y = act(BN_train(z) + residual); `out` may be a channel slice of a concat buffer."""
+    def bn_act(self, z: V, bn, act: int, residual: Optional[V] = None, out: Optional[V] = None,
+               pool: Optional[Tuple[int, int, int]] = None) -> V:
+        """y = act(BN_train(z) + residual); `out` may be a channel slice of a concat buffer.
+        pool = (k, stride, pad): y = max_pool(act(BN_train(z))) in ONE pass over z (the stem: bn1 -> relu -> maxpool, resnet.py:187-190) -
+        the un-pooled activation is never stored; the backward routes the pooled gradient through the arg-max first and then is the
+        ordinary BatchNorm + activation backward with the mask re-derived from z."""
         c = bn.num_features
         rows = z.t.numel() // z.t.shape[-1]
         scale, shift, mean, rstd = (self.empty((c,), torch.float32) for _ in range(4))
@@ -719,20 +724,34 @@ class TrainPass:
                                 mean, rstd)
         if track and bn.num_batches_tracked is not None:
             self._nbt.append(bn.num_batches_tracked)
-        y = out if out is not None else V(self.empty(z.t.shape, z.t.dtype))
-        T.scale_shift_act(z.t, scale, shift, y.t, act, residual=residual.t if residual is not None else None)
+        am = None
+        if pool is not None:
+            if residual is not None or out is not None or z.t.dim() != 4:
+                raise ValueError("bn_act(pool=...): plain NHWC BatchNorm + activation only")
+            pk, ps, pp = pool
+            n_, h_, w_, c_ = z.t.shape
+            y = V(self.empty((n_, (h_ + 2 * pp - pk) // ps + 1, (w_ + 2 * pp - pk) // ps + 1, c_), z.t.dtype))
+            am = torch.empty(y.t.shape, dtype=torch.uint8, device=self.dev)
+            ops.maxpool(z.t, y.t, pk, ps, pp, argmax=am, scale=scale, shift=shift, act=act)
+        else:
+            y = out if out is not None else V(self.empty(z.t.shape, z.t.dtype))
+            T.scale_shift_act(z.t, scale, shift, y.t, act, residual=residual.t if residual is not None else None)
 
         self._use(residual)
         # (ReLU only: its mask is idempotent, so the fallback - a later contribution drops the partial sums and the separate reduce / apply
         # passes mask the already-masked sum once more - stays exact; a LeakyReLU slope would be applied twice.  No LeakyReLU layer
         # of the CAVP graph qualified anyway: ASPP's outputs are concat slices.)
-        if _FUSE_BN_BWD and not sync and not frozen and act == ACT_RELU and y.parent is None and z.t.dim() == 4:
+        if _FUSE_BN_BWD and not sync and not frozen and act == ACT_RELU and y.parent is None and z.t.dim() == 4 and pool is None:
             y.bnb = dict(z=z.t, out=y.t if residual is not None else None, scale=scale, shift=shift, mean=mean, rstd=rstd, act=act)
 
         def bwd():
             dy = y.g
             if dy is None:
                 return
+            if pool is not None:   # pooled gradient -> gradient of the (never stored) activation, through the recorded arg-max
+                dpool = dy if dy.is_contiguous() else self._dense_copy(dy)
+                dy = self.empty(z.t.shape, z.t.dtype)
+                T.maxpool_bwd(am, dpool, dy, *pool)
             direct = (not sync and id(bn.weight) not in self.grads and id(bn.bias) not in self.grads)
             if y.bnb_part is not None:
                 # the launch that completed dy already applied the activation's derivative and summed g and g * zhat per tile:
@@ -756,7 +775,7 @@ class TrainPass:
             else:
                 sums = self.zeros_f32(2, c)
             # without a residual the activation mask follows from z and the folded (scale, shift): y is not re-read
-            yb = y.t if (residual is not None or _BN_BWD_READ_Y) else None
+            yb = y.t if ((residual is not None or _BN_BWD_READ_Y) and pool is None) else None
             T.bn_act_bwd_reduce(dy, yb, z.t, mean, rstd, act, sums[0], sums[1], fwd_scale=scale, fwd_shift=shift)
             local = sums
             if sync and not frozen:   # (frozen statistics: dz has no batch-mean terms, nothing to exchange)
@@ -1250,8 +1269,11 @@ def run_train_forward(model, image: torch.Tensor, audio: torch.Tensor, tp: Train
         z = tp.conv_smallcin(image, "stem0", 2, ACT_NONE)
         x = tp.bn_act(z, rn.conv1[1], ACT_RELU)
         x = tp.bn_act(tp.conv(x, "stem1", stats=rn.conv1[4]), rn.conv1[4], ACT_RELU)
-        x = tp.bn_act(tp.conv(x, "stem2", stats=rn.bn1), rn.bn1, ACT_RELU)
-        x = tp.maxpool(x, 3, 2, 1)
+        if _FUSE_STEM_POOL:
+            x = tp.bn_act(tp.conv(x, "stem2", stats=rn.bn1), rn.bn1, ACT_RELU, pool=(3, 2, 1))
+        else:
+            x = tp.bn_act(tp.conv(x, "stem2", stats=rn.bn1), rn.bn1, ACT_RELU)
+            x = tp.maxpool(x, 3, 2, 1)
         feats = []
         for si, stage in enumerate(rn.block_table):
             for bi, (_, _, _, has_ds) in enumerate(stage):

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define CAVP_ABI_VERSION 11
+#define CAVP_ABI_VERSION 12
 
 typedef enum { CAVP_F32 = 0, CAVP_BF16 = 1 } cavp_dtype_t;
 typedef enum { CAVP_ACT_NONE = 0, CAVP_ACT_RELU = 1, CAVP_ACT_LEAKY = 2, CAVP_ACT_GELU = 3 } cavp_act_t;
@@ -180,6 +180,13 @@ int cavp_conv3x3_smallcin_nchw(int32_t dtype, const float* x_nchw, const float* 
  * consumed by cavp_maxpool_bwd_nhwc. */
 int cavp_maxpool_nhwc(int32_t dtype, const void* x, void* y, uint8_t* argmax, int32_t N, int32_t H, int32_t W,
                       int32_t C, int32_t k, int32_t stride, int32_t pad, void* stream);
+
+/* ABI 12.  The same pool over act(x * scale + shift) (per-channel f32 scale / shift, rounded to dtype before the comparison): the training step's
+ * BatchNorm apply + ReLU in front of the stem pool (resnet.py:187-190: bn1 -> relu -> maxpool) without the activation tensor in memory.
+ * Values and arg-max are bit-identical to cavp_scale_shift_act followed by cavp_maxpool_nhwc. */
+int cavp_maxpool_affine_nhwc(int32_t dtype, const void* x, const float* scale, const float* shift, int32_t act, void* y,
+                             uint8_t* argmax, int32_t N, int32_t H, int32_t W, int32_t C, int32_t k, int32_t stride, int32_t pad,
+                             void* stream);
 
 /* x.view(N, C, -1).mean(-1) for NHWC x; output f32 [N][C] (ASPP._global_pooling, encoder_decoder.py:158-161). */
 int cavp_global_avgpool_nhwc(int32_t dtype, const void* x, float* y, int32_t N, int32_t HW, int32_t C, int32_t ldx,

@@ -349,3 +349,25 @@ def test_dwconv_and_patch_embed_and_sr_conv(dtype):
         out = torch.empty((2, 16 // sr, 32 // sr, C), dtype=dtype, device=DEV)
         ops.conv2d(xin, ops.pack_weight(ws.to(DEV), dtype), out, kh=sr, kw=1, stride=sr, stride_w=1, shift=bs.to(DEV))
         _check(out.permute(0, 3, 1, 2), ref, dtype, f"sr_conv{sr}")
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+@pytest.mark.parametrize("k,s,p,hw,ch", [(3, 2, 1, (28, 30), 64), (2, 2, 0, (12, 8), 48), (3, 2, 1, (15, 9), 128)])
+def test_maxpool_affine_equals_scale_shift_act_then_maxpool(k, s, p, hw, ch, dtype):
+    """cavp_maxpool_affine_nhwc (round 6) == cavp_scale_shift_act + cavp_maxpool_nhwc, values AND arg-max, bit for bit; and the values match
+    torch on the same quantised input."""
+    ops = _ops()
+    from cavp_amd import train_ops as T
+    x = _q(_rand(2, ch, *hw, seed=61), dtype)
+    sc, sh = torch.rand(ch, generator=torch.Generator().manual_seed(62)) + 0.5, _rand(ch, seed=63)
+    xd = x.permute(0, 2, 3, 1).contiguous().to(dtype).to(DEV)
+    act = torch.empty_like(xd)
+    T.scale_shift_act(xd, sc.to(DEV), sh.to(DEV), act, ops.ACT_RELU)
+    ho, wo = (hw[0] + 2 * p - k) // s + 1, (hw[1] + 2 * p - k) // s + 1
+    y0, y1 = (torch.empty((2, ho, wo, ch), dtype=dtype, device=DEV) for _ in range(2))
+    a0, a1 = (torch.empty((2, ho, wo, ch), dtype=torch.uint8, device=DEV) for _ in range(2))
+    ops.maxpool(act, y0, k, s, p, argmax=a0)
+    ops.maxpool(xd, y1, k, s, p, argmax=a1, scale=sc.to(DEV), shift=sh.to(DEV), act=ops.ACT_RELU)
+    assert torch.equal(y0, y1) and torch.equal(a0, a1)
+    ref = F.max_pool2d(F.relu(x * sc[None, :, None, None] + sh[None, :, None, None]), k, s, p)
+    _check(y1.permute(0, 3, 1, 2), ref, dtype, "maxpool_affine")

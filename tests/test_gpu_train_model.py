@@ -657,3 +657,33 @@ def test_fused_bn_backward_statistics_equal_separate_reduce(dtype, streams):
     finally:
         T.bn_act_bwd_reduce = orig
         TR._FUSE_BN_BWD, TR._SIDE_STREAM = old, old_side
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+def test_stem_pool_fused_with_bn_apply_is_bit_identical(dtype):
+    """Round 6: the stem's bn1 -> ReLU -> max pool (resnet.py:187-190) runs as ONE pass over the conv output (cavp_maxpool_affine_nhwc:
+    the pool compares act(z * scale + shift) rounded to the storage dtype, exactly the values scale_shift_act used to store), the
+    un-pooled activation is never written; the backward routes the pooled gradient through the recorded arg-max and is then the same
+    BatchNorm + ReLU backward as before.  Deterministic mode: loss and EVERY gradient bit-identical to the two-launch route.
+    (HIP on both sides: a bit-identity screen; the reference-golden train steps run with the fused route as the default.)"""
+    import cavp_amd.train as TR
+    from cavp_amd import _lib
+    cfg = dict(C=3, B=4, hw=(64, 96), lds=[False, False, False])
+    image, audio, label = [t.to(DEV) for t in synth_inputs(cfg["B"], cfg["hw"], audio_batch=2 * cfg["B"], num_classes=cfg["C"], seed=12)]
+    old = TR._FUSE_STEM_POOL
+    _lib.set_deterministic(True)
+    try:
+        res = []
+        for fused in (False, True):
+            TR._FUSE_STEM_POOL = fused
+            m, _ = _build(cfg)
+            m.set_compute_dtype(dtype)
+            m.train()
+            loss = m.train_step(image, audio, label, all_reduce=False)
+            torch.cuda.synchronize()
+            res.append((float(loss.item()), m._grad_arena.flat.clone()))
+        assert res[0][0] == res[1][0], (res[0][0], res[1][0])
+        assert torch.equal(res[0][1], res[1][1]), float((res[0][1] - res[1][1]).abs().max())
+    finally:
+        _lib.set_deterministic(False)
+        TR._FUSE_STEM_POOL = old

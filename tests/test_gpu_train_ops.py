@@ -43,6 +43,11 @@ CONV = [
     ("3x3_s2", 2, 16, 16, 64, 128, 3, 2, 1, 1),
     ("3x3_s2_odd", 1, 15, 13, 64, 64, 3, 2, 1, 1),
     ("1x1_s2", 2, 16, 16, 128, 256, 1, 2, 0, 1),
+    # (stride-2 data gradients run on parity-ordered pixel tiles since round 6: odd extents = classes of different sizes, 28 x 28 x 3 =
+    # several tiles per class, 1x1 = three of the four classes without any tap)
+    ("1x1_s2_odd", 2, 15, 9, 64, 64, 1, 2, 0, 1),
+    ("3x3_s2_28", 3, 28, 28, 128, 128, 3, 2, 1, 1),
+    ("3x3_s2_d2", 1, 17, 12, 64, 64, 3, 2, 2, 2),
     ("3x3_d2", 1, 14, 14, 128, 128, 3, 1, 2, 2),
     ("3x3_d12", 1, 14, 14, 128, 64, 3, 1, 12, 12),
     ("3x3_d18_dead_taps", 1, 14, 14, 128, 64, 3, 1, 18, 18),   # ASPP rate 18 at 14x14: only the centre tap is live
@@ -288,16 +293,18 @@ def test_attn_gate_bwd(dt, H, hd):
 
 
 @pytest.mark.parametrize("dt", DTYPES, ids=IDS)
-@pytest.mark.parametrize("k,s,p,hw", [(3, 2, 1, (28, 30)), (2, 2, 0, (12, 8)), (3, 2, 1, (15, 9))])
-def test_maxpool_bwd(k, s, p, hw, dt):
+@pytest.mark.parametrize("ch", [64, 48], ids=["c64", "c48"])
+@pytest.mark.parametrize("k,s,p,hw", [(3, 2, 1, (28, 30)), (2, 2, 0, (12, 8)), (3, 2, 1, (15, 9)), (3, 1, 1, (9, 7))])
+def test_maxpool_bwd(k, s, p, hw, dt, ch):
+    """(stride 2 takes the row-mapped kernel of round 6 - channel-vector counts that are / are not a power of two; stride 1 the flat one)"""
     ops, T = _mods()
     # post-ReLU style input: exact ties (zeros) inside windows exercise the first-maximum rule
-    x = _q(torch.relu(_rand(2, 64, *hw, seed=25)), dt).requires_grad_(True)
+    x = _q(torch.relu(_rand(2, ch, *hw, seed=25)), dt).requires_grad_(True)
     y = F.max_pool2d(x, k, s, p)
     dy = _q(_rand(*y.shape, seed=26), dt)
     y.backward(dy)
-    dx = torch.empty((2, hw[0], hw[1], 64), dtype=dt, device=DEV)
-    yo = torch.empty((2, y.shape[2], y.shape[3], 64), dtype=dt, device=DEV)
+    dx = torch.empty((2, hw[0], hw[1], ch), dtype=dt, device=DEV)
+    yo = torch.empty((2, y.shape[2], y.shape[3], ch), dtype=dt, device=DEV)
     am = torch.empty(yo.shape, dtype=torch.uint8, device=DEV)
     ops.maxpool(_nhwc(x.detach(), dt), yo, k, s, p, argmax=am)
     _check(yo.permute(0, 3, 1, 2), y.detach(), dt, "maxpool fwd (argmax variant)", 1e-6, 1e-2)
@@ -399,15 +406,17 @@ def test_bcast_add_and_smallcin_wgrad(dt):
     xv = _nhwc(x, dt)
     T.bcast_add(xv, v.to(DEV), 1.0 / 35)
     _check(xv.permute(0, 3, 1, 2), x + v[:, :, None, None] / 35, dt, "bcast_add")
-    for cin, stride, hw in [(3, 2, (32, 40)), (1, 1, (24, 16))]:
+    # (bf16 / 64 channels = the fused matrix-core kernel of round 6: ragged rows, several 128-pixel runs per row, more items than
+    # persistent workgroups (224 x 224), accumulation into a non-zero gradient; f32 = the im2col + GEMM route)
+    for cin, stride, hw in [(3, 2, (32, 40)), (1, 1, (24, 16)), (3, 2, (31, 45)), (2, 1, (9, 300)), (3, 2, (224, 224))]:
         xi = _rand(2, cin, *hw, seed=34)
         w = _rand(64, cin, 3, 3, seed=35, scale=0.3).requires_grad_(True)
         y = F.conv2d(xi, w, None, stride, 1)
         dy = _q(_rand(*y.shape, seed=36), dt)
         y.backward(dy)
-        dw = torch.zeros((64, cin, 3, 3), device=DEV)
+        dw = torch.full((64, cin, 3, 3), 0.5, device=DEV)
         T.smallcin_wgrad(xi.to(DEV), _nhwc(dy, dt), dw, stride)
-        _check(dw, w.grad, dt, "smallcin wgrad", 1e-4, 1e-2)
+        _check(dw - 0.5, w.grad, dt, f"smallcin wgrad {cin} s{stride} {hw}", 1e-4, 1e-2)
 
 
 @pytest.mark.parametrize("dt", DTYPES, ids=IDS)
@@ -570,6 +579,8 @@ BNB_CASES = [
     ("1x1_out_res", 8, 56, 56, 256, 64, 1, 1, 0, 1, True),
     ("1x1_s2_out_res", 4, 56, 56, 256, 128, 1, 2, 0, 1, True),
     ("ragged_1x1", 3, 13, 11, 72, 48, 1, 1, 0, 1, False),
+    ("3x3_s2_odd", 3, 15, 13, 64, 64, 3, 2, 1, 1, False),
+    ("1x1_s2_odd_out_res", 3, 15, 13, 128, 64, 1, 2, 0, 1, True),
     ("wide_14", 8, 14, 14, 1024, 256, 1, 1, 0, 1, True),
 ]
 
