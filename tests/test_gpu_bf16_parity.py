@@ -109,12 +109,16 @@ def test_bf16_teacher_forced_layer_by_layer():
         stats.append((float((a @ b) / (a.norm() * b.norm())), float(a.norm() / b.norm()), k))
     worst_cos = min(stats)
     print("worst gradient cosine:", worst_cos, " norm ratio range:", min(s[1] for s in stats), max(s[1] for s in stats))
-    # bound: cosine >= 0.98 everywhere (worst measured 0.985, on the stem conv at the far end of the 55-layer backward chain,
-    # where two f32 runs of the same step already differ by ~2.5e-2 of the gradient norm), median >= 0.99 (measured 0.995)
+    # bound: median >= 0.99 (measured 0.995); worst >= 0.97 with at most two parameters below 0.98.  The worst value sits on the stem
+    # BatchNorm parameters at the far end of the 55-layer backward chain, where two f32 runs of the same step already differ by ~2.5e-2 of
+    # the gradient norm, and it moves by +-4e-3 with any change of a summation order: profiles/r06_bf16_teacher_seeds.txt
+    # (six input seeds, the trees before / after round 6: 0.9833 -> 0.9793 at this seed, 0.9816 -> 0.9830 at the next; the former bound of
+    # 0.98 everywhere was 3e-3 above one measurement and fails on the OLD tree for two of the other five seeds).
     cs = sorted(s[0] for s in stats)
     assert cs[len(cs) // 2] >= 0.99, cs[len(cs) // 2]
+    assert sum(c < 0.98 for c in cs) <= 2, [s for s in sorted(stats)[:4]]
     for cos, ratio, k in stats:
-        assert cos >= 0.98, (k, cos, ratio)
+        assert cos >= 0.97, (k, cos, ratio)
         assert 0.9 <= ratio <= 1.1, (k, cos, ratio)
 
 
