@@ -112,8 +112,12 @@ def test_bf16_step_vs_oracle_on_conditioned_weights(conditioned, oracle_step):
     print("bf16:", r)
     assert r["logits_rel"] <= 2e-2, r                             # measured 3e-3 .. 5e-3 (VERDICT r02 target: <= 2 %)
     assert abs(r["loss"] - r["ref_loss"]) <= 5e-3 * max(1.0, r["ref_loss"]), r
-    assert r["whole_cos"] >= 0.96, r                              # measured 0.979
-    assert r["cos_med"] >= 0.93 and r["cos_p05"] >= 0.80, r       # measured 0.958 / 0.891
+    # The figures follow the conditioned WEIGHTS, which 100 f32 training steps with the tree's own kernels produce: any change of an f32
+    # summation order gives this test another instance.  profiles/r06_conditioned_cross.txt (2 x 2 cross of weights x kernels, rounds
+    # 5 / 6): whole-gradient cosine 0.982 on one weight set and 0.950 on the other with EITHER kernel build (the builds agree to <= 3e-3
+    # on the same weights), median 0.966 / 0.958, p05 0.91 / 0.90.  (Round 3 .. 5 instance: 0.979 / 0.958 / 0.891, bound 0.96.)
+    assert r["whole_cos"] >= 0.93, r
+    assert r["cos_med"] >= 0.93 and r["cos_p05"] >= 0.80, r
 
 
 @pytest.fixture(scope="module")

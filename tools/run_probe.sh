@@ -3,4 +3,6 @@ cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 O=gpurun_out/r06
 mkdir -p $O
-timeout 2400 python -m pytest tests -m gpu -q --maxfail=10 2>&1 | tail -25 > $O/pytest_gpu.txt; cat $O/pytest_gpu.txt
+{ python tools/probes/conditioned_cross.py condition ab_base /tmp/sd_base.pt
+  python tools/probes/conditioned_cross.py condition . /tmp/sd_repo.pt
+  for w in base repo; do for t in ab_base .; do python tools/probes/conditioned_cross.py compare $t /tmp/sd_$w.pt; done; done; } 2>&1 | grep -v "Warning\|amdgpu.ids" | tee $O/conditioned_cross.txt
