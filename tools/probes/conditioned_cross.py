@@ -3,7 +3,7 @@
 synthetic weights for 100 f32 steps with the tree's own kernels, so any change of an f32 summation order gives it different weights to be measured on.
   condition <tree> <out.pt>   100 deterministic f32 steps with <tree>/cavp_amd -> state_dict file
   compare   <tree> <sd.pt>    the test's bf16 (and f32) step-vs-oracle figures of <tree>/cavp_amd on those weights
-GPU box only (tools/run_probe.sh drives the 2 x 2 cross)."""
+GPU box only (`tools/ab_r06.sh cross` drives the 2 x 2 cross)."""
 import importlib.util
 import os
 import sys
