@@ -1296,6 +1296,10 @@ extern "C" size_t cavp_conv2d_workspace_bytes(const cavp_conv_desc* d) {
   Plan pl = make_plan(d);
   if (pl.status != CAVP_OK) return 0;
   size_t need = pl.ws_bytes;
+  if (pl.p.up_par) {   // a launch with a per-image bias / auxiliary tensor re-plans without the parity-ordered tiles: that plan may split K
+    Plan lin = make_plan(d, true, false);
+    if (lin.status == CAVP_OK && lin.ws_bytes > need) need = lin.ws_bytes;
+  }
   if (tile_is_big(pl.tile_id)) {   // the launch re-plans without the 256x256 tile when an operand is not 16-byte aligned: that
     Plan alt = make_plan(d, false);   // plan may split K
     if (alt.status == CAVP_OK && alt.ws_bytes > need) need = alt.ws_bytes;
