@@ -673,6 +673,13 @@ __global__ __launch_bounds__(64 * WC * WP, (WC * WP == 4 ? (BC * BP <= 64 * 64 &
       }
     }
     for (int i0 = 0; i0 < ITER; i0 += G) {
+      // UP: the output pixels of this batch's chunks, mapped ONCE (three multiply-shift divisions each) and used by the residual / z /
+      // output loads and the store below
+      int opb[UP ? G : 1];
+      if constexpr (UP) {
+#pragma unroll
+        for (int g = 0; g < G; ++g) opb[g] = opix_of(i0 + g);
+      }
       u32x4_t rr[G];
       if (rp) {
 #pragma unroll
@@ -680,7 +687,7 @@ __global__ __launch_bounds__(64 * WC * WP, (WC * WP == 4 ? (BC * BP <= 64 * 64 &
           if (GH > 0 && i0 == 0 && g < GH) { rr[g] = rr0[g < GH ? g : 0]; continue; }
           rr[g] = (u32x4_t){0u, 0u, 0u, 0u};
           if constexpr (UP) {
-            const int op_ = opix_of(i0 + g);
+            const int op_ = opb[g];
             if (ec_ok && op_ >= 0) rr[g] = *(const u32x4_t*)((const T*)p.res + (size_t)op_ * p.ldr + ec);
           } else {
             if (ec_ok && (i0 + g) * RSTR < rows_left) rr[g] = *(const u32x4_t*)(rp + (size_t)(i0 + g) * rstep);
@@ -695,7 +702,7 @@ __global__ __launch_bounds__(64 * WC * WP, (WC * WP == 4 ? (BC * BP <= 64 * 64 &
           zz[g] = (u32x4_t){0u, 0u, 0u, 0u};
           oo[g] = (u32x4_t){0u, 0u, 0u, 0u};
           if constexpr (UP) {
-            const int op_ = opix_of(i0 + g);
+            const int op_ = opb[g];
             if (ec_ok && op_ >= 0) {
               zz[g] = *(const u32x4_t*)((const T*)p.bnb_z + (size_t)op_ * p.ld_bnb_z + ec);
               if (op) oo[g] = *(const u32x4_t*)((const T*)p.bnb_out + (size_t)op_ * p.ld_bnb_out + ec);
@@ -713,7 +720,7 @@ __global__ __launch_bounds__(64 * WC * WP, (WC * WP == 4 ? (BC * BP <= 64 * 64 &
         // a loaded value that stays unused on some static path is still "pending" at the tile loop's latch for hipcc's wait-count
         // pass, which then parks an s_waitcnt vmcnt(0) there: every tile waited for the acknowledgement of its own global stores
         // before the next tile's operands were requested.  Dead chunks compute on zeros; only their stores and sums are masked.)
-        const int opk = UP ? opix_of(k) : 0;   // (UP: this chunk's output pixel)
+        const int opk = UP ? opb[UP ? g : 0] : 0;   // (UP: this chunk's output pixel)
         const bool live = ec_ok && (UP ? opk >= 0 : k * RSTR < rows_left);
         float v[VE];
         {
