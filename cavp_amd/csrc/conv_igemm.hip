@@ -1185,6 +1185,14 @@ Plan make_plan(const cavp_conv_desc* d_in, bool allow_big = true, bool allow_par
     for (int i = 0; i < kNumTiles; ++i)
       if (kTiles[i].id == 11) { best = i; best_sk = 1; }
   }
+  // A/B probe (profile builds: CAVP_IGEMM_UP1X1_TILE=<id>): tile of the 1x1 stride-2 data gradients, whose launches are bound by the four
+  // streams of their epilogue, not by their K loop
+  {
+    static const int up1 = cavp_knob_int("CAVP_IGEMM_UP1X1_TILE", 0);
+    if (up1 > 0 && want_tile == 0 && up == 2 && p.ntaps == 1 && d->splitk <= 0)
+      for (int i = 0; i < kNumTiles; ++i)
+        if (kTiles[i].id == up1) { best = i; best_sk = 1; }
+  }
   // The 256x256 ping-pong tile (conv_igemm_big.hip) by rule, not by the time model: measured on MI355X (bench_conv,
   // profiles/r02_notes.md) it wins where its whole-tile quantisation is harmless - the output is (nearly) a multiple of 256
   // channels wide, there are at least four K tiles to amortise its ~6 us epilogue, and the tiles fill whole rounds of 256
