@@ -152,6 +152,11 @@ __global__ __launch_bounds__(64 * WC * WP, (WC * WP == 4 ? (BC * BP <= 64 * 64 &
                          p.Ho == p.H && p.Wo == p.W;
   int z = 0, tc = 0, tp = 0, c_base = 0, p_base = 0, it_begin = 0, it_end = 0;   // logical workgroup: split-K slice, channel tile, pixel tile
   int pq = 0;   // UP, parity-ordered tiles (igemm_params.h): the tile's output parity class
+  int par_rot = 0;   // UP, parity-ordered tiles: log2 of the quadruples a workgroup strides per trip (see start_tile)
+  if constexpr (UP) {
+    const int step = fast_div((int)(gridDim.x >> 5), p.div_tc_m, p.div_tc_s);   // (gridDim.x / 8 / tiles_c) / 4
+    par_rot = step > 1 ? 31 - __builtin_clz((unsigned)step) : 0;
+  }
   float bcf[4] = {1.f, 0.f, 0.f, 1.f};
   int g_ti = 0, g_cc = 0;
 
@@ -221,7 +226,13 @@ __global__ __launch_bounds__(64 * WC * WP, (WC * WP == 4 ? (BC * BP <= 64 * 64 &
       // parity-ordered tiles: consecutive tile ids cycle through the four classes.  In class-major order the XCD remap hands the one class
       // of a 1x1 stride-2 gradient that has any tap (a quarter of the tiles, all of the K loops) to two of the eight XCDs: 74 us where
       // the image-order launch took 69.
-      if (p.up_par) tp = (tp & 3) * (p.tiles_p >> 2) + (tp >> 2);
+      // ... and the class of a quadruple is rotated by (quadruple index >> par_rot): a persistent workgroup strides gridDim.x / 8 / tiles_c pixel
+      // tiles per trip - a multiple of four - and so met ONE class in all its tiles (a 1x1 gradient's workgroups were either all K loop or
+      // none).  Any function of the quadruple index keeps the map a bijection.
+      if (p.up_par) {
+        const int quad = tp >> 2;
+        tp = (((tp & 3) + (quad >> par_rot)) & 3) * (p.tiles_p >> 2) + quad;
+      }
     }
     c_base = tc * BC;
     p_base = tp * BP;
