@@ -1002,9 +1002,21 @@ hipError_t launch_cfg(const IgemmParams& p, int nblk, hipStream_t s) {
                               hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr_set = true;
   }
-  int bpc = (160 * 1024) / lds;   // resident workgroups per CU (LDS-limited; the 4-wave tiles use <= 128 VGPRs)
+  int bpc = (160 * 1024) / lds;   // resident workgroups per CU by LDS ...
   if (bpc > 4) bpc = 4;
   if (bpc < 1) bpc = 1;
+  // ... and by registers: the 64 x 128 / 128 x 64 tiles hold 194 .. 233 VGPRs = two waves per SIMD = TWO workgroups per CU, while their 49 KiB of
+  // LDS would admit three.  A persistent grid of 3 x 256 leaves 256 workgroups queued behind the resident 512 until those have walked ALL their
+  // tiles (the surplus of a persistent grid starts when a resident workgroup EXITS): two waves of workgroups instead of 1.5.  (Grid only: the
+  // planner's time model keeps its LDS-based slot count, so tile choices - and with them every summation order - stay what they were.)
+  static int occ = -1;
+  if (occ < 0) {
+    int n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void*)igemm_kernel<T, BC, BP, WC, WP, UP, NS, BNB>, 64 * WC * WP, lds) != hipSuccess || n < 1)
+      n = 4;
+    occ = n;
+  }
+  if (bpc > occ) bpc = occ;
   static const int bpc_cap = cavp_knob_int("CAVP_IGEMM_BPC", 0);   // A/B knob: resident workgroups per CU
   if (bpc_cap > 0 && bpc > bpc_cap) bpc = bpc_cap;
   static const bool persistent = cavp_knob_int("CAVP_IGEMM_PERSISTENT", 1) != 0;
